@@ -1,0 +1,36 @@
+# Build of the MI355X TetRex query engine.  gfx950 only; hipcc cross-compiles without a GPU.
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+ARCH    ?= gfx950
+CSRC    := tetrex_amd/csrc
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+HIP_SRCS := $(CSRC)/txq_api.hip $(CSRC)/txq_probe.hip $(CSRC)/txq_hibf.hip $(CSRC)/txq_exec.hip
+HIP_OBJS := $(HIP_SRCS:.hip=.o)
+HIP_HDRS := $(wildcard $(CSRC)/*.hpp) include/txq.h include/txq_program.h
+
+all: tetrex_amd/libtxq.so oracle/liboracle.so
+
+$(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+# The HIP runtime is linked by its UNVERSIONED name (libamdhip64.so) so that a process which
+# already carries a HIP runtime under that name (PyTorch-ROCm bundles one) shares it instead
+# of loading a second copy; standalone use resolves it through the rpath to /opt/rocm/lib.
+tetrex_amd/libtxq.so: $(HIP_OBJS) $(CSRC)/hiprt_stub/libamdhip64.so
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -no-hip-rt -o $@ $(HIP_OBJS) \
+	    -L$(CSRC)/hiprt_stub -lamdhip64 -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
+
+# A link-time-only stand-in that carries no SONAME, so DT_NEEDED becomes "libamdhip64.so".
+# It is never loaded: at run time the real runtime is found by name.
+$(CSRC)/hiprt_stub/libamdhip64.so:
+	mkdir -p $(CSRC)/hiprt_stub
+	echo "" | $(CXX) -shared -fPIC -x c - -o $@
+
+oracle/liboracle.so: $(wildcard oracle/*.hpp) oracle/txo_capi.cpp
+	$(MAKE) -C oracle liboracle.so
+
+clean:
+	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so
+	rm -rf $(CSRC)/hiprt_stub
+	$(MAKE) -C oracle clean
+.PHONY: all clean

@@ -1,0 +1,140 @@
+/* txq.h — C-ABI of the MI355X (gfx950) TetRex query engine (libtxq.so).
+ *
+ * This is the drop-in boundary for the (H)IBF probe hot path of remyschwab/TetRex.  Every
+ * entry point replaces one seam of the reference (paths relative to the reference root):
+ *
+ *   txq_index_upload        <- TetrexIndex::spawn_agent()            include/index_base.h:145
+ *                              IBFIndex::spawn_agent / HIBFIndex::spawn_agent
+ *                                                                     include/index_ibf.h:141-144, index_hibf.h:149-152
+ *                              (the agent's raw pointer into the bit matrix becomes an HBM-resident copy)
+ *   txq_probe / _device     <- TetrexIndex::query(uint64_t) -> bitvector  include/index_base.h:104-107
+ *                              IBFIndex::query  -> bulk_contains      include/index_ibf.h:146-150
+ *                              HIBFIndex::query -> membership_for(.,1) + populate_bitvector
+ *                                                                     include/index_hibf.h:132-147
+ *                              (batched: one call probes n k-mers; call sites include/otf_collector.h:262,273)
+ *   txq_run_programs        <- OTFCollector::collect()               include/otf_collector.h:341-393
+ *                              (the mask algebra of the collector — path_ &= hits, absorb |=, Match |= —
+ *                               compiled by the host into mask-DAG programs, see txq_program.h)
+ *   txq_emplace_device      <- interleaved_bloom_filter::emplace     include/index_ibf.h:94-98 (index build, "next")
+ *
+ * Conventions: plain C, no exceptions cross the boundary.  Every function returns 0 on success or a
+ * negative txq_status; txq_last_error() gives the message for the calling thread.  Host buffers are
+ * owned by the caller; device memory is owned by the library unless the function name ends in
+ * _device (then pointers are HIP device pointers owned by the caller and `stream` is a hipStream_t,
+ * NULL = default stream, and the call is asynchronous on that stream).  One txq_index may be used
+ * from one host thread at a time; distinct indexes are independent.
+ *
+ * Bit layout (identical to seqan::hibf::bit_vector as used by the reference): mask word w, bit b
+ * (LSB first) <-> bin 64*w + b.  Bits >= bins in the last word are zero.
+ */
+#ifndef TXQ_H
+#define TXQ_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TXQ_VERSION 1
+
+typedef enum {
+    TXQ_OK = 0,
+    TXQ_ERR_ARG = -1,      /* invalid argument / inconsistent descriptor            */
+    TXQ_ERR_HIP = -2,      /* a HIP runtime call failed (message has the HIP error)  */
+    TXQ_ERR_NOMEM = -3,    /* host or device allocation failed                       */
+    TXQ_ERR_STATE = -4,    /* txq_init not called / no GPU present                   */
+    TXQ_ERR_OVERFLOW = -5, /* an internal work queue overflowed (HIBF frontier)      */
+    TXQ_ERR_PROGRAM = -6   /* malformed mask-DAG program                             */
+} txq_status;
+
+typedef struct txq_index txq_index; /* opaque; owns device memory */
+
+/* Host view of one interleaved Bloom filter, exactly the six scalars + the word array that
+ * seqan::hibf::interleaved_bloom_filter serialises (SURVEY.md §8c ".ibf layout"):
+ * words[r * bin_words + w] holds technical bins 64w..64w+63 of row r. */
+typedef struct {
+    uint64_t bins;       /* number of (technical) bins in use, B                  */
+    uint64_t tech_bins;  /* 64 * ceil(B / 64)                                     */
+    uint64_t bin_size;   /* rows m                                                */
+    uint64_t hash_shift; /* countl_zero(bin_size)                                 */
+    uint64_t bin_words;  /* tech_bins / 64                                        */
+    uint64_t hash_funs;  /* h, 1..5                                               */
+    const uint64_t* words;
+} txq_ibf_desc;
+
+#define TXQ_MERGED_BIN UINT64_MAX
+
+/* Host view of a whole index.  n_ibf == 1 and NULL maps: a flat IBF (IBFIndex).  Otherwise an
+ * HIBF: ibf[0] is the root, next_ibf_id[i][b] is the child IBF of merged technical bin b of
+ * IBF i, tb_to_user_bin[i][b] its user bin or TXQ_MERGED_BIN; each map has ibf[i].bins entries. */
+typedef struct {
+    uint64_t n_ibf;
+    const txq_ibf_desc* ibf;
+    const uint64_t* const* next_ibf_id;
+    const uint64_t* const* tb_to_user_bin;
+    uint64_t user_bins; /* bits in a result mask (== ibf[0].bins for a flat IBF) */
+} txq_index_desc;
+
+typedef struct {
+    uint64_t user_bins;    /* bits of a full (unsharded) mask                         */
+    uint64_t mask_words;   /* words of a full mask = ceil(user_bins / 64)             */
+    uint64_t shard_word0;  /* first mask word owned by this shard                     */
+    uint64_t shard_words;  /* mask words owned by this shard (what txq_probe emits)   */
+    uint64_t n_ibf;        /* 1 for a flat IBF                                        */
+    uint64_t device_bytes; /* HBM held by the index                                   */
+    int      is_hibf;
+    int      device;       /* HIP device ordinal                                      */
+} txq_index_info;
+
+/* Bind this process to one GPU (one process per GPU; n_devices must be 1 for now).
+ * device_ids == NULL selects device 0.  Fails with TXQ_ERR_STATE when no GPU is present:
+ * there is no CPU fallback anywhere in this library. */
+int txq_init(int n_devices, const int* device_ids);
+int txq_shutdown(void);
+const char* txq_last_error(void);
+int txq_device_count(void); /* >= 0, or a negative txq_status */
+
+/* Copy an index into HBM.  With n_shards > 1 only the mask-word columns of shard
+ * `shard_rank` are kept (flat IBF: words [W*r/R, W*(r+1)/R) of every row, re-laid out
+ * contiguously; HIBF: the whole tree is kept and only the user-bin mask columns are sharded). */
+int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out);
+int txq_index_get_info(const txq_index* ix, txq_index_info* info);
+int txq_index_free(txq_index* ix);
+
+/* An empty (all-zero) flat IBF living only in HBM, for device-side construction. */
+int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, int shard_rank, int n_shards,
+                         txq_index** out);
+/* Copy the shard's bit matrix back, row-major [bin_size][shard_words]. */
+int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_words);
+
+/* Batched bulk_contains: masks[i * shard_words + w] for k-mer i.  Host buffers; synchronous. */
+int txq_probe(txq_index* ix, const uint64_t* kmers, size_t n, uint64_t* masks);
+/* Same on device-resident buffers, asynchronous on `stream`.  d_alive may be NULL; otherwise it
+ * receives ceil(n/64) words, bit i set iff mask i has any bit set in this shard
+ * (bitvector::none() of include/otf_collector.h:383, per shard). */
+int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive,
+                     void* stream);
+
+/* Device-side emplace: value i is inserted into bin bins_of[i] (flat IBF only; bins outside this
+ * shard's columns are skipped). */
+int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* d_bins_of, size_t n, void* stream);
+
+/* Mask-DAG programs (format: include/txq_program.h).  Runs n_programs programs found in
+ * `blob`; final_masks receives n_programs x shard_words words (host buffer, synchronous). */
+int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* final_masks);
+int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs,
+                            uint64_t* d_final_masks, void* stream);
+
+/* Plain device-memory helpers so that a host program needs no HIP headers. */
+int txq_malloc(void** dptr, size_t bytes);
+int txq_free(void* dptr);
+int txq_memcpy_h2d(void* dst, const void* src, size_t bytes);
+int txq_memcpy_d2h(void* dst, const void* src, size_t bytes);
+int txq_synchronize(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TXQ_H */

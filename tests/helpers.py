@@ -1,0 +1,138 @@
+"""Shared builders for the parity tests: the same synthetic index in the oracle and in HBM."""
+import numpy as np
+
+MERGED = 0xFFFFFFFFFFFFFFFF
+
+
+def splitmix64(seed, n):
+    """Vectorised splitmix64 stream (the PRNG SURVEY.md §8d prescribes for synthetic inputs)."""
+    with np.errstate(over="ignore"):
+        x = (np.uint64(seed) + np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15))
+        z = x
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def random_words(bins, bin_size, density, seed):
+    """Row-major [bin_size][ceil(bins/64)] matrix with Bernoulli(density) bits; bits >= bins are 0."""
+    rng = np.random.default_rng(seed)
+    W = (bins + 63) // 64
+    bits = rng.random((bin_size, W * 64)) < density
+    bits[:, bins:] = False
+    packed = np.packbits(bits.reshape(bin_size, W, 64), axis=-1, bitorder="little")
+    return packed.view("<u8").reshape(bin_size * W).copy()
+
+
+def oracle_ibf_from_words(O, bins, bin_size, h, words, dna=False, k=4, reduction=0):
+    ix = O.Index.ibf(bins, bin_size, h, dna=dna, k=k, reduction=reduction)
+    ix.set_words(words)
+    return ix
+
+
+def random_hibf(O, seed, user_bins=300, tmax=128, h=2, n_values=40, value_bits=20, levels=3):
+    """A random HIBF: the same tree in the oracle and as upload descriptors.
+
+    Layout rule (own, simple): user bins are dealt over `tmax`-wide IBFs; some technical bins of
+    an inner IBF are merged bins pointing at a child; some user bins are split over 2-3
+    consecutive technical bins.  Values of a user bin are inserted in its leaf technical bins
+    and in every merged bin on the path to the root.
+    """
+    rng = np.random.default_rng(seed)
+    values = [rng.integers(0, 1 << value_bits, size=n_values, dtype=np.uint64) for _ in range(user_bins)]
+    ibfs = []  # dicts: bins, bin_size, hash_funs, tb (list of (kind, payload)), content per tb
+
+    def build(ub_list, level):
+        my = len(ibfs)
+        ibfs.append(None)
+        tbs = []  # (user_bin or MERGED, child id, values array)
+        if level + 1 < levels and len(ub_list) > 4:
+            # split the list: ~half directly here, the rest into 1-3 merged children
+            rng.shuffle(ub_list)
+            cut = max(1, len(ub_list) // 2)
+            direct, rest = ub_list[:cut], ub_list[cut:]
+            n_child = int(rng.integers(1, 4))
+            parts = [list(p) for p in np.array_split(np.array(rest, dtype=np.int64), n_child) if len(p)]
+        else:
+            direct, parts = ub_list, []
+        entries = []
+        for ub in direct:
+            split = int(rng.integers(1, 4)) if rng.random() < 0.3 else 1
+            chunks = np.array_split(values[ub], split)
+            entries.append([(ub, 0, c) for c in chunks])
+        for part in parts:
+            child = build([int(x) for x in part], level + 1)
+            allv = np.concatenate([values[u] for u in part])
+            entries.append([(MERGED, child, allv)])
+        order = rng.permutation(len(entries))
+        for i in order:
+            tbs.extend(entries[i])
+        bins = len(tbs)
+        n_max = max(len(t[2]) for t in tbs) if tbs else 1
+        bin_size = max(8, int(np.ceil(-max(n_max, 1) * np.log(0.05) / np.log(2) ** 2)))
+        ibfs[my] = dict(bins=bins, bin_size=bin_size, hash_funs=h, tbs=tbs)
+        return my
+
+    build(list(range(user_bins)), 0)
+    ox = O.Index.hibf(user_bins, dna=False, k=4)
+    descs = []
+    for f in ibfs:
+        nxt = np.array([t[1] if t[0] == MERGED else 0 for t in f["tbs"]], dtype=np.uint64)
+        tbu = np.array([t[0] for t in f["tbs"]], dtype=np.uint64)
+        i = ox.add_ibf(f["bins"], f["bin_size"], f["hash_funs"], nxt, tbu)
+        for tb, t in enumerate(f["tbs"]):
+            if len(t[2]):
+                ox.hibf_emplace(i, t[2], tb)
+        descs.append(dict(bins=f["bins"], bin_size=f["bin_size"], hash_funs=f["hash_funs"],
+                          words=None, next_ibf_id=nxt, tb_to_user=tbu))
+    for i, d in enumerate(descs):
+        d["words"] = ox.hibf_words(i)
+    return ox, descs, values
+
+
+NO_KMER = 0xFFFFFFFF
+
+
+def make_blob(kmers, programs):
+    """Serialise a txq_program.h blob.  programs: list of (n_slots, [(kmer, dst, a, b), ...])."""
+    import struct
+    kmers = np.ascontiguousarray(kmers, dtype=np.uint64)
+    n_ops = sum(len(p[1]) for p in programs)
+    hdr = 48
+    k_off = hdr
+    p_off = k_off + kmers.size * 8
+    o_off = p_off + len(programs) * 16
+    out = bytearray()
+    out += struct.pack("<6I3Q", 0x50515854, 1, len(programs), kmers.size, n_ops, 0, k_off, p_off, o_off)
+    out += kmers.tobytes()
+    first = 0
+    for n_slots, ops in programs:
+        out += struct.pack("<4I", first, len(ops), n_slots, 0)
+        first += len(ops)
+    for _, ops in programs:
+        for (k, d, a, b) in ops:
+            out += struct.pack("<4I", k, d, a, b)
+    return bytes(out)
+
+
+def eval_program(n_slots, ops, M, ones):
+    """numpy evaluation of one mask-DAG program; M: (n_kmers, W) masks, ones: (W,) ONES slot."""
+    W = ones.size
+    S = np.zeros((n_slots, W), dtype=np.uint64)
+    S[1] = ones
+    for (k, d, a, b) in ops:
+        x = S[a].copy()
+        if k != NO_KMER:
+            x &= M[k]
+        S[d] = x | S[b]
+    return S[2]
+
+
+def ones_mask(user_bins, word0=0, words=None):
+    W = (user_bins + 63) // 64
+    m = np.full(W, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64)
+    if user_bins % 64:
+        m[-1] = np.uint64((1 << (user_bins % 64)) - 1)
+    if words is None:
+        return m
+    return m[word0:word0 + words]

@@ -1,0 +1,201 @@
+"""GPU parity: the HIP probe path (through the C-ABI of include/txq.h) against the CPU oracle.
+
+Bit-exact comparison on the same seeded inputs — integer/bit work, tolerance zero.
+Edge cases follow the domain: empty and ragged batches, 1-word and odd-word rows, rows wider
+than one wave sweep, every hash-function count, column shards, all-zero / all-one rows.
+"""
+import numpy as np
+import pytest
+
+from helpers import random_words, oracle_ibf_from_words, random_hibf, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from tetrex_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _check_ibf(capi, oracle, bins, bin_size, h, n, seed, density=0.35, shards=(1,)):
+    words = random_words(bins, bin_size, density, seed)
+    ox = oracle_ibf_from_words(oracle, bins, bin_size, h, words)
+    kmers = splitmix64(seed + 1, n) >> np.uint64(int(np.random.default_rng(seed).integers(0, 44)))
+    want = ox.probe(kmers)
+    W = (bins + 63) // 64
+    for R in shards:
+        got_cols = []
+        for r in range(R):
+            ix = capi.Index.upload_ibf(bins, bin_size, h, words, shard_rank=r, n_shards=R)
+            lo, nw = int(ix.info.shard_word0), ix.shard_words
+            got = ix.probe(kmers)
+            assert got.shape == (n, nw)
+            assert np.array_equal(got, want[:, lo:lo + nw]), (bins, bin_size, h, n, R, r)
+            got_cols.append(got)
+            ix.free()
+        assert sum(g.shape[1] for g in got_cols) == W
+
+
+@pytest.mark.parametrize("bins", [5, 64, 65, 128, 200, 300, 1024, 3000, 8192, 9000])
+def test_probe_matches_oracle_across_row_widths(capi, oracle, bins):
+    _check_ibf(capi, oracle, bins, bin_size=4099, h=3, n=1000, seed=bins)
+
+
+@pytest.mark.parametrize("h", [1, 2, 3, 4, 5])
+def test_probe_every_hash_count(capi, oracle, h):
+    for bins in (40, 1024, 777):
+        _check_ibf(capi, oracle, bins, bin_size=10007, h=h, n=513, seed=100 + h)
+
+
+@pytest.mark.parametrize("n", [0, 1, 63, 64, 65, 127, 129, 100003])
+def test_probe_ragged_batch_sizes(capi, oracle, n):
+    _check_ibf(capi, oracle, 1024, bin_size=2053, h=3, n=n, seed=7 + n)
+    _check_ibf(capi, oracle, 50, bin_size=2053, h=2, n=n, seed=9 + n)
+
+
+@pytest.mark.parametrize("shards", [2, 3, 8, 16, 17])
+def test_probe_column_shards_tile_the_full_mask(capi, oracle, shards):
+    _check_ibf(capi, oracle, 1024, bin_size=3001, h=3, n=700, seed=shards, shards=(shards,))
+    _check_ibf(capi, oracle, 130, bin_size=3001, h=3, n=300, seed=shards + 50, shards=(shards,))
+
+
+def test_probe_bin_size_extremes(capi, oracle):
+    # one row (every k-mer maps to row 0), power-of-two rows, rows not a power of two
+    for m in (1, 2, 64, 65, 4096, 1 << 20):
+        _check_ibf(capi, oracle, 192, bin_size=m, h=3, n=300, seed=m, density=0.5)
+
+
+def test_probe_all_zero_and_all_one_matrices(capi, oracle):
+    bins, m = 1000, 997
+    W = (bins + 63) // 64
+    kmers = splitmix64(3, 500)
+    zeros = np.zeros(m * W, dtype=np.uint64)
+    ix = capi.Index.upload_ibf(bins, m, 3, zeros)
+    assert not ix.probe(kmers).any()
+    ix.free()
+    ones = random_words(bins, m, 1.1, 0)  # density > 1: every real bin set, padding bits clear
+    ix = capi.Index.upload_ibf(bins, m, 3, ones)
+    got = ix.probe(kmers)
+    want = oracle_ibf_from_words(oracle, bins, m, 3, ones).probe(kmers)
+    assert np.array_equal(got, want)
+    assert int(got[0, -1]) == (1 << (bins % 64)) - 1  # bits >= bins stay zero
+    ix.free()
+
+
+def test_alive_bits_match_mask_nonzero(capi, oracle):
+    for bins, dens in ((1024, 0.1), (40, 0.26), (3000, 0.07), (9000, 0.048)):
+        m, n = 1553, 1000
+        words = random_words(bins, m, dens, bins)
+        ix = capi.Index.upload_ibf(bins, m, 3, words)
+        kmers = splitmix64(11, n)
+        dk = capi.DeviceBuffer.from_numpy(kmers)
+        dm = capi.DeviceBuffer(n * ix.shard_words * 8)
+        da = capi.DeviceBuffer(((n + 63) // 64) * 8)
+        ix.probe_device(dk.ptr, n, dm.ptr, da.ptr)
+        capi.synchronize()
+        masks = dm.to_numpy(np.uint64, (n, ix.shard_words))
+        alive = da.to_numpy(np.uint64, ((n + 63) // 64,))
+        want = oracle_ibf_from_words(oracle, bins, m, 3, words).probe(kmers)
+        assert np.array_equal(masks, want)
+        bits = np.unpackbits(alive.view(np.uint8), bitorder="little")[:n].astype(bool)
+        assert np.array_equal(bits, want.any(axis=1))
+        assert 0 < bits.sum() < n  # the test exercises both outcomes
+        ix.free()
+
+
+def test_device_emplace_builds_the_oracle_matrix(capi, oracle):
+    for bins, m, h in ((5, 106, 3), (1024, 5003, 3), (300, 999, 2), (64, 64, 3)):
+        n = 20000
+        rng = np.random.default_rng(bins)
+        values = rng.integers(0, 1 << 20, size=n, dtype=np.uint64)
+        bins_of = rng.integers(0, bins, size=n, dtype=np.uint32)
+        ox = oracle.Index.ibf(bins, m, h, dna=False, k=4)
+        ox.emplace_pairs(values, bins_of)
+        ix = capi.Index.create_ibf(bins, m, h)
+        dv = capi.DeviceBuffer.from_numpy(values)
+        db = capi.DeviceBuffer.from_numpy(bins_of)
+        ix.emplace_device(dv.ptr, db.ptr, n)
+        capi.synchronize()
+        assert np.array_equal(ix.download_words_rows(m), ox.words())
+        # no false negatives: every inserted value reports its bin
+        got = ix.probe(values[:2000])
+        b = bins_of[:2000].astype(np.int64)
+        assert np.all((got[np.arange(2000), b >> 6] >> (b & 63).astype(np.uint64)) & np.uint64(1))
+        ix.free()
+
+
+def test_fixture_bits_on_gpu(capi, oracle, golden):
+    """The reference-built fixture probed on the GPU: M[ACG]=M[ACC]=0b11, M[CCG]=0b01."""
+    import os
+    from conftest import GOLDEN
+    fx = oracle.read_legacy_fixture(os.path.join(GOLDEN, "ibf_idx.ibf"))
+    ix = capi.Index.upload_ibf(2, 64, 3, fx["words"])
+    got = ix.probe([7, 5, 23])
+    assert [int(x) for x in got[:, 0]] == [0b11, 0b11, 0b01]
+    ix.free()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_hibf_descent_matches_oracle(capi, oracle, seed):
+    ox, descs, values = random_hibf(oracle, seed, user_bins=300, levels=3)
+    ix = capi.Index.upload_hibf(300, descs)
+    assert ix.info.is_hibf == 1 and ix.info.n_ibf == len(descs)
+    rng = np.random.default_rng(seed)
+    present = np.concatenate([v[:5] for v in values])
+    absent = rng.integers(0, 1 << 20, size=3000, dtype=np.uint64)
+    kmers = np.concatenate([present, absent])
+    got = ix.probe(kmers)
+    want = ox.probe(kmers)
+    assert np.array_equal(got, want)
+    # no false negatives for inserted values
+    for ub in range(300):
+        for j in range(5):
+            assert (int(got[ub * 5 + j, ub >> 6]) >> (ub & 63)) & 1
+    ix.free()
+
+
+def test_hibf_sharded_masks_and_wide_tree(capi, oracle):
+    ox, descs, values = random_hibf(oracle, 9, user_bins=1500, tmax=512, levels=4, n_values=10)
+    kmers = np.concatenate([np.concatenate([v[:2] for v in values]), splitmix64(5, 2000) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    for R in (1, 3):
+        for r in range(R):
+            ix = capi.Index.upload_hibf(1500, descs, shard_rank=r, n_shards=R)
+            lo, nw = int(ix.info.shard_word0), ix.shard_words
+            assert np.array_equal(ix.probe(kmers), want[:, lo:lo + nw])
+            ix.free()
+
+
+def test_full_size_swissprot_shape_properties(capi, oracle):
+    """BASELINE configs[1] shape (1024 bins, h=3, m=1,247,045 rows, 160 MB): size-independent
+    properties at full size, and a sampled bit-exact comparison against the oracle."""
+    bins, m, h = 1024, oracle.compute_bitcount(200000, 0.05), 3
+    assert m == 1247045
+    ix = capi.Index.create_ibf(bins, m, h)
+    n_ins = 1 << 22
+    values = splitmix64(1, n_ins) >> np.uint64(44)          # uniform 20-bit k-mers (k=4, 5 bits/residue)
+    bins_of = (splitmix64(2, n_ins) % np.uint64(bins)).astype(np.uint32)
+    dv, db = capi.DeviceBuffer.from_numpy(values), capi.DeviceBuffer.from_numpy(bins_of)
+    ix.emplace_device(dv.ptr, db.ptr, n_ins)
+    capi.synchronize()
+    # (1) no false negatives, (2) idempotence of insertion, (3) probe determinism
+    q = values[:50000]
+    g1 = ix.probe(q)
+    b = bins_of[:50000].astype(np.int64)
+    assert np.all((g1[np.arange(q.size), b >> 6] >> (b & 63).astype(np.uint64)) & np.uint64(1))
+    ix.emplace_device(dv.ptr, db.ptr, n_ins)
+    capi.synchronize()
+    assert np.array_equal(ix.probe(q), g1)
+    # (4) sampled parity: the oracle gets the device-built matrix and must agree on fresh k-mers
+    words = ix.download_words_rows(m)
+    ox = oracle_ibf_from_words(oracle, bins, m, h, words)
+    fresh = splitmix64(3, 20000) >> np.uint64(44)
+    assert np.array_equal(ix.probe(fresh), ox.probe(fresh))
+    # (5) the matrix itself equals an oracle build of a slice of the insertions? -> checksum of rows
+    sub = oracle.Index.ibf(bins, m, h, dna=False, k=4)
+    sub.emplace_pairs(values[:200000], bins_of[:200000])
+    w_sub = sub.words()
+    assert np.array_equal(w_sub & words, w_sub)  # every bit the oracle sets is set on the device
+    ix.free()

@@ -1,0 +1,257 @@
+"""ctypes view of the C-ABI declared in include/txq.h (tetrex_amd/libtxq.so).
+
+Mirrors the reference's seam for the probe path (see include/txq.h for the file:line of
+each replaced interface).  There is deliberately no fallback: a missing library or a missing
+GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtxq.so")
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+
+TXQ_MERGED_BIN = 0xFFFFFFFFFFFFFFFF
+
+# every symbol include/txq.h declares (checked by tests/test_capi_symbols.py)
+SYMBOLS = [
+    "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
+    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_create_ibf",
+    "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
+    "txq_run_programs", "txq_run_programs_device",
+    "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize",
+]
+
+
+class TxqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("txq error %d: %s" % (code, msg))
+        self.code = code
+
+
+class IbfDesc(C.Structure):
+    _fields_ = [("bins", C.c_uint64), ("tech_bins", C.c_uint64), ("bin_size", C.c_uint64),
+                ("hash_shift", C.c_uint64), ("bin_words", C.c_uint64), ("hash_funs", C.c_uint64),
+                ("words", u64p)]
+
+
+class IndexDesc(C.Structure):
+    _fields_ = [("n_ibf", C.c_uint64), ("ibf", C.POINTER(IbfDesc)),
+                ("next_ibf_id", C.POINTER(u64p)), ("tb_to_user_bin", C.POINTER(u64p)),
+                ("user_bins", C.c_uint64)]
+
+
+class IndexInfo(C.Structure):
+    _fields_ = [("user_bins", C.c_uint64), ("mask_words", C.c_uint64), ("shard_word0", C.c_uint64),
+                ("shard_words", C.c_uint64), ("n_ibf", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("is_hibf", C.c_int), ("device", C.c_int)]
+
+
+_LIB = None
+
+
+def lib():
+    """Load libtxq.so; raises if it has not been built (there is no fallback path)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `make` (or __graft_entry__.build()); "
+                              "tetrex_amd has no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.txq_last_error.restype = C.c_char_p
+        L.txq_init.argtypes = [C.c_int, C.POINTER(C.c_int)]
+        L.txq_index_upload.argtypes = [C.POINTER(IndexDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.txq_index_get_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
+        L.txq_index_free.argtypes = [C.c_void_p]
+        L.txq_index_create_ibf.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.txq_index_download_words.argtypes = [C.c_void_p, u64p, C.c_size_t]
+        L.txq_probe.argtypes = [C.c_void_p, u64p, C.c_size_t, u64p]
+        L.txq_probe_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.txq_emplace_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.txq_run_programs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, u64p]
+        L.txq_run_programs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.txq_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.txq_free.argtypes = [C.c_void_p]
+        L.txq_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.txq_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        _LIB = L
+    return _LIB
+
+
+def check(rc):
+    if rc != 0:
+        raise TxqError(rc, lib().txq_last_error().decode(errors="replace"))
+
+
+def init(device=0):
+    dev = C.c_int(device)
+    check(lib().txq_init(1, C.byref(dev)))
+
+
+def shutdown():
+    check(lib().txq_shutdown())
+
+
+def device_count():
+    n = lib().txq_device_count()
+    if n < 0:
+        check(n)
+    return n
+
+
+def device_count_safe():
+    """Number of visible GPUs, 0 when the HIP runtime reports none (or errors)."""
+    n = lib().txq_device_count()
+    return n if n > 0 else 0
+
+
+def synchronize():
+    check(lib().txq_synchronize())
+
+
+class DeviceBuffer:
+    """A raw HBM allocation owned through txq_malloc/txq_free."""
+
+    def __init__(self, nbytes):
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib().txq_malloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, a):
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        if a.nbytes:
+            check(lib().txq_memcpy_h2d(b.ptr, a.ctypes.data, a.nbytes))
+        return b
+
+    def to_numpy(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        if out.nbytes:
+            check(lib().txq_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().txq_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _ibf_desc(bins, bin_size, hash_funs, words):
+    d = IbfDesc()
+    d.bins = bins
+    d.bin_words = (bins + 63) // 64
+    d.tech_bins = d.bin_words * 64
+    d.bin_size = bin_size
+    d.hash_shift = 64 - int(bin_size).bit_length()
+    d.hash_funs = hash_funs
+    d.words = words.ctypes.data_as(u64p) if words is not None else None
+    return d
+
+
+class Index:
+    """An (H)IBF resident in HBM (txq_index)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+        info = IndexInfo()
+        check(lib().txq_index_get_info(self._h, C.byref(info)))
+        self.info = info
+
+    # -- construction ---------------------------------------------------------------
+    @classmethod
+    def upload_ibf(cls, bins, bin_size, hash_funs, words, shard_rank=0, n_shards=1):
+        words = np.ascontiguousarray(words, dtype=np.uint64)
+        d = _ibf_desc(bins, bin_size, hash_funs, words)
+        assert words.size == bin_size * d.bin_words
+        desc = IndexDesc(1, C.pointer(d), None, None, bins)
+        h = C.c_void_p()
+        check(lib().txq_index_upload(C.byref(desc), shard_rank, n_shards, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def upload_hibf(cls, user_bins, ibfs, shard_rank=0, n_shards=1):
+        """ibfs: list of dicts {bins, bin_size, hash_funs, words, next_ibf_id, tb_to_user}."""
+        n = len(ibfs)
+        keep = []
+        descs = (IbfDesc * n)()
+        nxt = (u64p * n)()
+        tbu = (u64p * n)()
+        for i, f in enumerate(ibfs):
+            w = np.ascontiguousarray(f["words"], dtype=np.uint64)
+            a = np.ascontiguousarray(f["next_ibf_id"], dtype=np.uint64)
+            b = np.ascontiguousarray(f["tb_to_user"], dtype=np.uint64)
+            keep += [w, a, b]
+            descs[i] = _ibf_desc(f["bins"], f["bin_size"], f["hash_funs"], w)
+            nxt[i] = a.ctypes.data_as(u64p)
+            tbu[i] = b.ctypes.data_as(u64p)
+        desc = IndexDesc(n, descs, nxt, tbu, user_bins)
+        h = C.c_void_p()
+        check(lib().txq_index_upload(C.byref(desc), shard_rank, n_shards, C.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def create_ibf(cls, bins, bin_size, hash_funs, shard_rank=0, n_shards=1):
+        h = C.c_void_p()
+        check(lib().txq_index_create_ibf(bins, bin_size, hash_funs, shard_rank, n_shards, C.byref(h)))
+        return cls(h.value)
+
+    def free(self):
+        if self._h:
+            lib().txq_index_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    # -- queries ---------------------------------------------------------------------
+    @property
+    def shard_words(self):
+        return int(self.info.shard_words)
+
+    def probe(self, kmers):
+        """Host-buffer batched bulk_contains: (n, shard_words) uint64."""
+        k = np.ascontiguousarray(kmers, dtype=np.uint64)
+        out = np.zeros((k.size, self.shard_words), dtype=np.uint64)
+        check(lib().txq_probe(self._h, k.ctypes.data_as(u64p), k.size, out.ctypes.data_as(u64p)))
+        return out
+
+    def probe_device(self, d_kmers, n, d_masks, d_alive=None, stream=None):
+        check(lib().txq_probe_device(self._h, d_kmers, n, d_masks, d_alive, stream))
+
+    def emplace_device(self, d_values, d_bins_of, n, stream=None):
+        check(lib().txq_emplace_device(self._h, d_values, d_bins_of, n, stream))
+
+    def download_words(self):
+        n = int(self.info.shard_words)
+        # rows are not part of txq_index_info; callers know bin_size
+        raise NotImplementedError("use download_words_rows(bin_size)")
+
+    def download_words_rows(self, bin_size):
+        out = np.zeros(bin_size * self.shard_words, dtype=np.uint64)
+        check(lib().txq_index_download_words(self._h, out.ctypes.data_as(u64p), out.size))
+        return out
+
+    def run_programs(self, blob, n_programs):
+        buf = np.frombuffer(blob, dtype=np.uint8)
+        # 8-byte aligned copy
+        al = np.zeros((buf.size + 7) // 8, dtype=np.uint64)
+        al.view(np.uint8)[:buf.size] = buf
+        out = np.zeros((n_programs, self.shard_words), dtype=np.uint64)
+        check(lib().txq_run_programs(self._h, al.ctypes.data, buf.size, n_programs, out.ctypes.data_as(u64p)))
+        return out

@@ -1,0 +1,342 @@
+// C-ABI (include/txq.h) of the MI355X TetRex query engine: index residency in HBM and the
+// entry points the reference's seam would bind.  No CPU fallback: without a GPU every call
+// that needs one fails with TXQ_ERR_STATE.
+#include "../../include/txq.h"
+#include "txq_internal.hpp"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace txq {
+
+static thread_local std::string g_err;
+static int g_device = -1;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+int fail_hip(hipError_t e, const char* what) {
+    return fail(e == hipErrorOutOfMemory ? TXQ_ERR_NOMEM : TXQ_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+int require_init() {
+    if (g_device < 0) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
+    return TXQ_OK;
+}
+
+#define TXQ_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return fail_hip(e_, #call);    \
+    } while (0)
+
+// shard r of R owns mask words [lo, hi): as even as possible, earlier shards get the remainder
+static void shard_range(uint64_t words, int r, int R, uint64_t* lo, uint64_t* hi) {
+    uint64_t base = words / R, rem = words % R;
+    *lo = base * r + (r < (int)rem ? r : rem);
+    *hi = *lo + base + (r < (int)rem ? 1 : 0);
+}
+
+static int validate_ibf(const txq_ibf_desc& d, bool need_words) {
+    if (d.bins == 0 || d.bin_size == 0) return fail(TXQ_ERR_ARG, "IBF with zero bins or rows");
+    if (d.hash_funs < 1 || d.hash_funs > 5) return fail(TXQ_ERR_ARG, "hash_funs %llu outside 1..5", (unsigned long long)d.hash_funs);
+    if (d.bin_words != (d.bins + 63) / 64 || d.tech_bins != d.bin_words * 64)
+        return fail(TXQ_ERR_ARG, "inconsistent bins/tech_bins/bin_words (%llu/%llu/%llu)", (unsigned long long)d.bins,
+                    (unsigned long long)d.tech_bins, (unsigned long long)d.bin_words);
+    if (d.hash_shift != (uint64_t)__builtin_clzll(d.bin_size))
+        return fail(TXQ_ERR_ARG, "hash_shift %llu != countl_zero(bin_size)", (unsigned long long)d.hash_shift);
+    if (d.bin_words >> 31) return fail(TXQ_ERR_ARG, "more than 2^37 bins are not supported");
+    if (need_words && !d.words) return fail(TXQ_ERR_ARG, "IBF descriptor without words");
+    return TXQ_OK;
+}
+
+// Allocate one IBF (column slice [w0, w1) of its rows) in HBM; copies from `src` when given.
+int alloc_ibf(const txq_ibf_desc& d, uint64_t w0, uint64_t w1, IbfDev* out, uint64_t* bytes) {
+    IbfDev f{};
+    f.bin_size = d.bin_size;
+    f.hash_shift = (uint32_t)d.hash_shift;
+    f.hash_funs = (uint32_t)d.hash_funs;
+    f.bins = (uint32_t)d.bins;
+    f.word0 = (uint32_t)w0;
+    f.shard_words = (uint32_t)(w1 - w0);
+    f.stride = f.shard_words <= 1 ? 1u : ((f.shard_words + 1u) & ~1u);
+    f.words = nullptr;
+    *bytes = 0;
+    if (f.shard_words) {
+        const size_t nbytes = (size_t)d.bin_size * f.stride * 8;
+        TXQ_HIP(hipMalloc((void**)&f.words, nbytes));
+        *bytes = nbytes;
+        hipError_t e = hipSuccess;
+        if (f.stride != f.shard_words || !d.words) e = hipMemset(f.words, 0, nbytes);
+        if (e == hipSuccess && d.words)
+            e = hipMemcpy2D(f.words, (size_t)f.stride * 8, d.words + w0, (size_t)d.bin_words * 8, (size_t)f.shard_words * 8,
+                            (size_t)d.bin_size, hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(f.words);
+            return fail_hip(e, "uploading IBF words");
+        }
+    }
+    *out = f;
+    return TXQ_OK;
+}
+
+void Index::release() {
+    for (auto& f : ibf) if (f.words) (void)hipFree(f.words);
+    ibf.clear();
+    if (d_ibf) (void)hipFree(d_ibf);
+    if (d_next) (void)hipFree(d_next);
+    if (d_tb_user) (void)hipFree(d_tb_user);
+    if (d_map_off) (void)hipFree(d_map_off);
+    for (void* p : {(void*)scratch_kmers, (void*)scratch_masks, (void*)frontier[0], (void*)frontier[1], (void*)d_counts,
+                    (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final})
+        if (p) (void)hipFree(p);
+    d_ibf = nullptr; d_next = d_tb_user = nullptr; d_map_off = nullptr;
+    scratch_kmers = scratch_masks = nullptr; frontier[0] = frontier[1] = nullptr; d_counts = nullptr;
+    scratch_blob = nullptr; scratch_slots = scratch_final = nullptr;
+}
+
+int ensure(void** p, size_t* cap, size_t bytes) {
+    if (*cap >= bytes && *p) return TXQ_OK;
+    if (*p) (void)hipFree(*p);
+    *p = nullptr; *cap = 0;
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");
+    *cap = bytes;
+    return TXQ_OK;
+}
+
+}  // namespace txq
+
+using namespace txq;
+
+struct txq_index : txq::Index {};
+
+extern "C" {
+
+const char* txq_last_error(void) { return g_err.c_str(); }
+
+int txq_device_count(void) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return fail_hip(e, "hipGetDeviceCount");
+    return n;
+}
+
+int txq_init(int n_devices, const int* device_ids) {
+    if (n_devices != 1) return fail(TXQ_ERR_ARG, "one process drives one GPU: n_devices must be 1 (got %d)", n_devices);
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_device = -1;
+        return fail(TXQ_ERR_STATE, "no HIP device visible (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= n) return fail(TXQ_ERR_ARG, "device %d out of range (have %d)", dev, n);
+    TXQ_HIP(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    TXQ_HIP(hipGetDeviceProperties(&prop, dev));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(TXQ_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+    g_device = dev;
+    return TXQ_OK;
+}
+
+int txq_shutdown(void) {
+    g_device = -1;
+    return TXQ_OK;
+}
+
+int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out) {
+    if (int rc = require_init()) return rc;
+    if (!desc || !out || !desc->ibf || desc->n_ibf == 0) return fail(TXQ_ERR_ARG, "null descriptor");
+    if (n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) return fail(TXQ_ERR_ARG, "bad shard %d/%d", shard_rank, n_shards);
+    const bool hibf = desc->next_ibf_id != nullptr || desc->tb_to_user_bin != nullptr || desc->n_ibf > 1;
+    if (hibf && (!desc->next_ibf_id || !desc->tb_to_user_bin)) return fail(TXQ_ERR_ARG, "HIBF descriptor needs both maps");
+    for (uint64_t i = 0; i < desc->n_ibf; ++i)
+        if (int rc = validate_ibf(desc->ibf[i], true)) return rc;
+    if (!hibf && desc->user_bins != desc->ibf[0].bins) return fail(TXQ_ERR_ARG, "flat IBF: user_bins must equal ibf[0].bins");
+    if (desc->user_bins == 0) return fail(TXQ_ERR_ARG, "user_bins == 0");
+
+    txq_index* ix = new (std::nothrow) txq_index();
+    if (!ix) return fail(TXQ_ERR_NOMEM, "out of host memory");
+    ix->device = g_device;
+    ix->is_hibf = hibf;
+    ix->user_bins = desc->user_bins;
+    ix->mask_words = (desc->user_bins + 63) / 64;
+    uint64_t lo, hi;
+    shard_range(ix->mask_words, shard_rank, n_shards, &lo, &hi);
+    ix->shard_word0 = lo;
+    ix->shard_words = hi - lo;
+    int rc = TXQ_OK;
+    if (!hibf) {
+        IbfDev f;
+        uint64_t bytes;
+        rc = alloc_ibf(desc->ibf[0], lo, hi, &f, &bytes);
+        if (rc == TXQ_OK) { ix->ibf.push_back(f); ix->device_bytes += bytes; }
+    } else {
+        rc = hibf_upload(*ix, *desc);
+    }
+    if (rc != TXQ_OK) {
+        ix->release();
+        delete ix;
+        return rc;
+    }
+    *out = ix;
+    return TXQ_OK;
+}
+
+int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, int shard_rank, int n_shards, txq_index** out) {
+    if (int rc = require_init()) return rc;
+    if (!out || n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) return fail(TXQ_ERR_ARG, "bad arguments");
+    txq_ibf_desc d{};
+    d.bins = bins;
+    d.bin_words = (bins + 63) / 64;
+    d.tech_bins = d.bin_words * 64;
+    d.bin_size = bin_size;
+    d.hash_shift = bin_size ? (uint64_t)__builtin_clzll(bin_size) : 0;
+    d.hash_funs = hash_funs;
+    d.words = nullptr;
+    if (int rc = validate_ibf(d, false)) return rc;
+    txq_index* ix = new (std::nothrow) txq_index();
+    if (!ix) return fail(TXQ_ERR_NOMEM, "out of host memory");
+    ix->device = g_device;
+    ix->user_bins = bins;
+    ix->mask_words = d.bin_words;
+    uint64_t lo, hi;
+    shard_range(ix->mask_words, shard_rank, n_shards, &lo, &hi);
+    ix->shard_word0 = lo;
+    ix->shard_words = hi - lo;
+    IbfDev f;
+    uint64_t bytes;
+    int rc = alloc_ibf(d, lo, hi, &f, &bytes);
+    if (rc != TXQ_OK) { delete ix; return rc; }
+    ix->ibf.push_back(f);
+    ix->device_bytes = bytes;
+    *out = ix;
+    return TXQ_OK;
+}
+
+int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
+    if (!ix || !info) return fail(TXQ_ERR_ARG, "null argument");
+    info->user_bins = ix->user_bins;
+    info->mask_words = ix->mask_words;
+    info->shard_word0 = ix->shard_word0;
+    info->shard_words = ix->shard_words;
+    info->n_ibf = ix->ibf.size();
+    info->device_bytes = ix->device_bytes;
+    info->is_hibf = ix->is_hibf ? 1 : 0;
+    info->device = ix->device;
+    return TXQ_OK;
+}
+
+int txq_index_free(txq_index* ix) {
+    if (!ix) return TXQ_OK;
+    ix->release();
+    delete ix;
+    return TXQ_OK;
+}
+
+int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_words) {
+    if (int rc = require_init()) return rc;
+    if (!ix || !words) return fail(TXQ_ERR_ARG, "null argument");
+    if (ix->is_hibf) return fail(TXQ_ERR_ARG, "download_words is for flat IBFs");
+    const IbfDev& f = ix->ibf[0];
+    if (n_words != (size_t)f.bin_size * f.shard_words) return fail(TXQ_ERR_ARG, "expected %zu words", (size_t)f.bin_size * f.shard_words);
+    if (!f.shard_words) return TXQ_OK;
+    TXQ_HIP(hipMemcpy2D(words, (size_t)f.shard_words * 8, f.words, (size_t)f.stride * 8, (size_t)f.shard_words * 8,
+                        (size_t)f.bin_size, hipMemcpyDeviceToHost));
+    return TXQ_OK;
+}
+
+int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!ix || (n && (!d_kmers || !d_masks))) return fail(TXQ_ERR_ARG, "null argument");
+    if (n >> 32) return fail(TXQ_ERR_ARG, "at most 2^32-1 k-mers per call");
+    hipStream_t s = (hipStream_t)stream;
+    if (ix->is_hibf) return hibf_probe(*ix, d_kmers, n, d_masks, d_alive, s);
+    hipError_t e = launch_probe(ix->ibf[0], d_kmers, n, d_masks, d_alive, s);
+    if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
+    return TXQ_OK;
+}
+
+int txq_probe(txq_index* ix, const uint64_t* kmers, size_t n, uint64_t* masks) {
+    if (int rc = require_init()) return rc;
+    if (!ix || (n && (!kmers || !masks))) return fail(TXQ_ERR_ARG, "null argument");
+    const size_t W = ix->shard_words;
+    if (W == 0 || n == 0) return TXQ_OK;
+    // bounded staging: chunks of <= 2^20 k-mers
+    const size_t chunk = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
+    if (int rc = ensure((void**)&ix->scratch_kmers, &ix->cap_kmers, chunk * 8)) return rc;
+    if (int rc = ensure((void**)&ix->scratch_masks, &ix->cap_masks, chunk * W * 8)) return rc;
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        TXQ_HIP(hipMemcpy(ix->scratch_kmers, kmers + off, m * 8, hipMemcpyHostToDevice));
+        if (int rc = txq_probe_device(ix, ix->scratch_kmers, m, ix->scratch_masks, nullptr, nullptr)) return rc;
+        TXQ_HIP(hipMemcpy(masks + off * W, ix->scratch_masks, m * W * 8, hipMemcpyDeviceToHost));
+    }
+    return TXQ_OK;
+}
+
+int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* d_bins_of, size_t n, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!ix || (n && (!d_values || !d_bins_of))) return fail(TXQ_ERR_ARG, "null argument");
+    if (ix->is_hibf) return fail(TXQ_ERR_ARG, "emplace is for flat IBFs");
+    hipError_t e = launch_emplace(ix->ibf[0], d_values, d_bins_of, n, (hipStream_t)stream);
+    if (e != hipSuccess) return fail_hip(e, "emplace kernel launch");
+    return TXQ_OK;
+}
+
+int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final_masks, void* stream) {
+    if (int rc = require_init()) return rc;
+    if (!ix || !blob || (n_programs && !d_final_masks)) return fail(TXQ_ERR_ARG, "null argument");
+    return run_programs(*ix, blob, blob_bytes, n_programs, d_final_masks, (hipStream_t)stream);
+}
+
+int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* final_masks) {
+    if (int rc = require_init()) return rc;
+    if (!ix || !blob || (n_programs && !final_masks)) return fail(TXQ_ERR_ARG, "null argument");
+    const size_t bytes = n_programs * ix->shard_words * 8;
+    if (bytes == 0) return TXQ_OK;
+    if (int rc = ensure((void**)&ix->scratch_final, &ix->cap_final, bytes)) return rc;
+    if (int rc = run_programs(*ix, blob, blob_bytes, n_programs, ix->scratch_final, nullptr)) return rc;
+    TXQ_HIP(hipMemcpy(final_masks, ix->scratch_final, bytes, hipMemcpyDeviceToHost));
+    return TXQ_OK;
+}
+
+int txq_malloc(void** dptr, size_t bytes) {
+    if (int rc = require_init()) return rc;
+    if (!dptr) return fail(TXQ_ERR_ARG, "null argument");
+    TXQ_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+    return TXQ_OK;
+}
+int txq_free(void* dptr) {
+    if (dptr) TXQ_HIP(hipFree(dptr));
+    return TXQ_OK;
+}
+int txq_memcpy_h2d(void* dst, const void* src, size_t bytes) {
+    if (int rc = require_init()) return rc;
+    TXQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return TXQ_OK;
+}
+int txq_memcpy_d2h(void* dst, const void* src, size_t bytes) {
+    if (int rc = require_init()) return rc;
+    TXQ_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return TXQ_OK;
+}
+int txq_synchronize(void) {
+    if (int rc = require_init()) return rc;
+    TXQ_HIP(hipDeviceSynchronize());
+    return TXQ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,55 @@
+// Internal (non-ABI) declarations shared by the translation units of libtxq.so.
+#pragma once
+#include "txq_kernels.hpp"
+#include "../../include/txq.h"
+#include <vector>
+
+namespace txq {
+
+// One HIBF work item: k-mer `kmer` (index into the batch) must be looked up in IBF `ibf`.
+struct WorkItem { uint32_t kmer; uint32_t ibf; };
+
+struct Index {
+    int device = 0;
+    bool is_hibf = false;
+    uint64_t user_bins = 0, mask_words = 0, shard_word0 = 0, shard_words = 0, device_bytes = 0;
+    std::vector<IbfDev> ibf;  // host copies of the device descriptors ([0] = flat IBF / HIBF root)
+
+    // HIBF tree in HBM
+    IbfDev* d_ibf = nullptr;         // [n_ibf]
+    uint64_t* d_next = nullptr;      // flattened next_ibf_id
+    uint64_t* d_tb_user = nullptr;   // flattened tb_to_user_bin (TXQ_MERGED_BIN for merged)
+    uint64_t* d_map_off = nullptr;   // [n_ibf] offset of IBF i's maps in the flattened arrays
+    uint32_t depth = 1;              // levels of the tree
+    uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
+    uint32_t max_stride = 1;         // widest row over all IBFs (words)
+
+    // grow-only scratch (owned by the index; one host thread at a time)
+    uint64_t* scratch_kmers = nullptr; size_t cap_kmers = 0;
+    uint64_t* scratch_masks = nullptr; size_t cap_masks = 0;
+    WorkItem* frontier[2] = {nullptr, nullptr}; size_t cap_frontier[2] = {0, 0};
+    uint32_t* d_counts = nullptr; size_t cap_counts = 0;
+    unsigned char* scratch_blob = nullptr; size_t cap_blob = 0;
+    uint64_t* scratch_slots = nullptr; size_t cap_slots = 0;
+    uint64_t* scratch_final = nullptr; size_t cap_final = 0;
+
+    void release();
+};
+
+int fail(int code, const char* fmt, ...);
+int fail_hip(hipError_t e, const char* what);
+int ensure(void** p, size_t* cap, size_t bytes);
+int alloc_ibf(const txq_ibf_desc& d, uint64_t w0, uint64_t w1, IbfDev* out, uint64_t* bytes);
+
+// txq_probe.hip
+hipError_t launch_probe(const IbfDev& f, const uint64_t* kmers, size_t n, uint64_t* masks, uint64_t* alive, hipStream_t s);
+hipError_t launch_emplace(const IbfDev& f, const uint64_t* values, const uint32_t* bins_of, size_t n, hipStream_t s);
+
+// txq_hibf.hip
+int hibf_upload(Index& ix, const txq_index_desc& desc);
+int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s);
+
+// txq_exec.hip
+int run_programs(Index& ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final, hipStream_t s);
+
+}  // namespace txq

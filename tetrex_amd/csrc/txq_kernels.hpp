@@ -1,0 +1,41 @@
+// Device-side data structures and kernels of the MI355X TetRex query engine (gfx950 only).
+//
+// HBM layout of a flat IBF shard ("column shard"):
+//   words[r * stride + w], r < bin_size, w < shard_words; stride = shard_words rounded up to an
+//   even number of 64-bit words (16-byte lane accesses) unless shard_words == 1.  For the
+//   1024-bin configuration a row is exactly one 128-byte line.
+// The on-disk matrix is row-major over ALL technical bins (include/txq.h: txq_ibf_desc); the
+// re-layout to a contiguous per-rank column slice happens once at upload.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace txq {
+
+// seqan::hibf::interleaved_bloom_filter::hash_seeds / hash_and_fit constants (restated; the
+// library is absent from the reference tree — see include/txq.h and DESIGN.md §Oracle).
+__device__ __constant__ const uint64_t kSeeds[5] = {
+    13572355802537770549ULL, 13043817825332782213ULL, 10650232656628343401ULL,
+    16499269484942379435ULL, 4893150838803335377ULL};
+static constexpr uint64_t kGolden = 11400714819323198485ULL;
+
+struct IbfDev {
+    uint64_t* words;      // device pointer, [bin_size][stride]
+    uint64_t bin_size;    // rows
+    uint32_t hash_shift;  // countl_zero(bin_size)
+    uint32_t hash_funs;   // 1..5
+    uint32_t stride;      // words per row in HBM
+    uint32_t shard_words; // mask words this shard owns (<= stride)
+    uint32_t word0;       // first full-mask word owned by this shard
+    uint32_t bins;        // technical bins in use (unsharded)
+};
+
+// row index of `v` under hash function i: fastrange of the mixed hash onto [0, bin_size)
+__device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t shift, uint64_t bin_size) {
+    v *= seed;
+    v ^= v >> shift;
+    v *= kGolden;
+    return __umul64hi(v, bin_size);
+}
+
+}  // namespace txq
