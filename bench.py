@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py — k-mer IBF probes/s of the MI355X TetRex probe path (BASELINE.json metric).
+
+One "step" = one pass of the bulk_contains hot path (k-mer -> h hashes -> gather h bin-wide
+rows -> AND -> per-bin hit mask written to HBM) over one resident batch of synthetic k-mers.
+
+Workload (config.workload = "S-IBF-1024", BASELINE configs[1] shape):
+  1024 bins per GPU, h = 3, m = compute_bitcount(200000, 0.05f) = 1,247,045 rows (159.6 MB),
+  filled by inserting 200,000 uniform 20-bit values (k = 4 x 5 bits/residue) per bin with the
+  real hash; probe batch = 2^24 uniform 20-bit k-mers (splitmix64, fixed seeds).
+Multi-GPU (--gpus N, launched by torch.distributed.run): the index has 1024*N bins and is
+sharded by bin-word columns, 1024 bins per rank (BASELINE configs[3] layout); every rank probes
+the same batch against its own column shard; no collective on the probe path (bins are
+independent), so scaling is "weak".  A probe is one k-mer tested against one 1024-bin shard.
+
+Output: ONE JSON line on rank 0 (contract in the task description), including
+  roofline     — algorithmic bytes of the probe kernel / its HIP-event duration vs 8 TB/s HBM,
+  cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def splitmix64(seed, n, start=0):
+    with np.errstate(over="ignore"):
+        x = np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) + np.uint64(start)) * np.uint64(0x9E3779B97F4A7C15)
+        z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def build_index(capi, torch, bins_total, bins_local, m, h, rank, world, per_bin, value_bits):
+    """Device-side construction: per_bin uniform values into each of this rank's bins."""
+    ix = capi.Index.create_ibf(bins_total, m, h, shard_rank=rank, n_shards=world)
+    first_bin = int(ix.info.shard_word0) * 64
+    chunk_bins = 64
+    shift = np.uint64(64 - value_bits)
+    for b0 in range(0, bins_local, chunk_bins):
+        nb = min(chunk_bins, bins_local - b0)
+        n = nb * per_bin
+        # value stream is a function of the GLOBAL bin id, so a shard holds the same bits at every N
+        vals = splitmix64(1, n, start=(first_bin + b0) * per_bin) >> shift
+        bins_of = (first_bin + b0 + np.repeat(np.arange(nb, dtype=np.uint32), per_bin)).astype(np.uint32)
+        dv = torch.from_numpy(vals.view(np.int64)).cuda()
+        db = torch.from_numpy(bins_of.view(np.int32)).cuda()
+        ix.emplace_device(dv.data_ptr(), db.data_ptr(), n, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    return ix
+
+
+def pmc_traffic(args, n, W, h, m):
+    """HBM bytes per probe-kernel launch from the committed rocprofv3 PMC passes
+    (profiles/r*_pmc_traffic_*.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction).
+    PMC counters cannot be collected from inside this process, so the figure is only reported for
+    the exact workload those passes ran; otherwise null."""
+    if not (args.rows == 0 and n == (1 << 24) and W == 16 and h == 3 and args.per_bin == 200000):
+        return None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_S-IBF-1024.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        k = json.load(f)["kernels"]["void txq::probe_kernel<8, 3>"]
+    return k["hbm_traffic_bytes_per_launch_corrected"]
+
+
+def cpu_baseline(ix, m, h, bins_local, kmers, sample, threads):
+    """The oracle (CPU restatement of the reference probe path) on this host's cores.
+    Uses the device-built matrix so GPU and CPU probe the same bits."""
+    import oracle as O
+    words = ix.download_words_rows(m)
+    ox = O.Index.ibf(bins_local, m, h, dna=False, k=4)
+    ox.set_words(words)
+    q = kmers[:sample]
+    ox.probe(q[:4096])  # touch code and pages
+    t0 = time.perf_counter()
+    out = ox.probe(q, threads=threads)
+    dt = time.perf_counter() - t0
+    return out, q.size / dt, dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--kmers", type=int, default=1 << 24, help="k-mers per step (batch resident in HBM)")
+    ap.add_argument("--bins-per-gpu", type=int, default=1024)
+    ap.add_argument("--per-bin", type=int, default=200000, help="values inserted per bin")
+    ap.add_argument("--hash", type=int, default=3)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="k-mers timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
+    ap.add_argument("--kmer-bits", type=int, default=20)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from tetrex_amd import capi
+    import oracle as O  # only for compute_bitcount of the workload shape and the cpu_baseline leg
+
+    capi.init(local_rank)
+    h = args.hash
+    bins_local = args.bins_per_gpu
+    bins_total = bins_local * world
+    m = args.rows if args.rows > 0 else O.compute_bitcount(args.per_bin, 0.05)
+    value_bits = args.kmer_bits
+
+    t_build = time.perf_counter()
+    ix = build_index(capi, torch, bins_total, bins_local, m, h, rank, world, args.per_bin, value_bits)
+    t_build = time.perf_counter() - t_build
+    W = ix.shard_words
+    assert W == (bins_local + 63) // 64, (W, bins_local)
+
+    n = args.kmers
+    kmers_host = splitmix64(2, n) >> np.uint64(64 - value_bits)
+    d_kmers = torch.from_numpy(kmers_host.view(np.int64)).cuda()
+    d_masks = torch.empty((n, W), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ix.probe_device(d_kmers.data_ptr(), n, d_masks.data_ptr(), None, stream.cuda_stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+
+    bytes_per_probe = h * W * 8 + W * 8 + 8  # rows + mask write + k-mer read
+    achieved = bytes_per_probe * n / avg_kernel_s / 1e9
+    value = world * n * args.steps / elapsed
+
+    out = {
+        "metric": "k-mer IBF probes/sec",
+        "value": value,
+        "unit": "probes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {
+            "workload": "S-IBF-1024" if args.rows == 0 else "S-IBF-1024-rows%d" % m,
+            "bins_per_gpu": bins_local, "bins_total": bins_total, "hash_funs": h, "bin_size_rows": m,
+            "kmers_per_step": n, "kmer_bits": value_bits, "values_per_bin": args.per_bin,
+            "matrix_bytes_per_gpu": int(ix.info.device_bytes), "mask_words": W,
+            "parallelism": "bin-column shards x%d, no collective on the probe path" % world,
+            "probe_unit": "one k-mer against one %d-bin shard" % bins_local,
+            "index_build_s": round(t_build, 2),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "kernel": "txq::probe_kernel<8,3>" if (W == 16 and h == 3) else "txq::probe_kernel",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "bytes_per_probe": bytes_per_probe,
+            "avg_kernel_ms": avg_kernel_s * 1e3,
+            "traffic": pmc_traffic(args, n, W, h, m),
+        },
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu:
+        sample = min(args.cpu_sample, n)
+        cpu_masks, cpu_rate, cpu_dt = cpu_baseline(ix, m, h, bins_local, kmers_host, sample, threads=1)
+        # the timed GPU output doubles as a parity check on the CPU sample
+        got = d_masks[:sample].cpu().numpy().view(np.uint64)
+        if not np.array_equal(got, cpu_masks):
+            raise SystemExit("bench: GPU masks differ from the CPU oracle on the baseline sample")
+        out["cpu_baseline"] = {
+            "value": cpu_rate, "unit": "probes/s", "cores": 1, "kind": "port",
+            "sample": "first %d k-mers of the same batch on the same matrix, single thread (the reference probes single-threaded), %.1f s" % (sample, cpu_dt),
+            "host_cpus": os.cpu_count(),
+        }
+        ncores = min(os.cpu_count() or 1, 16)
+        if ncores > 1:
+            _, mt_rate, mt_dt = cpu_baseline(ix, m, h, bins_local, kmers_host, sample, threads=ncores)
+            out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "probes/s", "cores": ncores, "kind": "port",
+                                             "sample": "same sample, %d threads, %.1f s" % (ncores, mt_dt)}
+        out["parity_checked_probes"] = int(sample)
+
+    ix.free()
+    if world > 1:
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
