@@ -8,7 +8,15 @@ HIP_SRCS := $(CSRC)/txq_api.hip $(CSRC)/txq_probe.hip $(CSRC)/txq_hibf.hip $(CSR
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.hpp) include/txq.h include/txq_program.h
 
-all: tetrex_amd/libtxq.so oracle/liboracle.so
+HOST_DIR  := $(CSRC)/host
+HOST_SRCS := $(HOST_DIR)/encoder.cpp $(HOST_DIR)/regex_front.cpp $(HOST_DIR)/kgraph.cpp $(HOST_DIR)/compiler.cpp $(HOST_DIR)/host_capi.cpp
+HOST_HDRS := $(wildcard $(HOST_DIR)/*.hpp) include/txh.h include/txq_program.h
+HOSTFLAGS := -O2 -g -std=c++20 -fPIC -Wall -Wextra -pthread
+
+all: tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so oracle/liboracle.so
+
+tetrex_amd/libtetrex_host.so: $(HOST_SRCS) $(HOST_HDRS)
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS)
 
 $(CSRC)/%.o: $(CSRC)/%.hip $(HIP_HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
@@ -30,7 +38,7 @@ oracle/liboracle.so: $(wildcard oracle/*.hpp) oracle/txo_capi.cpp
 	$(MAKE) -C oracle liboracle.so
 
 clean:
-	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so
+	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so
 	rm -rf $(CSRC)/hiprt_stub
 	$(MAKE) -C oracle clean
 .PHONY: all clean

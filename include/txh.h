@@ -1,0 +1,48 @@
+/* txh.h — C view of the C++ host front-end (libtetrex_host.so): regex -> postfix -> k-graph ->
+ * mask-DAG programs, k-mer encoders, .ibf codec.  It exists so that tests (and foreign-language
+ * callers) can drive the host stages one by one; the `tetrex` CLI links the same C++ directly.
+ * Reference interfaces mirrored: translate() src/utils.cpp:3-15; preprocess_query()
+ * include/query.h:80-94; construct_kgraph()/construct_reduced_kgraph() src/construct_nfa.cpp:265,
+ * src/construct_reduced_nfa.cpp:313; OTFCollector::collect() include/otf_collector.h:341-393;
+ * MoleculeDecomposer::decompose_record() include/molecule_decomposer.h:92-96;
+ * load_ibf()/store_ibf() include/index_base.h:181-195.
+ * All functions return 0 / a non-negative count on success and a negative value on error
+ * (message via txh_last_error()). */
+#ifndef TXH_H
+#define TXH_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* txh_last_error(void);
+
+/* string outputs: returns the length written (excluding NUL) or <0 */
+int txh_translate(const char* regex, char* out, size_t cap);
+int txh_preprocess(const char* regex, int dna, unsigned k, unsigned reduction, char* preprocessed, size_t cap1,
+                   char* postfix, size_t cap2);
+
+/* k-graph of a postfix string: labels[n], next_a[n], next_b[n]; returns n or <0 */
+int txh_kgraph(const char* postfix, unsigned k, int reduced, int32_t* labels, int32_t* next_a, int32_t* next_b,
+               int32_t cap);
+
+/* Compile a batch of queries for an index with `bins` bins into one program blob.
+ * status[i] receives 0 or a negative code for query i (a failed query becomes an empty program
+ * whose result mask is zero); the blob is owned by the library until txh_blob_free. */
+typedef struct txh_blob txh_blob;
+int txh_compile_batch(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
+                      txh_blob** out, int* status);
+const void* txh_blob_data(const txh_blob* b, size_t* bytes);
+/* stats4[i*4..]: ops, slots, states, probe ops of query i */
+int txh_blob_stats(const txh_blob* b, uint64_t* stats4, size_t n);
+void txh_blob_free(txh_blob* b);
+
+/* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
+int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
+                          uint64_t* out, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,308 @@
+#include "kgraph.hpp"
+
+#include <cctype>
+#include <stdexcept>
+
+namespace tetrex {
+
+int32_t KGraph::add(int32_t lab) {
+    label.push_back(lab);
+    next_a.push_back(kNone);
+    next_b.push_back(kNone);
+    return size() - 1;
+}
+
+void KGraph::link(int32_t from, int32_t to) {
+    arc_src.push_back(from);
+    arc_dst.push_back(to);
+    const int32_t lab = label[from];
+    if (lab != kSplit) {                       // one successor: the newest arc wins both slots
+        next_a[from] = next_b[from] = to;
+    } else if (next_a[from] == kNone) {
+        next_a[from] = to;                     // a split fills the first slot once ...
+    } else {
+        next_b[from] = to;                     // ... and the second slot with every later arc
+    }
+}
+
+std::vector<int32_t> KGraph::topological_order() const {
+    // Kahn's algorithm over the arc list; any topological order gives the same masks.
+    const int32_t n = size();
+    std::vector<int32_t> indeg(n, 0), head(n + 1, 0), adj(arc_src.size());
+    for (size_t a = 0; a < arc_src.size(); ++a) { ++indeg[arc_dst[a]]; ++head[arc_src[a] + 1]; }
+    for (int32_t i = 0; i < n; ++i) head[i + 1] += head[i];
+    std::vector<int32_t> fill(head.begin(), head.end() - 1);
+    for (size_t a = 0; a < arc_src.size(); ++a) adj[fill[arc_src[a]]++] = arc_dst[a];
+    std::vector<int32_t> order;
+    order.reserve(n);
+    for (int32_t i = 0; i < n; ++i)
+        if (indeg[i] == 0) order.push_back(i);
+    for (size_t at = 0; at < order.size(); ++at) {
+        const int32_t u = order[at];
+        for (int32_t e = head[u]; e < head[u + 1]; ++e)
+            if (--indeg[adj[e]] == 0) order.push_back(adj[e]);
+    }
+    if ((int32_t)order.size() != n) throw std::runtime_error("k-graph has a cycle");
+    return order;
+}
+
+namespace {
+
+// A partially built piece of the graph: entry/exit node, or a symbol that the reduced builder
+// has not turned into a node yet.
+struct Fragment {
+    int32_t entry = KGraph::kNone, exit = KGraph::kNone;
+    bool pending = false;
+    bool single() const { return pending || entry == exit; }
+};
+
+class Builder {
+  public:
+    Builder(unsigned k, bool reduced) : k_(k), reduced_(reduced) {}
+
+    KGraph finish(const std::string& postfix) {
+        const int32_t start = g_.add(KGraph::kGhost);
+        bool skip_concat = false;
+        for (size_t i = 0; i < postfix.size(); ++i) {
+            const unsigned char c = (unsigned char)postfix[i];
+            if (std::isdigit(c)) continue;
+            switch (c) {
+                case '-':
+                    if (skip_concat) skip_concat = false;
+                    else concat();
+                    break;
+                case '|': alternate(); break;
+                case '?': optional(); break;
+                case '*': star((uint8_t)k_); break;
+                case '+': plus(); break;
+                case '{': {
+                    size_t lo, hi;
+                    counts(postfix, i, lo, hi);
+                    if (lo == 0 && hi == 1) optional();
+                    else skip_concat = counted(lo, hi);
+                    break;
+                }
+                case '}': case ',': break;
+                default: symbol(c); break;
+            }
+        }
+        if (stack_.empty()) throw std::runtime_error("empty query: nothing to search for");
+        if (stack_.back().pending) throw std::runtime_error("single-residue query in a reduced alphabet is undefined in the reference");
+        const Fragment whole = stack_.back();
+        stack_.pop_back();
+        if (!stack_.empty()) throw std::runtime_error("malformed postfix: operands left over");
+        g_.link(start, whole.entry);
+        const int32_t match = g_.add(KGraph::kMatch);
+        g_.link(whole.exit, match);
+        return std::move(g_);
+    }
+
+  private:
+    KGraph g_;
+    unsigned k_;
+    bool reduced_;
+    std::vector<Fragment> stack_;
+    std::vector<int32_t> symbols_;  // reduced builder: residues waiting to become nodes
+
+    static void counts(const std::string& p, size_t at, size_t& lo, size_t& hi) {
+        const size_t close = p.find('}', at), comma = p.find(',', at);
+        if (close == std::string::npos) throw std::runtime_error("quantifier without '}'");
+        if (comma == std::string::npos || comma > close) {
+            lo = (size_t)std::stoi(p.substr(at + 1, close - at));
+            hi = 0;
+        } else {
+            lo = (size_t)std::stoi(p.substr(at + 1, comma - at));
+            hi = (size_t)std::stoi(p.substr(comma + 1, close - comma - 1));
+        }
+    }
+
+    Fragment take() {
+        if (stack_.empty()) throw std::runtime_error("malformed query: operator without operand");
+        Fragment f = stack_.back();
+        stack_.pop_back();
+        return f;
+    }
+    int32_t waiting_symbol() const {
+        if (symbols_.empty()) throw std::runtime_error("reduced alphabet: no buffered residue (undefined in the reference)");
+        return symbols_.back();
+    }
+    // the reduced builder turns ANY single-node fragment into a fresh node labelled with the
+    // newest buffered residue (twin_test is `start == end`, construct_reduced_nfa.cpp:91-111)
+    void realise(Fragment& f) {
+        if (!reduced_ || !f.single()) return;
+        const int32_t s = waiting_symbol();
+        symbols_.pop_back();
+        const int32_t n = g_.add(s);
+        f = Fragment{n, n, false};
+    }
+
+    void symbol(int32_t s) {
+        if (reduced_) {
+            symbols_.push_back(s);
+            stack_.push_back(Fragment{KGraph::kNone, KGraph::kNone, true});
+        } else {
+            const int32_t n = g_.add(s);
+            stack_.push_back(Fragment{n, n, false});
+        }
+    }
+
+    void concat() {
+        Fragment right = take(), left = take();
+        realise(right);
+        realise(left);
+        g_.link(left.exit, right.entry);
+        stack_.push_back(Fragment{left.entry, right.exit, false});
+    }
+
+    void alternate() {
+        Fragment right = take(), left = take();
+        if (reduced_) {
+            const size_t n = symbols_.size();
+            if (left.single() && right.single() && n >= 2 && symbols_[n - 1] == symbols_[n - 2]) {
+                const int32_t s = symbols_.back();  // both branches are the same reduced letter
+                symbols_.pop_back();
+                symbols_.pop_back();
+                symbol(s);
+                return;
+            }
+            realise(left);
+            realise(right);
+        }
+        const int32_t fork = g_.add(KGraph::kSplit);
+        g_.link(fork, left.entry);
+        g_.link(fork, right.entry);
+        const int32_t join = g_.add(KGraph::kGhost);
+        g_.link(left.exit, join);
+        g_.link(right.exit, join);
+        stack_.push_back(Fragment{fork, join, false});
+    }
+
+    void optional() {
+        Fragment body = take();
+        realise(body);
+        const int32_t fork = g_.add(KGraph::kSplit);
+        g_.link(fork, body.entry);
+        const int32_t join = g_.add(KGraph::kGhost);
+        g_.link(fork, join);
+        g_.link(body.exit, join);
+        stack_.push_back(Fragment{fork, join, false});
+    }
+
+    // duplicate the sub-graph between f.entry and f.exit (nodes on some entry->exit path)
+    Fragment duplicate(const Fragment& f) {
+        if (f.single()) {
+            const int32_t n = g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]);
+            return Fragment{n, n, false};
+        }
+        const int32_t n0 = g_.size();
+        const size_t a0 = g_.arc_src.size();
+        std::vector<uint8_t> mark(n0, 0);
+        flood(f.entry, true, mark, 1);
+        flood(f.exit, false, mark, 2);
+        std::vector<int32_t> image(n0, KGraph::kNone);
+        for (int32_t v = n0 - 1; v >= 0; --v)         // newest node first, as lemon's NodeIt
+            if (mark[v] == 3) image[v] = g_.add(g_.label[v]);
+        for (size_t a = a0; a-- > 0;) {                // newest arc first, as lemon's ArcIt
+            const int32_t u = g_.arc_src[a], v = g_.arc_dst[a];
+            if (image[u] != KGraph::kNone && image[v] != KGraph::kNone) g_.link(image[u], image[v]);
+        }
+        return Fragment{image[f.entry], image[f.exit], false};
+    }
+    void flood(int32_t from, bool forward, std::vector<uint8_t>& mark, uint8_t bit) const {
+        // adjacency (CSR) of the current arc list in the requested direction
+        const int32_t n = g_.size();
+        const std::vector<int32_t>& tail = forward ? g_.arc_src : g_.arc_dst;
+        const std::vector<int32_t>& head = forward ? g_.arc_dst : g_.arc_src;
+        std::vector<int32_t> first(n + 1, 0), nbr(tail.size());
+        for (int32_t u : tail) ++first[u + 1];
+        for (int32_t i = 0; i < n; ++i) first[i + 1] += first[i];
+        std::vector<int32_t> fill(first.begin(), first.end() - 1);
+        for (size_t a = 0; a < tail.size(); ++a) nbr[fill[tail[a]]++] = head[a];
+        std::vector<int32_t> todo{from};
+        mark[from] |= bit;
+        while (!todo.empty()) {
+            const int32_t u = todo.back();
+            todo.pop_back();
+            for (int32_t e = first[u]; e < first[u + 1]; ++e) {
+                const int32_t t = nbr[e];
+                if (!(mark[t] & bit)) { mark[t] |= bit; todo.push_back(t); }
+            }
+        }
+    }
+
+    // X* unrolled to at most depth-1 repetitions; depth arrives as uint8_t in the reference
+    // (`const uint8_t& k`), so {0,n} with n+1 > 255 wraps exactly like there.
+    void star(uint8_t depth) {
+        Fragment body = take();
+        realise(body);
+        const int32_t fork = g_.add(KGraph::kSplit);
+        g_.link(fork, body.entry);
+        const int32_t join = g_.add(KGraph::kGhost);
+        g_.link(fork, join);
+        int32_t tail = body.exit;
+        for (int i = 1; i < (int)depth - 1; ++i) {
+            const int32_t again = g_.add(KGraph::kSplit);
+            g_.link(again, join);
+            const Fragment copy = duplicate(body);
+            g_.link(tail, again);
+            g_.link(again, copy.entry);
+            if (i == (int)depth - 2) { g_.link(copy.exit, join); break; }
+            tail = copy.exit;
+        }
+        stack_.push_back(Fragment{fork, join, false});
+    }
+
+    void plus() {
+        Fragment body = take();
+        realise(body);
+        const int32_t join = g_.add(KGraph::kGhost);
+        int32_t tail = body.exit;
+        for (int i = 1; i < (int)k_ - 1; ++i) {
+            const int32_t again = g_.add(KGraph::kSplit);
+            const Fragment copy = duplicate(body);
+            g_.link(tail, again);
+            g_.link(again, join);
+            g_.link(again, copy.entry);
+            if (i == (int)k_ - 2) { g_.link(copy.exit, join); break; }
+            tail = copy.exit;
+        }
+        stack_.push_back(Fragment{body.entry, join, false});
+    }
+
+    // X{lo} / X{lo,hi}; returns true when the following '-' of the postfix has been consumed
+    bool counted(size_t lo, size_t hi) {
+        bool consumed = false;
+        if (lo == 0) {
+            star((uint8_t)(hi + 1));
+            if (stack_.size() != 1) { concat(); consumed = true; }
+            return consumed;
+        }
+        if (stack_.empty()) throw std::runtime_error("malformed query: quantifier without operand");
+        const Fragment body = stack_.back();
+        const int32_t s = reduced_ ? waiting_symbol() : 0;
+        if (stack_.size() != 1) {
+            concat();
+            if (reduced_ && body.single()) symbol(s);
+            consumed = true;
+        }
+        const size_t extra = hi == 0 ? 0 : hi - lo;
+        for (size_t i = 1; i < lo; ++i) {
+            if (!reduced_) stack_.push_back(duplicate(body));
+            concat();
+        }
+        for (size_t i = 0; i < extra; ++i) {
+            stack_.push_back(duplicate(body));
+            optional();
+            concat();
+        }
+        return consumed;
+    }
+};
+
+}  // namespace
+
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet) {
+    return Builder(k, reduced_alphabet).finish(postfix);
+}
+
+}  // namespace tetrex

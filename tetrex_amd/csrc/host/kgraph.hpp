@@ -1,0 +1,38 @@
+// Host side: the k-graph (NFA with loops unrolled to depth k-1) of one query — product code.
+// Behavioural contract = the reference's builders driven by the postfix text:
+//   construct_kgraph          src/construct_nfa.cpp:265-335 (+ procedures :78-262, copy_subgraph :4-76)
+//   construct_reduced_kgraph  src/construct_reduced_nfa.cpp:313-383 (+ :79-310)
+//   update_arc_map            src/construction_tools.cpp:136-158 (two successor slots per node)
+//   parse_quant               src/construction_tools.cpp:4-18
+// Node labels: a byte value for a residue node, or one of the markers below
+// (include/construction_tools.h:40-46).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace tetrex {
+
+struct KGraph {
+    static constexpr int32_t kMatch = 256, kGhost = 257, kSplit = 258, kGap = 259;
+    static constexpr int32_t kNone = -1;
+
+    std::vector<int32_t> label;   // per node
+    std::vector<int32_t> next_a;  // first successor slot (kNone = no arc yet)
+    std::vector<int32_t> next_b;  // second successor slot (== next_a unless the node is a Split)
+    std::vector<int32_t> arc_src, arc_dst;
+
+    int32_t size() const { return (int32_t)label.size(); }
+    int32_t add(int32_t lab);
+    void link(int32_t from, int32_t to);
+    // nodes in an order in which every arc goes forward (node 0, the start ghost, first)
+    std::vector<int32_t> topological_order() const;
+};
+
+// Builds the k-graph of `postfix` for k-mer size k.  reduced_alphabet selects the reduced
+// builder (symbols are buffered and identical reduced letters of a union collapse).
+// Throws std::runtime_error where the reference would run into undefined behaviour
+// (stack underflow, empty symbol buffer) instead of reproducing it.
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet);
+
+}  // namespace tetrex
