@@ -9,11 +9,18 @@ HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.hpp) include/txq.h include/txq_program.h
 
 HOST_DIR  := $(CSRC)/host
-HOST_SRCS := $(HOST_DIR)/encoder.cpp $(HOST_DIR)/regex_front.cpp $(HOST_DIR)/kgraph.cpp $(HOST_DIR)/compiler.cpp $(HOST_DIR)/host_capi.cpp
+HOST_SRCS := $(HOST_DIR)/encoder.cpp $(HOST_DIR)/regex_front.cpp $(HOST_DIR)/kgraph.cpp $(HOST_DIR)/compiler.cpp $(HOST_DIR)/index_file.cpp $(HOST_DIR)/host_capi.cpp
+CLI_SRCS  := $(HOST_DIR)/main.cpp $(HOST_DIR)/device_index.cpp $(HOST_DIR)/verify.cpp $(HOST_DIR)/fasta.cpp
 HOST_HDRS := $(wildcard $(HOST_DIR)/*.hpp) include/txh.h include/txq_program.h
 HOSTFLAGS := -O2 -g -std=c++20 -fPIC -Wall -Wextra -pthread
 
-all: tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so oracle/liboracle.so
+all: tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so bin/tetrex oracle/liboracle.so
+
+# The `tetrex` CLI: C++ host + libtxq.so (GPU) + zlib; the HIP runtime comes in through libtxq.so.
+bin/tetrex: $(CLI_SRCS) $(HOST_SRCS) $(HOST_HDRS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so
+	mkdir -p bin
+	$(CXX) $(HOSTFLAGS) -fopenmp -o $@ $(CLI_SRCS) -Ltetrex_amd -ltetrex_host -ltxq -lz \
+	    -Wl,-rpath,'$$ORIGIN/../tetrex_amd' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
 
 tetrex_amd/libtetrex_host.so: $(HOST_SRCS) $(HOST_HDRS)
 	$(CXX) $(HOSTFLAGS) -shared -o $@ $(HOST_SRCS)
@@ -38,7 +45,7 @@ oracle/liboracle.so: $(wildcard oracle/*.hpp) oracle/txo_capi.cpp
 	$(MAKE) -C oracle liboracle.so
 
 clean:
-	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so
+	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so bin/tetrex
 	rm -rf $(CSRC)/hiprt_stub
 	$(MAKE) -C oracle clean
 .PHONY: all clean

@@ -42,6 +42,22 @@ void txh_blob_free(txh_blob* b);
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap);
 
+/* ---- .ibf index files (include/index_base.h:160-202 layout; see host/index_file.hpp) ---- */
+typedef struct txh_index txh_index;
+int txh_index_parse(const void* bytes, size_t n, txh_index** out);
+/* a flat IBF index image from raw words; paths = '\n'-separated bin paths (one per bin) */
+int txh_index_from_ibf(unsigned k, int dna, unsigned reduction, unsigned hash_count, uint64_t bins, uint64_t bin_size,
+                       const uint64_t* words, const char* paths, txh_index** out);
+/* JSON summary: k, molecule, is_hibf, reduction, hash_count, bins, format, per-IBF shapes, paths */
+int txh_index_describe(const txh_index* ix, char* json, size_t cap);
+/* words of IBF `ibf_id` (0 for a flat IBF); returns the word count (nothing written past cap) */
+int64_t txh_index_words(const txh_index* ix, uint64_t ibf_id, uint64_t* out, size_t cap);
+/* HIBF maps of IBF `ibf_id`: next_ibf_id and tb_to_user_bin, `bins` entries each; returns bins */
+int64_t txh_index_maps(const txh_index* ix, uint64_t ibf_id, uint64_t* next_ibf_id, uint64_t* tb_to_user, size_t cap);
+/* serialised file image; valid until the next call on this handle or txh_index_free */
+const void* txh_index_serialise(txh_index* ix, size_t* bytes);
+void txh_index_free(txh_index* ix);
+
 #ifdef __cplusplus
 }
 #endif

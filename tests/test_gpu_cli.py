@@ -1,0 +1,128 @@
+"""The `tetrex` command line on the GPU box, in the style of the reference's CLI tests
+(test/cli/cli_test.hpp: spawn the binary, capture stdout/stderr).  Expectations come from the
+reference's README (README.md:43-51) and its test/cli/kbioreg_test.cpp:66-79."""
+import glob
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT
+
+pytestmark = pytest.mark.gpu
+TETREX = os.path.join(ROOT, "bin", "tetrex")
+
+
+def run(*args, cwd=None, stdin=None):
+    r = subprocess.run([TETREX, *args], capture_output=True, text=True, cwd=cwd, input=stdin, timeout=300)
+    return r.returncode, r.stdout, r.stderr
+
+
+def rows(stdout):
+    return [tuple(line.split("\t")) for line in stdout.splitlines() if line]
+
+
+@pytest.fixture(scope="module")
+def toy(tmp_path_factory):
+    d = tmp_path_factory.mktemp("toy")
+    files = sorted(glob.glob(os.path.join(GOLDEN, "dna_example_split", "*.fa")))
+    out = {}
+    for flavour, flag in (("ibf", ["-i"]), ("hibf", [])):
+        rc, so, se = run("index", "-n", "-k", "3", *flag, str(d / flavour), *files)
+        assert rc == 0, se
+        assert "Indexed 5 sequences across 5 bins." in se and "DONE" in se
+        out[flavour] = str(d / (flavour + ".ibf"))
+    return out
+
+
+@pytest.mark.parametrize("flavour", ["ibf", "hibf"])
+def test_readme_example(toy, flavour):
+    """tetrex query test.ibf "A(C+|G+)T": Sequence1 ACT x3, Sequence2 ACT + AGT, Sequence4 ACCCT."""
+    rc, so, se = run("query", "-v", toy[flavour], "A(C+|G+)T")
+    assert rc == 0, se
+    fwd = [(os.path.basename(r[0]), r[1], r[2]) for r in rows(so) if "REVERSE" not in r[3]]
+    assert fwd == [("sequence1.fa", ">Sequence1", "ACT")] * 3 + [("sequence2.fa", ">Sequence2", "ACT"),
+                                                                 ("sequence2.fa", ">Sequence2", "AGT"),
+                                                                 ("sequence4.fa", ">Sequence4", "ACCCT")]
+    # start,end columns of the current format (src/query.cpp:212-216)
+    assert [r[3] for r in rows(so) if "sequence1" in r[0] and "REVERSE" not in r[3]] == ["0,3", "4,7", "8,11"]
+    assert "Narrowed Search to 3 possible bins" in se and "Query Time: " in se
+
+
+def test_inspect(toy):
+    rc, so, se = run("inspect", toy["ibf"])
+    assert "INDEX TYPE: IBF" in so and "BIN COUNT (BFs): 5" in so and "BIN SIZE (bits): 106" in so
+    assert "HASH COUNT (hash functions): 3" in so and "KMER LENGTH (bases): 3" in so
+    rc, so, se = run("inspect", toy["hibf"])
+    assert "INDEX TYPE: HIBF" in so and "FALSE POSITIVE RATE: 0.05" in so and so.count("\t- ") == 5
+
+
+def test_index_reproduces_the_reference_built_fixture(tmp_path, oracle):
+    """`tetrex index` (bits set by the GPU emplace kernel) on file1.fa/file2.fa with the fixture's
+    shape gives the byte-identical bit matrix of the reference-built test/data/ibf_idx.ibf, and the
+    query of test/cli/kbioreg_test.cpp:66-79 finds Snippet1.1 ACCG and Snippet1.2 ACG only."""
+    from tetrex_amd import host
+    fx = oracle.read_legacy_fixture(os.path.join(GOLDEN, "ibf_idx.ibf"))
+    fpr = "0.022"  # 8 k-mers in the larger bin (file2) -> ceil(-8 ln p / ln^2 2) = 64 rows, the fixture's bin size
+    assert oracle.compute_bitcount(8, float(fpr)) == 64
+    rc, so, se = run("index", "-n", "-i", "-k", "3", "-p", fpr, "--no-wraparound", str(tmp_path / "fx"),
+                     os.path.join(GOLDEN, "file1.fa"), os.path.join(GOLDEN, "file2.fa"))
+    assert rc == 0, se
+    mine = host.IndexFile.load(str(tmp_path / "fx.ibf"))
+    assert mine.describe()["ibfs"][0] == dict(bins=2, tech_bins=64, bin_size=64, hash_shift=57, bin_words=1, hash_funs=3)
+    assert np.array_equal(mine.words(), fx["words"])
+    rc, so, se = run("query", str(tmp_path / "fx.ibf"), "AC+G")
+    got = [(r[1], r[2]) for r in rows(so) if "REVERSE" not in r[3]]
+    assert got == [(">Snippet1.1", "ACCG"), (">Snippet1.2", "ACG")]
+
+
+def test_query_reads_regex_from_stdin_and_writes_to_file(toy, tmp_path):
+    dest = tmp_path / "hits.tsv"
+    rc, so, se = run("query", "-o", str(dest), toy["ibf"], "-", stdin="A(C+|G+)T\n")
+    assert rc == 0
+    assert len([l for l in dest.read_text().splitlines() if l]) == 6
+    assert all("REVERSE STRAND HIT" in l for l in so.splitlines() if l)  # reverse hits always go to stdout
+
+
+def test_motif_file_mode(toy, tmp_path):
+    motifs = tmp_path / "motifs.tsv"
+    motifs.write_text("m1\tA(C+|G+)T\nm2\tCCCGTACCC\n\nm3\tTTTTTT\n")
+    rc, so, se = run("query", "-f", toy["ibf"], str(motifs), cwd=str(tmp_path))
+    assert rc == 0, se
+    assert (tmp_path / "m1.tsv").exists() and (tmp_path / "m2.tsv").exists()
+    assert len((tmp_path / "m1.tsv").read_text().splitlines()) == 6
+    m2 = [l.split("\t")[1] for l in (tmp_path / "m2.tsv").read_text().splitlines()]
+    assert m2 == [">Sequence4", ">Sequence5"]
+    lines = [l for l in se.splitlines() if l.startswith("m")]
+    assert lines[0].startswith("m1\tBin Count: 3\tQuery Time: ") and lines[2].startswith("m3\tBin Count: ")
+
+
+def test_peptide_index_and_query(tmp_path):
+    rng = np.random.default_rng(0)
+    aa = list("ACDEFGHIKLMNPQRSTVWY")
+    files = []
+    for b in range(70):
+        seqs = ["".join(rng.choice(aa, size=200)) for _ in range(5)]
+        if b in (7, 33):
+            seqs[2] = seqs[2][:50] + "LMAEGLYN" + seqs[2][58:]
+        if b == 50:
+            seqs[1] = seqs[1][:10] + "LMAQGLYN" + seqs[1][18:]
+        p = tmp_path / ("bin%02d.fa" % b)
+        p.write_text("".join(">s%d_%d some comment\n%s\n" % (b, i, s) for i, s in enumerate(seqs)))
+        files.append(str(p))
+    for flag in (["-i"], []):
+        rc, so, se = run("index", "-k", "4", *flag, str(tmp_path / "pep"), *files)
+        assert rc == 0 and "Indexed 350 sequences across 70 bins." in se
+        rc, so, se = run("query", "-v", "-t", "4", str(tmp_path / "pep.ibf"), "LMA(E|Q)GLYN")
+        got = sorted((os.path.basename(r[0]), r[2]) for r in rows(so))
+        assert got == [("bin07.fa", "LMAEGLYN"), ("bin33.fa", "LMAEGLYN"), ("bin50.fa", "LMAQGLYN")]
+    rc, so, se = run("query", "-c", str(tmp_path / "pep.ibf"), "LMAEG:GLYN")
+    assert sorted(os.path.basename(r[0]) for r in rows(so)) == ["bin07.fa", "bin33.fa"]
+
+
+def test_bad_index_path_and_bad_query(toy):
+    rc, so, se = run("query", "/nonexistent.ibf", "ACGT")
+    assert "Filepath to (H)IBF Index not valid" in se
+    rc, so, se = run("query", toy["ibf"], "A{2,}")
+    assert rc != 0 and "not searchable" in se

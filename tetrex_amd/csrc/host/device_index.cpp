@@ -1,0 +1,218 @@
+#include "device_index.hpp"
+#include "fasta.hpp"
+#include "kgraph.hpp"
+#include "regex_front.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <stdexcept>
+
+namespace tetrex {
+
+void txq_check(int rc, const char* what) {
+    if (rc != TXQ_OK) throw std::runtime_error(std::string(what) + ": " + txq_last_error());
+}
+
+static void ensure_device(int device) {
+    static int bound = -1;
+    if (bound == device) return;
+    txq_check(txq_init(1, &device), "txq_init");
+    bound = device;
+}
+
+DeviceIndex::~DeviceIndex() {
+    if (ix_) txq_index_free(ix_);
+}
+
+static txq_ibf_desc describe(const IbfImage& f) {
+    return txq_ibf_desc{f.bins, f.tech_bins, f.bin_size, f.hash_shift, f.bin_words, f.hash_funs, f.words.data()};
+}
+
+void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, int n_shards) {
+    ensure_device(device);
+    if (ix_) { txq_index_free(ix_); ix_ = nullptr; }
+    enc_ = KmerEncoder(image.molecule == "na" ? Molecule::DNA : Molecule::Peptide, image.k, (Alphabet)image.reduction);
+    if (!image.is_hibf) {
+        txq_ibf_desc d = describe(image.ibf);
+        txq_index_desc desc{1, &d, nullptr, nullptr, image.ibf.bins};
+        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix_), "txq_index_upload");
+    } else {
+        const HibfImage& h = image.hibf;
+        std::vector<txq_ibf_desc> ds;
+        std::vector<const uint64_t*> nx, tb;
+        for (size_t i = 0; i < h.ibfs.size(); ++i) {
+            ds.push_back(describe(h.ibfs[i]));
+            nx.push_back(h.next_ibf_id[i].data());
+            tb.push_back(h.tb_to_user_bin[i].data());
+        }
+        txq_index_desc desc{ds.size(), ds.data(), nx.data(), tb.data(), h.user_bins};
+        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix_), "txq_index_upload");
+    }
+    txq_check(txq_index_get_info(ix_, &info_), "txq_index_get_info");
+}
+
+std::vector<uint64_t> DeviceIndex::query_masks(const std::vector<std::string>& regexes, std::vector<int>* status,
+                                               std::vector<std::string>* messages) {
+    if (!ix_) throw std::runtime_error("index not uploaded");
+    ProgramBatch batch(enc_);
+    if (status) status->assign(regexes.size(), 0);
+    if (messages) messages->assign(regexes.size(), std::string());
+    for (size_t i = 0; i < regexes.size(); ++i) {
+        try {
+            if (bins() <= 1) { batch.add_passthrough(); continue; }  // include/query.h:265-272
+            const std::string postfix = preprocess_query(regexes[i], enc_);
+            batch.add(build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base));
+        } catch (const std::exception& e) {
+            batch.add_empty();
+            if (status) (*status)[i] = -1;
+            if (messages) (*messages)[i] = e.what();
+        }
+    }
+    const std::vector<uint8_t> blob = batch.serialise();
+    // txq wants an 8-byte aligned blob
+    std::vector<uint64_t> aligned((blob.size() + 7) / 8);
+    std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
+    std::vector<uint64_t> masks(regexes.size() * info_.shard_words);
+    txq_check(txq_run_programs(ix_, aligned.data(), blob.size(), regexes.size(), masks.data()), "txq_run_programs");
+    return masks;
+}
+
+std::vector<uint64_t> set_bins(const uint64_t* mask, uint64_t bins) {
+    std::vector<uint64_t> out;
+    if (bins == 1) { out.push_back(0); return out; }  // a 1-bin library is always scanned
+    const uint64_t words = (bins + 63) / 64;
+    for (uint64_t w = 0; w < words; ++w)
+        for (uint64_t v = mask[w]; v; v &= v - 1) out.push_back(w * 64 + (unsigned)__builtin_ctzll(v));
+    return out;
+}
+
+uint64_t compute_bitcount(uint64_t n, float fpr) {
+    const double num = -static_cast<double>(n) * std::log(fpr);  // float log, as in the reference
+    const double den = std::pow(std::log(2), 2);
+    return static_cast<uint64_t>(std::ceil(num / den));
+}
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { txq_check(txq_malloc(&p, bytes), "txq_malloc"); }
+    ~DevBuf() { txq_free(p); }
+};
+
+// Build one flat IBF on the device from per-bin value lists and copy its words back.
+IbfImage build_flat(const std::vector<const std::vector<uint64_t>*>& per_bin, uint64_t rows, unsigned h) {
+    IbfImage img;
+    img.shape(per_bin.size(), rows, h);
+    txq_index* ix = nullptr;
+    txq_check(txq_index_create_ibf(img.bins, rows, h, 0, 1, &ix), "txq_index_create_ibf");
+    try {
+        std::vector<uint64_t> vals;
+        std::vector<uint32_t> bins;
+        auto flush = [&]() {
+            if (vals.empty()) return;
+            DevBuf dv(vals.size() * 8), db(bins.size() * 4);
+            txq_check(txq_memcpy_h2d(dv.p, vals.data(), vals.size() * 8), "h2d");
+            txq_check(txq_memcpy_h2d(db.p, bins.data(), bins.size() * 4), "h2d");
+            txq_check(txq_emplace_device(ix, (const uint64_t*)dv.p, (const uint32_t*)db.p, vals.size(), nullptr), "txq_emplace_device");
+            txq_check(txq_synchronize(), "txq_synchronize");
+            vals.clear();
+            bins.clear();
+        };
+        for (size_t b = 0; b < per_bin.size(); ++b) {
+            for (uint64_t v : *per_bin[b]) { vals.push_back(v); bins.push_back((uint32_t)b); }
+            if (vals.size() >= (1u << 24)) flush();
+        }
+        flush();
+        txq_check(txq_index_download_words(ix, img.words.data(), img.words.size()), "txq_index_download_words");
+    } catch (...) {
+        txq_index_free(ix);
+        throw;
+    }
+    txq_index_free(ix);
+    return img;
+}
+
+}  // namespace
+
+IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOptions& opt, size_t* n_sequences) {
+    if (bin_files.empty()) throw std::runtime_error("no input libraries");
+    if (!opt.dna && opt.k > 12) throw std::runtime_error("Max kmer size for amino acids is 12");
+    if (opt.dna && opt.k > 32) throw std::runtime_error("Max kmer size for nucleic acids is 32");
+    ensure_device(opt.device);
+    const KmerEncoder enc(opt.dna ? Molecule::DNA : Molecule::Peptide, opt.k, (Alphabet)opt.reduction);
+    std::vector<std::vector<uint64_t>> values(bin_files.size());
+    size_t seqs = 0;
+    for (size_t b = 0; b < bin_files.size(); ++b)
+        for_each_record(bin_files[b], [&](const FastaRecord& r) {
+            if (r.seq.size() < opt.k) return;  // "RECORD TOO SHORT"
+            ++seqs;
+            enc.record_values(r.seq, opt.dna_wraparound, values[b]);
+        });
+    if (n_sequences) *n_sequences = seqs;
+
+    IndexImage img;
+    img.k = (uint8_t)opt.k;
+    img.molecule = opt.dna ? "na" : "aa";
+    img.reduction = (uint8_t)opt.reduction;
+    img.hash_count = (uint8_t)opt.hash_count;
+    img.fpr = opt.fpr;
+    img.bin_paths = bin_files;
+    auto largest = [](const std::vector<const std::vector<uint64_t>*>& v) {
+        size_t m = 0;
+        for (auto* p : v) m = std::max(m, p->size());
+        return m;
+    };
+    if (!opt.hibf) {
+        // IBFIndex::init_ibf: size every bin like the largest one, occurrences not deduplicated
+        std::vector<const std::vector<uint64_t>*> per_bin;
+        for (auto& v : values) per_bin.push_back(&v);
+        const uint64_t rows = std::max<uint64_t>(1, compute_bitcount(largest(per_bin), opt.fpr));
+        img.ibf = build_flat(per_bin, rows, opt.hash_count);
+        img.format = "ibf";
+        return img;
+    }
+    // HIBF with this project's own two-level layout (the reference delegates the layout to
+    // seqan::hibf's sketch-based algorithm, which is index construction, not query): user bins are
+    // dealt in order over t_max = 64*ceil(sqrt(B)/64) merged technical bins of the root, each
+    // pointing at a child IBF with one technical bin per user bin.  B <= t_max: a single level.
+    img.is_hibf = true;
+    HibfImage& h = img.hibf;
+    const uint64_t B = bin_files.size();
+    h.user_bins = B;
+    const uint64_t tmax = 64 * (((uint64_t)std::ceil(std::sqrt((double)B)) + 63) / 64);
+    if (B <= tmax) {
+        std::vector<const std::vector<uint64_t>*> per_bin;
+        for (auto& v : values) per_bin.push_back(&v);
+        h.ibfs.push_back(build_flat(per_bin, std::max<uint64_t>(1, compute_bitcount(largest(per_bin), opt.fpr)), opt.hash_count));
+        h.next_ibf_id.emplace_back(B, 0);
+        h.tb_to_user_bin.emplace_back();
+        for (uint64_t b = 0; b < B; ++b) h.tb_to_user_bin.back().push_back(b);
+    } else {
+        const uint64_t per_child = (B + tmax - 1) / tmax, n_child = (B + per_child - 1) / per_child;
+        std::vector<std::vector<uint64_t>> merged(n_child);
+        h.ibfs.resize(1 + n_child);
+        h.next_ibf_id.resize(1 + n_child);
+        h.tb_to_user_bin.resize(1 + n_child);
+        for (uint64_t c = 0; c < n_child; ++c) {
+            const uint64_t lo = c * per_child, hi = std::min(B, lo + per_child);
+            std::vector<const std::vector<uint64_t>*> per_bin;
+            for (uint64_t b = lo; b < hi; ++b) {
+                per_bin.push_back(&values[b]);
+                merged[c].insert(merged[c].end(), values[b].begin(), values[b].end());
+                h.tb_to_user_bin[1 + c].push_back(b);
+            }
+            h.next_ibf_id[1 + c].assign(hi - lo, 0);
+            h.ibfs[1 + c] = build_flat(per_bin, std::max<uint64_t>(1, compute_bitcount(largest(per_bin), opt.fpr)), opt.hash_count);
+            h.next_ibf_id[0].push_back(1 + c);
+            h.tb_to_user_bin[0].push_back(UINT64_MAX);
+        }
+        std::vector<const std::vector<uint64_t>*> per_bin;
+        for (auto& v : merged) per_bin.push_back(&v);
+        h.ibfs[0] = build_flat(per_bin, std::max<uint64_t>(1, compute_bitcount(largest(per_bin), opt.fpr)), opt.hash_count);
+    }
+    img.format = "hibf";
+    return img;
+}
+
+}  // namespace tetrex

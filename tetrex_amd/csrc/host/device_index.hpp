@@ -1,0 +1,62 @@
+// Host side: an index resident on the GPU, and its construction/query through the C-ABI
+// (include/txq.h).  This is the host mirror of the reference's TetrexIndex façade for the
+// query path: spawn_agent() -> upload, query() -> probe / run_programs
+// (reference include/index_base.h:104-107,145-148).  Product code; requires a gfx950 GPU.
+#pragma once
+#include "compiler.hpp"
+#include "encoder.hpp"
+#include "index_file.hpp"
+#include "../../../include/txq.h"
+
+#include <string>
+#include <vector>
+
+namespace tetrex {
+
+// Throws std::runtime_error carrying txq_last_error() when a txq call fails.
+void txq_check(int rc, const char* what);
+
+class DeviceIndex {
+  public:
+    DeviceIndex() = default;
+    DeviceIndex(const DeviceIndex&) = delete;
+    DeviceIndex& operator=(const DeviceIndex&) = delete;
+    ~DeviceIndex();
+
+    // txq_init + txq_index_upload of a parsed index file
+    void upload(const IndexImage& image, int device = 0, int shard_rank = 0, int n_shards = 1);
+    const txq_index_info& info() const { return info_; }
+    KmerEncoder encoder() const { return enc_; }
+    uint64_t bins() const { return info_.user_bins; }
+
+    // candidate-bin masks for a batch of queries: n x shard_words words
+    // status[i] != 0: query i could not be compiled (its mask is zero); messages[i] says why
+    std::vector<uint64_t> query_masks(const std::vector<std::string>& regexes, std::vector<int>* status = nullptr,
+                                      std::vector<std::string>* messages = nullptr);
+
+  private:
+    txq_index* ix_ = nullptr;
+    txq_index_info info_{};
+    KmerEncoder enc_;
+};
+
+// ascending ids of the set bits (compute_set_bins, reference src/query.cpp:40-75)
+std::vector<uint64_t> set_bins(const uint64_t* mask, uint64_t bins);
+
+// IBFIndex::compute_bitcount (reference include/index_ibf.h:133-139)
+uint64_t compute_bitcount(uint64_t n, float fpr);
+
+struct BuildOptions {
+    unsigned k = 6;
+    float fpr = 0.05f;
+    unsigned hash_count = 3;
+    bool dna = false;
+    bool hibf = true;       // the reference's default flavour
+    unsigned reduction = 0; // 0 None, 1 murphy, 2 li
+    bool dna_wraparound = true;  // reproduce include/nucleotide_decomposer.h:106-110
+    int device = 0;
+};
+// `tetrex index`: FASTA files -> index image, bits set on the GPU (txq_emplace_device).
+IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOptions& opt, size_t* n_sequences = nullptr);
+
+}  // namespace tetrex

@@ -2,6 +2,7 @@
 #include "../../../include/txh.h"
 #include "compiler.hpp"
 #include "encoder.hpp"
+#include "index_file.hpp"
 #include "kgraph.hpp"
 #include "regex_front.hpp"
 
@@ -27,6 +28,11 @@ KmerEncoder encoder(int dna, unsigned k, unsigned reduction) {
 struct txh_blob {
     std::vector<uint8_t> bytes;
     std::vector<uint64_t> stats;
+};
+
+struct txh_index {
+    IndexImage image;
+    std::vector<uint8_t> file;
 };
 
 extern "C" {
@@ -111,5 +117,103 @@ int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* s
     for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
     return (int64_t)v.size();
 }
+
+int txh_index_parse(const void* bytes, size_t n, txh_index** out) {
+    try {
+        std::vector<uint8_t> v((const uint8_t*)bytes, (const uint8_t*)bytes + n);
+        auto ix = std::make_unique<txh_index>();
+        ix->image = parse_index(v);
+        *out = ix.release();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int txh_index_from_ibf(unsigned k, int dna, unsigned reduction, unsigned hash_count, uint64_t bins, uint64_t bin_size,
+                       const uint64_t* words, const char* paths, txh_index** out) {
+    try {
+        auto ix = std::make_unique<txh_index>();
+        IndexImage& im = ix->image;
+        im.k = (uint8_t)k;
+        im.molecule = dna ? "na" : "aa";
+        im.reduction = (uint8_t)reduction;
+        im.hash_count = (uint8_t)hash_count;
+        im.ibf.shape(bins, bin_size, hash_count);
+        std::memcpy(im.ibf.words.data(), words, im.ibf.words.size() * 8);
+        std::string all = paths ? paths : "";
+        size_t at = 0;
+        while (at <= all.size() && im.bin_paths.size() < bins) {
+            const size_t nl = all.find('\n', at);
+            im.bin_paths.push_back(all.substr(at, nl == std::string::npos ? std::string::npos : nl - at));
+            if (nl == std::string::npos) break;
+            at = nl + 1;
+        }
+        if (im.bin_paths.size() != bins) return fail("need exactly one path per bin");
+        if (!im.ibf.consistent()) return fail("inconsistent IBF shape");
+        *out = ix.release();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+static std::string json_str(const std::string& s) {
+    std::string o = "\"";
+    for (char c : s) {
+        if (c == '"' || c == '\\') { o += '\\'; o += c; }
+        else if ((unsigned char)c < 0x20) o += ' ';
+        else o += c;
+    }
+    return o + "\"";
+}
+
+int txh_index_describe(const txh_index* ix, char* json, size_t cap) {
+    const IndexImage& im = ix->image;
+    std::string j = "{\"k\":" + std::to_string(im.k) + ",\"molecule\":" + json_str(im.molecule) + ",\"is_hibf\":" + (im.is_hibf ? "true" : "false") +
+                    ",\"reduction\":" + std::to_string(im.reduction) + ",\"hash_count\":" + std::to_string(im.hash_count) +
+                    ",\"bins\":" + std::to_string(im.bin_count()) + ",\"format\":" + json_str(im.format) + ",\"ibfs\":[";
+    auto one = [](const IbfImage& f) {
+        return "{\"bins\":" + std::to_string(f.bins) + ",\"tech_bins\":" + std::to_string(f.tech_bins) + ",\"bin_size\":" + std::to_string(f.bin_size) +
+               ",\"hash_shift\":" + std::to_string(f.hash_shift) + ",\"bin_words\":" + std::to_string(f.bin_words) + ",\"hash_funs\":" + std::to_string(f.hash_funs) + "}";
+    };
+    if (im.is_hibf) for (size_t i = 0; i < im.hibf.ibfs.size(); ++i) j += (i ? "," : "") + one(im.hibf.ibfs[i]);
+    else j += one(im.ibf);
+    j += "],\"paths\":[";
+    for (size_t i = 0; i < im.bin_paths.size(); ++i) j += (i ? "," : "") + json_str(im.bin_paths[i]);
+    j += "]}";
+    return put(j, json, cap);
+}
+
+static const IbfImage* pick(const txh_index* ix, uint64_t id) {
+    const IndexImage& im = ix->image;
+    if (!im.is_hibf) return id == 0 ? &im.ibf : nullptr;
+    return id < im.hibf.ibfs.size() ? &im.hibf.ibfs[id] : nullptr;
+}
+
+int64_t txh_index_words(const txh_index* ix, uint64_t ibf_id, uint64_t* out, size_t cap) {
+    const IbfImage* f = pick(ix, ibf_id);
+    if (!f) return fail("IBF id out of range");
+    if (out && cap >= f->words.size()) std::memcpy(out, f->words.data(), f->words.size() * 8);
+    return (int64_t)f->words.size();
+}
+
+int64_t txh_index_maps(const txh_index* ix, uint64_t ibf_id, uint64_t* next_ibf_id, uint64_t* tb_to_user, size_t cap) {
+    const IndexImage& im = ix->image;
+    if (!im.is_hibf || ibf_id >= im.hibf.ibfs.size()) return fail("not an HIBF / IBF id out of range");
+    const auto& nx = im.hibf.next_ibf_id[ibf_id];
+    const auto& tb = im.hibf.tb_to_user_bin[ibf_id];
+    if (cap >= nx.size()) {
+        std::memcpy(next_ibf_id, nx.data(), nx.size() * 8);
+        std::memcpy(tb_to_user, tb.data(), tb.size() * 8);
+    }
+    return (int64_t)nx.size();
+}
+
+const void* txh_index_serialise(txh_index* ix, size_t* bytes) {
+    try {
+        ix->file = serialise_index(ix->image);
+        if (bytes) *bytes = ix->file.size();
+        return ix->file.data();
+    } catch (const std::exception& e) { fail(e.what()); return nullptr; }
+}
+
+void txh_index_free(txh_index* ix) { delete ix; }
 
 }  // extern "C"

@@ -1,0 +1,120 @@
+#include "verify.hpp"
+#include "fasta.hpp"
+#include "regex_front.hpp"
+
+#include <algorithm>
+#include <regex>
+#include <sstream>
+#include <stdexcept>
+
+namespace tetrex {
+
+namespace {
+
+char complement(char c) {
+    switch (c) {  // comp_tab of src/query.cpp:7-16 restricted to the IUPAC letters
+        case 'A': return 'T'; case 'C': return 'G'; case 'G': return 'C'; case 'T': return 'A'; case 'U': return 'A';
+        case 'a': return 't'; case 'c': return 'g'; case 'g': return 'c'; case 't': return 'a'; case 'u': return 'a';
+        case 'M': return 'K'; case 'K': return 'M'; case 'R': return 'Y'; case 'Y': return 'R';
+        case 'V': return 'B'; case 'B': return 'V'; case 'H': return 'D'; case 'D': return 'H';
+        default: return c;
+    }
+}
+
+// successive non-overlapping matches, each searched on the remaining text (RE2::FindAndConsume)
+template <class Fn>
+void find_all(const std::string& text, const std::regex& rx, Fn&& fn) {
+    size_t pos = 0;
+    std::smatch m;
+    while (pos <= text.size()) {
+        if (!std::regex_search(text.begin() + (std::ptrdiff_t)pos, text.end(), m, rx)) break;
+        const size_t start = pos + (size_t)m.position(0), len = (size_t)m.length(0);
+        fn(start, len);
+        pos = start + (len ? len : 1);
+    }
+}
+
+}  // namespace
+
+size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths, const std::string& regex,
+                   const KmerEncoder& enc, std::ostream& out, std::ostream& reverse_out, const VerifyOptions& opt) {
+    const bool dna = enc.molecule() == Molecule::DNA;
+    const bool reduced = !dna && enc.alphabet() != Alphabet::Base;
+    std::string pattern = regex;
+    if (reduced) pattern = reduce_query_alphabet(pattern, enc.reduce_table());
+    pattern = "(" + pattern + ")";
+    const std::regex rx(pattern, dna ? std::regex::ECMAScript : std::regex::extended);
+    std::vector<std::string> fwd(bins.size()), rev(bins.size());
+    std::vector<size_t> found(bins.size(), 0);
+    std::string error;
+#pragma omp parallel for schedule(dynamic) num_threads(opt.threads > 0 ? opt.threads : 1)
+    for (size_t i = 0; i < bins.size(); ++i) {
+        try {
+            const std::string& path = bin_paths.at(bins[i]);
+            std::ostringstream f, r;
+            for_each_record(path, [&](const FastaRecord& rec) {
+                std::string seq = rec.seq;
+                if (reduced) for (char& c : seq) c = enc.reduce((unsigned char)c);
+                find_all(seq, rx, [&](size_t s, size_t n) {
+                    f << path << "\t>" << rec.name << "\t" << seq.substr(s, n) << "\t" << s << "," << s + n << "\n";
+                    ++found[i];
+                });
+                if (dna) {
+                    std::string rc(seq.rbegin(), seq.rend());
+                    for (char& c : rc) c = complement(c);
+                    find_all(rc, rx, [&](size_t s, size_t n) {
+                        r << path << "\t>" << rec.name << "\t" << rc.substr(s, n) << "\tREVERSE STRAND HIT\n";
+                        ++found[i];
+                    });
+                }
+            });
+            fwd[i] = f.str();
+            rev[i] = r.str();
+        } catch (const std::exception& e) {
+#pragma omp critical
+            error = e.what();
+        }
+    }
+    if (!error.empty()) throw std::runtime_error(error);
+    size_t total = 0;
+    for (size_t i = 0; i < bins.size(); ++i) {
+        out << fwd[i];
+        reverse_out << rev[i];
+        total += found[i];
+    }
+    return total;
+}
+
+size_t verify_conjunction(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths,
+                          const std::vector<std::string>& queries, std::ostream& out, const VerifyOptions& opt) {
+    std::vector<std::regex> rxs;
+    for (const auto& q : queries) rxs.emplace_back("(" + q + ")", std::regex::ECMAScript);
+    std::vector<std::string> rows(bins.size());
+    std::vector<size_t> found(bins.size(), 0);
+    std::string error;
+#pragma omp parallel for schedule(dynamic) num_threads(opt.threads > 0 ? opt.threads : 1)
+    for (size_t i = 0; i < bins.size(); ++i) {
+        try {
+            const std::string& path = bin_paths.at(bins[i]);
+            std::ostringstream o;
+            for_each_record(path, [&](const FastaRecord& rec) {
+                for (const auto& rx : rxs)
+                    if (!std::regex_search(rec.seq, rx)) return;
+                o << path << "\t>" << rec.name << "\tN --> ";
+                for (const auto& q : queries) o << q << " --> ";
+                o << "C\n";
+                ++found[i];
+            });
+            rows[i] = o.str();
+        } catch (const std::exception& e) {
+#pragma omp critical
+            error = e.what();
+        }
+    }
+    if (!error.empty()) throw std::runtime_error(error);
+    size_t total = 0;
+    for (size_t i = 0; i < bins.size(); ++i) { out << rows[i]; total += found[i]; }
+    return total;
+}
+
+}  // namespace tetrex

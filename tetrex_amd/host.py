@@ -106,3 +106,96 @@ def parse_blob(blob):
     for first, cnt, n_slots, _ in progs:
         out.append((int(n_slots), ops[first:first + cnt]))
     return kmers, out
+
+
+# ---- .ibf index files ------------------------------------------------------------------------
+def _index_api():
+    L = lib()
+    if not hasattr(L, "_index_ready"):
+        L.txh_index_parse.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.txh_index_from_ibf.argtypes = [C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_uint64, u64p, C.c_char_p,
+                                         C.POINTER(C.c_void_p)]
+        L.txh_index_describe.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.txh_index_words.restype = C.c_int64
+        L.txh_index_words.argtypes = [C.c_void_p, C.c_uint64, u64p, C.c_size_t]
+        L.txh_index_maps.restype = C.c_int64
+        L.txh_index_maps.argtypes = [C.c_void_p, C.c_uint64, u64p, u64p, C.c_size_t]
+        L.txh_index_serialise.restype = C.c_void_p
+        L.txh_index_serialise.argtypes = [C.c_void_p, C.POINTER(C.c_size_t)]
+        L.txh_index_free.argtypes = [C.c_void_p]
+        L._index_ready = True
+    return L
+
+
+class IndexFile:
+    """A parsed / constructed TetRex index image (host/index_file.hpp)."""
+
+    def __init__(self, handle):
+        self._h = C.c_void_p(handle)
+
+    @classmethod
+    def parse(cls, data):
+        L = _index_api()
+        h = C.c_void_p()
+        if L.txh_index_parse(data, len(data), C.byref(h)) != 0:
+            raise _err()
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path):
+        with open(path, "rb") as f:
+            return cls.parse(f.read())
+
+    @classmethod
+    def from_ibf(cls, k, dna, reduction, hash_count, bins, bin_size, words, paths):
+        L = _index_api()
+        w = np.ascontiguousarray(words, dtype=np.uint64)
+        h = C.c_void_p()
+        if L.txh_index_from_ibf(k, int(dna), reduction, hash_count, bins, bin_size, w.ctypes.data_as(u64p),
+                                "\n".join(paths).encode(), C.byref(h)) != 0:
+            raise _err()
+        return cls(h.value)
+
+    def describe(self):
+        import json
+        buf = C.create_string_buffer(1 << 22)
+        if _index_api().txh_index_describe(self._h, buf, len(buf)) < 0:
+            raise _err()
+        return json.loads(buf.value.decode())
+
+    def words(self, ibf_id=0):
+        L = _index_api()
+        n = L.txh_index_words(self._h, ibf_id, None, 0)
+        if n < 0:
+            raise _err()
+        out = np.zeros(n, dtype=np.uint64)
+        L.txh_index_words(self._h, ibf_id, out.ctypes.data_as(u64p), n)
+        return out
+
+    def maps(self, ibf_id):
+        L = _index_api()
+        a = np.zeros(1 << 20, dtype=np.uint64)
+        b = np.zeros(1 << 20, dtype=np.uint64)
+        n = L.txh_index_maps(self._h, ibf_id, a.ctypes.data_as(u64p), b.ctypes.data_as(u64p), a.size)
+        if n < 0:
+            raise _err()
+        return a[:n].copy(), b[:n].copy()
+
+    def serialise(self):
+        size = C.c_size_t()
+        p = _index_api().txh_index_serialise(self._h, C.byref(size))
+        if not p:
+            raise _err()
+        return C.string_at(p, size.value)
+
+    def save(self, path):
+        with open(path, "wb") as f:
+            f.write(self.serialise())
+
+    def __del__(self):
+        try:
+            if self._h:
+                _index_api().txh_index_free(self._h)
+                self._h = None
+        except Exception:
+            pass
