@@ -1,0 +1,73 @@
+"""Two ranks, one GPU: each rank uploads its bin-column shard of the same index, runs the same
+query programs through libtxq, and the final masks are all-gathered (gloo on host tensors here;
+RCCL in bench.py on a multi-GPU node).  The reassembled masks must equal the oracle's."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import oracle as O
+        from tetrex_amd import capi, host
+        from tetrex_amd.dist import shard_range, gather_final_masks
+        from motifs import PEPTIDE_QUERIES
+        capi.init(0)
+        bins, m, h, k = 1000, 4099, 3, 4
+        ox = O.Index.ibf(bins, m, h, dna=False, k=k)
+        rng = np.random.default_rng(5)
+        for b in range(bins):
+            ox.emplace(rng.integers(0, 1 << 20, size=1500, dtype=np.uint64), b)
+        queries = [q_ for q_ in PEPTIDE_QUERIES if "{2,4}" not in q_][:24]
+        blob, status, _ = host.compile_batch(queries, False, k, 0, bins)
+        ix = capi.Index.upload_ibf(bins, m, h, ox.words(), shard_rank=rank, n_shards=world)
+        W = int(ix.info.mask_words)
+        assert (int(ix.info.shard_word0), int(ix.info.shard_word0) + ix.shard_words) == shard_range(W, rank, world)
+        local = ix.run_programs(blob, len(queries))
+        full = gather_final_masks(torch.from_numpy(local.view(np.int64)), W).numpy().view(np.uint64)
+        ok = True
+        for i, rx in enumerate(queries):
+            want, st = ox.query(rx, with_stats=True)
+            if st["quirk_merges"] == 0:
+                ok = ok and np.array_equal(full[i], want)
+        ix.free()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_shards_on_one_gpu_gather_to_the_oracle_masks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]
