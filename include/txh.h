@@ -38,6 +38,17 @@ const void* txh_blob_data(const txh_blob* b, size_t* bytes);
 int txh_blob_stats(const txh_blob* b, uint64_t* stats4, size_t n);
 void txh_blob_free(txh_blob* b);
 
+/* Staged expansion against a caller-supplied executor (the GPU session in production, a
+ * simulator in CPU tests).  `fn` runs one stage: blob = the NEW ops of all n programs
+ * (txq_program.h format), and must fill alive[i] for the n_q feedback questions
+ * (program qp[i], slot qs[i]); it returns 0 on success.  stats6: stages, ops, kmers, states,
+ * pruned states, feedback questions. */
+typedef int (*txh_stage_fn)(void* user, const void* blob, size_t bytes, const uint32_t* qp, const uint32_t* qs, size_t n_q,
+                            uint8_t* alive);
+int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
+                   size_t ops_per_query_per_stage, size_t ops_per_stage, txh_stage_fn fn, void* user, int* status,
+                   uint64_t* stats6);
+
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap);

@@ -127,6 +127,21 @@ int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t 
 int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs,
                             uint64_t* d_final_masks, void* stream);
 
+/* Staged execution: the host expands the frontier of a batch of queries piecewise and streams
+ * each piece (a blob with the NEW ops of every program; slot contents persist in HBM between
+ * stages).  After a stage the library answers n_queries feedback questions "has slot
+ * query_slot[i] of program query_program[i] any bit set?" (bitvector::none() of
+ * include/otf_collector.h:383) into alive[i] (1/0), so the host can prune dead states before
+ * expanding them.  Every stage's blob must hold exactly n_programs programs (possibly with no
+ * ops) and their current n_slots.  txq_session_end copies the RESULT slot of every program to
+ * final_masks (n_programs x shard_words, host) and destroys the session; a NULL final_masks
+ * just destroys it. */
+typedef struct txq_session txq_session;
+int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out);
+int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const uint32_t* query_program,
+                      const uint32_t* query_slot, size_t n_queries, uint8_t* alive);
+int txq_session_end(txq_session* s, uint64_t* final_masks);
+
 /* Plain device-memory helpers so that a host program needs no HIP headers. */
 int txq_malloc(void** dptr, size_t bytes);
 int txq_free(void* dptr);

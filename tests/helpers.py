@@ -136,3 +136,50 @@ def ones_mask(user_bins, word0=0, words=None):
     if words is None:
         return m
     return m[word0:word0 + words]
+
+
+class SessionSimulator:
+    """CPU stand-in for a txq session (test double): keeps every program's slot masks, runs a
+    stage's ops with numpy over oracle-probed masks and answers the alive questions."""
+
+    def __init__(self, oracle_index, n_programs):
+        from tetrex_amd import host
+        self.host = host
+        self.ox = oracle_index
+        self.W = oracle_index.words_per_mask
+        self.ones = ones_mask(oracle_index.bins)
+        self.slots = [dict() for _ in range(n_programs)]
+        self.stages = 0
+
+    def _get(self, p, s):
+        if s == 0:
+            return np.zeros(self.W, dtype=np.uint64)
+        if s == 1:
+            return self.ones
+        return self.slots[p].get(s, np.zeros(self.W, dtype=np.uint64) if s == 2 else None)
+
+    def stage(self, blob, qp, qs):
+        kmers, progs = self.host.parse_blob(blob)
+        assert len(progs) == len(self.slots)
+        M = self.ox.probe(kmers) if kmers.size else np.zeros((0, self.W), dtype=np.uint64)
+        for p, (n_slots, ops) in enumerate(progs):
+            for k, d, a, b in ops:
+                x = self._get(p, int(a))
+                assert x is not None, "slot read before written"
+                x = x.copy()
+                if k != NO_KMER:
+                    x &= M[k]
+                y = self._get(p, int(b))
+                assert y is not None
+                assert int(d) < n_slots and int(d) >= 2
+                self.slots[p][int(d)] = x | y
+        self.stages += 1
+        out = []
+        for p, s in zip(qp, qs):
+            v = self._get(p, s)
+            assert v is not None
+            out.append(bool(v.any()))
+        return out
+
+    def result(self, p):
+        return self._get(p, 2)

@@ -1,0 +1,85 @@
+"""CPU tests of staged execution (host/compiler.cpp run_staged): the frontier is expanded piecewise
+and dead states are pruned on feedback.  The device session is replaced by a numpy simulator over
+oracle-probed masks; the final masks must equal the oracle's collect() for every stage budget."""
+import numpy as np
+import pytest
+
+from helpers import SessionSimulator
+from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
+
+
+@pytest.fixture(scope="module")
+def host():
+    from tetrex_amd import host as H
+    H.lib()
+    return H
+
+
+def _index(oracle, bins, m, h, k, dna, per_bin, seed):
+    ox = oracle.Index.ibf(bins, m, h, dna=dna, k=k)
+    rng = np.random.default_rng(seed)
+    bits = (2 if dna else 5) * k
+    for b in range(bins):
+        ox.emplace(rng.integers(0, 1 << min(bits, 62), size=per_bin, dtype=np.uint64), b)
+    return ox
+
+
+def _run(host, ox, queries, dna, k, per_query, per_stage=0):
+    sim = SessionSimulator(ox, len(queries))
+    status, stats = host.run_staged(queries, dna, k, 0, ox.bins, sim.stage, per_query, per_stage)
+    checked = 0
+    for i, q in enumerate(queries):
+        try:
+            want, ost = ox.query(q, with_stats=True)
+        except Exception:
+            assert status[i] != 0
+            continue
+        assert status[i] == 0, q
+        if ost["quirk_merges"]:
+            continue
+        assert np.array_equal(sim.result(i), want), q
+        checked += 1
+    return checked, stats, sim
+
+
+@pytest.mark.parametrize("per_query", [1, 7, 64, 4096, 1 << 30])
+def test_every_stage_budget_gives_the_oracle_masks(host, oracle, per_query):
+    ox = _index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
+    qs = [q for q in PEPTIDE_QUERIES if "{2,4}C" not in q] + random_prosite_motifs(25, 3, wildcard=0.05, ranges=0.0)
+    checked, stats, sim = _run(host, ox, qs, False, 4, per_query)
+    assert checked >= len(qs) - 6
+    if per_query == 1 << 30:
+        assert stats["stages"] == 1 and stats["pruned"] == 0
+    if per_query == 1:
+        assert stats["stages"] > 10
+
+
+def test_feedback_prunes_an_exploding_motif(host, oracle):
+    """A wildcard-rich motif on a SPARSE index: without feedback the frontier is 20^(k-1) states per
+    node; with feedback dead states are dropped and the op count collapses — same result mask."""
+    ox = _index(oracle, bins=128, m=60013, h=3, k=4, dna=False, per_bin=400, seed=2)
+    qs = ["LMA.{2,4}E.{2}GLY", "W.{2}[LIVM]D[VFY][LIVM]{3}D.PPGT[GS]D"]
+    _, one_shot, _ = _run(host, ox, qs, False, 4, 1 << 30)
+    _, staged, sim = _run(host, ox, qs, False, 4, 512)
+    assert staged["pruned"] > 0 and staged["stages"] > 1
+    assert staged["ops"] < one_shot["ops"] / 5
+    for i, q in enumerate(qs):
+        assert np.array_equal(sim.result(i), ox.query(q))
+
+
+def test_stage_blob_budget_delays_queries_without_changing_results(host, oracle):
+    ox = _index(oracle, bins=70, m=257, h=3, k=3, dna=True, per_bin=8, seed=3)
+    checked, stats, _ = _run(host, ox, DNA_QUERIES, True, 3, per_query=4, per_stage=6)
+    assert checked >= 10 and stats["stages"] >= 4
+
+
+def test_one_bin_index_and_failed_queries(host, oracle):
+    ox = oracle.Index.ibf(1, 64, 3, dna=False, k=4)
+    sim = SessionSimulator(ox, 2)
+    status, _ = host.run_staged(["LMAEGLYN", "ACDE"], False, 4, 0, 1, sim.stage)
+    assert status == [0, 0] and int(sim.result(0)[0]) == 1 and int(sim.result(1)[0]) == 1
+    ox = _index(oracle, bins=100, m=509, h=3, k=4, dna=False, per_bin=100, seed=4)
+    sim = SessionSimulator(ox, 3)
+    status, _ = host.run_staged(["LMAEG", "A{2,}", "LMAE"], False, 4, 0, 100, sim.stage)
+    assert status[0] == 0 and status[1] != 0 and status[2] == 0
+    assert np.array_equal(sim.result(0), ox.query("LMAEG")) and not sim.result(1).any()

@@ -22,7 +22,7 @@ SYMBOLS = [
     "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
     "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
-    "txq_run_programs", "txq_run_programs_device",
+    "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_stage", "txq_session_end",
     "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize",
 ]
 
@@ -74,6 +74,9 @@ def lib():
         L.txq_emplace_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
         L.txq_run_programs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, u64p]
         L.txq_run_programs_device.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        L.txq_session_begin.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.txq_session_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, u32p, u32p, C.c_size_t, C.POINTER(C.c_uint8)]
+        L.txq_session_end.argtypes = [C.c_void_p, u64p]
         L.txq_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.txq_free.argtypes = [C.c_void_p]
         L.txq_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -247,6 +250,9 @@ class Index:
         check(lib().txq_index_download_words(self._h, out.ctypes.data_as(u64p), out.size))
         return out
 
+    def session(self, n_programs):
+        return Session(self, n_programs)
+
     def run_programs(self, blob, n_programs):
         buf = np.frombuffer(blob, dtype=np.uint8)
         # 8-byte aligned copy
@@ -255,3 +261,44 @@ class Index:
         out = np.zeros((n_programs, self.shard_words), dtype=np.uint64)
         check(lib().txq_run_programs(self._h, al.ctypes.data, buf.size, n_programs, out.ctypes.data_as(u64p)))
         return out
+
+
+def _aligned(blob):
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    al = np.zeros((buf.size + 7) // 8, dtype=np.uint64)
+    al.view(np.uint8)[:buf.size] = buf
+    return al, buf.size
+
+
+class Session:
+    """Staged execution of a batch of programs (txq_session_*)."""
+
+    def __init__(self, index, n_programs):
+        self.index = index
+        self.n = n_programs
+        h = C.c_void_p()
+        check(lib().txq_session_begin(index._h, n_programs, C.byref(h)))
+        self._h = h
+
+    def stage(self, blob, query_program=(), query_slot=()):
+        al, size = _aligned(blob)
+        qp = np.ascontiguousarray(query_program, dtype=np.uint32)
+        qs = np.ascontiguousarray(query_slot, dtype=np.uint32)
+        alive = np.zeros(max(qp.size, 1), dtype=np.uint8)
+        check(lib().txq_session_stage(self._h, al.ctypes.data, size, qp.ctypes.data_as(u32p), qs.ctypes.data_as(u32p),
+                                      qp.size, alive.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return alive[:qp.size].astype(bool)
+
+    def end(self):
+        out = np.zeros((self.n, self.index.shard_words), dtype=np.uint64)
+        h, self._h = self._h, None
+        check(lib().txq_session_end(h, out.ctypes.data_as(u64p)))
+        return out
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().txq_session_end(self._h, None)
+                self._h = None
+        except Exception:
+            pass

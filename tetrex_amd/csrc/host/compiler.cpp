@@ -1,4 +1,5 @@
 #include "compiler.hpp"
+#include "regex_front.hpp"
 
 #include <cstring>
 #include <stdexcept>
@@ -6,44 +7,278 @@
 namespace tetrex {
 
 namespace {
+constexpr uint32_t kPinned = 0x7FFFFFFF;  // reference count of the constant slots
 
-// Slot allocator with reference counts; slots 0..2 are the constants of txq_program.h.
-class Slots {
-  public:
-    Slots() : refs_(TXQ_SLOT_FIRST_FREE, kPinned) {}
-    static constexpr uint32_t kPinned = 0x7FFFFFFF;
-
-    uint32_t fresh() {
-        uint32_t s;
-        if (!free_.empty()) { s = free_.back(); free_.pop_back(); }
-        else { s = (uint32_t)refs_.size(); refs_.push_back(0); }
-        refs_[s] = 1;
-        return s;
+std::vector<uint8_t> make_blob(const std::vector<uint64_t>& kmers, const std::vector<txq_program>& programs,
+                               const std::vector<const std::vector<txq_op>*>& ops_of) {
+    size_t n_ops = 0;
+    for (const auto* v : ops_of) n_ops += v ? v->size() : 0;
+    if (n_ops > 0xFFFFFFFFu) throw std::runtime_error("batch has more than 2^32 operations");
+    txq_blob_header h{};
+    h.magic = TXQ_PROGRAM_MAGIC;
+    h.version = TXQ_PROGRAM_VERSION;
+    h.n_programs = (uint32_t)programs.size();
+    h.n_kmers = (uint32_t)kmers.size();
+    h.n_ops = (uint32_t)n_ops;
+    h.kmers_offset = sizeof(txq_blob_header);
+    h.programs_offset = h.kmers_offset + kmers.size() * sizeof(uint64_t);
+    h.ops_offset = h.programs_offset + programs.size() * sizeof(txq_program);
+    std::vector<uint8_t> blob(h.ops_offset + n_ops * sizeof(txq_op));
+    std::memcpy(blob.data(), &h, sizeof h);
+    if (!kmers.empty()) std::memcpy(blob.data() + h.kmers_offset, kmers.data(), kmers.size() * 8);
+    if (!programs.empty()) std::memcpy(blob.data() + h.programs_offset, programs.data(), programs.size() * sizeof(txq_program));
+    uint8_t* at = blob.data() + h.ops_offset;
+    for (const auto* v : ops_of) {
+        if (!v || v->empty()) continue;
+        std::memcpy(at, v->data(), v->size() * sizeof(txq_op));
+        at += v->size() * sizeof(txq_op);
     }
-    void share(uint32_t s) { if (refs_[s] != kPinned) ++refs_[s]; }
-    void drop(uint32_t s) {
-        if (refs_[s] == kPinned) return;
-        if (--refs_[s] == 0) free_.push_back(s);
-    }
-    bool exclusive(uint32_t s) const { return refs_[s] == 1; }
-    uint32_t high_water() const { return (uint32_t)refs_.size(); }
-
-  private:
-    std::vector<uint32_t> refs_, free_;
-};
-
-struct State {
-    uint64_t kmer;   // forward k-mer so far
-    uint32_t slot;   // mask of the bins still compatible with this path
-    uint8_t shift;   // symbols seen, saturating at k (shift_count_ of the reference)
-};
-
-struct NodeStates {
-    std::vector<State> items;
-    std::unordered_map<uint64_t, uint32_t> by_key;
-};
-
+    return blob;
+}
 }  // namespace
+
+// ---- QueryExpansion -----------------------------------------------------------------------
+
+QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits)
+    : enc_(enc), g_(std::move(graph)), limits_(limits) {
+    if (enc_.k() < 2) throw std::runtime_error("k must be at least 2");
+    order_ = g_.topological_order();
+    table_.resize(g_.size());
+    refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
+    std::vector<txq_op> none;
+    arrive(0, State{0, TXQ_SLOT_ONES, 0}, none);
+}
+
+uint32_t QueryExpansion::fresh() {
+    uint32_t s;
+    if (!free_.empty()) { s = free_.back(); free_.pop_back(); }
+    else { s = (uint32_t)refs_.size(); refs_.push_back(0); }
+    refs_[s] = 1;
+    if (s + 1 > high_water_) high_water_ = s + 1;
+    return s;
+}
+void QueryExpansion::share(uint32_t s) { if (refs_[s] != kPinned) ++refs_[s]; }
+void QueryExpansion::drop(uint32_t s) {
+    if (refs_[s] == kPinned) return;
+    if (--refs_[s] == 0) free_.push_back(s);
+}
+bool QueryExpansion::exclusive(uint32_t s) const { return refs_[s] == 1; }
+
+void QueryExpansion::emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b) {
+    if (++total_ops_ > limits_.max_ops) throw std::runtime_error("query expands to too many mask operations");
+    out.push_back(txq_op{kmer, dst, a, b});
+}
+
+// hand a state (owning one reference to its slot) to node `to`
+void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
+    if (to == KGraph::kNone) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    NodeStates& ns = table_[to];
+    // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just
+    // above them, so paths of different length < k-1 never share a key
+    const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
+    const uint64_t key = (s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits));
+    auto [it, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
+    if (inserted) {
+        ns.items.push_back(s);
+        if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+        return;
+    }
+    State& have = ns.items[it->second];
+    if (have.shift < s.shift) have.shift = s.shift;  // k-1 and k behave alike from here on
+    if (have.slot == s.slot) { drop(s.slot); return; }
+    // absorb: have.path |= s.path
+    if (exclusive(have.slot)) {
+        emit(out, TXQ_NO_KMER, have.slot, have.slot, s.slot);
+        drop(s.slot);
+    } else if (exclusive(s.slot)) {
+        emit(out, TXQ_NO_KMER, s.slot, s.slot, have.slot);
+        drop(have.slot);
+        have.slot = s.slot;
+    } else {
+        const uint32_t d = fresh();
+        emit(out, TXQ_NO_KMER, d, have.slot, s.slot);
+        drop(have.slot);
+        drop(s.slot);
+        have.slot = d;
+    }
+}
+
+void QueryExpansion::advance(size_t op_budget, const Intern& intern, std::vector<txq_op>& out) {
+    const unsigned k = enc_.k();
+    const size_t start = out.size();
+    while (cursor_ < order_.size() && out.size() - start < op_budget) {
+        const int32_t node = order_[cursor_++];
+        NodeStates ns;
+        ns.items.swap(table_[node].items);
+        table_[node].by_key.clear();
+        const int32_t lab = g_.label[node];
+        for (State s : ns.items) {
+            switch (lab) {
+                case KGraph::kMatch:
+                    emit(out, TXQ_NO_KMER, TXQ_SLOT_RESULT, s.slot, TXQ_SLOT_RESULT);
+                    drop(s.slot);
+                    break;
+                case '$':  // passes through untouched (include/otf_collector.h:364-368)
+                case KGraph::kGhost:
+                    arrive(g_.next_a[node], s, out);
+                    break;
+                case KGraph::kSplit:
+                    share(s.slot);
+                    arrive(g_.next_a[node], s, out);
+                    arrive(g_.next_b[node], s, out);
+                    break;
+                case KGraph::kGap:
+                    throw std::runtime_error("gap nodes (-a/-g) are not supported yet");
+                default: {
+                    const uint64_t probe = enc_.roll((unsigned char)lab, s.kmer);
+                    if (s.shift < k - 1) {
+                        ++s.shift;
+                    } else {
+                        const uint32_t id = intern(probe);
+                        ++probes_;
+                        if (exclusive(s.slot)) {
+                            emit(out, id, s.slot, s.slot, TXQ_SLOT_ZERO);
+                        } else {
+                            const uint32_t d = fresh();
+                            emit(out, id, d, s.slot, TXQ_SLOT_ZERO);
+                            drop(s.slot);
+                            s.slot = d;
+                        }
+                        s.shift = (uint8_t)k;
+                    }
+                    arrive(g_.next_a[node], s, out);
+                    break;
+                }
+            }
+        }
+    }
+}
+
+void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) const {
+    std::vector<uint8_t> seen(refs_.size(), 0);
+    for (size_t c = cursor_; c < order_.size(); ++c)
+        for (const State& s : table_[order_[c]].items)
+            if (s.slot >= TXQ_SLOT_FIRST_FREE && !seen[s.slot]) { seen[s.slot] = 1; out.push_back(s.slot); }
+}
+
+void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
+    for (size_t c = cursor_; c < order_.size(); ++c) {
+        NodeStates& ns = table_[order_[c]];
+        bool any = false;
+        for (const State& s : ns.items)
+            if (s.slot < dead.size() && dead[s.slot]) { any = true; break; }
+        if (!any) continue;
+        std::vector<State> keep;
+        for (const State& s : ns.items) {
+            if (s.slot < dead.size() && dead[s.slot]) { drop(s.slot); ++pruned_; }
+            else keep.push_back(s);
+        }
+        ns.items.swap(keep);
+        ns.by_key.clear();
+        const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+        for (uint32_t i = 0; i < ns.items.size(); ++i) {
+            const State& s = ns.items[i];
+            const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
+            ns.by_key.emplace((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)), i);
+        }
+    }
+}
+
+// ---- staged driver ------------------------------------------------------------------------
+
+StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
+                       const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages) {
+    const size_t n = regexes.size();
+    if (status) status->assign(n, 0);
+    if (messages) messages->assign(n, std::string());
+    std::vector<std::unique_ptr<QueryExpansion>> q(n);
+    std::vector<uint8_t> passthrough(n, 0);
+    auto failed = [&](size_t i, const char* why) {
+        q[i].reset();
+        if (status) (*status)[i] = -1;
+        if (messages) (*messages)[i] = why;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        try {
+            if (bins <= 1) { passthrough[i] = 1; continue; }  // include/query.h:265-272
+            const std::string postfix = preprocess_query(regexes[i], enc);
+            q[i] = std::make_unique<QueryExpansion>(enc, build_kgraph(postfix, enc.k(), enc.alphabet() != Alphabet::Base), opt.limits);
+        } catch (const std::exception& e) { failed(i, e.what()); }
+    }
+    StagedStats st;
+    std::vector<std::vector<txq_op>> ops(n);
+    std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
+    bool first = true;
+    for (;;) {
+        std::vector<uint64_t> kmers;
+        std::unordered_map<uint64_t, uint32_t> index;
+        const QueryExpansion::Intern intern = [&](uint64_t v) {
+            auto [it, fresh] = index.emplace(v, (uint32_t)kmers.size());
+            if (fresh) kmers.push_back(v);
+            return it->second;
+        };
+        size_t total = 0;
+        bool pending = false;
+        for (size_t i = 0; i < n; ++i) {
+            ops[i].clear();
+            if (first && passthrough[i]) ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
+            if (!q[i] || q[i]->done()) continue;
+            if (total < opt.ops_per_stage) {
+                try {
+                    q[i]->advance(opt.ops_per_query_per_stage, intern, ops[i]);
+                } catch (const std::exception& e) {
+                    // ops already emitted in earlier stages only ever feed RESULT through a Match
+                    // op, so an abandoned query is neutralised by not emitting anything further
+                    ops[i].clear();
+                    failed(i, e.what());
+                    continue;
+                }
+                total += ops[i].size();
+                slots[i] = q[i]->n_slots();
+            }
+            if (!q[i]->done()) pending = true;
+        }
+        if (!first && total == 0 && !pending) break;
+        std::vector<txq_program> programs(n);
+        std::vector<const std::vector<txq_op>*> ops_of(n);
+        uint32_t at = 0;
+        for (size_t i = 0; i < n; ++i) {
+            programs[i] = txq_program{at, (uint32_t)ops[i].size(), slots[i], 0};
+            at += (uint32_t)ops[i].size();
+            ops_of[i] = &ops[i];
+        }
+        std::vector<uint32_t> qp, qs;
+        for (size_t i = 0; i < n; ++i) {
+            if (!q[i] || q[i]->done()) continue;
+            const size_t before = qs.size();
+            q[i]->frontier_slots(qs);
+            qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
+        }
+        std::vector<uint8_t> alive(qp.size(), 1);
+        exec.stage(make_blob(kmers, programs, ops_of), qp, qs, alive);
+        ++st.stages;
+        st.ops += total;
+        st.kmers += kmers.size();
+        st.feedback_queries += qp.size();
+        // prune dead frontier states
+        for (size_t a = 0; a < qp.size();) {
+            const uint32_t p = qp[a];
+            std::vector<uint8_t> dead(q[p]->n_slots(), 0);
+            bool any = false;
+            for (; a < qp.size() && qp[a] == p; ++a)
+                if (!alive[a]) { dead[qs[a]] = 1; any = true; }
+            if (any) q[p]->prune(dead);
+        }
+        first = false;
+        if (!pending) break;
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (q[i]) { st.states += q[i]->states(); st.pruned += q[i]->pruned(); }
+    return st;
+}
+
+// ---- one-shot batches ----------------------------------------------------------------------
 
 uint32_t ProgramBatch::intern(uint64_t value) {
     auto it = kmer_index_.find(value);
@@ -68,131 +303,26 @@ size_t ProgramBatch::add_empty() {
 }
 
 size_t ProgramBatch::add(const KGraph& g) {
-    const unsigned k = enc_.k();
-    if (k < 2) throw std::runtime_error("k must be at least 2");
-    const uint64_t suffix = enc_.suffix_mask();
-    const unsigned bits = enc_.bits_per_symbol();
+    QueryExpansion x(enc_, g, limits_);
     QueryProgram prog;
-    Slots slots;
-    std::vector<NodeStates> table(g.size());
-    const std::vector<int32_t> order = g.topological_order();
-
-    auto emit = [&](uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b) {
-        if (prog.ops.size() >= limits_.max_ops) throw std::runtime_error("query expands to too many mask operations");
-        prog.ops.push_back(txq_op{kmer, dst, a, b});
-    };
-    // hand a state (owning one reference to its slot) to node `to`
-    auto arrive = [&](int32_t to, State s) {
-        if (to == KGraph::kNone) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
-        NodeStates& ns = table[to];
-        // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker
-        // bit just above them, so paths of different length < k-1 never share a key
-        const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
-        const uint64_t key = (s.kmer & suffix) | (1ULL << (phase * bits));
-        auto [it, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
-        if (inserted) {
-            ns.items.push_back(s);
-            if (++prog.states > limits_.max_states) throw std::runtime_error("query expands to too many states");
-            return;
-        }
-        State& have = ns.items[it->second];
-        if (have.shift < s.shift) have.shift = s.shift;  // k-1 and k behave alike from here on
-        if (have.slot == s.slot) { slots.drop(s.slot); return; }
-        // absorb: have.path |= s.path
-        if (slots.exclusive(have.slot)) {
-            emit(TXQ_NO_KMER, have.slot, have.slot, s.slot);
-            slots.drop(s.slot);
-        } else if (slots.exclusive(s.slot)) {
-            emit(TXQ_NO_KMER, s.slot, s.slot, have.slot);
-            slots.drop(have.slot);
-            have.slot = s.slot;
-        } else {
-            const uint32_t d = slots.fresh();
-            emit(TXQ_NO_KMER, d, have.slot, s.slot);
-            slots.drop(have.slot);
-            slots.drop(s.slot);
-            have.slot = d;
-        }
-    };
-
-    arrive(0, State{0, TXQ_SLOT_ONES, 0});
-    for (int32_t node : order) {
-        NodeStates& ns = table[node];
-        const int32_t lab = g.label[node];
-        for (size_t i = 0; i < ns.items.size(); ++i) {
-            State s = ns.items[i];
-            switch (lab) {
-                case KGraph::kMatch:
-                    emit(TXQ_NO_KMER, TXQ_SLOT_RESULT, s.slot, TXQ_SLOT_RESULT);
-                    slots.drop(s.slot);
-                    break;
-                case '$':  // passes through untouched (include/otf_collector.h:364-368)
-                case KGraph::kGhost:
-                    arrive(g.next_a[node], s);
-                    break;
-                case KGraph::kSplit:
-                    slots.share(s.slot);
-                    arrive(g.next_a[node], s);
-                    arrive(g.next_b[node], s);
-                    break;
-                case KGraph::kGap:
-                    throw std::runtime_error("gap nodes (-a/-g) are not supported yet");
-                default: {
-                    const uint64_t probe = enc_.roll((unsigned char)lab, s.kmer);
-                    if (s.shift < k - 1) {
-                        ++s.shift;
-                    } else {
-                        const uint32_t id = intern(probe);
-                        ++prog.probes;
-                        if (slots.exclusive(s.slot)) {
-                            emit(id, s.slot, s.slot, TXQ_SLOT_ZERO);
-                        } else {
-                            const uint32_t d = slots.fresh();
-                            emit(id, d, s.slot, TXQ_SLOT_ZERO);
-                            slots.drop(s.slot);
-                            s.slot = d;
-                        }
-                        s.shift = (uint8_t)k;
-                    }
-                    arrive(g.next_a[node], s);
-                    break;
-                }
-            }
-        }
-        NodeStates().items.swap(ns.items);
-        ns.by_key.clear();
-    }
-    prog.n_slots = slots.high_water();
+    x.advance(SIZE_MAX, [this](uint64_t v) { return intern(v); }, prog.ops);
+    prog.n_slots = x.n_slots();
+    prog.states = x.states();
+    prog.probes = x.probes();
     programs_.push_back(std::move(prog));
     return programs_.size() - 1;
 }
 
 std::vector<uint8_t> ProgramBatch::serialise() const {
-    size_t n_ops = 0;
-    for (const auto& p : programs_) n_ops += p.ops.size();
-    if (n_ops > 0xFFFFFFFFu) throw std::runtime_error("batch has more than 2^32 operations");
-    txq_blob_header h{};
-    h.magic = TXQ_PROGRAM_MAGIC;
-    h.version = TXQ_PROGRAM_VERSION;
-    h.n_programs = (uint32_t)programs_.size();
-    h.n_kmers = (uint32_t)kmers_.size();
-    h.n_ops = (uint32_t)n_ops;
-    h.kmers_offset = sizeof(txq_blob_header);
-    h.programs_offset = h.kmers_offset + kmers_.size() * sizeof(uint64_t);
-    h.ops_offset = h.programs_offset + programs_.size() * sizeof(txq_program);
-    std::vector<uint8_t> blob(h.ops_offset + n_ops * sizeof(txq_op));
-    std::memcpy(blob.data(), &h, sizeof h);
-    if (!kmers_.empty()) std::memcpy(blob.data() + h.kmers_offset, kmers_.data(), kmers_.size() * 8);
-    txq_program* pr = reinterpret_cast<txq_program*>(blob.data() + h.programs_offset);
-    txq_op* ops = reinterpret_cast<txq_op*>(blob.data() + h.ops_offset);
+    std::vector<txq_program> pr(programs_.size());
+    std::vector<const std::vector<txq_op>*> ops_of(programs_.size());
     uint32_t first = 0;
     for (size_t i = 0; i < programs_.size(); ++i) {
-        const QueryProgram& p = programs_[i];
-        pr[i] = txq_program{first, (uint32_t)p.ops.size(), p.n_slots, 0};
-        if (!p.ops.empty()) std::memcpy(ops + first, p.ops.data(), p.ops.size() * sizeof(txq_op));
-        first += (uint32_t)p.ops.size();
+        pr[i] = txq_program{first, (uint32_t)programs_[i].ops.size(), programs_[i].n_slots, 0};
+        first += (uint32_t)programs_[i].ops.size();
+        ops_of[i] = &programs_[i].ops;
     }
-    return blob;
+    return make_blob(kmers_, pr, ops_of);
 }
 
 }  // namespace tetrex

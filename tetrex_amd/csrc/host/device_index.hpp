@@ -31,8 +31,11 @@ class DeviceIndex {
 
     // candidate-bin masks for a batch of queries: n x shard_words words
     // status[i] != 0: query i could not be compiled (its mask is zero); messages[i] says why
+    // Staged execution (compiler.hpp run_staged): the frontier is expanded on the host and
+    // streamed to the device piecewise, with dead-state feedback between stages.
     std::vector<uint64_t> query_masks(const std::vector<std::string>& regexes, std::vector<int>* status = nullptr,
-                                      std::vector<std::string>* messages = nullptr);
+                                      std::vector<std::string>* messages = nullptr, StagedStats* stats = nullptr,
+                                      const StagedOptions* options = nullptr);
 
   private:
     txq_index* ix_ = nullptr;

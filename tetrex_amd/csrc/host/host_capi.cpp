@@ -98,6 +98,48 @@ int txh_compile_batch(const char* const* regex, size_t n, int dna, unsigned k, u
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+namespace {
+struct CallbackExecutor final : StageExecutor {
+    txh_stage_fn fn;
+    void* user;
+    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+               std::vector<uint8_t>& alive) override {
+        std::vector<uint64_t> aligned((blob.size() + 7) / 8);
+        std::memcpy(aligned.data(), blob.data(), blob.size());
+        alive.assign(qp.size(), 1);
+        if (fn(user, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()) != 0)
+            throw std::runtime_error("stage executor callback failed");
+    }
+};
+}  // namespace
+
+int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
+                   size_t ops_per_query_per_stage, size_t ops_per_stage, txh_stage_fn fn, void* user, int* status,
+                   uint64_t* stats6) {
+    try {
+        KmerEncoder enc = encoder(dna, k, reduction);
+        std::vector<std::string> rx(regex, regex + n);
+        CallbackExecutor exec;
+        exec.fn = fn;
+        exec.user = user;
+        StagedOptions opt;
+        if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
+        if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
+        std::vector<int> st;
+        std::vector<std::string> why;
+        const StagedStats s = run_staged(enc, bins, rx, exec, opt, &st, &why);
+        int failures = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (status) status[i] = st[i];
+            if (st[i]) { ++failures; g_err = "query " + std::to_string(i) + ": " + why[i]; }
+        }
+        if (stats6) {
+            stats6[0] = s.stages; stats6[1] = s.ops; stats6[2] = s.kmers; stats6[3] = s.states; stats6[4] = s.pruned; stats6[5] = s.feedback_queries;
+        }
+        return failures;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 const void* txh_blob_data(const txh_blob* b, size_t* bytes) {
     if (bytes) *bytes = b->bytes.size();
     return b->bytes.data();

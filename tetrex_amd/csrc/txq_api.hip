@@ -119,6 +119,7 @@ int ensure(void** p, size_t* cap, size_t bytes) {
 using namespace txq;
 
 struct txq_index : txq::Index {};
+struct txq_session : txq::Session {};
 
 extern "C" {
 
@@ -311,6 +312,40 @@ int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t 
     if (int rc = run_programs(*ix, blob, blob_bytes, n_programs, ix->scratch_final, nullptr)) return rc;
     TXQ_HIP(hipMemcpy(final_masks, ix->scratch_final, bytes, hipMemcpyDeviceToHost));
     return TXQ_OK;
+}
+
+int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out) {
+    if (int rc = require_init()) return rc;
+    if (!ix || !out) return fail(TXQ_ERR_ARG, "null argument");
+    Session* s = nullptr;
+    if (int rc = session_begin(*ix, n_programs, &s)) return rc;
+    *out = static_cast<txq_session*>(s);
+    return TXQ_OK;
+}
+
+int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const uint32_t* query_program,
+                      const uint32_t* query_slot, size_t n_queries, uint8_t* alive) {
+    if (int rc = require_init()) return rc;
+    if (!s || !blob || (n_queries && (!query_program || !query_slot || !alive))) return fail(TXQ_ERR_ARG, "null argument");
+    return session_stage(*s, blob, blob_bytes, query_program, query_slot, n_queries, alive, nullptr);
+}
+
+int txq_session_end(txq_session* s, uint64_t* final_masks) {
+    if (!s) return TXQ_OK;
+    int rc = TXQ_OK;
+    if (final_masks && s->n_programs && s->W) {
+        Index& ix = *s->ix;
+        const size_t bytes = s->n_programs * (size_t)s->W * 8;
+        rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);
+        if (rc == TXQ_OK) rc = session_finish(*s, ix.scratch_final, nullptr);
+        if (rc == TXQ_OK) {
+            hipError_t e = hipMemcpy(final_masks, ix.scratch_final, bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) rc = fail_hip(e, "copying final masks");
+        }
+    }
+    (void)hipDeviceSynchronize();
+    delete static_cast<Session*>(s);
+    return rc;
 }
 
 int txq_malloc(void** dptr, size_t bytes) {

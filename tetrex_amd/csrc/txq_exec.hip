@@ -1,14 +1,19 @@
 // Mask-DAG executor for gfx950: the bit algebra of OTFCollector::collect()
-// (reference include/otf_collector.h:341-393) for a whole batch of queries in two launches.
+// (reference include/otf_collector.h:341-393) for a whole batch of queries.
 //
-//   phase 1  probe every DISTINCT k-mer of the batch once (flat IBF: txq_probe.hip gather/AND;
-//            HIBF: txq_hibf.hip descent)  ->  M[n_kmers][W] in HBM.  This is the reference's
-//            kmer_cache_ made batch-wide.
-//   phase 2  one lane group per program walks its op list; every lane owns fixed mask-word
-//            columns, so the whole program needs no barrier and no cross-lane traffic: bins are
-//            independent in every operation of the collector.  Slot masks live in a per-program
-//            HBM scratch arena that stays L2-resident (programs touch a few KiB each).
-// Format of the op list: include/txq_program.h.
+// A *session* holds the slot masks of a batch of programs in HBM while the host streams the
+// expanded frontier to the device in stages (BASELINE north star: "the NFA k-mer-path frontier
+// ... is expanded on the host and streamed to the device in batches"):
+//   per stage  (1) probe every DISTINCT k-mer of the stage once (flat IBF: txq_probe.hip;
+//                  HIBF: txq_hibf.hip)  ->  M[n_kmers][W].  The reference's kmer_cache_, batch-wide.
+//              (2) one lane group per program walks its new ops; every lane owns fixed mask-word
+//                  columns, so a program needs no barrier and no cross-lane traffic — bins are
+//                  independent in every operation of the collector.
+//              (3) optional feedback: "is slot s of program p all zero?" (path_.none(),
+//                  include/otf_collector.h:383) for the host to prune dead frontier states before
+//                  it expands them further.  One __ballot per queried slot.
+// Most queries finish in one stage; txq_run_programs is exactly that case.
+// Format of a stage's op list: include/txq_program.h.
 #include "txq_internal.hpp"
 #include "../../include/txq_program.h"
 #include <cstring>
@@ -18,25 +23,15 @@ namespace txq {
 // G lanes per program (pow2 >= W, <= 64); lane `sub` owns words sub, sub+G, ...
 template <int G>
 __global__ __launch_bounds__(256) void exec_kernel(const txq_program* __restrict__ progs, const txq_op* __restrict__ ops,
-                                                   const uint64_t* __restrict__ slot_off, uint32_t n_programs,
-                                                   const uint64_t* __restrict__ M, uint64_t* __restrict__ slots,
-                                                   uint64_t* __restrict__ final_masks, uint32_t W, uint64_t user_bins,
-                                                   uint64_t word0) {
+                                                   uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                   const uint64_t* __restrict__ M, uint32_t W) {
     const uint32_t sub = threadIdx.x % G;
     const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const size_t n_groups = ((size_t)gridDim.x * blockDim.x) / G;
     for (size_t p = group; p < n_programs; p += n_groups) {
         const txq_program pr = progs[p];
-        uint64_t* S = slots + slot_off[p];  // [n_slots][W]
-        for (uint32_t w = sub; w < W; w += G) {
-            // ONES = hit_vector(bin_count, true): bits of this shard's word that are real bins
-            const uint64_t first_bin = (word0 + w) * 64;
-            uint64_t ones = 0;
-            if (first_bin < user_bins) ones = (user_bins - first_bin >= 64) ? ~0ULL : ((1ULL << (user_bins - first_bin)) - 1ULL);
-            S[(size_t)TXQ_SLOT_ZERO * W + w] = 0;
-            S[(size_t)TXQ_SLOT_ONES * W + w] = ones;
-            S[(size_t)TXQ_SLOT_RESULT * W + w] = 0;
-        }
+        if (pr.n_ops == 0) continue;
+        uint64_t* S = slot_base[p];  // [slots][W]
         const txq_op* op = ops + pr.first_op;
         for (uint32_t i = 0; i < pr.n_ops; ++i) {
             const txq_op o = op[i];
@@ -47,7 +42,47 @@ __global__ __launch_bounds__(256) void exec_kernel(const txq_program* __restrict
                 S[(size_t)o.dst * W + w] = x;
             }
         }
-        for (uint32_t w = sub; w < W; w += G) final_masks[p * W + w] = S[(size_t)TXQ_SLOT_RESULT * W + w];
+    }
+}
+
+// constants of programs that just received their first slot region
+__global__ __launch_bounds__(256) void init_slots_kernel(uint64_t* const* __restrict__ slot_base, const uint32_t* __restrict__ which,
+                                                         uint32_t n, uint32_t W, uint64_t user_bins, uint64_t word0) {
+    const size_t total = (size_t)n * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t p = which[i / W], w = (uint32_t)(i % W);
+        uint64_t* S = slot_base[p];
+        // ONES = hit_vector(bin_count, true): the bits of this shard's word that are real bins
+        const uint64_t first_bin = (word0 + w) * 64;
+        uint64_t ones = 0;
+        if (first_bin < user_bins) ones = (user_bins - first_bin >= 64) ? ~0ULL : ((1ULL << (user_bins - first_bin)) - 1ULL);
+        S[(size_t)TXQ_SLOT_ZERO * W + w] = 0;
+        S[(size_t)TXQ_SLOT_ONES * W + w] = ones;
+        S[(size_t)TXQ_SLOT_RESULT * W + w] = 0;
+    }
+}
+
+// alive[i] = any bit set in slot q_slot[i] of program q_prog[i]; one wave per query
+__global__ __launch_bounds__(256) void slot_alive_kernel(uint64_t* const* __restrict__ slot_base, const uint32_t* __restrict__ q_prog,
+                                                         const uint32_t* __restrict__ q_slot, uint32_t n, uint32_t W,
+                                                         uint8_t* __restrict__ alive) {
+    const uint32_t lane = threadIdx.x & 63;
+    const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
+    for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += n_waves) {
+        const uint64_t* s = slot_base[q_prog[i]] + (size_t)q_slot[i] * W;
+        uint64_t any = 0;
+        for (uint32_t w = lane; w < W; w += 64) any |= s[w];
+        const bool live = __ballot(any != 0) != 0;
+        if (lane == 0) alive[i] = live ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void gather_result_kernel(uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
+                                                            uint64_t* __restrict__ final_masks) {
+    const size_t total = (size_t)n_programs * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / W, w = i % W;
+        final_masks[i] = slot_base[p][(size_t)TXQ_SLOT_RESULT * W + w];
     }
 }
 
@@ -88,61 +123,168 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     return TXQ_OK;
 }
 
-int run_programs(Index& ix, const void* blob_v, size_t bytes, size_t n_programs, uint64_t* d_final, hipStream_t s) {
+Session::~Session() {
+    for (uint64_t* c : chunks) (void)hipFree(c);
+    for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
+}
+
+// bump allocation of `words` 64-bit words of slot storage
+static int arena_alloc(Session& s, size_t words, uint64_t** out) {
+    if (s.chunks.empty() || s.chunk_used + words > s.chunk_cap) {
+        size_t cap = (size_t)8 << 20;  // 64 MiB chunks
+        if (words > cap) cap = words;
+        uint64_t* c = nullptr;
+        TXQ_HIP(hipMalloc((void**)&c, cap * 8));
+        s.chunks.push_back(c);
+        s.chunk_cap = cap;
+        s.chunk_used = 0;
+    }
+    *out = s.chunks.back() + s.chunk_used;
+    s.chunk_used += words;
+    return TXQ_OK;
+}
+
+int session_begin(Index& ix, size_t n_programs, Session** out) {
+    if (n_programs >> 31) return fail(TXQ_ERR_ARG, "too many programs");
+    Session* s = new (std::nothrow) Session();
+    if (!s) return fail(TXQ_ERR_NOMEM, "out of host memory");
+    s->ix = &ix;
+    s->n_programs = n_programs;
+    s->W = (uint32_t)ix.shard_words;
+    s->base.assign(n_programs, nullptr);
+    s->cap.assign(n_programs, 0);
+    if (n_programs) {
+        hipError_t e = hipMalloc((void**)&s->d_base, n_programs * sizeof(uint64_t*));
+        if (e != hipSuccess) { delete s; return fail_hip(e, "hipMalloc(session)"); }
+    }
+    *out = s;
+    return TXQ_OK;
+}
+
+int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
+                  uint8_t* alive, hipStream_t st) {
+    Index& ix = *s.ix;
     const unsigned char* blob = (const unsigned char*)blob_v;
     const txq_blob_header* h = nullptr;
-    if (int rc = validate_blob(blob, bytes, n_programs, &h)) return rc;
-    const uint32_t W = (uint32_t)ix.shard_words;
-    if (n_programs == 0 || W == 0) return TXQ_OK;
-
-    // slot arena offsets (in words) per program, appended to the device copy of the blob
+    if (int rc = validate_blob(blob, bytes, s.n_programs, &h)) return rc;
+    const uint32_t W = s.W;
     const txq_program* pr = (const txq_program*)(blob + h->programs_offset);
-    std::vector<uint64_t> slot_off(n_programs);
-    uint64_t total = 0;
-    for (size_t p = 0; p < n_programs; ++p) { slot_off[p] = total; total += (uint64_t)pr[p].n_slots * W; }
+    for (size_t i = 0; i < n_q; ++i) {
+        if (q_prog[i] >= s.n_programs) return fail(TXQ_ERR_ARG, "feedback query %zu: program out of range", i);
+        const uint32_t lim = pr[q_prog[i]].n_slots > s.cap[q_prog[i]] ? pr[q_prog[i]].n_slots : s.cap[q_prog[i]];
+        if (q_slot[i] >= lim) return fail(TXQ_ERR_ARG, "feedback query %zu: slot out of range", i);
+    }
+    if (W == 0 || s.n_programs == 0) {
+        for (size_t i = 0; i < n_q; ++i) alive[i] = 0;
+        return TXQ_OK;
+    }
+    // (re)size slot regions; a grown region keeps its contents
+    std::vector<uint32_t> fresh;
+    bool moved = false;
+    for (size_t p = 0; p < s.n_programs; ++p) {
+        const uint32_t need = pr[p].n_slots;
+        if (need <= s.cap[p]) continue;
+        uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
+        if (cap < need) cap = need;
+        uint64_t* region = nullptr;
+        if (int rc = arena_alloc(s, (size_t)cap * W, &region)) return rc;
+        if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * W * 8, hipMemcpyDeviceToDevice, st));
+        else fresh.push_back((uint32_t)p);
+        s.base[p] = region;
+        s.cap[p] = cap;
+        moved = true;
+    }
+    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
 
-    const size_t off_bytes = (bytes + 7) & ~(size_t)7;
-    if (int rc = ensure((void**)&ix.scratch_blob, &ix.cap_blob, off_bytes + n_programs * 8)) return rc;
-    if (int rc = ensure((void**)&ix.scratch_slots, &ix.cap_slots, total * 8)) return rc;
+    // staging: blob | fresh-program list | feedback queries | alive bytes
+    const size_t blob_pad = (bytes + 7) & ~(size_t)7;
+    if (int rc = ensure((void**)&s.d_blob, &s.cap_blob, blob_pad)) return rc;
+    const size_t aux_bytes = fresh.size() * 4 + n_q * 8 + n_q + 64;
+    if (int rc = ensure((void**)&s.d_aux, &s.cap_aux, aux_bytes)) return rc;
     const size_t nk = h->n_kmers;
     if (int rc = ensure((void**)&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
-    // The staging copies below read pageable host memory; they are synchronous with respect to
-    // the host buffer, so `blob` may be reused by the caller as soon as this function returns.
-    TXQ_HIP(hipMemcpyAsync(ix.scratch_blob, blob, bytes, hipMemcpyHostToDevice, s));
-    TXQ_HIP(hipMemcpyAsync(ix.scratch_blob + off_bytes, slot_off.data(), n_programs * 8, hipMemcpyHostToDevice, s));
-    TXQ_HIP(hipStreamSynchronize(s));  // slot_off is a local; the blob copy must also have left host memory
+    TXQ_HIP(hipMemcpyAsync(s.d_blob, blob, bytes, hipMemcpyHostToDevice, st));
+    uint32_t* d_fresh = (uint32_t*)s.d_aux;
+    uint32_t* d_qp = d_fresh + fresh.size();
+    uint32_t* d_qs = d_qp + n_q;
+    uint8_t* d_alive = (uint8_t*)(d_qs + n_q);
+    if (!fresh.empty()) TXQ_HIP(hipMemcpyAsync(d_fresh, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice, st));
+    if (n_q) {
+        TXQ_HIP(hipMemcpyAsync(d_qp, q_prog, n_q * 4, hipMemcpyHostToDevice, st));
+        TXQ_HIP(hipMemcpyAsync(d_qs, q_slot, n_q * 4, hipMemcpyHostToDevice, st));
+    }
+    // pageable host buffers: the copies above have left host memory once the stream drains;
+    // `fresh`/`base` are locals, so drain before they go out of scope or are reused
+    TXQ_HIP(hipStreamSynchronize(st));
 
-    const uint64_t* d_kmers = (const uint64_t*)(ix.scratch_blob + h->kmers_offset);
+    if (!fresh.empty()) {
+        size_t blocks = (fresh.size() * W + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
+    }
+    const uint64_t* d_kmers = (const uint64_t*)(s.d_blob + h->kmers_offset);
     if (nk) {
         if (ix.is_hibf) {
-            if (int rc = hibf_probe(ix, d_kmers, nk, ix.scratch_masks, nullptr, s)) return rc;
+            if (int rc = hibf_probe(ix, d_kmers, nk, ix.scratch_masks, nullptr, st)) return rc;
         } else {
-            hipError_t e = launch_probe(ix.ibf[0], d_kmers, nk, ix.scratch_masks, nullptr, s);
+            hipError_t e = launch_probe(ix.ibf[0], d_kmers, nk, ix.scratch_masks, nullptr, st);
             if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
         }
     }
-    int g = 1;
-    while (g < 64 && (uint32_t)g < W) g <<= 1;
-    size_t blocks = (n_programs * g + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    const txq_program* d_pr = (const txq_program*)(ix.scratch_blob + h->programs_offset);
-    const txq_op* d_ops = (const txq_op*)(ix.scratch_blob + h->ops_offset);
-    const uint64_t* d_off = (const uint64_t*)(ix.scratch_blob + off_bytes);
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 256, 0, s>>>(d_pr, d_ops, d_off, (uint32_t)n_programs, ix.scratch_masks, \
-                                                                    ix.scratch_slots, d_final, W, ix.user_bins, ix.shard_word0)
-    switch (g) {
-        case 1: TXQ_EXEC(1); break;
-        case 2: TXQ_EXEC(2); break;
-        case 4: TXQ_EXEC(4); break;
-        case 8: TXQ_EXEC(8); break;
-        case 16: TXQ_EXEC(16); break;
-        case 32: TXQ_EXEC(32); break;
-        default: TXQ_EXEC(64); break;
-    }
+    if (h->n_ops) {
+        int g = 1;
+        while (g < 64 && (uint32_t)g < W) g <<= 1;
+        size_t blocks = (s.n_programs * g + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        const txq_program* d_pr = (const txq_program*)(s.d_blob + h->programs_offset);
+        const txq_op* d_ops = (const txq_op*)(s.d_blob + h->ops_offset);
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 256, 0, st>>>(d_pr, d_ops, s.d_base, (uint32_t)s.n_programs, ix.scratch_masks, W)
+        switch (g) {
+            case 1: TXQ_EXEC(1); break;
+            case 2: TXQ_EXEC(2); break;
+            case 4: TXQ_EXEC(4); break;
+            case 8: TXQ_EXEC(8); break;
+            case 16: TXQ_EXEC(16); break;
+            case 32: TXQ_EXEC(32); break;
+            default: TXQ_EXEC(64); break;
+        }
 #undef TXQ_EXEC
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "exec kernel launch");
+    if (n_q) {
+        size_t blocks = (n_q + 3) / 4;
+        if (blocks > 2048) blocks = 2048;
+        slot_alive_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_qp, d_qs, (uint32_t)n_q, W, d_alive);
+        TXQ_HIP(hipGetLastError());
+        TXQ_HIP(hipMemcpyAsync(alive, d_alive, n_q, hipMemcpyDeviceToHost, st));
+        TXQ_HIP(hipStreamSynchronize(st));
+    }
     return TXQ_OK;
+}
+
+int session_finish(Session& s, uint64_t* d_final, hipStream_t st) {
+    const uint32_t W = s.W;
+    if (W == 0 || s.n_programs == 0) return TXQ_OK;
+    for (size_t p = 0; p < s.n_programs; ++p)
+        if (!s.base[p]) return fail(TXQ_ERR_STATE, "program %zu never ran a stage", p);
+    size_t blocks = (s.n_programs * W + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    gather_result_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, (uint32_t)s.n_programs, W, d_final);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "gather kernel launch");
+    return TXQ_OK;
+}
+
+int run_programs(Index& ix, const void* blob, size_t bytes, size_t n_programs, uint64_t* d_final, hipStream_t st) {
+    Session* s = nullptr;
+    if (int rc = session_begin(ix, n_programs, &s)) return rc;
+    int rc = session_stage(*s, blob, bytes, nullptr, nullptr, 0, nullptr, st);
+    if (rc == TXQ_OK) rc = session_finish(*s, d_final, st);
+    // the slot arena must outlive the kernels that read it
+    if (hipStreamSynchronize(st) != hipSuccess && rc == TXQ_OK) rc = fail(TXQ_ERR_HIP, "stream synchronize failed");
+    delete s;
+    return rc;
 }
 
 }  // namespace txq

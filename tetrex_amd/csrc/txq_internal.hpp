@@ -36,6 +36,21 @@ struct Index {
     void release();
 };
 
+// A batch of programs whose slot masks persist in HBM across stages (txq_exec.hip).
+struct Session {
+    Index* ix = nullptr;
+    size_t n_programs = 0;
+    uint32_t W = 0;
+    std::vector<uint64_t*> chunks;  // arena chunks
+    size_t chunk_used = 0, chunk_cap = 0;
+    std::vector<uint64_t*> base;    // per program: its slot region [cap][W]
+    std::vector<uint32_t> cap;      // per program: slots allocated
+    uint64_t** d_base = nullptr;
+    unsigned char* d_blob = nullptr; size_t cap_blob = 0;
+    unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+    ~Session();
+};
+
 int fail(int code, const char* fmt, ...);
 int fail_hip(hipError_t e, const char* what);
 int ensure(void** p, size_t* cap, size_t bytes);
@@ -51,5 +66,9 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
 
 // txq_exec.hip
 int run_programs(Index& ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final, hipStream_t s);
+int session_begin(Index& ix, size_t n_programs, Session** out);
+int session_stage(Session& s, const void* blob, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
+                  uint8_t* alive, hipStream_t st);
+int session_finish(Session& s, uint64_t* d_final, hipStream_t st);
 
 }  // namespace txq

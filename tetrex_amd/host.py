@@ -87,6 +87,43 @@ def compile_batch(regexes, dna, k, reduction, bins):
     return blob, list(status), stats
 
 
+STAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.c_size_t,
+                       C.POINTER(C.c_uint8))
+
+
+def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0):
+    """Drive the C++ staged expansion with a Python executor.
+
+    stage(blob: bytes, query_program: list, query_slot: list) -> iterable of bool (alive)."""
+    L = lib()
+    L.txh_run_staged.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
+                                 C.c_size_t, STAGE_FN, C.c_void_p, C.POINTER(C.c_int), u64p]
+    n = len(regexes)
+    arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
+    status = (C.c_int * n)()
+    stats = (C.c_uint64 * 6)()
+    err = []
+
+    def cb(user, blob, size, qp, qs, nq, alive):
+        try:
+            res = stage(C.string_at(blob, size), [qp[i] for i in range(nq)], [qs[i] for i in range(nq)])
+            for i, a in enumerate(res):
+                alive[i] = 1 if a else 0
+            return 0
+        except Exception as e:  # noqa: BLE001 - reported through the return code
+            err.append(e)
+            return -1
+
+    rc = L.txh_run_staged(arr, n, int(dna), k, reduction, bins, ops_per_query_per_stage, ops_per_stage, STAGE_FN(cb), None,
+                          status, stats)
+    if err:
+        raise err[0]
+    if rc < 0:
+        raise _err()
+    keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries")
+    return list(status), dict(zip(keys, (int(x) for x in stats)))
+
+
 def record_values(seq, k, dna=True, reduction=0, wraparound=False):
     s = seq.encode() if isinstance(seq, str) else seq
     cap = len(s) + 2
