@@ -14,7 +14,13 @@ CLI_SRCS  := $(HOST_DIR)/main.cpp $(HOST_DIR)/device_index.cpp $(HOST_DIR)/verif
 HOST_HDRS := $(wildcard $(HOST_DIR)/*.hpp) include/txh.h include/txq_program.h
 HOSTFLAGS := -O2 -g -std=c++20 -fPIC -Wall -Wextra -pthread
 
-all: tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so bin/tetrex oracle/liboracle.so
+all: tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so tetrex_amd/libtetrex_query.so bin/tetrex oracle/liboracle.so
+
+# whole-query execution on a GPU-resident index (host front-end + libtxq session), for bindings
+QUERY_SRCS := $(HOST_DIR)/query_capi.cpp $(HOST_DIR)/device_index.cpp $(HOST_DIR)/fasta.cpp
+tetrex_amd/libtetrex_query.so: $(QUERY_SRCS) $(HOST_SRCS) $(HOST_HDRS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so
+	$(CXX) $(HOSTFLAGS) -shared -o $@ $(QUERY_SRCS) -Ltetrex_amd -ltetrex_host -ltxq -lz \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,--enable-new-dtags
 
 # The `tetrex` CLI: C++ host + libtxq.so (GPU) + zlib; the HIP runtime comes in through libtxq.so.
 bin/tetrex: $(CLI_SRCS) $(HOST_SRCS) $(HOST_HDRS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so
@@ -45,7 +51,7 @@ oracle/liboracle.so: $(wildcard oracle/*.hpp) oracle/txo_capi.cpp
 	$(MAKE) -C oracle liboracle.so
 
 clean:
-	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so bin/tetrex
+	rm -f $(HIP_OBJS) tetrex_amd/libtxq.so tetrex_amd/libtetrex_host.so tetrex_amd/libtetrex_query.so bin/tetrex
 	rm -rf $(CSRC)/hiprt_stub
 	$(MAKE) -C oracle clean
 .PHONY: all clean

@@ -90,6 +90,50 @@ def cpu_baseline(ix, m, h, bins_local, kmers, sample, threads):
     return out, q.size / dt, dt
 
 
+def end_to_end_queries(ix, torch, dist, world, rank, args):
+    """Second headline metric (BASELINE.json): end-to-end queries/s = regex -> candidate-bin mask.
+    Host: C++ front-end (regex -> k-graph -> staged frontier expansion); device: probe + mask-DAG
+    executor with dead-state feedback; N>1: RCCL all-gather of the final per-query masks.
+    Verification of the candidate bins (disk + regex scan) is not part of this figure.
+    Runs after the timed probe steps; it does not touch `value`."""
+    from motifs import random_prosite_motifs
+    from tetrex_amd.dist import gather_final_masks
+    k = 4
+    single = "LMA(E|Q)GLYN"  # BASELINE configs[1] motif
+    ix.query_masks([single], False, k)  # warm-up (library load, first launches)
+    lat = []
+    for _ in range(20):
+        t0 = time.perf_counter()
+        ix.query_masks([single], False, k)
+        lat.append(time.perf_counter() - t0)
+    motifs = random_prosite_motifs(args.motifs, 6)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    masks, status, stats = ix.query_masks(motifs, False, k)
+    t1 = time.perf_counter()
+    gather_s = 0.0
+    if world > 1:
+        local = torch.from_numpy(masks.view(np.int64)).cuda()
+        full = gather_final_masks(local, ix.info.mask_words)
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - t1
+        t = torch.tensor([t1 - t0 + gather_s], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+        assert full.shape == (len(motifs), int(ix.info.mask_words))
+    else:
+        total = t1 - t0
+    return {
+        "metric": "end-to-end queries/sec (regex -> candidate-bin mask, verification excluded)",
+        "batch_queries_per_s": len(motifs) / total,
+        "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
+                  "k": k, **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
+        "single_query": {"motif": single, "median_latency_ms": float(np.median(lat)) * 1e3,
+                         "queries_per_s": 1.0 / float(np.median(lat))},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +145,8 @@ def main():
     ap.add_argument("--hash", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="k-mers timed on the CPU oracle (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-queries", action="store_true", help="skip the end-to-end queries/s leg")
+    ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
     ap.add_argument("--kmer-bits", type=int, default=20)
     args = ap.parse_args()
@@ -227,6 +273,9 @@ def main():
             out["cpu_baseline_all_cores"] = {"value": mt_rate, "unit": "probes/s", "cores": ncores, "kind": "port",
                                              "sample": "same sample, %d threads, %.1f s" % (ncores, mt_dt)}
         out["parity_checked_probes"] = int(sample)
+
+    if not args.no_queries:
+        out["end_to_end"] = end_to_end_queries(ix, torch, dist, world, rank, args)
 
     ix.free()
     if world > 1:

@@ -49,6 +49,14 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
                    size_t ops_per_query_per_stage, size_t ops_per_stage, txh_stage_fn fn, void* user, int* status,
                    uint64_t* stats6);
 
+/* End-to-end candidate masks on an index that already lives on the GPU (a txq_index* from
+ * include/txq.h, passed as void* so this header stays free of txq types): host expansion +
+ * staged device execution.  masks: n x shard_words words.  stats6 as in txh_run_staged.
+ * Exported by libtetrex_query.so (which links libtxq.so), not by libtetrex_host.so. */
+int txe_query_masks(void* txq_index_handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
+                    size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6);
+const char* txe_last_error(void);
+
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap);

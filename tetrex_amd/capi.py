@@ -85,6 +85,24 @@ def lib():
     return _LIB
 
 
+_QLIB = None
+
+
+def _query_lib():
+    global _QLIB
+    if _QLIB is None:
+        lib()  # libtxq.so first, so the query library binds to the same copy
+        path = os.path.join(_HERE, "libtetrex_query.so")
+        if not os.path.exists(path):
+            raise ImportError("%s is missing: run `make`" % path)
+        L = C.CDLL(path)
+        L.txe_last_error.restype = C.c_char_p
+        L.txe_query_masks.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t,
+                                      u64p, C.POINTER(C.c_int), u64p]
+        _QLIB = L
+    return _QLIB
+
+
 def check(rc):
     if rc != 0:
         raise TxqError(rc, lib().txq_last_error().decode(errors="replace"))
@@ -252,6 +270,22 @@ class Index:
 
     def session(self, n_programs):
         return Session(self, n_programs)
+
+    def query_masks(self, regexes, dna, k, reduction=0, ops_per_query_per_stage=0):
+        """Whole queries on this GPU-resident index through the C++ host (libtetrex_query.so):
+        returns (masks [n, shard_words], status list, stats dict)."""
+        Lq = _query_lib()
+        n = len(regexes)
+        arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
+        masks = np.zeros((n, self.shard_words), dtype=np.uint64)
+        status = (C.c_int * n)()
+        stats = (C.c_uint64 * 6)()
+        rc = Lq.txe_query_masks(self._h, int(dna), k, reduction, arr, n, ops_per_query_per_stage,
+                                masks.ctypes.data_as(u64p), status, stats)
+        if rc < 0:
+            raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
+        keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries")
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)))
 
     def run_programs(self, blob, n_programs):
         buf = np.frombuffer(blob, dtype=np.uint8)

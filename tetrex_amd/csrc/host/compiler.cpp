@@ -1,7 +1,11 @@
 #include "compiler.hpp"
 #include "regex_front.hpp"
 
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <map>
+#include <thread>
 #include <stdexcept>
 
 namespace tetrex {
@@ -39,14 +43,88 @@ std::vector<uint8_t> make_blob(const std::vector<uint64_t>& kmers, const std::ve
 
 // ---- QueryExpansion -----------------------------------------------------------------------
 
+static bool is_epsilon(int32_t label) { return label == KGraph::kGhost || label == KGraph::kSplit || label == '$'; }
+
 QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits)
     : enc_(enc), g_(std::move(graph)), limits_(limits) {
     if (enc_.k() < 2) throw std::runtime_error("k must be at least 2");
-    order_ = g_.topological_order();
-    table_.resize(g_.size());
+    const int32_t n = n_nodes_ = g_.size();
+    const std::vector<int32_t> topo = g_.topological_order();
+    for (int32_t v : topo)
+        if (g_.label[v] == KGraph::kGap) throw std::runtime_error("gap nodes (-a/-g) are not supported yet");
+    // closure[v] of epsilon nodes, successors first
+    std::vector<std::vector<int32_t>> closure(n);
+    std::vector<uint8_t> hole(n, 0);
+    auto through = [&](int32_t t, std::vector<int32_t>& out, uint8_t& dang) {
+        if (t == KGraph::kNone) { dang = 1; return; }
+        if (!is_epsilon(g_.label[t])) { out.push_back(t); return; }
+        out.insert(out.end(), closure[t].begin(), closure[t].end());
+        dang |= hole[t];
+    };
+    auto unique = [](std::vector<int32_t>& v) {
+        std::sort(v.begin(), v.end());
+        v.erase(std::unique(v.begin(), v.end()), v.end());
+    };
+    for (size_t i = topo.size(); i-- > 0;) {
+        const int32_t v = topo[i];
+        if (!is_epsilon(g_.label[v])) continue;
+        through(g_.next_a[v], closure[v], hole[v]);
+        if (g_.label[v] == KGraph::kSplit) through(g_.next_b[v], closure[v], hole[v]);
+        unique(closure[v]);
+    }
+    // per source item (residue nodes and the entry n): its target set -> join or single target
+    forward_.assign(n + 1, KGraph::kNone);
+    dangling_.assign(n + 1, 0);
+    fan_first_.assign(1, 0);
+    std::map<std::vector<int32_t>, int32_t> join_of;
+    for (int32_t u = 0; u <= n; ++u) {
+        std::vector<int32_t> t;
+        if (u == n) through(0, t, dangling_[u]);
+        else if (!is_epsilon(g_.label[u]) && g_.label[u] != KGraph::kMatch) through(g_.next_a[u], t, dangling_[u]);
+        else continue;
+        unique(t);
+        if (t.empty()) continue;
+        if (t.size() == 1) { forward_[u] = t[0]; continue; }
+        auto [it, fresh_join] = join_of.emplace(t, n + 1 + (int32_t)join_of.size());
+        if (fresh_join) {
+            fan_.insert(fan_.end(), t.begin(), t.end());
+            fan_first_.push_back((uint32_t)fan_.size());
+        }
+        forward_[u] = it->second;
+    }
+    const int32_t items = n + 1 + (int32_t)join_of.size();
+    forward_.resize(items, KGraph::kNone);
+    dangling_.resize(items, 0);
+    // topological order of the derived graph (Kahn): edges u -> forward_[u], join -> its targets
+    std::vector<int32_t> indeg(items, 0);
+    auto targets_of = [&](int32_t item, auto&& fn) {
+        if (item > n) { for (uint32_t i = fan_first_[item - n - 1]; i < fan_first_[item - n]; ++i) fn(fan_[i]); }
+        else if (forward_[item] != KGraph::kNone) fn(forward_[item]);
+    };
+    std::vector<uint8_t> live(items, 0);
+    for (int32_t v = 0; v < n; ++v) live[v] = !is_epsilon(g_.label[v]);
+    for (int32_t v = n; v < items; ++v) live[v] = 1;
+    for (int32_t v = 0; v < items; ++v)
+        if (live[v]) targets_of(v, [&](int32_t t) { ++indeg[t]; });
+    std::vector<int32_t> ready;
+    for (int32_t v = 0; v < items; ++v)
+        if (live[v] && indeg[v] == 0) ready.push_back(v);
+    for (size_t at = 0; at < ready.size(); ++at) {
+        const int32_t v = ready[at];
+        if (v != n) order_.push_back(v);
+        targets_of(v, [&](int32_t t) { if (--indeg[t] == 0) ready.push_back(t); });
+    }
+    table_.resize(items);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
     std::vector<txq_op> none;
-    arrive(0, State{0, TXQ_SLOT_ONES, 0}, none);
+    hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0}, none);
+}
+
+// a state leaves item `from` (a residue node or the entry): to its join or only target
+void QueryExpansion::hand_on(int32_t from, State s, std::vector<txq_op>& out) {
+    if (dangling_[from]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
+    if (forward_[from] == KGraph::kNone) { drop(s.slot); return; }
+    arrive(forward_[from], s, out);
 }
 
 uint32_t QueryExpansion::fresh() {
@@ -71,20 +149,20 @@ void QueryExpansion::emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst,
 
 // hand a state (owning one reference to its slot) to node `to`
 void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
-    if (to == KGraph::kNone) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
     // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just
     // above them, so paths of different length < k-1 never share a key
     const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
     const uint64_t key = (s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits));
-    auto [it, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
+    auto [where, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
     if (inserted) {
+        s.asked = 0;
         ns.items.push_back(s);
         if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         return;
     }
-    State& have = ns.items[it->second];
+    State& have = ns.items[*where];
     if (have.shift < s.shift) have.shift = s.shift;  // k-1 and k behave alike from here on
     if (have.slot == s.slot) { drop(s.slot); return; }
     // absorb: have.path |= s.path
@@ -104,65 +182,64 @@ void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     }
 }
 
-void QueryExpansion::advance(size_t op_budget, const Intern& intern, std::vector<txq_op>& out) {
+void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op>& out) {
     const unsigned k = enc_.k();
     const size_t start = out.size();
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
-        const int32_t node = order_[cursor_++];
+        const int32_t item = order_[cursor_++];
         NodeStates ns;
-        ns.items.swap(table_[node].items);
-        table_[node].by_key.clear();
-        const int32_t lab = g_.label[node];
-        for (State s : ns.items) {
-            switch (lab) {
-                case KGraph::kMatch:
-                    emit(out, TXQ_NO_KMER, TXQ_SLOT_RESULT, s.slot, TXQ_SLOT_RESULT);
-                    drop(s.slot);
-                    break;
-                case '$':  // passes through untouched (include/otf_collector.h:364-368)
-                case KGraph::kGhost:
-                    arrive(g_.next_a[node], s, out);
-                    break;
-                case KGraph::kSplit:
-                    share(s.slot);
-                    arrive(g_.next_a[node], s, out);
-                    arrive(g_.next_b[node], s, out);
-                    break;
-                case KGraph::kGap:
-                    throw std::runtime_error("gap nodes (-a/-g) are not supported yet");
-                default: {
-                    const uint64_t probe = enc_.roll((unsigned char)lab, s.kmer);
-                    if (s.shift < k - 1) {
-                        ++s.shift;
-                    } else {
-                        const uint32_t id = intern(probe);
-                        ++probes_;
-                        if (exclusive(s.slot)) {
-                            emit(out, id, s.slot, s.slot, TXQ_SLOT_ZERO);
-                        } else {
-                            const uint32_t d = fresh();
-                            emit(out, id, d, s.slot, TXQ_SLOT_ZERO);
-                            drop(s.slot);
-                            s.slot = d;
-                        }
-                        s.shift = (uint8_t)k;
-                    }
-                    arrive(g_.next_a[node], s, out);
-                    break;
-                }
+        ns.items.swap(table_[item].items);
+        table_[item].by_key.clear();
+        if (item > n_nodes_) {  // join: equal states were merged on arrival; fan out
+            const uint32_t lo = fan_first_[item - n_nodes_ - 1], hi = fan_first_[item - n_nodes_];
+            for (const State& s : ns.items) {
+                for (uint32_t i = lo + 1; i < hi; ++i) share(s.slot);
+                for (uint32_t i = lo; i < hi; ++i) arrive(fan_[i], s, out);
             }
+            continue;
+        }
+        const int32_t lab = g_.label[item];
+        if (lab == KGraph::kMatch) {
+            for (const State& s : ns.items) {
+                emit(out, TXQ_NO_KMER, TXQ_SLOT_RESULT, s.slot, TXQ_SLOT_RESULT);
+                drop(s.slot);
+            }
+            continue;
+        }
+        for (State s : ns.items) {
+            const uint64_t probe = enc_.roll((unsigned char)lab, s.kmer);
+            if (s.shift < k - 1) {
+                ++s.shift;
+            } else {
+                const uint32_t id = intern.intern(probe);
+                ++probes_;
+                if (exclusive(s.slot)) {
+                    emit(out, id, s.slot, s.slot, TXQ_SLOT_ZERO);
+                } else {
+                    const uint32_t d = fresh();
+                    emit(out, id, d, s.slot, TXQ_SLOT_ZERO);
+                    drop(s.slot);
+                    s.slot = d;
+                }
+                s.shift = (uint8_t)k;
+            }
+            hand_on(item, s, out);
         }
     }
 }
 
-void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) const {
+void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) {
     std::vector<uint8_t> seen(refs_.size(), 0);
     for (size_t c = cursor_; c < order_.size(); ++c)
-        for (const State& s : table_[order_[c]].items)
-            if (s.slot >= TXQ_SLOT_FIRST_FREE && !seen[s.slot]) { seen[s.slot] = 1; out.push_back(s.slot); }
+        for (State& s : table_[order_[c]].items) {
+            if (s.asked) continue;
+            s.asked = 1;
+            if (s.slot >= TXQ_SLOT_FIRST_FREE && !seen[s.slot]) { seen[s.slot] = 1; out.push_back(s.slot); ++asked_; }
+        }
 }
 
 void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     for (size_t c = cursor_; c < order_.size(); ++c) {
         NodeStates& ns = table_[order_[c]];
         bool any = false;
@@ -176,7 +253,6 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         }
         ns.items.swap(keep);
         ns.by_key.clear();
-        const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
@@ -190,56 +266,85 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
 StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
                        const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages) {
     const size_t n = regexes.size();
-    if (status) status->assign(n, 0);
-    if (messages) messages->assign(n, std::string());
+    std::vector<int> st_local(n, 0);
+    std::vector<std::string> why(n);
     std::vector<std::unique_ptr<QueryExpansion>> q(n);
     std::vector<uint8_t> passthrough(n, 0);
-    auto failed = [&](size_t i, const char* why) {
-        q[i].reset();
-        if (status) (*status)[i] = -1;
-        if (messages) (*messages)[i] = why;
+    int threads = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n) threads = n ? (int)n : 1;
+
+    // every query is expanded by one thread at a time; threads own disjoint queries
+    auto parallel_for = [&](const std::function<void(size_t, int)>& body) {
+        if (threads == 1) { for (size_t i = 0; i < n; ++i) body(i, 0); return; }
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t]() {
+                for (size_t i; (i = next.fetch_add(1)) < n;) body(i, t);
+            });
+        for (auto& th : pool) th.join();
     };
-    for (size_t i = 0; i < n; ++i) {
+
+    parallel_for([&](size_t i, int) {
         try {
-            if (bins <= 1) { passthrough[i] = 1; continue; }  // include/query.h:265-272
+            if (bins <= 1) { passthrough[i] = 1; return; }  // include/query.h:265-272
             const std::string postfix = preprocess_query(regexes[i], enc);
             q[i] = std::make_unique<QueryExpansion>(enc, build_kgraph(postfix, enc.k(), enc.alphabet() != Alphabet::Base), opt.limits);
-        } catch (const std::exception& e) { failed(i, e.what()); }
-    }
+        } catch (const std::exception& e) {
+            q[i].reset();
+            st_local[i] = -1;
+            why[i] = e.what();
+        }
+    });
+
     StagedStats st;
     std::vector<std::vector<txq_op>> ops(n);
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
+    std::vector<int> owner(n, 0);  // which thread's k-mer table the ops of query i refer to
+    std::vector<KmerTable> tables(threads);
     bool first = true;
     for (;;) {
-        std::vector<uint64_t> kmers;
-        std::unordered_map<uint64_t, uint32_t> index;
-        const QueryExpansion::Intern intern = [&](uint64_t v) {
-            auto [it, fresh] = index.emplace(v, (uint32_t)kmers.size());
-            if (fresh) kmers.push_back(v);
-            return it->second;
-        };
-        size_t total = 0;
-        bool pending = false;
-        for (size_t i = 0; i < n; ++i) {
+        for (auto& t : tables) t.clear();
+        std::atomic<size_t> total{0};
+        parallel_for([&](size_t i, int t) {
             ops[i].clear();
+            owner[i] = t;
             if (first && passthrough[i]) ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
-            if (!q[i] || q[i]->done()) continue;
-            if (total < opt.ops_per_stage) {
-                try {
-                    q[i]->advance(opt.ops_per_query_per_stage, intern, ops[i]);
-                } catch (const std::exception& e) {
-                    // ops already emitted in earlier stages only ever feed RESULT through a Match
-                    // op, so an abandoned query is neutralised by not emitting anything further
-                    ops[i].clear();
-                    failed(i, e.what());
-                    continue;
-                }
-                total += ops[i].size();
-                slots[i] = q[i]->n_slots();
+            if (!q[i] || q[i]->done()) return;
+            if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
+            try {
+                q[i]->advance(opt.ops_per_query_per_stage, tables[t], ops[i]);
+            } catch (const std::exception& e) {
+                // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
+                // query is neutralised by not emitting anything further
+                ops[i].clear();
+                q[i].reset();
+                st_local[i] = -1;
+                why[i] = e.what();
+                return;
             }
-            if (!q[i]->done()) pending = true;
+            total.fetch_add(ops[i].size(), std::memory_order_relaxed);
+            slots[i] = q[i]->n_slots();
+        });
+        bool pending = false;
+        for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
+        if (!first && total.load() == 0 && !pending) break;
+
+        // merge the per-thread k-mer tables into the stage table and renumber the ops
+        KmerTable merged;
+        std::vector<std::vector<uint32_t>> remap(threads);
+        for (int t = 0; t < threads; ++t) {
+            remap[t].reserve(tables[t].values().size());
+            for (uint64_t v : tables[t].values()) remap[t].push_back(merged.intern(v));
         }
-        if (!first && total == 0 && !pending) break;
+        if (threads > 1)
+            parallel_for([&](size_t i, int) {
+                const std::vector<uint32_t>& m = remap[owner[i]];
+                for (txq_op& o : ops[i])
+                    if (o.kmer != TXQ_NO_KMER) o.kmer = m[o.kmer];
+            });
+
         std::vector<txq_program> programs(n);
         std::vector<const std::vector<txq_op>*> ops_of(n);
         uint32_t at = 0;
@@ -250,16 +355,16 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         }
         std::vector<uint32_t> qp, qs;
         for (size_t i = 0; i < n; ++i) {
-            if (!q[i] || q[i]->done()) continue;
+            if (!q[i] || q[i]->done() || !q[i]->wants_feedback()) continue;
             const size_t before = qs.size();
             q[i]->frontier_slots(qs);
             qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        exec.stage(make_blob(kmers, programs, ops_of), qp, qs, alive);
+        exec.stage(make_blob(merged.values(), programs, ops_of), qp, qs, alive);
         ++st.stages;
-        st.ops += total;
-        st.kmers += kmers.size();
+        st.ops += total.load();
+        st.kmers += merged.values().size();
         st.feedback_queries += qp.size();
         // prune dead frontier states
         for (size_t a = 0; a < qp.size();) {
@@ -275,20 +380,12 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     }
     for (size_t i = 0; i < n; ++i)
         if (q[i]) { st.states += q[i]->states(); st.pruned += q[i]->pruned(); }
+    if (status) *status = st_local;
+    if (messages) *messages = why;
     return st;
 }
 
 // ---- one-shot batches ----------------------------------------------------------------------
-
-uint32_t ProgramBatch::intern(uint64_t value) {
-    auto it = kmer_index_.find(value);
-    if (it != kmer_index_.end()) return it->second;
-    if (kmers_.size() >= 0xFFFFFFFEu) throw std::runtime_error("k-mer table overflow");
-    const uint32_t id = (uint32_t)kmers_.size();
-    kmers_.push_back(value);
-    kmer_index_.emplace(value, id);
-    return id;
-}
 
 size_t ProgramBatch::add_passthrough() {
     QueryProgram p;
@@ -305,7 +402,7 @@ size_t ProgramBatch::add_empty() {
 size_t ProgramBatch::add(const KGraph& g) {
     QueryExpansion x(enc_, g, limits_);
     QueryProgram prog;
-    x.advance(SIZE_MAX, [this](uint64_t v) { return intern(v); }, prog.ops);
+    x.advance(SIZE_MAX, table_, prog.ops);
     prog.n_slots = x.n_slots();
     prog.states = x.states();
     prog.probes = x.probes();
@@ -322,7 +419,7 @@ std::vector<uint8_t> ProgramBatch::serialise() const {
         first += (uint32_t)programs_[i].ops.size();
         ops_of[i] = &programs_[i].ops;
     }
-    return make_blob(kmers_, pr, ops_of);
+    return make_blob(table_.values(), pr, ops_of);
 }
 
 }  // namespace tetrex

@@ -7,8 +7,12 @@
 // of performing them.  The k-mers a query needs are collected into a batch-wide, deduplicated
 // table (the reference's kmer_cache_, :54,260-264), so the device probes each one once.
 //
-// Differences to the reference, both result-preserving on inputs where the reference's result
+// Differences to the reference, all result-preserving on inputs where the reference's result
 // is well defined:
+//   * Ghost, Split and '$' nodes never touch a mask, so they are removed up front (epsilon
+//     closure): a state leaving a residue node is handed directly to every residue/Match node it
+//     can reach.  The reference walks a 20-way wildcard union through 19 Split and 19 Ghost
+//     nodes, i.e. ~250 state visits per incoming state; here it is 20;
 //   * states are never pruned (path_.none(), :383): a dead state only contributes zero masks;
 //   * the state key also contains min(shift_count, k-1), so a path that has not yet seen k-1
 //     symbols is never merged into one that has (the reference merges them when the leading
@@ -16,6 +20,7 @@
 //     SURVEY.md §7 "state-merge quirk").
 #pragma once
 #include "encoder.hpp"
+#include "flat_map.hpp"
 #include "kgraph.hpp"
 #include "../../../include/txq_program.h"
 
@@ -41,18 +46,37 @@ struct QueryProgram {
 
 // Resumable expansion of ONE query: emits ops node by node (topological order) and can pause
 // between nodes so that the device can report which waiting states are already dead.
+// k-mer value -> dense index, in first-seen order (one per stage and per expansion thread)
+class KmerTable {
+  public:
+    uint32_t intern(uint64_t value) {
+        auto [slot, fresh] = index_.emplace(value, (uint32_t)values_.size());
+        if (fresh) values_.push_back(value);
+        return *slot;
+    }
+    const std::vector<uint64_t>& values() const { return values_; }
+    void clear() { index_.clear(); values_.clear(); }
+
+  private:
+    FlatMap index_;
+    std::vector<uint64_t> values_;
+};
+
 class QueryExpansion {
   public:
-    using Intern = std::function<uint32_t(uint64_t)>;  // k-mer value -> index in the current stage's table
+    using Intern = KmerTable&;
     QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits);
 
     bool done() const { return cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
-    void advance(size_t op_budget, const Intern& intern, std::vector<txq_op>& out);
+    void advance(size_t op_budget, Intern intern, std::vector<txq_op>& out);
     uint32_t n_slots() const { return high_water_; }
-    // distinct non-constant slots held by states that wait at unexpanded nodes
-    void frontier_slots(std::vector<uint32_t>& out) const;
+    // distinct non-constant slots of waiting states that were not asked about before (a waiting
+    // state's mask only ever grows, so one answer per state is enough); marks them as asked
+    void frontier_slots(std::vector<uint32_t>& out);
+    // feedback is pointless where (almost) nothing dies: stop asking after enough evidence
+    bool wants_feedback() const { return asked_ < 2048 || pruned_ * 50 >= asked_; }
     // drop every waiting state whose slot is listed as dead (dead[slot] != 0)
     void prune(const std::vector<uint8_t>& dead_by_slot);
     uint64_t states() const { return states_; }
@@ -61,23 +85,34 @@ class QueryExpansion {
     uint64_t total_ops() const { return total_ops_; }
 
   private:
-    struct State { uint64_t kmer; uint32_t slot; uint8_t shift; };
-    struct NodeStates { std::vector<State> items; std::unordered_map<uint64_t, uint32_t> by_key; };
+    struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; };
+    struct NodeStates { std::vector<State> items; FlatMap by_key; };
     const KmerEncoder& enc_;
     KGraph g_;
     CompileLimits limits_;
-    std::vector<int32_t> order_;
+    // Derived, epsilon-free graph.  Items 0..n-1 are the k-graph's nodes (only residue and Match
+    // nodes are ever visited), item n is the entry, items > n are JOINS: one per distinct set of
+    // >= 2 residue/Match nodes reachable through Ghost/Split/'$' nodes.  A state leaving a residue
+    // node goes to that node's join (or straight to its only target); the join merges equal
+    // states ONCE and then fans them out to its targets.
+    std::vector<int32_t> order_;      // residue, Match and join items, topologically sorted
     size_t cursor_ = 0;
+    std::vector<int32_t> forward_;    // per item: the join or single target it hands states to, kNone = none
+    std::vector<uint32_t> fan_first_; // per join (item - n - 1): CSR into fan_
+    std::vector<int32_t> fan_;
+    std::vector<uint8_t> dangling_;   // some path out of the item ends in a node without successor
+    int32_t n_nodes_ = 0;
     std::vector<NodeStates> table_;
     std::vector<uint32_t> refs_, free_;
     uint32_t high_water_ = TXQ_SLOT_FIRST_FREE;
-    uint64_t states_ = 0, probes_ = 0, pruned_ = 0, total_ops_ = 0;
+    uint64_t states_ = 0, probes_ = 0, pruned_ = 0, total_ops_ = 0, asked_ = 0;
 
     uint32_t fresh();
     void share(uint32_t s);
     void drop(uint32_t s);
     bool exclusive(uint32_t s) const;
     void arrive(int32_t to, State s, std::vector<txq_op>& out);
+    void hand_on(int32_t from, State s, std::vector<txq_op>& out);
     void emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b);
 };
 
@@ -91,6 +126,7 @@ struct StageExecutor {
 };
 
 struct StagedOptions {
+    int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
     size_t ops_per_stage = 4u << 20;         // bound on one stage's blob
     CompileLimits limits;
@@ -119,19 +155,16 @@ class ProgramBatch {
     size_t add_empty();
 
     size_t size() const { return programs_.size(); }
-    size_t kmer_count() const { return kmers_.size(); }
-    const std::vector<uint64_t>& kmers() const { return kmers_; }
+    size_t kmer_count() const { return table_.values().size(); }
+    const std::vector<uint64_t>& kmers() const { return table_.values(); }
     const QueryProgram& program(size_t i) const { return programs_[i]; }
     std::vector<uint8_t> serialise() const;
 
   private:
     const KmerEncoder& enc_;
     CompileLimits limits_;
-    std::vector<uint64_t> kmers_;
-    std::unordered_map<uint64_t, uint32_t> kmer_index_;
+    KmerTable table_;
     std::vector<QueryProgram> programs_;
-
-    uint32_t intern(uint64_t value);
 };
 
 }  // namespace tetrex

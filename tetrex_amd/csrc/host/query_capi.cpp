@@ -1,0 +1,68 @@
+// C entry point for whole-query execution on a GPU-resident index (libtetrex_query.so).
+#include "../../../include/txh.h"
+#include "device_index.hpp"
+
+#include <string>
+
+using namespace tetrex;
+
+namespace {
+thread_local std::string g_qerr;
+
+class Executor final : public StageExecutor {
+  public:
+    Executor(txq_index* ix, size_t n) { txq_check(txq_session_begin(ix, n, &s_), "txq_session_begin"); }
+    ~Executor() override { if (s_) txq_session_end(s_, nullptr); }
+    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+               std::vector<uint8_t>& alive) override {
+        std::vector<uint64_t> aligned((blob.size() + 7) / 8);
+        std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
+        alive.assign(qp.size(), 1);
+        txq_check(txq_session_stage(s_, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
+    }
+    void finish(uint64_t* masks) {
+        txq_session* s = s_;
+        s_ = nullptr;
+        txq_check(txq_session_end(s, masks), "txq_session_end");
+    }
+
+  private:
+    txq_session* s_ = nullptr;
+};
+}  // namespace
+
+extern "C" {
+
+const char* txe_last_error(void) { return g_qerr.c_str(); }
+
+int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
+                    size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6) {
+    try {
+        txq_index* ix = static_cast<txq_index*>(handle);
+        txq_index_info info{};
+        txq_check(txq_index_get_info(ix, &info), "txq_index_get_info");
+        const KmerEncoder enc(dna ? Molecule::DNA : Molecule::Peptide, k, (Alphabet)reduction);
+        std::vector<std::string> rx(regex, regex + n);
+        StagedOptions opt;
+        if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
+        std::vector<int> st;
+        std::vector<std::string> why;
+        Executor exec(ix, n);
+        const StagedStats s = run_staged(enc, info.user_bins, rx, exec, opt, &st, &why);
+        exec.finish(masks);
+        int failures = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (status) status[i] = st[i];
+            if (st[i]) { ++failures; g_qerr = "query " + std::to_string(i) + ": " + why[i]; }
+        }
+        if (stats6) {
+            stats6[0] = s.stages; stats6[1] = s.ops; stats6[2] = s.kmers; stats6[3] = s.states; stats6[4] = s.pruned; stats6[5] = s.feedback_queries;
+        }
+        return failures;
+    } catch (const std::exception& e) {
+        g_qerr = e.what();
+        return -1;
+    }
+}
+
+}  // extern "C"
