@@ -41,8 +41,8 @@ void txh_blob_free(txh_blob* b);
 /* Staged expansion against a caller-supplied executor (the GPU session in production, a
  * simulator in CPU tests).  `fn` runs one stage: blob = the NEW ops of all n programs
  * (txq_program.h format), and must fill alive[i] for the n_q feedback questions
- * (program qp[i], slot qs[i]); it returns 0 on success.  stats6: stages, ops, kmers, states,
- * pruned states, feedback questions. */
+ * (program qp[i], slot qs[i]); it returns 0 on success.  stats6 (8 entries): stages, ops,
+ * kmers, states, pruned states, feedback questions, host expansion us, stage execution us. */
 typedef int (*txh_stage_fn)(void* user, const void* blob, size_t bytes, const uint32_t* qp, const uint32_t* qs, size_t n_q,
                             uint8_t* alive);
 int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
@@ -51,7 +51,7 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
 
 /* End-to-end candidate masks on an index that already lives on the GPU (a txq_index* from
  * include/txq.h, passed as void* so this header stays free of txq types): host expansion +
- * staged device execution.  masks: n x shard_words words.  stats6 as in txh_run_staged.
+ * staged device execution.  masks: n x shard_words words.  stats6 (8 entries) as in txh_run_staged.
  * Exported by libtetrex_query.so (which links libtxq.so), not by libtetrex_host.so. */
 int txe_query_masks(void* txq_index_handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6);

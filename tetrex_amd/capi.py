@@ -279,12 +279,12 @@ class Index:
         arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
         masks = np.zeros((n, self.shard_words), dtype=np.uint64)
         status = (C.c_int * n)()
-        stats = (C.c_uint64 * 6)()
+        stats = (C.c_uint64 * 8)()
         rc = Lq.txe_query_masks(self._h, int(dna), k, reduction, arr, n, ops_per_query_per_stage,
                                 masks.ctypes.data_as(u64p), status, stats)
         if rc < 0:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
-        keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries")
+        keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
         return masks, list(status), dict(zip(keys, (int(x) for x in stats)))
 
     def run_programs(self, blob, n_programs):

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <thread>
@@ -270,7 +272,16 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     std::vector<std::string> why(n);
     std::vector<std::unique_ptr<QueryExpansion>> q(n);
     std::vector<uint8_t> passthrough(n, 0);
-    int threads = opt.threads > 0 ? opt.threads : (int)std::thread::hardware_concurrency();
+    // default: the hardware threads, but at most 16 — one GPU's CPU share on a multi-GPU node
+    // (override with StagedOptions::threads or the TETREX_THREADS environment variable)
+    int threads = opt.threads;
+    if (threads <= 0) {
+        if (const char* env = std::getenv("TETREX_THREADS")) threads = std::atoi(env);
+    }
+    if (threads <= 0) {
+        threads = (int)std::thread::hardware_concurrency();
+        if (threads > 16) threads = 16;
+    }
     if (threads < 1) threads = 1;
     if ((size_t)threads > n) threads = n ? (int)n : 1;
 
@@ -299,6 +310,8 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     });
 
     StagedStats st;
+    auto clock = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double mark = clock();
     std::vector<std::vector<txq_op>> ops(n);
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
     std::vector<int> owner(n, 0);  // which thread's k-mer table the ops of query i refer to
@@ -361,7 +374,12 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        exec.stage(make_blob(merged.values(), programs, ops_of), qp, qs, alive);
+        const std::vector<uint8_t> blob = make_blob(merged.values(), programs, ops_of);
+        st.expand_seconds += clock() - mark;
+        mark = clock();
+        exec.stage(blob, qp, qs, alive);
+        st.execute_seconds += clock() - mark;
+        mark = clock();
         ++st.stages;
         st.ops += total.load();
         st.kmers += merged.values().size();

@@ -135,6 +135,7 @@ struct StagedOptions {
 struct StagedStats {
     size_t stages = 0;
     uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0;
+    double expand_seconds = 0, execute_seconds = 0;  // host expansion vs. StageExecutor::stage
 };
 
 // Drives a batch of queries through staged execution.  status[i] != 0: query i could not be

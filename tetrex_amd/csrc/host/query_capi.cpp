@@ -57,6 +57,7 @@ int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const
         }
         if (stats6) {
             stats6[0] = s.stages; stats6[1] = s.ops; stats6[2] = s.kmers; stats6[3] = s.states; stats6[4] = s.pruned; stats6[5] = s.feedback_queries;
+            stats6[6] = (uint64_t)(s.expand_seconds * 1e6); stats6[7] = (uint64_t)(s.execute_seconds * 1e6);
         }
         return failures;
     } catch (const std::exception& e) {

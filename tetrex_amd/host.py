@@ -101,7 +101,7 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
     n = len(regexes)
     arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
     status = (C.c_int * n)()
-    stats = (C.c_uint64 * 6)()
+    stats = (C.c_uint64 * 8)()
     err = []
 
     def cb(user, blob, size, qp, qs, nq, alive):
@@ -120,7 +120,7 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
         raise err[0]
     if rc < 0:
         raise _err()
-    keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries")
+    keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
     return list(status), dict(zip(keys, (int(x) for x in stats)))
 
 
