@@ -183,3 +183,32 @@ class SessionSimulator:
 
     def result(self, p):
         return self._get(p, 2)
+
+
+def regular_hibf(O, user_bins, children, per_bin, value_fn, h=2, fpr=0.05, dna=False, k=4, reduction=0):
+    """A regular two-level HIBF (root: `children` merged technical bins; child c: one technical bin
+    per user bin of its contiguous range), the layout `tetrex index` writes.  value_fn(user_bin) ->
+    uint64 array of that bin's values.  Returns (oracle index, upload descriptors)."""
+    per_child = -(-user_bins // children)
+    ranges = [(c * per_child, min(user_bins, (c + 1) * per_child)) for c in range(children) if c * per_child < user_bins]
+    values = [value_fn(b) for b in range(user_bins)]
+    ox = O.Index.hibf(user_bins, dna=dna, k=k, reduction=reduction)
+    root_vals = [np.concatenate([values[b] for b in range(lo, hi)]) for lo, hi in ranges]
+    m_root = max(1, O.compute_bitcount(max(len(v) for v in root_vals), fpr))
+    nxt = np.arange(1, len(ranges) + 1, dtype=np.uint64)
+    tbu = np.full(len(ranges), MERGED, dtype=np.uint64)
+    descs = [dict(bins=len(ranges), bin_size=m_root, hash_funs=h, next_ibf_id=nxt, tb_to_user=tbu, words=None)]
+    ox.add_ibf(len(ranges), m_root, h, nxt, tbu)
+    for tb, v in enumerate(root_vals):
+        ox.hibf_emplace(0, v, tb)
+    for c, (lo, hi) in enumerate(ranges):
+        m = max(1, O.compute_bitcount(max(len(values[b]) for b in range(lo, hi)), fpr))
+        nx = np.zeros(hi - lo, dtype=np.uint64)
+        tb = np.arange(lo, hi, dtype=np.uint64)
+        i = ox.add_ibf(hi - lo, m, h, nx, tb)
+        for t, b in enumerate(range(lo, hi)):
+            ox.hibf_emplace(i, values[b], t)
+        descs.append(dict(bins=hi - lo, bin_size=m, hash_funs=h, next_ibf_id=nx, tb_to_user=tb, words=None))
+    for i, d in enumerate(descs):
+        d["words"] = ox.hibf_words(i)
+    return ox, descs, values
