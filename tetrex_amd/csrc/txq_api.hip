@@ -67,6 +67,8 @@ int alloc_ibf(const txq_ibf_desc& d, uint64_t w0, uint64_t w1, IbfDev* out, uint
     f.hash_funs = (uint32_t)d.hash_funs;
     f.bins = (uint32_t)d.bins;
     f.word0 = (uint32_t)w0;
+    f.ident_word = kNoIdent;
+    f.reserved = 0;
     f.shard_words = (uint32_t)(w1 - w0);
     f.stride = f.shard_words <= 1 ? 1u : ((f.shard_words + 1u) & ~1u);
     f.words = nullptr;
@@ -96,6 +98,9 @@ void Index::release() {
     if (d_next) (void)hipFree(d_next);
     if (d_tb_user) (void)hipFree(d_tb_user);
     if (d_map_off) (void)hipFree(d_map_off);
+    if (d_merged) (void)hipFree(d_merged);
+    if (d_merged_off) (void)hipFree(d_merged_off);
+    d_merged = d_merged_off = nullptr;
     for (void* p : {(void*)scratch_kmers, (void*)scratch_masks, (void*)frontier[0], (void*)frontier[1], (void*)d_counts,
                     (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final})
         if (p) (void)hipFree(p);

@@ -19,44 +19,95 @@ struct HibfView {
     const uint64_t* next;
     const uint64_t* tb_user;
     const uint64_t* map_off;
+    const uint64_t* merged;      // per IBF word: bit b set <=> technical bin 64w+b is a merged bin
+    const uint64_t* merged_off;  // [n_ibf] offset of IBF i's words in `merged`
 };
 
-// G lanes per work item, one 64-bit word of the IBF row per lane (G = pow2 >= widest row, <= 64).
+// exclusive prefix sum of `v` over the 64 lanes of a wave; *total receives the wave sum
+__device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t* total) {
+    const int lane = threadIdx.x & 63;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d);
+        if (lane >= d) incl += up;
+    }
+    *total = __shfl(incl, 63);
+    return incl - v;
+}
+
+// G lanes per work item, one 64-bit word of the IBF row per lane (G = pow2 >= widest row, <= 64;
+// rows wider than 64 words take `w_iters` sweeps).  Children are appended to the next frontier
+// with ONE atomicAdd per wave (prefix sum of the per-lane child counts).
 template <int G>
 __global__ __launch_bounds__(256) void hibf_level_kernel(HibfView t, const uint64_t* __restrict__ kmers,
                                                          const WorkItem* __restrict__ in, const uint32_t* __restrict__ in_count,
                                                          uint32_t n_level0, WorkItem* __restrict__ out, uint32_t* __restrict__ out_count,
                                                          uint32_t out_cap, uint32_t* __restrict__ overflow,
-                                                         uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0) {
+                                                         uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0, uint32_t w_iters) {
     const uint32_t count = in ? *in_count : n_level0;
     const uint32_t sub = threadIdx.x % G;
     const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
     const size_t n_groups = ((size_t)gridDim.x * blockDim.x) / G;
-    for (size_t item = group; item < count; item += n_groups) {
-        const uint32_t kidx = in ? in[item].kmer : (uint32_t)item;
-        const uint32_t id = in ? in[item].ibf : 0u;
+    const size_t rounds = ((size_t)count + n_groups - 1) / n_groups;  // uniform over the grid
+    for (size_t r = 0; r < rounds; ++r) {
+        const size_t item = r * n_groups + group;
+        const bool live = item < count;
+        uint32_t kidx = 0, id = 0;
+        if (live) {
+            kidx = in ? in[item].kmer : (uint32_t)item;
+            id = in ? in[item].ibf : 0u;
+        }
         const IbfDev f = t.ibf[id];
         const uint64_t off = t.map_off[id];
-        const uint64_t v = kmers[kidx];
+        const uint64_t moff = t.merged_off[id];
+        const uint64_t v = live ? kmers[kidx] : 0;
         uint64_t row[5];
-        for (uint32_t j = 0; j < f.hash_funs; ++j) row[j] = hash_row(v, kSeeds[j], f.hash_shift, f.bin_size);
-        for (uint32_t w = sub; w < f.shard_words; w += G) {
-            uint64_t acc = ~0ULL;
-            for (uint32_t j = 0; j < f.hash_funs; ++j) acc &= f.words[row[j] * f.stride + w];
-            while (acc) {
-                const uint32_t tb = w * 64u + (uint32_t)__builtin_ctzll(acc);
-                acc &= acc - 1;
+#pragma unroll
+        for (uint32_t j = 0; j < 5; ++j) row[j] = j < f.hash_funs ? hash_row(v, kSeeds[j], f.hash_shift, f.bin_size) : 0;
+        for (uint32_t wi = 0; wi < w_iters; ++wi) {
+            const uint32_t w = wi * G + sub;
+            uint64_t acc = 0;
+            if (live && w < f.shard_words) {
+                acc = ~0ULL;
+#pragma unroll
+                for (uint32_t j = 0; j < 5; ++j)
+                    if (j < f.hash_funs) acc &= f.words[row[j] * f.stride + w];
+            }
+            uint64_t kids = acc ? (acc & t.merged[moff + w]) : 0;
+            uint64_t hits = acc & ~kids;
+            // children -> next frontier, one atomic per wave
+            uint32_t total;
+            const uint32_t mine = (uint32_t)__builtin_popcountll(kids);
+            uint32_t at = wave_exclusive_scan(mine, &total);
+            if (total) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63) == 63) base = atomicAdd(out_count, total);
+                base = __shfl(base, 63);
+                at += base;
+                while (kids) {
+                    const uint32_t tb = w * 64u + (uint32_t)__builtin_ctzll(kids);
+                    kids &= kids - 1;
+                    if (at < out_cap) out[at] = WorkItem{kidx, (uint32_t)t.next[off + tb]};
+                    else *overflow = 1u;
+                    ++at;
+                }
+            }
+            // user bins -> result mask
+            if (f.ident_word != kNoIdent) {  // the row word is a mask word
+                const uint64_t word = (uint64_t)f.ident_word + w;
+                if (hits && word >= word0 && word < (uint64_t)word0 + w_out)
+                    atomicOr((unsigned long long*)(masks + (size_t)kidx * w_out + (word - word0)), hits);
+                hits = 0;
+            }
+            while (hits) {
+                const uint32_t tb = w * 64u + (uint32_t)__builtin_ctzll(hits);
+                hits &= hits - 1;
                 if (tb >= f.bins) break;  // never set; guards the map look-up
                 const uint64_t ub = t.tb_user[off + tb];
-                if (ub == TXQ_MERGED_BIN) {
-                    const uint32_t pos = atomicAdd(out_count, 1u);
-                    if (pos < out_cap) out[pos] = WorkItem{kidx, (uint32_t)t.next[off + tb]};
-                    else *overflow = 1u;
-                } else {
-                    const uint64_t word = ub >> 6;
-                    if (word >= word0 && word < (uint64_t)word0 + w_out)
-                        atomicOr((unsigned long long*)(masks + (size_t)kidx * w_out + (word - word0)), 1ULL << (ub & 63));
-                }
+                const uint64_t word = ub >> 6;
+                if (word >= word0 && word < (uint64_t)word0 + w_out)
+                    atomicOr((unsigned long long*)(masks + (size_t)kidx * w_out + (word - word0)), 1ULL << (ub & 63));
             }
         }
     }
@@ -135,6 +186,12 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
         uint64_t bytes;
         // every IBF of the tree is kept whole; only the user-bin mask columns are sharded
         if (int rc = alloc_ibf(desc.ibf[i], 0, desc.ibf[i].bin_words, &f, &bytes)) return rc;
+        {   // identity-mapped leaf?
+            const uint64_t base = tbu[off[i]];
+            bool ident = base != TXQ_MERGED_BIN && base % 64 == 0 && (base >> 6) + desc.ibf[i].bin_words < kNoIdent;
+            for (uint64_t b = 0; ident && b < desc.ibf[i].bins; ++b) ident = tbu[off[i] + b] == base + b;
+            if (ident) f.ident_word = (uint32_t)(base >> 6);
+        }
         ix.ibf.push_back(f);
         ix.device_bytes += bytes;
         if (f.stride > ix.max_stride) ix.max_stride = f.stride;
@@ -143,6 +200,17 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     TXQ_HIP(hipMalloc((void**)&ix.d_next, (off[n] ? off[n] : 1) * 8));
     TXQ_HIP(hipMalloc((void**)&ix.d_tb_user, (off[n] ? off[n] : 1) * 8));
     TXQ_HIP(hipMalloc((void**)&ix.d_map_off, n * 8));
+    // merged-bin bitmasks, one 64-bit word per row word of every IBF
+    std::vector<uint64_t> moff(n + 1, 0);
+    for (uint64_t i = 0; i < n; ++i) moff[i + 1] = moff[i] + desc.ibf[i].bin_words;
+    std::vector<uint64_t> merged(moff[n], 0);
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+            if (desc.tb_to_user_bin[i][b] == TXQ_MERGED_BIN) merged[moff[i] + (b >> 6)] |= 1ULL << (b & 63);
+    TXQ_HIP(hipMalloc((void**)&ix.d_merged, (moff[n] ? moff[n] : 1) * 8));
+    TXQ_HIP(hipMalloc((void**)&ix.d_merged_off, n * 8));
+    TXQ_HIP(hipMemcpy(ix.d_merged, merged.data(), moff[n] * 8, hipMemcpyHostToDevice));
+    TXQ_HIP(hipMemcpy(ix.d_merged_off, moff.data(), n * 8, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_ibf, ix.ibf.data(), n * sizeof(IbfDev), hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_next, next.data(), off[n] * 8, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_tb_user, tbu.data(), off[n] * 8, hipMemcpyHostToDevice));
@@ -154,8 +222,8 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
 template <int G>
 static hipError_t launch_level(unsigned grid, hipStream_t s, HibfView t, const uint64_t* kmers, const WorkItem* in,
                                const uint32_t* in_count, uint32_t n0, WorkItem* out, uint32_t* out_count, uint32_t cap,
-                               uint32_t* overflow, uint64_t* masks, uint32_t w_out, uint32_t word0) {
-    hibf_level_kernel<G><<<grid, 256, 0, s>>>(t, kmers, in, in_count, n0, out, out_count, cap, overflow, masks, w_out, word0);
+                               uint32_t* overflow, uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters) {
+    hibf_level_kernel<G><<<grid, 256, 0, s>>>(t, kmers, in, in_count, n0, out, out_count, cap, overflow, masks, w_out, word0, w_iters);
     return hipGetLastError();
 }
 
@@ -176,9 +244,10 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
     }
     if (int rc = ensure((void**)&ix.d_counts, &ix.cap_counts, ((size_t)ix.depth + 2) * 4)) return rc;
     uint32_t* overflow = ix.d_counts + ix.depth + 1;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off};
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged_off};
     int g = 1;
     while (g < 64 && (uint32_t)g < ix.max_stride) g <<= 1;
+    const uint32_t w_iters = (ix.max_stride + (uint32_t)g - 1) / (uint32_t)g;
 
     for (size_t off = 0; off < n; off += chunk) {
         const size_t m = n - off < chunk ? n - off : chunk;
@@ -194,7 +263,7 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
             if (blocks == 0) blocks = 1;
             hipError_t e;
 #define TXQ_LVL(G) e = launch_level<G>((unsigned)blocks, s, t, d_kmers + off, in, in_count, (uint32_t)m, out, ix.d_counts + lvl, \
-                                       (uint32_t)(ix.depth > 1 ? cap : 0), overflow, d_masks + off * w_out, w_out, (uint32_t)ix.shard_word0)
+                                       (uint32_t)(ix.depth > 1 ? cap : 0), overflow, d_masks + off * w_out, w_out, (uint32_t)ix.shard_word0, w_iters)
             switch (g) {
                 case 1: TXQ_LVL(1); break;
                 case 2: TXQ_LVL(2); break;

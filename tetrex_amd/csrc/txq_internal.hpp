@@ -20,6 +20,8 @@ struct Index {
     uint64_t* d_next = nullptr;      // flattened next_ibf_id
     uint64_t* d_tb_user = nullptr;   // flattened tb_to_user_bin (TXQ_MERGED_BIN for merged)
     uint64_t* d_map_off = nullptr;   // [n_ibf] offset of IBF i's maps in the flattened arrays
+    uint64_t* d_merged = nullptr;    // merged-bin bitmask words of every IBF, flattened
+    uint64_t* d_merged_off = nullptr;
     uint32_t depth = 1;              // levels of the tree
     uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
     uint32_t max_stride = 1;         // widest row over all IBFs (words)

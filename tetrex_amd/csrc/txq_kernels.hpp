@@ -28,7 +28,12 @@ struct IbfDev {
     uint32_t shard_words; // mask words this shard owns (<= stride)
     uint32_t word0;       // first full-mask word owned by this shard
     uint32_t bins;        // technical bins in use (unsharded)
+    // HIBF leaves whose technical bin b is user bin 64*ident_word + b (no merged bins): a hit word
+    // of the row IS a word of the result mask.  ident_word == kNoIdent otherwise.
+    uint32_t ident_word;
+    uint32_t reserved;
 };
+static constexpr uint32_t kNoIdent = 0xFFFFFFFFu;
 
 // row index of `v` under hash function i: fastrange of the mixed hash onto [0, bin_size)
 __device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t shift, uint64_t bin_size) {
