@@ -51,40 +51,46 @@ void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, in
     txq_check(txq_index_get_info(ix_, &info_), "txq_index_get_info");
 }
 
-namespace {
-// StageExecutor over a txq session: slot masks stay in HBM between stages.
-class TxqExecutor final : public StageExecutor {
-  public:
-    TxqExecutor(txq_index* ix, size_t n_programs) { txq_check(txq_session_begin(ix, n_programs, &s_), "txq_session_begin"); }
-    ~TxqExecutor() override { if (s_) txq_session_end(s_, nullptr); }
-    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
-               std::vector<uint8_t>& alive) override {
-        std::vector<uint64_t> aligned((blob.size() + 7) / 8);  // txq wants an 8-byte aligned blob
-        std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
-        alive.assign(qp.size(), 1);
-        txq_check(txq_session_stage(s_, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
-    }
-    void finish(uint64_t* masks) {
-        txq_session* s = s_;
-        s_ = nullptr;
-        txq_check(txq_session_end(s, masks), "txq_session_end");
-    }
+TxqStageExecutor::TxqStageExecutor(txq_index* ix, size_t n_programs) {
+    txq_check(txq_session_begin(ix, n_programs, &session_), "txq_session_begin");
+}
+TxqStageExecutor::~TxqStageExecutor() {
+    if (session_) txq_session_end(session_, nullptr);
+}
+void TxqStageExecutor::stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+                             std::vector<uint8_t>& alive) {
+    std::vector<uint64_t> aligned((blob.size() + 7) / 8);  // txq wants an 8-byte aligned blob
+    std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
+    alive.assign(qp.size(), 1);
+    txq_check(txq_session_stage(session_, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()),
+              "txq_session_stage");
+}
+void TxqStageExecutor::finish(uint64_t* masks) {
+    txq_session* s = session_;
+    session_ = nullptr;
+    txq_check(txq_session_end(s, masks), "txq_session_end");
+}
 
-  private:
-    txq_session* s_ = nullptr;
-};
-}  // namespace
+std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
+                                  std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
+                                  const StagedOptions* options) {
+    txq_index_info info{};
+    txq_check(txq_index_get_info(ix, &info), "txq_index_get_info");
+    std::vector<uint64_t> masks(regexes.size() * info.shard_words);
+    if (status) status->assign(regexes.size(), 0);
+    if (messages) messages->assign(regexes.size(), std::string());
+    if (regexes.empty()) return masks;
+    TxqStageExecutor exec(ix, regexes.size());
+    const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, options ? *options : StagedOptions{}, status, messages);
+    if (stats) *stats = st;
+    exec.finish(masks.data());
+    return masks;
+}
 
 std::vector<uint64_t> DeviceIndex::query_masks(const std::vector<std::string>& regexes, std::vector<int>* status,
                                                std::vector<std::string>* messages, StagedStats* stats, const StagedOptions* options) {
     if (!ix_) throw std::runtime_error("index not uploaded");
-    std::vector<uint64_t> masks(regexes.size() * info_.shard_words);
-    if (regexes.empty()) return masks;
-    TxqExecutor exec(ix_, regexes.size());
-    const StagedStats st = run_staged(enc_, bins(), regexes, exec, options ? *options : StagedOptions{}, status, messages);
-    if (stats) *stats = st;
-    exec.finish(masks.data());
-    return masks;
+    return run_queries(ix_, enc_, regexes, status, messages, stats, options);
 }
 
 std::vector<uint64_t> set_bins(const uint64_t* mask, uint64_t bins) {

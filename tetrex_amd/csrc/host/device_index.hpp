@@ -16,6 +16,25 @@ namespace tetrex {
 // Throws std::runtime_error carrying txq_last_error() when a txq call fails.
 void txq_check(int rc, const char* what);
 
+// StageExecutor over a txq session: slot masks stay in HBM between stages.
+class TxqStageExecutor final : public StageExecutor {
+  public:
+    TxqStageExecutor(txq_index* ix, size_t n_programs);
+    ~TxqStageExecutor() override;
+    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& query_program,
+               const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) override;
+    // copies every program's RESULT mask (n_programs x shard_words words) and ends the session
+    void finish(uint64_t* masks);
+
+  private:
+    txq_session* session_ = nullptr;
+};
+
+// Whole queries on an uploaded index: staged expansion + device execution.
+std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
+                                  std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
+                                  const StagedOptions* options);
+
 class DeviceIndex {
   public:
     DeviceIndex() = default;

@@ -9,26 +9,6 @@ using namespace tetrex;
 namespace {
 thread_local std::string g_qerr;
 
-class Executor final : public StageExecutor {
-  public:
-    Executor(txq_index* ix, size_t n) { txq_check(txq_session_begin(ix, n, &s_), "txq_session_begin"); }
-    ~Executor() override { if (s_) txq_session_end(s_, nullptr); }
-    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
-               std::vector<uint8_t>& alive) override {
-        std::vector<uint64_t> aligned((blob.size() + 7) / 8);
-        std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
-        alive.assign(qp.size(), 1);
-        txq_check(txq_session_stage(s_, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
-    }
-    void finish(uint64_t* masks) {
-        txq_session* s = s_;
-        s_ = nullptr;
-        txq_check(txq_session_end(s, masks), "txq_session_end");
-    }
-
-  private:
-    txq_session* s_ = nullptr;
-};
 }  // namespace
 
 extern "C" {
@@ -39,17 +19,15 @@ int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6) {
     try {
         txq_index* ix = static_cast<txq_index*>(handle);
-        txq_index_info info{};
-        txq_check(txq_index_get_info(ix, &info), "txq_index_get_info");
         const KmerEncoder enc(dna ? Molecule::DNA : Molecule::Peptide, k, (Alphabet)reduction);
         std::vector<std::string> rx(regex, regex + n);
         StagedOptions opt;
         if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
         std::vector<int> st;
         std::vector<std::string> why;
-        Executor exec(ix, n);
-        const StagedStats s = run_staged(enc, info.user_bins, rx, exec, opt, &st, &why);
-        exec.finish(masks);
+        StagedStats s;
+        const std::vector<uint64_t> out = run_queries(ix, enc, rx, &st, &why, &s, &opt);
+        std::copy(out.begin(), out.end(), masks);
         int failures = 0;
         for (size_t i = 0; i < n; ++i) {
             if (status) status[i] = st[i];
