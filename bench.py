@@ -106,6 +106,12 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
         t0 = time.perf_counter()
         ix.query_masks([single], False, k)
         lat.append(time.perf_counter() - t0)
+    # a batch without gaps/wildcards (literal residues and residue classes only) for contrast
+    plain = random_prosite_motifs(args.motifs, 7, wildcard=0.0, classes=0.3, ranges=0.0)
+    ix.query_masks(plain[:10], False, k)
+    tp = time.perf_counter()
+    _, plain_status, plain_stats = ix.query_masks(plain, False, k)
+    plain_s = time.perf_counter() - tp
     motifs = random_prosite_motifs(args.motifs, 6)
     if world > 1:
         dist.barrier()
@@ -129,6 +135,8 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
         "batch_queries_per_s": len(motifs) / total,
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
                   "k": k, **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
+        "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
+                               "failed": int(sum(1 for s in plain_status if s)), **plain_stats},
         "single_query": {"motif": single, "median_latency_ms": float(np.median(lat)) * 1e3,
                          "queries_per_s": 1.0 / float(np.median(lat))},
     }

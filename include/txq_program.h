@@ -27,7 +27,8 @@
 #include <stdint.h>
 
 #define TXQ_PROGRAM_MAGIC 0x50515854u /* "TXQP" */
-#define TXQ_PROGRAM_VERSION 1u
+#define TXQ_PROGRAM_VERSION 1u   /* programs are executed strictly in op order                  */
+#define TXQ_PROGRAM_VERSION_LEVELS 2u /* ops are grouped into dependency levels (see below)      */
 #define TXQ_NO_KMER 0xFFFFFFFFu
 #define TXQ_SLOT_ZERO 0u
 #define TXQ_SLOT_ONES 1u
@@ -59,5 +60,38 @@ typedef struct {
     uint32_t a;
     uint32_t b;
 } txq_op;
+
+/* Version 2 — level-scheduled programs.  The ops of a program are ordered by dependency LEVEL:
+ * all ops of one level may execute concurrently, a level starts when the previous one is
+ * complete.  Within a level
+ *   - no op reads a slot that another op of the level writes,
+ *   - no two ops write the same slot, EXCEPT accumulations  slot[dst] |= slot[x]  (kmer ==
+ *     TXQ_NO_KMER and dst == a or dst == b), any number of which may target the same dst
+ *     (the device applies them atomically).
+ * Layout: txq_blob_header_v2 | kmers | programs (txq_program_v2) | ops | levels, where
+ * levels[first_level .. first_level + n_levels) are the END op indices (relative to first_op,
+ * ascending, the last equal to n_ops) of the program's levels.  n_levels == 0 with n_ops > 0
+ * means "execute in op order" as in version 1. */
+typedef struct {
+    uint32_t magic;
+    uint32_t version; /* TXQ_PROGRAM_VERSION_LEVELS */
+    uint32_t n_programs;
+    uint32_t n_kmers;
+    uint32_t n_ops;
+    uint32_t n_levels; /* total entries of the levels table */
+    uint64_t kmers_offset;
+    uint64_t programs_offset;
+    uint64_t ops_offset;
+    uint64_t levels_offset;
+} txq_blob_header_v2;
+
+typedef struct {
+    uint32_t first_op;
+    uint32_t n_ops;
+    uint32_t n_slots;
+    uint32_t first_level;
+    uint32_t n_levels;
+    uint32_t reserved;
+} txq_program_v2;
 
 #endif /* TXQ_PROGRAM_H */

@@ -184,3 +184,41 @@ def test_config1_through_host_compiler(host, oracle, golden):
     kmers, progs = host.parse_blob(blob)
     got = eval_program(progs[0][0], [tuple(int(x) for x in o) for o in progs[0][1]], ox.probe(kmers), ones_mask(5))
     assert [b for b in range(5) if (int(got[0]) >> b) & 1] == golden("config1_masks.json")["quirk"]["candidate_bins"]
+
+
+def test_level_schedule_is_race_free(host, oracle):
+    """Version-2 blobs: within one dependency level no op may read a slot another op of the level
+    writes, plain writes are unique, and only accumulations (dst |= src) may share a destination."""
+    NO = 0xFFFFFFFF
+    qs = PEPTIDE_QUERIES + random_prosite_motifs(30, 21)
+    blob, status, _ = host.compile_batch(qs, False, 4, 0, 256)
+    _, progs = host.parse_blob(blob)
+    levels = host.blob_levels(blob)
+    assert levels is not None and len(levels) == len(progs)
+    deep = 0
+    for (n_slots, ops), ends in zip(progs, levels):
+        if len(ops) == 0:
+            assert ends == []
+            continue
+        assert ends[-1] == len(ops) and ends == sorted(ends)
+        deep = max(deep, len(ends))
+        begin = 0
+        for end in ends:
+            writes, accs, reads = {}, set(), {}
+            for i in range(begin, end):
+                k, d, a, b = (int(x) for x in ops[i])
+                if k == NO and (d == a or d == b):
+                    accs.add(d)
+                    reads.setdefault(b if d == a else a, set()).add(i)
+                else:
+                    assert d not in writes, "two plain writes to one slot in a level"
+                    writes[d] = i
+                    reads.setdefault(a, set()).add(i)
+                    reads.setdefault(b, set()).add(i)
+            for d, i in writes.items():
+                assert d not in accs
+                assert reads.get(d, set()) <= {i}, "slot written and read by different ops of one level"
+            for d in accs:
+                assert not reads.get(d), "accumulated slot read in the same level"
+            begin = end
+    assert deep >= 5

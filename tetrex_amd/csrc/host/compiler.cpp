@@ -16,25 +16,36 @@ namespace {
 constexpr uint32_t kPinned = 0x7FFFFFFF;  // reference count of the constant slots
 
 std::vector<uint8_t> make_blob(const std::vector<uint64_t>& kmers, const std::vector<txq_program>& programs,
-                               const std::vector<const std::vector<txq_op>*>& ops_of) {
-    size_t n_ops = 0;
+                               const std::vector<const std::vector<txq_op>*>& ops_of,
+                               const std::vector<const std::vector<uint32_t>*>& levels_of) {
+    size_t n_ops = 0, n_levels = 0;
     for (const auto* v : ops_of) n_ops += v ? v->size() : 0;
-    if (n_ops > 0xFFFFFFFFu) throw std::runtime_error("batch has more than 2^32 operations");
-    txq_blob_header h{};
+    for (const auto* v : levels_of) n_levels += v ? v->size() : 0;
+    if (n_ops > 0xFFFFFFFFu || n_levels > 0xFFFFFFFFu) throw std::runtime_error("batch has more than 2^32 operations");
+    txq_blob_header_v2 h{};
     h.magic = TXQ_PROGRAM_MAGIC;
-    h.version = TXQ_PROGRAM_VERSION;
+    h.version = TXQ_PROGRAM_VERSION_LEVELS;
     h.n_programs = (uint32_t)programs.size();
     h.n_kmers = (uint32_t)kmers.size();
     h.n_ops = (uint32_t)n_ops;
-    h.kmers_offset = sizeof(txq_blob_header);
+    h.n_levels = (uint32_t)n_levels;
+    h.kmers_offset = sizeof(txq_blob_header_v2);
     h.programs_offset = h.kmers_offset + kmers.size() * sizeof(uint64_t);
-    h.ops_offset = h.programs_offset + programs.size() * sizeof(txq_program);
-    std::vector<uint8_t> blob(h.ops_offset + n_ops * sizeof(txq_op));
+    h.ops_offset = h.programs_offset + programs.size() * sizeof(txq_program_v2);
+    h.levels_offset = h.ops_offset + n_ops * sizeof(txq_op);
+    std::vector<uint8_t> blob(h.levels_offset + ((n_levels * 4 + 7) & ~(size_t)7));
     std::memcpy(blob.data(), &h, sizeof h);
     if (!kmers.empty()) std::memcpy(blob.data() + h.kmers_offset, kmers.data(), kmers.size() * 8);
-    if (!programs.empty()) std::memcpy(blob.data() + h.programs_offset, programs.data(), programs.size() * sizeof(txq_program));
+    txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob.data() + h.programs_offset);
     uint8_t* at = blob.data() + h.ops_offset;
-    for (const auto* v : ops_of) {
+    uint32_t* lv = reinterpret_cast<uint32_t*>(blob.data() + h.levels_offset);
+    uint32_t first_level = 0;
+    for (size_t i = 0; i < programs.size(); ++i) {
+        const uint32_t nl = levels_of[i] ? (uint32_t)levels_of[i]->size() : 0;
+        pr[i] = txq_program_v2{programs[i].first_op, programs[i].n_ops, programs[i].n_slots, first_level, nl, 0};
+        if (nl) std::memcpy(lv + first_level, levels_of[i]->data(), nl * 4);
+        first_level += nl;
+        const auto* v = ops_of[i];
         if (!v || v->empty()) continue;
         std::memcpy(at, v->data(), v->size() * sizeof(txq_op));
         at += v->size() * sizeof(txq_op);
@@ -131,8 +142,10 @@ void QueryExpansion::hand_on(int32_t from, State s, std::vector<txq_op>& out) {
 
 uint32_t QueryExpansion::fresh() {
     uint32_t s;
-    if (!free_.empty()) { s = free_.back(); free_.pop_back(); }
-    else { s = (uint32_t)refs_.size(); refs_.push_back(0); }
+    if (free_head_ < free_.size()) {
+        s = free_[free_head_++];
+        if (free_head_ == free_.size()) { free_.clear(); free_head_ = 0; }
+    } else { s = (uint32_t)refs_.size(); refs_.push_back(0); }
     refs_[s] = 1;
     if (s + 1 > high_water_) high_water_ = s + 1;
     return s;
@@ -140,7 +153,7 @@ uint32_t QueryExpansion::fresh() {
 void QueryExpansion::share(uint32_t s) { if (refs_[s] != kPinned) ++refs_[s]; }
 void QueryExpansion::drop(uint32_t s) {
     if (refs_[s] == kPinned) return;
-    if (--refs_[s] == 0) free_.push_back(s);
+    if (--refs_[s] == 0) parked_.push_back(s);
 }
 bool QueryExpansion::exclusive(uint32_t s) const { return refs_[s] == 1; }
 
@@ -188,6 +201,10 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op
     const unsigned k = enc_.k();
     const size_t start = out.size();
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
+        if (!parked_.empty()) {  // slots freed by the previous item become reusable now
+            free_.insert(free_.end(), parked_.begin(), parked_.end());
+            parked_.clear();
+        }
         const int32_t item = order_[cursor_++];
         NodeStates ns;
         ns.items.swap(table_[item].items);
@@ -263,6 +280,58 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
     }
 }
 
+// ---- level scheduling ---------------------------------------------------------------------
+
+std::vector<uint32_t> schedule_levels(std::vector<txq_op>& ops, uint32_t n_slots, LevelScratch& sc) {
+    std::vector<uint32_t> ends;
+    if (ops.empty()) return ends;
+    if (sc.stamp.size() < n_slots) { sc.stamp.resize(n_slots, 0); sc.wr.resize(n_slots); sc.rd.resize(n_slots); sc.acc.resize(n_slots); }
+    if (++sc.epoch == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0); sc.epoch = 1; }
+    auto touch = [&](uint32_t s) {
+        if (sc.stamp[s] != sc.epoch) { sc.stamp[s] = sc.epoch; sc.wr[s] = sc.rd[s] = sc.acc[s] = 0; }
+    };
+    // level of op = smallest level that respects every hazard against earlier ops (levels from 1)
+    sc.level_of.resize(ops.size());
+    uint32_t top = 0;
+    for (size_t i = 0; i < ops.size(); ++i) {
+        const txq_op& o = ops[i];
+        touch(o.dst); touch(o.a); touch(o.b);
+        const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
+        uint32_t lvl = 1;
+        auto after = [&](uint32_t l) { if (l + 1 > lvl) lvl = l + 1; };
+        if (accumulate) {
+            const uint32_t src = o.dst == o.a ? o.b : o.a;
+            after(sc.wr[src]); after(sc.acc[src]);   // RAW on the source
+            after(sc.wr[o.dst]); after(sc.rd[o.dst]); // after the last full write and every earlier reader
+            if (sc.acc[o.dst] > lvl) lvl = sc.acc[o.dst];  // may share a level with other accumulations
+            if (sc.rd[src] < lvl) sc.rd[src] = lvl;
+            sc.acc[o.dst] = lvl;
+        } else {
+            after(sc.wr[o.a]); after(sc.acc[o.a]);
+            after(sc.wr[o.b]); after(sc.acc[o.b]);
+            // WAR / WAW on dst; an in-place op (dst == a or b) reads its own old value, which is fine
+            after(sc.wr[o.dst]); after(sc.acc[o.dst]);
+            const uint32_t rd_dst = sc.rd[o.dst];
+            after(rd_dst);
+            if (sc.rd[o.a] < lvl) sc.rd[o.a] = lvl;
+            if (sc.rd[o.b] < lvl) sc.rd[o.b] = lvl;
+            sc.wr[o.dst] = lvl;
+        }
+        sc.level_of[i] = lvl;
+        if (lvl > top) top = lvl;
+    }
+    // stable counting sort by level
+    ends.assign(top, 0);
+    for (uint32_t l : sc.level_of) ++ends[l - 1];
+    std::vector<uint32_t> pos(top, 0);
+    for (uint32_t l = 1; l < top; ++l) pos[l] = pos[l - 1] + ends[l - 1];
+    sc.sorted.resize(ops.size());
+    for (size_t i = 0; i < ops.size(); ++i) sc.sorted[pos[sc.level_of[i] - 1]++] = ops[i];
+    ops.swap(sc.sorted);
+    for (uint32_t l = 1; l < top; ++l) ends[l] += ends[l - 1];
+    return ends;
+}
+
 // ---- staged driver ------------------------------------------------------------------------
 
 StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
@@ -316,6 +385,8 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
     std::vector<int> owner(n, 0);  // which thread's k-mer table the ops of query i refer to
     std::vector<KmerTable> tables(threads);
+    std::vector<LevelScratch> scratch(threads);
+    std::vector<std::vector<uint32_t>> levels(n);
     bool first = true;
     for (;;) {
         for (auto& t : tables) t.clear();
@@ -340,6 +411,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             total.fetch_add(ops[i].size(), std::memory_order_relaxed);
             slots[i] = q[i]->n_slots();
         });
+        parallel_for([&](size_t i, int t) { levels[i] = schedule_levels(ops[i], slots[i], scratch[t]); });
         bool pending = false;
         for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
         if (!first && total.load() == 0 && !pending) break;
@@ -360,11 +432,13 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
 
         std::vector<txq_program> programs(n);
         std::vector<const std::vector<txq_op>*> ops_of(n);
+        std::vector<const std::vector<uint32_t>*> levels_of(n);
         uint32_t at = 0;
         for (size_t i = 0; i < n; ++i) {
             programs[i] = txq_program{at, (uint32_t)ops[i].size(), slots[i], 0};
             at += (uint32_t)ops[i].size();
             ops_of[i] = &ops[i];
+            levels_of[i] = &levels[i];
         }
         std::vector<uint32_t> qp, qs;
         for (size_t i = 0; i < n; ++i) {
@@ -374,7 +448,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        const std::vector<uint8_t> blob = make_blob(merged.values(), programs, ops_of);
+        const std::vector<uint8_t> blob = make_blob(merged.values(), programs, ops_of, levels_of);
         st.expand_seconds += clock() - mark;
         mark = clock();
         exec.stage(blob, qp, qs, alive);
@@ -430,14 +504,21 @@ size_t ProgramBatch::add(const KGraph& g) {
 
 std::vector<uint8_t> ProgramBatch::serialise() const {
     std::vector<txq_program> pr(programs_.size());
+    std::vector<std::vector<txq_op>> ops(programs_.size());
+    std::vector<std::vector<uint32_t>> levels(programs_.size());
     std::vector<const std::vector<txq_op>*> ops_of(programs_.size());
+    std::vector<const std::vector<uint32_t>*> levels_of(programs_.size());
+    LevelScratch scratch;
     uint32_t first = 0;
     for (size_t i = 0; i < programs_.size(); ++i) {
-        pr[i] = txq_program{first, (uint32_t)programs_[i].ops.size(), programs_[i].n_slots, 0};
-        first += (uint32_t)programs_[i].ops.size();
-        ops_of[i] = &programs_[i].ops;
+        ops[i] = programs_[i].ops;
+        levels[i] = schedule_levels(ops[i], programs_[i].n_slots, scratch);
+        pr[i] = txq_program{first, (uint32_t)ops[i].size(), programs_[i].n_slots, 0};
+        first += (uint32_t)ops[i].size();
+        ops_of[i] = &ops[i];
+        levels_of[i] = &levels[i];
     }
-    return make_blob(table_.values(), pr, ops_of);
+    return make_blob(table_.values(), pr, ops_of, levels_of);
 }
 
 }  // namespace tetrex

@@ -103,7 +103,12 @@ class QueryExpansion {
     std::vector<uint8_t> dangling_;   // some path out of the item ends in a node without successor
     int32_t n_nodes_ = 0;
     std::vector<NodeStates> table_;
-    std::vector<uint32_t> refs_, free_;
+    std::vector<uint32_t> refs_;
+    // Freed slots are recycled oldest-first and only after the node item that freed them is
+    // finished: immediate (LIFO) reuse would chain unrelated ops through write-after-read
+    // hazards on the recycled slot and serialise the dependency levels of the schedule.
+    std::vector<uint32_t> free_, parked_;
+    size_t free_head_ = 0;
     uint32_t high_water_ = TXQ_SLOT_FIRST_FREE;
     uint64_t states_ = 0, probes_ = 0, pruned_ = 0, total_ops_ = 0, asked_ = 0;
 
@@ -115,6 +120,12 @@ class QueryExpansion {
     void hand_on(int32_t from, State s, std::vector<txq_op>& out);
     void emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b);
 };
+
+// Reorders `ops` (one program's ops of one stage, in a valid sequential order) into dependency
+// levels as defined in txq_program.h (version 2) and returns the end index of every level.
+// Scratch vectors are reused across calls (sized to n_slots).
+struct LevelScratch { std::vector<uint32_t> wr, rd, acc, stamp; uint32_t epoch = 0; std::vector<uint32_t> level_of; std::vector<txq_op> sorted; };
+std::vector<uint32_t> schedule_levels(std::vector<txq_op>& ops, uint32_t n_slots, LevelScratch& scratch);
 
 // What executes a stage: the GPU session (device_index.cpp) or a test double.
 struct StageExecutor {

@@ -6,9 +6,11 @@
 // ... is expanded on the host and streamed to the device in batches"):
 //   per stage  (1) probe every DISTINCT k-mer of the stage once (flat IBF: txq_probe.hip;
 //                  HIBF: txq_hibf.hip)  ->  M[n_kmers][W].  The reference's kmer_cache_, batch-wide.
-//              (2) one lane group per program walks its new ops; every lane owns fixed mask-word
-//                  columns, so a program needs no barrier and no cross-lane traffic — bins are
-//                  independent in every operation of the collector.
+//              (2) the new ops run level by level (the host orders them into dependency levels,
+//                  txq_program.h v2): small programs get one workgroup each (__syncthreads between
+//                  levels), big ones are cut into units and every level is one launch over the
+//                  whole GPU.  Every lane owns fixed mask-word columns: bins are independent in
+//                  every operation of the collector, so an op is W independent 64-bit lanes.
 //              (3) optional feedback: "is slot s of program p all zero?" (path_.none(),
 //                  include/otf_collector.h:383) for the host to prune dead frontier states before
 //                  it expands them further.  One __ballot per queried slot.
@@ -20,21 +22,90 @@
 
 namespace txq {
 
-// G lanes per program (pow2 >= W, <= 64); lane `sub` owns words sub, sub+G, ...
+// Slot words are shared between the waves of a workgroup across levels: every access is a relaxed
+// workgroup-scope atomic, so that the barrier between two levels orders them whatever the cache
+// policy of plain loads would be, and concurrent accumulations into one slot are exact.
+__device__ __forceinline__ uint64_t slot_load(const uint64_t* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void slot_store(uint64_t* p, uint64_t v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 template <int G>
-__global__ __launch_bounds__(256) void exec_kernel(const txq_program* __restrict__ progs, const txq_op* __restrict__ ops,
-                                                   uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                   const uint64_t* __restrict__ M, uint32_t W) {
+__device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, const uint64_t* __restrict__ M, uint32_t W, uint32_t sub,
+                                        bool concurrent) {
+    const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
+    if (concurrent && accumulate) {  // slot[dst] |= slot[src]; other ops of the level may hit dst too
+        const uint32_t src = o.dst == o.a ? o.b : o.a;
+        for (uint32_t w = sub; w < W; w += G) {
+            const uint64_t x = slot_load(S + (size_t)src * W + w);
+            if (x) __hip_atomic_fetch_or(S + (size_t)o.dst * W + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        return;
+    }
+    for (uint32_t w = sub; w < W; w += G) {
+        uint64_t x = slot_load(S + (size_t)o.a * W + w);
+        if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
+        x |= slot_load(S + (size_t)o.b * W + w);
+        slot_store(S + (size_t)o.dst * W + w, x);
+    }
+}
+
+// One workgroup per program.  G lanes per op (pow2 >= W, <= 64); lane `sub` owns words sub, sub+G, ...
+// A level's ops are dealt round-robin to the workgroup's lane groups; __syncthreads() separates
+// levels.  Programs without a level table run in op order on lane group 0.
+template <int G>
+__global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict__ progs, const txq_op* __restrict__ ops,
+                                                    const uint32_t* __restrict__ levels, uint64_t* const* __restrict__ slot_base,
+                                                    uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W) {
     const uint32_t sub = threadIdx.x % G;
-    const size_t group = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / G;
-    const size_t n_groups = ((size_t)gridDim.x * blockDim.x) / G;
-    for (size_t p = group; p < n_programs; p += n_groups) {
-        const txq_program pr = progs[p];
+    const uint32_t group = threadIdx.x / G, n_groups = blockDim.x / G;
+    for (uint32_t p = blockIdx.x; p < n_programs; p += gridDim.x) {
+        const DevProgram pr = progs[p];
         if (pr.n_ops == 0) continue;
         uint64_t* S = slot_base[p];  // [slots][W]
         const txq_op* op = ops + pr.first_op;
-        for (uint32_t i = 0; i < pr.n_ops; ++i) {
-            const txq_op o = op[i];
+        if (pr.n_levels == 0) {
+            if (group == 0)
+                for (uint32_t i = 0; i < pr.n_ops; ++i) run_op<G>(op[i], S, M, W, sub, false);
+            __syncthreads();
+            continue;
+        }
+        const uint32_t* lv = levels + pr.first_level;
+        uint32_t begin = 0;
+        for (uint32_t l = 0; l < pr.n_levels; ++l) {
+            const uint32_t end = lv[l];
+            for (uint32_t i = begin + group; i < end; i += n_groups) run_op<G>(op[i], S, M, W, sub, true);
+            __syncthreads();
+            begin = end;
+        }
+    }
+}
+
+// Big programs: one launch per dependency level, the level's ops of ALL big programs cut into
+// units of <= kUnitOps ops; one workgroup per unit, G lanes per op.  The kernel boundary is the
+// barrier between levels, so slot words are plain loads/stores; concurrent accumulations use
+// agent-scope atomics (units of one program may run on different XCDs).
+struct ExecUnit { uint32_t program, begin, end; };
+static constexpr uint32_t kUnitOps = 128;
+
+template <int G>
+__global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
+                                                         uint64_t* const* __restrict__ slot_base, const uint64_t* __restrict__ M,
+                                                         uint32_t W) {
+    const ExecUnit u = units[blockIdx.x];
+    const uint32_t sub = threadIdx.x % G, group = threadIdx.x / G, n_groups = blockDim.x / G;
+    uint64_t* S = slot_base[u.program];
+    for (uint32_t i = u.begin + group; i < u.end; i += n_groups) {
+        const txq_op o = ops[i];
+        if (o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b)) {
+            const uint32_t src = o.dst == o.a ? o.b : o.a;
+            for (uint32_t w = sub; w < W; w += G) {
+                const uint64_t x = S[(size_t)src * W + w];
+                if (x) __hip_atomic_fetch_or(S + (size_t)o.dst * W + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
             for (uint32_t w = sub; w < W; w += G) {
                 uint64_t x = S[(size_t)o.a * W + w];
                 if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
@@ -93,33 +164,81 @@ __global__ __launch_bounds__(256) void gather_result_kernel(uint64_t* const* __r
     } while (0)
 
 // Host-side validation: nothing malformed may reach the GPU (a stray slot or k-mer index would
-// be an out-of-bounds access there).
-static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, const txq_blob_header** hdr_out) {
+// be an out-of-bounds access there).  Accepts version 1 (op order) and version 2 (levels) blobs and
+// normalises the program table.
+struct BlobView {
+    uint32_t n_kmers = 0, n_ops = 0, n_levels = 0;
+    uint64_t kmers_offset = 0, ops_offset = 0, levels_offset = 0;
+    std::vector<DevProgram> programs;
+    std::vector<uint32_t> n_slots;
+};
+
+static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, BlobView* out) {
     if (bytes < sizeof(txq_blob_header)) return fail(TXQ_ERR_PROGRAM, "blob shorter than its header");
     if ((uintptr_t)blob % 8) return fail(TXQ_ERR_PROGRAM, "blob must be 8-byte aligned");
-    const txq_blob_header* h = (const txq_blob_header*)blob;
-    if (h->magic != TXQ_PROGRAM_MAGIC || h->version != TXQ_PROGRAM_VERSION) return fail(TXQ_ERR_PROGRAM, "bad blob magic/version");
-    if (h->n_programs != n_programs) return fail(TXQ_ERR_PROGRAM, "blob holds %u programs, caller says %zu", h->n_programs, n_programs);
-    auto in_range = [&](uint64_t off, uint64_t count, uint64_t elem) {
-        return off % 8 == 0 && off <= bytes && count <= (bytes - off) / elem;
-    };
-    if (!in_range(h->kmers_offset, h->n_kmers, 8) || !in_range(h->programs_offset, h->n_programs, sizeof(txq_program)) ||
-        !in_range(h->ops_offset, h->n_ops, sizeof(txq_op)))
-        return fail(TXQ_ERR_PROGRAM, "blob table outside the blob");
-    const txq_program* pr = (const txq_program*)(blob + h->programs_offset);
-    const txq_op* ops = (const txq_op*)(blob + h->ops_offset);
-    for (uint32_t p = 0; p < h->n_programs; ++p) {
-        if (pr[p].n_slots < TXQ_SLOT_FIRST_FREE) return fail(TXQ_ERR_PROGRAM, "program %u: n_slots < 3", p);
-        if (pr[p].first_op > h->n_ops || pr[p].n_ops > h->n_ops - pr[p].first_op) return fail(TXQ_ERR_PROGRAM, "program %u: ops out of range", p);
-        for (uint32_t i = 0; i < pr[p].n_ops; ++i) {
-            const txq_op& o = ops[pr[p].first_op + i];
-            if (o.dst >= pr[p].n_slots || o.a >= pr[p].n_slots || o.b >= pr[p].n_slots)
-                return fail(TXQ_ERR_PROGRAM, "program %u op %u: slot out of range", p, i);
-            if (o.dst == TXQ_SLOT_ZERO || o.dst == TXQ_SLOT_ONES) return fail(TXQ_ERR_PROGRAM, "program %u op %u: writes a constant slot", p, i);
-            if (o.kmer != TXQ_NO_KMER && o.kmer >= h->n_kmers) return fail(TXQ_ERR_PROGRAM, "program %u op %u: k-mer index out of range", p, i);
-        }
+    const txq_blob_header* h1 = (const txq_blob_header*)blob;
+    if (h1->magic != TXQ_PROGRAM_MAGIC) return fail(TXQ_ERR_PROGRAM, "bad blob magic");
+    const bool v2 = h1->version == TXQ_PROGRAM_VERSION_LEVELS;
+    if (!v2 && h1->version != TXQ_PROGRAM_VERSION) return fail(TXQ_ERR_PROGRAM, "unsupported blob version %u", h1->version);
+    if (v2 && bytes < sizeof(txq_blob_header_v2)) return fail(TXQ_ERR_PROGRAM, "blob shorter than its header");
+    const txq_blob_header_v2* h2 = (const txq_blob_header_v2*)blob;
+    BlobView v;
+    uint64_t programs_offset;
+    if (v2) {
+        v.n_kmers = h2->n_kmers; v.n_ops = h2->n_ops; v.n_levels = h2->n_levels;
+        v.kmers_offset = h2->kmers_offset; v.ops_offset = h2->ops_offset; v.levels_offset = h2->levels_offset;
+        programs_offset = h2->programs_offset;
+        if (h2->n_programs != n_programs) return fail(TXQ_ERR_PROGRAM, "blob holds %u programs, caller says %zu", h2->n_programs, n_programs);
+    } else {
+        v.n_kmers = h1->n_kmers; v.n_ops = h1->n_ops;
+        v.kmers_offset = h1->kmers_offset; v.ops_offset = h1->ops_offset;
+        programs_offset = h1->programs_offset;
+        if (h1->n_programs != n_programs) return fail(TXQ_ERR_PROGRAM, "blob holds %u programs, caller says %zu", h1->n_programs, n_programs);
     }
-    *hdr_out = h;
+    auto in_range = [&](uint64_t off, uint64_t count, uint64_t elem) {
+        return off % 4 == 0 && off <= bytes && count <= (bytes - off) / elem;
+    };
+    if (v.kmers_offset % 8 || !in_range(v.kmers_offset, v.n_kmers, 8) || !in_range(v.ops_offset, v.n_ops, sizeof(txq_op)) ||
+        !in_range(programs_offset, n_programs, v2 ? sizeof(txq_program_v2) : sizeof(txq_program)) ||
+        (v2 && !in_range(v.levels_offset, v.n_levels, 4)))
+        return fail(TXQ_ERR_PROGRAM, "blob table outside the blob");
+    v.programs.resize(n_programs);
+    v.n_slots.resize(n_programs);
+    const txq_op* ops = (const txq_op*)(blob + v.ops_offset);
+    const uint32_t* levels = v2 ? (const uint32_t*)(blob + v.levels_offset) : nullptr;
+    for (uint32_t p = 0; p < n_programs; ++p) {
+        DevProgram d{};
+        if (v2) {
+            const txq_program_v2& s = ((const txq_program_v2*)(blob + programs_offset))[p];
+            d = DevProgram{s.first_op, s.n_ops, s.first_level, s.n_levels};
+            v.n_slots[p] = s.n_slots;
+        } else {
+            const txq_program& s = ((const txq_program*)(blob + programs_offset))[p];
+            d = DevProgram{s.first_op, s.n_ops, 0, 0};
+            v.n_slots[p] = s.n_slots;
+        }
+        const uint32_t n_slots = v.n_slots[p];
+        if (n_slots < TXQ_SLOT_FIRST_FREE) return fail(TXQ_ERR_PROGRAM, "program %u: n_slots < 3", p);
+        if (d.first_op > v.n_ops || d.n_ops > v.n_ops - d.first_op) return fail(TXQ_ERR_PROGRAM, "program %u: ops out of range", p);
+        if (d.n_levels) {
+            if (d.first_level > v.n_levels || d.n_levels > v.n_levels - d.first_level) return fail(TXQ_ERR_PROGRAM, "program %u: levels out of range", p);
+            uint32_t prev = 0;
+            for (uint32_t l = 0; l < d.n_levels; ++l) {
+                const uint32_t e = levels[d.first_level + l];
+                if (e < prev || e > d.n_ops) return fail(TXQ_ERR_PROGRAM, "program %u: level table not ascending", p);
+                prev = e;
+            }
+            if (prev != d.n_ops) return fail(TXQ_ERR_PROGRAM, "program %u: levels do not cover the ops", p);
+        }
+        for (uint32_t i = 0; i < d.n_ops; ++i) {
+            const txq_op& o = ops[d.first_op + i];
+            if (o.dst >= n_slots || o.a >= n_slots || o.b >= n_slots) return fail(TXQ_ERR_PROGRAM, "program %u op %u: slot out of range", p, i);
+            if (o.dst == TXQ_SLOT_ZERO || o.dst == TXQ_SLOT_ONES) return fail(TXQ_ERR_PROGRAM, "program %u op %u: writes a constant slot", p, i);
+            if (o.kmer != TXQ_NO_KMER && o.kmer >= v.n_kmers) return fail(TXQ_ERR_PROGRAM, "program %u op %u: k-mer index out of range", p, i);
+        }
+        v.programs[p] = d;
+    }
+    *out = std::move(v);
     return TXQ_OK;
 }
 
@@ -165,13 +284,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                   uint8_t* alive, hipStream_t st) {
     Index& ix = *s.ix;
     const unsigned char* blob = (const unsigned char*)blob_v;
-    const txq_blob_header* h = nullptr;
-    if (int rc = validate_blob(blob, bytes, s.n_programs, &h)) return rc;
+    BlobView bv;
+    if (int rc = validate_blob(blob, bytes, s.n_programs, &bv)) return rc;
+    const BlobView* h = &bv;
     const uint32_t W = s.W;
-    const txq_program* pr = (const txq_program*)(blob + h->programs_offset);
     for (size_t i = 0; i < n_q; ++i) {
         if (q_prog[i] >= s.n_programs) return fail(TXQ_ERR_ARG, "feedback query %zu: program out of range", i);
-        const uint32_t lim = pr[q_prog[i]].n_slots > s.cap[q_prog[i]] ? pr[q_prog[i]].n_slots : s.cap[q_prog[i]];
+        const uint32_t lim = bv.n_slots[q_prog[i]] > s.cap[q_prog[i]] ? bv.n_slots[q_prog[i]] : s.cap[q_prog[i]];
         if (q_slot[i] >= lim) return fail(TXQ_ERR_ARG, "feedback query %zu: slot out of range", i);
     }
     if (W == 0 || s.n_programs == 0) {
@@ -182,7 +301,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<uint32_t> fresh;
     bool moved = false;
     for (size_t p = 0; p < s.n_programs; ++p) {
-        const uint32_t need = pr[p].n_slots;
+        const uint32_t need = bv.n_slots[p];
         if (need <= s.cap[p]) continue;
         uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
         if (cap < need) cap = need;
@@ -196,18 +315,49 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     }
     if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
 
-    // staging: blob | fresh-program list | feedback queries | alive bytes
+    // Big level-scheduled programs leave the one-workgroup-per-program kernel: their ops are cut
+    // into units per dependency level and every level becomes one launch over the whole GPU.
+    const uint32_t* levels_host = h->n_levels ? (const uint32_t*)(blob + h->levels_offset) : nullptr;
+    std::vector<std::vector<ExecUnit>> per_level;
+    size_t n_small = 0;
+    for (size_t p = 0; p < s.n_programs; ++p) {
+        DevProgram& d = bv.programs[p];
+        if (d.n_levels == 0 || d.n_ops < 2048) { n_small += d.n_ops != 0; continue; }
+        if (per_level.size() < d.n_levels) per_level.resize(d.n_levels);
+        uint32_t begin = 0;
+        for (uint32_t l = 0; l < d.n_levels; ++l) {
+            const uint32_t end = levels_host[d.first_level + l];
+            for (uint32_t at = begin; at < end; at += kUnitOps)
+                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < kUnitOps ? end : at + kUnitOps)});
+            begin = end;
+        }
+        d.n_ops = 0;  // the per-program kernel skips it
+    }
+    std::vector<ExecUnit> units;
+    std::vector<size_t> level_units(per_level.size());
+    for (size_t l = 0; l < per_level.size(); ++l) {
+        level_units[l] = per_level[l].size();
+        units.insert(units.end(), per_level[l].begin(), per_level[l].end());
+    }
+
+    // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
     if (int rc = ensure((void**)&s.d_blob, &s.cap_blob, blob_pad)) return rc;
-    const size_t aux_bytes = fresh.size() * 4 + n_q * 8 + n_q + 64;
+    const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
+    const size_t small_bytes = prog_bytes + fresh.size() * 4 + n_q * 8 + ((n_q + 7) & ~(size_t)7) + 64;
+    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit);
     if (int rc = ensure((void**)&s.d_aux, &s.cap_aux, aux_bytes)) return rc;
     const size_t nk = h->n_kmers;
     if (int rc = ensure((void**)&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
     TXQ_HIP(hipMemcpyAsync(s.d_blob, blob, bytes, hipMemcpyHostToDevice, st));
-    uint32_t* d_fresh = (uint32_t*)s.d_aux;
+    DevProgram* d_progs = (DevProgram*)s.d_aux;
+    TXQ_HIP(hipMemcpyAsync(d_progs, bv.programs.data(), prog_bytes, hipMemcpyHostToDevice, st));
+    uint32_t* d_fresh = (uint32_t*)(s.d_aux + prog_bytes);
     uint32_t* d_qp = d_fresh + fresh.size();
     uint32_t* d_qs = d_qp + n_q;
     uint8_t* d_alive = (uint8_t*)(d_qs + n_q);
+    ExecUnit* d_units = (ExecUnit*)(s.d_aux + small_bytes - 32);
+    if (!units.empty()) TXQ_HIP(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(ExecUnit), hipMemcpyHostToDevice, st));
     if (!fresh.empty()) TXQ_HIP(hipMemcpyAsync(d_fresh, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice, st));
     if (n_q) {
         TXQ_HIP(hipMemcpyAsync(d_qp, q_prog, n_q * 4, hipMemcpyHostToDevice, st));
@@ -223,6 +373,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
     }
     const uint64_t* d_kmers = (const uint64_t*)(s.d_blob + h->kmers_offset);
+    const size_t nk_ = h->n_kmers; (void)nk_;
     if (nk) {
         if (ix.is_hibf) {
             if (int rc = hibf_probe(ix, d_kmers, nk, ix.scratch_masks, nullptr, st)) return rc;
@@ -234,21 +385,39 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (h->n_ops) {
         int g = 1;
         while (g < 64 && (uint32_t)g < W) g <<= 1;
-        size_t blocks = (s.n_programs * g + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        const txq_program* d_pr = (const txq_program*)(s.d_blob + h->programs_offset);
         const txq_op* d_ops = (const txq_op*)(s.d_blob + h->ops_offset);
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 256, 0, st>>>(d_pr, d_ops, s.d_base, (uint32_t)s.n_programs, ix.scratch_masks, W)
-        switch (g) {
-            case 1: TXQ_EXEC(1); break;
-            case 2: TXQ_EXEC(2); break;
-            case 4: TXQ_EXEC(4); break;
-            case 8: TXQ_EXEC(8); break;
-            case 16: TXQ_EXEC(16); break;
-            case 32: TXQ_EXEC(32); break;
-            default: TXQ_EXEC(64); break;
-        }
+        const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(s.d_blob + h->levels_offset) : nullptr;
+        if (n_small) {
+            size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, (uint32_t)s.n_programs, ix.scratch_masks, W)
+            switch (g) {
+                case 1: TXQ_EXEC(1); break;
+                case 2: TXQ_EXEC(2); break;
+                case 4: TXQ_EXEC(4); break;
+                case 8: TXQ_EXEC(8); break;
+                case 16: TXQ_EXEC(16); break;
+                case 32: TXQ_EXEC(32); break;
+                default: TXQ_EXEC(64); break;
+            }
 #undef TXQ_EXEC
+        }
+        size_t first = 0;
+        for (size_t l = 0; l < level_units.size(); ++l) {
+            const size_t cnt = level_units[l];
+            if (cnt == 0) continue;
+#define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, ix.scratch_masks, W)
+            switch (g) {
+                case 1: TXQ_UNITS(1); break;
+                case 2: TXQ_UNITS(2); break;
+                case 4: TXQ_UNITS(4); break;
+                case 8: TXQ_UNITS(8); break;
+                case 16: TXQ_UNITS(16); break;
+                case 32: TXQ_UNITS(32); break;
+                default: TXQ_UNITS(64); break;
+            }
+#undef TXQ_UNITS
+            first += cnt;
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "exec kernel launch");

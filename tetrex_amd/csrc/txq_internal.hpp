@@ -38,6 +38,9 @@ struct Index {
     void release();
 };
 
+// Normalised program descriptor the executor kernel reads (both blob versions map onto it).
+struct DevProgram { uint32_t first_op, n_ops, first_level, n_levels; };
+
 // A batch of programs whose slot masks persist in HBM across stages (txq_exec.hip).
 struct Session {
     Index* ix = nullptr;

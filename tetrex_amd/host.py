@@ -133,16 +133,35 @@ def record_values(seq, k, dna=True, reduction=0, wraparound=False):
 
 
 def parse_blob(blob):
-    """Decode a txq_program.h blob: (kmers uint64[], [(n_slots, ops array [n,4] = kmer,dst,a,b)])."""
-    magic, ver, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off = struct.unpack_from("<6I3Q", blob, 0)
-    assert magic == 0x50515854 and ver == 1
+    """Decode a txq_program.h blob (version 1 or 2): (kmers uint64[], [(n_slots, ops array [n,4] =
+    kmer,dst,a,b)]).  Version-2 ops are in level order, which is also a valid sequential order."""
+    magic, ver = struct.unpack_from("<2I", blob, 0)
+    assert magic == 0x50515854 and ver in (1, 2)
+    if ver == 1:
+        _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off = struct.unpack_from("<6I3Q", blob, 0)
+        stride = 4
+    else:
+        _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off, _ = struct.unpack_from("<6I4Q", blob, 0)
+        stride = 6
     kmers = np.frombuffer(blob, dtype="<u8", count=n_kmers, offset=k_off)
-    progs = np.frombuffer(blob, dtype="<u4", count=n_prog * 4, offset=p_off).reshape(n_prog, 4)
+    progs = np.frombuffer(blob, dtype="<u4", count=n_prog * stride, offset=p_off).reshape(n_prog, stride)
     ops = np.frombuffer(blob, dtype="<u4", count=n_ops * 4, offset=o_off).reshape(n_ops, 4)
     out = []
-    for first, cnt, n_slots, _ in progs:
-        out.append((int(n_slots), ops[first:first + cnt]))
+    for row in progs:
+        first, cnt, n_slots = int(row[0]), int(row[1]), int(row[2])
+        out.append((n_slots, ops[first:first + cnt]))
     return kmers, out
+
+
+def blob_levels(blob):
+    """Level tables of a version-2 blob: list of per-program end-index lists."""
+    magic, ver = struct.unpack_from("<2I", blob, 0)
+    if ver != 2:
+        return None
+    _, _, n_prog, n_kmers, n_ops, n_lv, k_off, p_off, o_off, l_off = struct.unpack_from("<6I4Q", blob, 0)
+    progs = np.frombuffer(blob, dtype="<u4", count=n_prog * 6, offset=p_off).reshape(n_prog, 6)
+    lv = np.frombuffer(blob, dtype="<u4", count=n_lv, offset=l_off)
+    return [list(int(x) for x in lv[int(r[3]):int(r[3]) + int(r[4])]) for r in progs]
 
 
 # ---- .ibf index files ------------------------------------------------------------------------
