@@ -4,6 +4,8 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -15,9 +17,14 @@ namespace tetrex {
 namespace {
 constexpr uint32_t kPinned = 0x7FFFFFFF;  // reference count of the constant slots
 
-std::vector<uint8_t> make_blob(const std::vector<uint64_t>& kmers, const std::vector<txq_program>& programs,
+using ParallelFor = std::function<void(size_t, const std::function<void(size_t, int)>&)>;
+
+std::vector<uint8_t> make_blob(const std::vector<const std::vector<uint64_t>*>& kmer_tables, const std::vector<txq_program>& programs,
                                const std::vector<const std::vector<txq_op>*>& ops_of,
-                               const std::vector<const std::vector<uint32_t>*>& levels_of) {
+                               const std::vector<const std::vector<uint32_t>*>& levels_of, const ParallelFor* par = nullptr) {
+    size_t n_kmers = 0;
+    for (const auto* t : kmer_tables) n_kmers += t->size();
+    if (n_kmers > 0xFFFFFFFEu) throw std::runtime_error("k-mer table overflow");
     size_t n_ops = 0, n_levels = 0;
     for (const auto* v : ops_of) n_ops += v ? v->size() : 0;
     for (const auto* v : levels_of) n_levels += v ? v->size() : 0;
@@ -26,30 +33,38 @@ std::vector<uint8_t> make_blob(const std::vector<uint64_t>& kmers, const std::ve
     h.magic = TXQ_PROGRAM_MAGIC;
     h.version = TXQ_PROGRAM_VERSION_LEVELS;
     h.n_programs = (uint32_t)programs.size();
-    h.n_kmers = (uint32_t)kmers.size();
+    h.n_kmers = (uint32_t)n_kmers;
     h.n_ops = (uint32_t)n_ops;
     h.n_levels = (uint32_t)n_levels;
     h.kmers_offset = sizeof(txq_blob_header_v2);
-    h.programs_offset = h.kmers_offset + kmers.size() * sizeof(uint64_t);
+    h.programs_offset = h.kmers_offset + n_kmers * sizeof(uint64_t);
     h.ops_offset = h.programs_offset + programs.size() * sizeof(txq_program_v2);
     h.levels_offset = h.ops_offset + n_ops * sizeof(txq_op);
     std::vector<uint8_t> blob(h.levels_offset + ((n_levels * 4 + 7) & ~(size_t)7));
     std::memcpy(blob.data(), &h, sizeof h);
-    if (!kmers.empty()) std::memcpy(blob.data() + h.kmers_offset, kmers.data(), kmers.size() * 8);
+    {
+        uint8_t* at = blob.data() + h.kmers_offset;
+        for (const auto* t : kmer_tables) {
+            if (!t->empty()) std::memcpy(at, t->data(), t->size() * 8);
+            at += t->size() * 8;
+        }
+    }
     txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob.data() + h.programs_offset);
-    uint8_t* at = blob.data() + h.ops_offset;
     uint32_t* lv = reinterpret_cast<uint32_t*>(blob.data() + h.levels_offset);
     uint32_t first_level = 0;
     for (size_t i = 0; i < programs.size(); ++i) {
         const uint32_t nl = levels_of[i] ? (uint32_t)levels_of[i]->size() : 0;
         pr[i] = txq_program_v2{programs[i].first_op, programs[i].n_ops, programs[i].n_slots, first_level, nl, 0};
-        if (nl) std::memcpy(lv + first_level, levels_of[i]->data(), nl * 4);
         first_level += nl;
-        const auto* v = ops_of[i];
-        if (!v || v->empty()) continue;
-        std::memcpy(at, v->data(), v->size() * sizeof(txq_op));
-        at += v->size() * sizeof(txq_op);
     }
+    uint8_t* ops_at = blob.data() + h.ops_offset;
+    auto copy_program = [&](size_t i, int) {
+        if (pr[i].n_levels) std::memcpy(lv + pr[i].first_level, levels_of[i]->data(), (size_t)pr[i].n_levels * 4);
+        const auto* v = ops_of[i];
+        if (v && !v->empty()) std::memcpy(ops_at + (size_t)pr[i].first_op * sizeof(txq_op), v->data(), v->size() * sizeof(txq_op));
+    };
+    if (par) (*par)(programs.size(), copy_program);
+    else for (size_t i = 0; i < programs.size(); ++i) copy_program(i, 0);
     return blob;
 }
 }  // namespace
@@ -354,17 +369,53 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     if (threads < 1) threads = 1;
     if ((size_t)threads > n) threads = n ? (int)n : 1;
 
-    // every query is expanded by one thread at a time; threads own disjoint queries
-    auto parallel_for = [&](const std::function<void(size_t, int)>& body) {
-        if (threads == 1) { for (size_t i = 0; i < n; ++i) body(i, 0); return; }
+    // every query is expanded by one thread at a time; threads own disjoint queries.
+    // A small persistent pool: workers pull indexes of the current job from an atomic counter.
+    struct Pool {
+        std::vector<std::thread> workers;
+        std::mutex m;
+        std::condition_variable wake, done;
+        const std::function<void(size_t, int)>* job = nullptr;
+        size_t count = 0, generation = 0, running = 0;
         std::atomic<size_t> next{0};
-        std::vector<std::thread> pool;
-        for (int t = 0; t < threads; ++t)
-            pool.emplace_back([&, t]() {
-                for (size_t i; (i = next.fetch_add(1)) < n;) body(i, t);
-            });
-        for (auto& th : pool) th.join();
-    };
+        bool stop = false;
+        explicit Pool(int n) {
+            for (int t = 1; t < n; ++t)
+                workers.emplace_back([this, t]() {
+                    size_t seen = 0;
+                    for (;;) {
+                        std::unique_lock<std::mutex> lk(m);
+                        wake.wait(lk, [&] { return stop || generation != seen; });
+                        if (stop) return;
+                        seen = generation;
+                        const auto* fn = job;
+                        const size_t cnt = count;
+                        lk.unlock();
+                        for (size_t i; (i = next.fetch_add(1)) < cnt;) (*fn)(i, t);
+                        lk.lock();
+                        if (--running == 0) done.notify_one();
+                    }
+                });
+        }
+        ~Pool() {
+            { std::lock_guard<std::mutex> lk(m); stop = true; }
+            wake.notify_all();
+            for (auto& w : workers) w.join();
+        }
+        void run(size_t cnt, const std::function<void(size_t, int)>& fn) {
+            if (workers.empty() || cnt < 2) { for (size_t i = 0; i < cnt; ++i) fn(i, 0); return; }
+            {
+                std::lock_guard<std::mutex> lk(m);
+                job = &fn; count = cnt; next.store(0); running = workers.size(); ++generation;
+            }
+            wake.notify_all();
+            for (size_t i; (i = next.fetch_add(1)) < cnt;) fn(i, 0);
+            std::unique_lock<std::mutex> lk(m);
+            done.wait(lk, [&] { return running == 0; });
+        }
+    } pool(threads);
+    auto parallel_for = [&](const std::function<void(size_t, int)>& body) { pool.run(n, body); };
+    const ParallelFor par_any = [&](size_t cnt, const std::function<void(size_t, int)>& body) { pool.run(cnt, body); };
 
     parallel_for([&](size_t i, int) {
         try {
@@ -383,22 +434,23 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     double mark = clock();
     std::vector<std::vector<txq_op>> ops(n);
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
-    std::vector<int> owner(n, 0);  // which thread's k-mer table the ops of query i refer to
-    std::vector<KmerTable> tables(threads);
+    // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
+    // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
+    std::vector<KmerTable> tables(n);
     std::vector<LevelScratch> scratch(threads);
     std::vector<std::vector<uint32_t>> levels(n);
     bool first = true;
     for (;;) {
-        for (auto& t : tables) t.clear();
         std::atomic<size_t> total{0};
-        parallel_for([&](size_t i, int t) {
+        parallel_for([&](size_t i, int) {
             ops[i].clear();
-            owner[i] = t;
+            tables[i].clear();
             if (first && passthrough[i]) ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
             if (!q[i] || q[i]->done()) return;
             if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
             try {
-                q[i]->advance(opt.ops_per_query_per_stage, tables[t], ops[i]);
+                // a query that gains nothing from feedback runs on without pausing
+                q[i]->advance(q[i]->wants_feedback() ? opt.ops_per_query_per_stage : SIZE_MAX, tables[i], ops[i]);
             } catch (const std::exception& e) {
                 // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
                 // query is neutralised by not emitting anything further
@@ -411,24 +463,27 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             total.fetch_add(ops[i].size(), std::memory_order_relaxed);
             slots[i] = q[i]->n_slots();
         });
-        parallel_for([&](size_t i, int t) { levels[i] = schedule_levels(ops[i], slots[i], scratch[t]); });
         bool pending = false;
         for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
         if (!first && total.load() == 0 && !pending) break;
 
-        // merge the per-thread k-mer tables into the stage table and renumber the ops
-        KmerTable merged;
-        std::vector<std::vector<uint32_t>> remap(threads);
-        for (int t = 0; t < threads; ++t) {
-            remap[t].reserve(tables[t].values().size());
-            for (uint64_t v : tables[t].values()) remap[t].push_back(merged.intern(v));
+        // the stage's k-mer table is the concatenation of the per-query tables
+        std::vector<uint32_t> base(n, 0);
+        std::vector<const std::vector<uint64_t>*> kmer_tables(n);
+        size_t stage_kmers = 0;
+        for (size_t i = 0; i < n; ++i) {
+            base[i] = (uint32_t)stage_kmers;
+            stage_kmers += tables[i].values().size();
+            kmer_tables[i] = &tables[i].values();
         }
-        if (threads > 1)
-            parallel_for([&](size_t i, int) {
-                const std::vector<uint32_t>& m = remap[owner[i]];
+        if (stage_kmers > 0xFFFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
+        parallel_for([&](size_t i, int t) {
+            const uint32_t add = base[i];
+            if (add)
                 for (txq_op& o : ops[i])
-                    if (o.kmer != TXQ_NO_KMER) o.kmer = m[o.kmer];
-            });
+                    if (o.kmer != TXQ_NO_KMER) o.kmer += add;
+            levels[i] = schedule_levels(ops[i], slots[i], scratch[t]);
+        });
 
         std::vector<txq_program> programs(n);
         std::vector<const std::vector<txq_op>*> ops_of(n);
@@ -448,7 +503,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        const std::vector<uint8_t> blob = make_blob(merged.values(), programs, ops_of, levels_of);
+        const std::vector<uint8_t> blob = make_blob(kmer_tables, programs, ops_of, levels_of, &par_any);
         st.expand_seconds += clock() - mark;
         mark = clock();
         exec.stage(blob, qp, qs, alive);
@@ -456,7 +511,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         mark = clock();
         ++st.stages;
         st.ops += total.load();
-        st.kmers += merged.values().size();
+        st.kmers += stage_kmers;
         st.feedback_queries += qp.size();
         // prune dead frontier states
         for (size_t a = 0; a < qp.size();) {
@@ -518,7 +573,7 @@ std::vector<uint8_t> ProgramBatch::serialise() const {
         ops_of[i] = &ops[i];
         levels_of[i] = &levels[i];
     }
-    return make_blob(table_.values(), pr, ops_of, levels_of);
+    return make_blob({&table_.values()}, pr, ops_of, levels_of);
 }
 
 }  // namespace tetrex

@@ -139,7 +139,7 @@ struct StageExecutor {
 struct StagedOptions {
     int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
-    size_t ops_per_stage = 4u << 20;         // bound on one stage's blob
+    size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)
     CompileLimits limits;
 };
 
