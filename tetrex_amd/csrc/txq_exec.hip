@@ -290,8 +290,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const uint32_t W = s.W;
     for (size_t i = 0; i < n_q; ++i) {
         if (q_prog[i] >= s.n_programs) return fail(TXQ_ERR_ARG, "feedback query %zu: program out of range", i);
-        const uint32_t lim = bv.n_slots[q_prog[i]] > s.cap[q_prog[i]] ? bv.n_slots[q_prog[i]] : s.cap[q_prog[i]];
-        if (q_slot[i] >= lim) return fail(TXQ_ERR_ARG, "feedback query %zu: slot out of range", i);
+        if (q_slot[i] >= bv.n_slots[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: slot out of range", i);
     }
     if (W == 0 || s.n_programs == 0) {
         for (size_t i = 0; i < n_q; ++i) alive[i] = 0;
