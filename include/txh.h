@@ -43,11 +43,20 @@ void txh_blob_free(txh_blob* b);
  * (txq_program.h format), and must fill alive[i] for the n_q feedback questions
  * (program qp[i], slot qs[i]); it returns 0 on success.  stats6 (8 entries): stages, ops,
  * kmers, states, pruned states, feedback questions, host expansion us, stage execution us. */
+/* -a / -g of `tetrex query` (reference include/arg_parse.h:64,68) */
+typedef struct {
+    int augment;       /* bypass catastrophic sub-graphs with Gap nodes */
+    int dgram_loaded;  /* a d-gram index is attached: probe across gaps */
+    uint64_t min_gap, max_gap;
+} txh_gap_options;
+
 typedef int (*txh_stage_fn)(void* user, const void* blob, size_t bytes, const uint32_t* qp, const uint32_t* qs, size_t n_q,
                             uint8_t* alive);
 int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
-                   size_t ops_per_query_per_stage, size_t ops_per_stage, txh_stage_fn fn, void* user, int* status,
-                   uint64_t* stats6);
+                   size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps, txh_stage_fn fn,
+                   void* user, int* status, uint64_t* stats6);
+/* the d-gram codes one record contributes (DGramIndex::process_sequence, include/dGramIndex.h:159-211) */
+int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, size_t cap);
 
 /* End-to-end candidate masks on an index that already lives on the GPU (a txq_index* from
  * include/txq.h, passed as void* so this header stays free of txq types): host expansion +
@@ -55,6 +64,10 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
  * Exported by libtetrex_query.so (which links libtxq.so), not by libtetrex_host.so. */
 int txe_query_masks(void* txq_index_handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6);
+/* the same with -a/-g: aux_index_handle is the GPU-resident d-gram index (or NULL) */
+int txe_query_masks_gapped(void* txq_index_handle, void* aux_index_handle, const txh_gap_options* gaps, int dna, unsigned k,
+                           unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,
+                           uint64_t* masks, int* status, uint64_t* stats6);
 const char* txe_last_error(void);
 
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */

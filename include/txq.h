@@ -138,6 +138,10 @@ int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, 
  * just destroys it. */
 typedef struct txq_session txq_session;
 int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out);
+/* Attach the d-gram index of `tetrex query -g` (reference include/otf_collector.h:235,
+ * include/dGramIndex.h:279-283): a flat IBF over the same bins, uploaded with the same shard.  The
+ * last n_aux_kmers entries of a stage's k-mer table (txq_program.h) are then probed on it. */
+int txq_session_set_aux_index(txq_session* s, txq_index* aux);
 int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const uint32_t* query_program,
                       const uint32_t* query_slot, size_t n_queries, uint8_t* alive);
 int txq_session_end(txq_session* s, uint64_t* final_masks);

@@ -83,6 +83,9 @@ typedef struct {
     uint64_t programs_offset;
     uint64_t ops_offset;
     uint64_t levels_offset;
+    uint64_t n_aux_kmers; /* the LAST n_aux_kmers entries of kmers[] are probed on the session's
+                             auxiliary index (the d-gram index of `tetrex query -g`), the others on
+                             the main index */
 } txq_blob_header_v2;
 
 typedef struct {

@@ -57,6 +57,9 @@ def lib():
         ip = C.POINTER(C.c_int)
         L.txo_kgraph.argtypes = [C.c_char_p, C.c_uint, C.c_int, ip, ip, ip, C.c_int, ip, C.c_int, ip]
         L.txo_query.argtypes = [C.c_void_p, C.c_char_p, u64p, u64p]
+        L.txo_query_aug.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, u64p, u64p]
+        L.txo_dgram_codes.restype = C.c_int64
+        L.txo_dgram_codes.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_uint64, u64p, C.c_uint64]
         _LIB = L
     return _LIB
 
@@ -175,6 +178,17 @@ class Index:
         p = lib().txo_hibf_words(self._h, ibf_id, C.byref(n))
         return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
 
+    def query_aug(self, regex, augment=True, dgram=None, min_gap=0, max_gap=0):
+        """Query with -a (and -g when `dgram`, an oracle flat IBF over d-gram codes, is given)."""
+        mask = np.zeros(self.words_per_mask, dtype=np.uint64)
+        stats = np.zeros(5, dtype=np.uint64)
+        rc = lib().txo_query_aug(self._h, regex.encode(), int(augment), dgram._h if dgram is not None else None,
+                                 min_gap, max_gap, mask.ctypes.data_as(u64p), stats.ctypes.data_as(u64p))
+        if rc != 0:
+            raise _err()
+        keys = ("probes", "states", "quirk_merges", "dgram_probes", "gap_nodes")
+        return mask, dict(zip(keys, (int(x) for x in stats)))
+
     def query(self, regex, with_stats=False):
         mask = np.zeros(self.words_per_mask, dtype=np.uint64)
         stats = np.zeros(3, dtype=np.uint64)
@@ -183,6 +197,14 @@ class Index:
         if with_stats:
             return mask, dict(probes=int(stats[0]), states=int(stats[1]), quirk_merges=int(stats[2]))
         return mask
+
+
+def dgram_codes(seq, min_gap, max_gap):
+    s = seq.encode() if isinstance(seq, str) else seq
+    cap = max(1, len(s) * (max_gap - min_gap + 1))
+    out = np.zeros(cap, dtype=np.uint64)
+    n = lib().txo_dgram_codes(s, len(s), min_gap, max_gap, out.ctypes.data_as(u64p), cap)
+    return out[:n].copy()
 
 
 def decompose(seq, k, dna=True, reduction=0, quirk=False):

@@ -210,6 +210,36 @@ int txo_kgraph(const char* postfix, unsigned k, int reduced, int* labels, int* s
     } catch (const std::exception& e) { return fail(e); }
 }
 
+// ---- d-gram index ("tetrex track") ---------------------------------------------------
+// codes one sequence record contributes (DGramIndex::process_sequence); returns the count
+int64_t txo_dgram_codes(const char* seq, uint64_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, uint64_t cap) {
+    std::vector<uint64_t> v;
+    dgram_codes(std::string_view(seq, len), min_gap, max_gap, v);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return (int64_t)v.size();
+}
+
+// query with -a (augment) and optionally -g (dgram: a flat-IBF txo_index over d-gram codes built
+// for gaps min_gap..max_gap).  stats5: probes, states, quirk_merges, dgram_probes, gap_nodes.
+int txo_query_aug(txo_index* ix, const char* regex, int augment, txo_index* dgram, uint64_t min_gap, uint64_t max_gap,
+                  uint64_t* mask, uint64_t* stats5) {
+    try {
+        DGramView dv;
+        if (dgram) {
+            if (dgram->is_hibf || dgram->ibf.bins != ix->view.bins) throw std::invalid_argument("d-gram index must be a flat IBF over the same bins");
+            dv.loaded = true; dv.min_gap = min_gap; dv.max_gap = max_gap;
+            dv.probe = [dgram](uint64_t v, uint64_t* out) { dgram->ibf.bulk_contains(v, out); };
+        }
+        QueryResult q = run_query(ix->view, regex, augment != 0, &dv);
+        std::memcpy(mask, q.mask.data(), q.mask.size() * 8);
+        if (stats5) {
+            stats5[0] = q.stats.probes; stats5[1] = q.stats.states; stats5[2] = q.stats.quirk_merges;
+            stats5[3] = q.stats.dgram_probes; stats5[4] = q.stats.gap_nodes;
+        }
+        return 0;
+    } catch (const std::exception& e) { return fail(e); }
+}
+
 // ---- whole query -------------------------------------------------------------------
 // mask: ceil(bins/64) words.  stats3: probes, states, quirk_merges.
 int txo_query(txo_index* ix, const char* regex, uint64_t* mask, uint64_t* stats3) {

@@ -32,18 +32,55 @@ struct IndexView {
     uint64_t words() const { return (bins + 63) / 64; }
 };
 
+// DGramIndex as the collector sees it (include/dGramIndex.h:63-103,213-283): a second IBF over
+// gapped 3+3 residue codes and the gap range it was built for.  A default-constructed DGramIndex
+// (no -g) has min_gap = max_gap = 0 and is never queried (has_dibf_ is false).
+struct DGramView {
+    bool loaded = false;
+    uint64_t min_gap = 0, max_gap = 0;
+    std::function<void(uint64_t, uint64_t*)> probe;
+};
+
+// DGramTools::aa_to_num (include/dGramIndex.h:24-60): Base residue code for 'A'..'Z', else 0.
+inline uint64_t aa_to_num(int c) {
+    static const uint8_t base[26] = {0, 2, 1, 2, 3, 4, 5, 6, 7, 9, 8, 9, 10, 11, 20, 12, 13, 14, 15, 16, 20, 17, 18, 20, 19, 3};
+    return (c >= 'A' && c <= 'Z') ? base[c - 'A'] : 0;
+}
+
+// DGramIndex::process_sequence (include/dGramIndex.h:159-211): the codes one record contributes.
+inline void dgram_codes(std::string_view seq, uint64_t min_gap, uint64_t max_gap, std::vector<uint64_t>& out) {
+    static const std::string alphabet = "ACDEFGHIKLMNPQRSTVWY";
+    auto idx = [&](char c) -> int { size_t p = alphabet.find(c); return p == std::string::npos ? -1 : (int)p; };
+    if (seq.size() < min_gap + 7) return;
+    for (size_t i = 2; i + min_gap + 3 < seq.size(); ++i) {
+        const int a1 = idx(seq[i - 2]), a2 = idx(seq[i - 1]), a3 = idx(seq[i]);
+        if (a1 < 0 || a2 < 0 || a3 < 0) continue;
+        for (uint64_t gap = min_gap; gap <= max_gap; ++gap) {
+            const size_t j = i + gap + 1;
+            if (j + 2 >= seq.size()) break;
+            const int b1 = idx(seq[j]), b2 = idx(seq[j + 1]), b3 = idx(seq[j + 2]);
+            if (b1 < 0 || b2 < 0 || b3 < 0) continue;
+            out.push_back(gap * 64000000ULL + a1 * 3200000ULL + a2 * 160000ULL + a3 * 8000ULL + b1 * 400ULL + b2 * 20ULL + b3);
+        }
+    }
+}
+
 struct CollectStats {
     uint64_t probes = 0;          // index look-ups actually issued (distinct forward k-mers)
     uint64_t states = 0;          // states popped
-    uint64_t quirk_merges = 0;    // merges of states with different shift_count_
+    uint64_t quirk_merges = 0;    // merges of states with different shift_count_ / gapped flag
+    uint64_t dgram_probes = 0;    // d-gram index look-ups
+    uint64_t gap_nodes = 0;       // Gap nodes added by augment()
 };
 
 struct Collector {
-    struct Item { int node; uint8_t shift; uint64_t kmer; Mask path; };
+    struct Item { int node; uint8_t shift; uint64_t kmer; Mask path; bool gapped = false; int res1 = 0, res2 = 0; };
     struct Bucket { std::vector<Item> items; std::unordered_map<uint64_t, size_t> at; size_t head = 0; };
 
-    const Graph& g;
+    Graph g;  // own copy: augment() adds Gap / guard nodes
     const IndexView& ix;
+    DGramView dgram;                 // default: not loaded
+    std::vector<uint64_t> gap_of;    // gap_map_: gap length of a Gap node
     std::vector<int> rank;
     std::vector<Bucket> table;
     uint64_t submask = 0;
@@ -54,6 +91,94 @@ struct Collector {
         for (unsigned c = ix.enc.k - 1; c > 0; --c) submask = (submask << ix.enc.lshift) | ix.enc.rmask;
         rank = g.ranks();
         table.resize(g.node_count());
+        gap_of.assign(g.node_count(), 0);
+    }
+
+    // ---- -a / --augment (include/otf_collector.h:395-493) -----------------------------------
+    int add_node(int label, uint64_t gap = 0) {
+        int n = g.add_node(label);
+        gap_of.push_back(gap);
+        return n;
+    }
+    void add_gap(const Catsite& c, uint64_t gap) {
+        int n = add_node(kGap, gap);
+        g.connect(c.site, n);
+        g.connect(n, c.downstream);
+    }
+    // merge_catsites (:439-464): adjacent catastrophic regions (by topological rank) fuse, their
+    // gap sets add pairwise
+    void merge_catsites(std::vector<Catsite>& cats) const {
+        std::sort(cats.begin(), cats.end(), [&](const Catsite& a, const Catsite& b) { return rank[a.first] < rank[b.first]; });
+        std::vector<Catsite> merged;
+        bool done = false;
+        for (const Catsite& c : cats) {
+            if (merged.empty() || rank[c.first] - 1 != rank[merged.back().last]) { merged.push_back(c); continue; }
+            Catsite& m = merged.back();
+            m.last = c.last;
+            std::set<uint64_t> sum;
+            for (uint64_t x : m.gaps) for (uint64_t y : c.gaps) sum.insert(x + y);
+            m.gaps = sum;
+            done = true;
+        }
+        if (done) cats = merged;
+    }
+    // augment (:466-493).  The reference iterates the gap set in robin_hood order; a Split keeps only
+    // its first and its LAST successor (update_arc_map), so with > 2 gaps the surviving pair is
+    // implementation-defined there.  Here: ascending order.
+    void augment(std::vector<Catsite> cats) {
+        merge_catsites(cats);
+        for (Catsite c : cats) {
+            const std::set<uint64_t> gaps = c.gaps;
+            c.downstream = g.succ[c.last].first;
+            if (c.downstream < 0) throw std::out_of_range("catsite without downstream node");
+            if (gaps.size() == 1) add_gap(c, *gaps.begin());
+            else {
+                int sp = add_node(kSplit), gh = add_node(kGhost);
+                g.connect(c.site, sp);
+                g.connect(gh, c.downstream);
+                c.site = sp;
+                c.downstream = gh;
+                for (uint64_t gp : gaps) add_gap(c, gp);
+            }
+        }
+        table.clear();
+        table.resize(g.node_count());
+        rank = g.ranks();
+    }
+
+    // gap_procedure (:290-312)
+    void gap_step(int id, Item& top) {
+        const uint64_t gap = gap_of[id];
+        int next = g.succ[id].first;
+        if (next < 0) throw std::out_of_range("arc_map_.at(): node without successor");
+        if (top.shift < 3 || gap < dgram.min_gap || gap > dgram.max_gap) {
+            push(Item{next, 0, 0, std::move(top.path), false, 0, 0});
+            return;
+        }
+        const uint64_t a1 = (top.kmer >> 10) & 31, a2 = (top.kmer >> 5) & 31, a3 = top.kmer & 31;
+        const uint64_t dg = gap * 64000000ULL + a1 * 3200000ULL + a2 * 160000ULL + a3 * 8000ULL;
+        push(Item{next, 0, dg, std::move(top.path), true, 0, 0});
+    }
+    // update_gapped (:216-245): the three residues after a gap complete the d-gram
+    void update_gapped(Item& s, int symbol) {
+        if (s.shift == 0) { s.kmer += 400ULL * aa_to_num(symbol); s.res1 = symbol; ++s.shift; }
+        else if (s.shift == 1) { s.kmer += 20ULL * aa_to_num(symbol); s.res2 = symbol; ++s.shift; }
+        else if (s.shift == 2) {
+            const uint64_t dg = s.kmer + aa_to_num(symbol);
+            if (dgram.loaded) {
+                Mask m(ix.words());
+                dgram.probe(dg, m.data());
+                ++stats.dgram_probes;
+                for (size_t w = 0; w < s.path.size(); ++w) s.path[w] &= m[w];
+            }
+            s.kmer = 0;
+            ix.enc.update_kmer(s.res1, s.kmer);
+            ix.enc.update_kmer(s.res2, s.kmer);
+            ix.enc.update_kmer(symbol, s.kmer);
+            ++s.shift;
+            s.gapped = false;
+            s.res1 = s.res2 = 0;
+        }
     }
 
     void push(Item&& it) {
@@ -63,7 +188,7 @@ struct Collector {
         if (f == b.at.end()) { b.at.emplace(key, b.items.size()); b.items.push_back(std::move(it)); }
         else {
             Item& dst = b.items[f->second];
-            if (dst.shift != it.shift) ++stats.quirk_merges;
+            if (dst.shift != it.shift || dst.gapped != it.gapped || dst.res1 != it.res1 || dst.res2 != it.res2) ++stats.quirk_merges;
             for (size_t w = 0; w < dst.path.size(); ++w) dst.path[w] |= it.path[w];
         }
     }
@@ -89,7 +214,7 @@ struct Collector {
         const uint64_t W = ix.words();
         Mask result(W, 0), ones(W, ~0ULL);
         if (ix.bins & 63) ones[W - 1] = (1ULL << (ix.bins & 63)) - 1;
-        push(Item{0, 0, 0, ones});
+        push(Item{0, 0, 0, ones, false, 0, 0});
         for (int r = 0; r < g.node_count(); ++r) {
             Bucket& b = table[r];
             while (b.head < b.items.size()) {
@@ -109,19 +234,20 @@ struct Collector {
                         break;
                     case 36:  // '$'
                     case kGhost:
-                        push(Item{succ(false), top.shift, top.kmer, std::move(top.path)});
+                        push(Item{succ(false), top.shift, top.kmer, std::move(top.path), top.gapped, top.res1, top.res2});
                         break;
                     case kSplit: {
                         int a = succ(false), c = succ(true);
-                        push(Item{a, top.shift, top.kmer, top.path});
-                        push(Item{c, top.shift, top.kmer, std::move(top.path)});
+                        push(Item{a, top.shift, top.kmer, top.path, top.gapped, top.res1, top.res2});
+                        push(Item{c, top.shift, top.kmer, std::move(top.path), top.gapped, top.res1, top.res2});
                         break;
                     }
-                    case kGap: throw std::runtime_error("Gap nodes (-a/-g) are not part of this oracle yet");
+                    case kGap: gap_step(id, top); break;
                     default:
-                        update_path(top, sym);
+                        if (top.gapped) update_gapped(top, sym);
+                        else update_path(top, sym);
                         if (mask_none(top.path)) break;
-                        push(Item{succ(false), top.shift, top.kmer, std::move(top.path)});
+                        push(Item{succ(false), top.shift, top.kmer, std::move(top.path), top.gapped, top.res1, top.res2});
                         break;
                 }
             }
@@ -139,7 +265,7 @@ struct QueryResult {
 };
 
 // preprocess_query + process_query + the `hit_vector &= ...` of run_collection.
-inline QueryResult run_query(const IndexView& ix, const std::string& regex) {
+inline QueryResult run_query(const IndexView& ix, const std::string& regex, bool augment = false, const DGramView* dgram = nullptr) {
     QueryResult q;
     std::string rx = regex;
     if (!ix.enc.dna) {
@@ -158,6 +284,12 @@ inline QueryResult run_query(const IndexView& ix, const std::string& regex) {
     kb.build(q.postfix);
     q.nodes = kb.g.node_count();
     Collector c(kb.g, ix);
+    if (dgram) c.dgram = *dgram;
+    if (augment && !kb.cats.empty()) {  // include/query.h:243
+        const int before = c.g.node_count();
+        c.augment(kb.cats);
+        for (int n = before; n < c.g.node_count(); ++n) c.stats.gap_nodes += c.g.label[n] == kGap;
+    }
     q.mask = c.collect();
     q.stats = c.stats;
     return q;

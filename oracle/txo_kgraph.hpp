@@ -12,6 +12,7 @@
 // visits the most recently added arc first, DFS-based topologicalSort.
 #pragma once
 #include <cstdint>
+#include <set>
 #include <string>
 #include <vector>
 #include <utility>
@@ -85,7 +86,26 @@ struct Graph {
     }
 };
 
-struct Sub { int start = -1, end = -1; bool twin = false; };  // twin: un-materialised single symbol (reduced builder)
+// Subgraph of include/construction_tools.h:71-142: entry/exit plus the bookkeeping the
+// "catastrophic sub-graph" detector needs (number of paths, set of path lengths).
+struct Sub {
+    int start = -1, end = -1;
+    bool twin = false;  // un-materialised single symbol (reduced builder)
+    uint64_t paths = 1;
+    std::set<uint64_t> lengths;
+    static Sub leaf(int n, bool twin) { Sub s; s.start = s.end = n; s.twin = twin; s.lengths = {1}; return s; }
+    void meta_from(const Sub& r) { paths = r.paths; lengths = r.lengths; }
+};
+
+// Catsite (include/construction_tools.h:147-185): a concatenation whose right operand has so many
+// paths that -a/--augment replaces it by Gap nodes.  Ids instead of lemon nodes.
+struct Catsite {
+    int site = -1;        // cleavage_site_: node before the high-complexity sub-graph
+    int first = -1;       // cleavage_start_
+    int last = -1;        // cleavage_end_
+    int downstream = -1;  // filled by complete()
+    std::set<uint64_t> gaps;
+};
 
 struct KGraphBuilder {
     Graph g;
@@ -93,6 +113,7 @@ struct KGraphBuilder {
     bool reduced;
     std::vector<Sub> st;
     std::vector<int> buf;  // reduced builder's symbol stack (buffer_t)
+    std::vector<Catsite> cats;
 
     KGraphBuilder(uint8_t ksize, bool reduced_alphabet) : k(ksize), reduced(reduced_alphabet) {}
 
@@ -116,7 +137,7 @@ struct KGraphBuilder {
         if (!s.twin) return;
         int sym = buf_top(); buf.pop_back();
         int n = g.add_node(sym);
-        s = {n, n, false};
+        s = Sub::leaf(n, false);
     }
     // In the reduced builder twin_test() is `start == end`, which is also true for a
     // materialised single node (construct_reduced_nfa.cpp:91-94).  `single(s)` restates that.
@@ -127,7 +148,7 @@ struct KGraphBuilder {
         if (s.start == s.end) {  // a real single node re-materialised from the buffer
             int sym = buf_top(); buf.pop_back();
             int n = g.add_node(sym);
-            s = {n, n, false};
+            s = Sub::leaf(n, false);
         }
     }
 
@@ -135,7 +156,9 @@ struct KGraphBuilder {
         if (s.twin || s.start == s.end) {
             int lab = reduced ? buf_top() : g.label[s.start];
             int n = g.add_node(lab);
-            return {n, n, false};
+            Sub c = Sub::leaf(n, false);
+            c.meta_from(s);
+            return c;
         }
         int n0 = g.node_count(), a0 = (int)g.arc.size();
         std::vector<char> f(n0, 0), b(n0, 0);
@@ -148,18 +171,31 @@ struct KGraphBuilder {
             auto [u, v] = g.arc[a];
             if (twin_of[u] >= 0 && twin_of[v] >= 0) g.connect(twin_of[u], twin_of[v]);
         }
-        return {twin_of[s.start], twin_of[s.end], false};
+        Sub c;
+        c.start = twin_of[s.start]; c.end = twin_of[s.end];
+        c.meta_from(s);
+        return c;
     }
 
     void op_symbol(int sym) {
-        if (reduced) { buf.push_back(sym); st.push_back({-1, -1, true}); }
-        else { int n = g.add_node(sym); st.push_back({n, n, false}); }
+        if (reduced) { buf.push_back(sym); st.push_back(Sub::leaf(-1, true)); }
+        else { int n = g.add_node(sym); st.push_back(Sub::leaf(n, false)); }
     }
     void op_concat() {
         Sub b = pop(), a = pop();
         materialise_if_twin(b); materialise_if_twin(a);
         g.connect(a.end, b.start);
-        st.push_back({a.start, b.end, false});
+        Sub c;
+        c.start = a.start; c.end = b.end;
+        c.paths = a.paths * b.paths;  // concatInfo
+        for (uint64_t x : a.lengths) for (uint64_t y : b.lengths) c.lengths.insert(x + y);
+        // detect_bad_graphs (src/construction_tools.cpp:161-180)
+        if (b.paths >= 15 || (c.paths >= 690000u && b.start != b.end)) {
+            Catsite cs;
+            cs.site = a.end; cs.first = b.start; cs.last = b.end; cs.gaps = b.lengths;
+            cats.push_back(cs);
+        }
+        st.push_back(c);
     }
     void op_union() {
         Sub b = pop(), a = pop();
@@ -176,7 +212,12 @@ struct KGraphBuilder {
         g.connect(sp, a.start); g.connect(sp, b.start);
         int gh = g.add_node(kGhost);
         g.connect(a.end, gh); g.connect(b.end, gh);
-        st.push_back({sp, gh, false});
+        Sub c;
+        c.start = sp; c.end = gh;
+        c.paths = a.paths + b.paths;  // unionInfo
+        c.lengths = a.lengths;
+        c.lengths.insert(b.lengths.begin(), b.lengths.end());
+        st.push_back(c);
     }
     void op_optional() {
         Sub a = pop();
@@ -185,7 +226,12 @@ struct KGraphBuilder {
         g.connect(sp, a.start);
         int gh = g.add_node(kGhost);
         g.connect(sp, gh); g.connect(a.end, gh);
-        st.push_back({sp, gh, false});
+        Sub c;
+        c.start = sp; c.end = gh;
+        c.paths = a.paths + 1;  // optionInfo
+        c.lengths = a.lengths;
+        c.lengths.insert(0);
+        st.push_back(c);
     }
     // `kk` arrives as `const uint8_t&` in the reference, so (max+1) is truncated mod 256.
     void op_kleene(uint8_t kk) {
@@ -205,7 +251,11 @@ struct KGraphBuilder {
             if ((int)i == (int)kk - 2) { g.connect(c.end, gh); break; }
             back = c.end;
         }
-        st.push_back({sp, gh, false});
+        Sub r;
+        r.start = sp; r.end = gh;
+        r.paths = a.paths * kk;  // kleeneInfo: lengths i*l for i < repeats
+        for (uint64_t i = 0; i < kk; ++i) for (uint64_t l : a.lengths) r.lengths.insert(i * l);
+        st.push_back(r);
     }
     void op_plus() {
         Sub a = pop();
@@ -221,7 +271,9 @@ struct KGraphBuilder {
             if ((int)i == (int)k - 2) { g.connect(c.end, gh); break; }
             back = c.end;
         }
-        st.push_back({a.start, gh, false});
+        Sub r;  // plus_procedure pushes a bare Subgraph{start, ghost}: paths 1, no lengths
+        r.start = a.start; r.end = gh;
+        st.push_back(r);
     }
     bool op_quant(size_t lo, size_t hi) {
         bool skip = false;

@@ -142,10 +142,11 @@ class SessionSimulator:
     """CPU stand-in for a txq session (test double): keeps every program's slot masks, runs a
     stage's ops with numpy over oracle-probed masks and answers the alive questions."""
 
-    def __init__(self, oracle_index, n_programs):
+    def __init__(self, oracle_index, n_programs, dgram_index=None):
         from tetrex_amd import host
         self.host = host
         self.ox = oracle_index
+        self.dg = dgram_index  # oracle flat IBF over d-gram codes (the session's auxiliary index)
         self.W = oracle_index.words_per_mask
         self.ones = ones_mask(oracle_index.bins)
         self.slots = [dict() for _ in range(n_programs)]
@@ -161,7 +162,12 @@ class SessionSimulator:
     def stage(self, blob, qp, qs):
         kmers, progs = self.host.parse_blob(blob)
         assert len(progs) == len(self.slots)
-        M = self.ox.probe(kmers) if kmers.size else np.zeros((0, self.W), dtype=np.uint64)
+        n_aux = self.host.blob_aux_kmers(blob)
+        n_main = kmers.size - n_aux
+        M = self.ox.probe(kmers[:n_main]) if n_main else np.zeros((0, self.W), dtype=np.uint64)
+        if n_aux:
+            assert self.dg is not None, "blob has d-gram k-mers but no auxiliary index is attached"
+            M = np.concatenate([M, self.dg.probe(kmers[n_main:])])
         for p, (n_slots, ops) in enumerate(progs):
             for k, d, a, b in ops:
                 x = self._get(p, int(a))

@@ -22,7 +22,7 @@ SYMBOLS = [
     "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
     "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
-    "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_stage", "txq_session_end",
+    "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_set_aux_index", "txq_session_stage", "txq_session_end",
     "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize",
 ]
 
@@ -77,6 +77,7 @@ def lib():
         L.txq_session_begin.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
         L.txq_session_stage.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, u32p, u32p, C.c_size_t, C.POINTER(C.c_uint8)]
         L.txq_session_end.argtypes = [C.c_void_p, u64p]
+        L.txq_session_set_aux_index.argtypes = [C.c_void_p, C.c_void_p]
         L.txq_malloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
         L.txq_free.argtypes = [C.c_void_p]
         L.txq_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -271,6 +272,27 @@ class Index:
     def session(self, n_programs):
         return Session(self, n_programs)
 
+    def query_masks_gapped(self, regexes, dna, k, reduction=0, augment=True, dgram=None, min_gap=0, max_gap=0,
+                           ops_per_query_per_stage=0):
+        """query_masks with -a (augment) and, when `dgram` (a GPU-resident flat IBF over d-gram codes)
+        is given, -g."""
+        from .host import GapOptions
+        Lq = _query_lib()
+        Lq.txe_query_masks_gapped.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(GapOptions), C.c_int, C.c_uint, C.c_uint,
+                                              C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t, u64p, C.POINTER(C.c_int), u64p]
+        n = len(regexes)
+        arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
+        masks = np.zeros((n, self.shard_words), dtype=np.uint64)
+        status = (C.c_int * n)()
+        stats = (C.c_uint64 * 8)()
+        g = GapOptions(int(augment), int(dgram is not None), min_gap, max_gap)
+        rc = Lq.txe_query_masks_gapped(self._h, dgram._h if dgram is not None else None, C.byref(g), int(dna), k, reduction,
+                                       arr, n, ops_per_query_per_stage, masks.ctypes.data_as(u64p), status, stats)
+        if rc < 0:
+            raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
+        keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)))
+
     def query_masks(self, regexes, dna, k, reduction=0, ops_per_query_per_stage=0):
         """Whole queries on this GPU-resident index through the C++ host (libtetrex_query.so):
         returns (masks [n, shard_words], status list, stats dict)."""
@@ -313,6 +335,10 @@ class Session:
         h = C.c_void_p()
         check(lib().txq_session_begin(index._h, n_programs, C.byref(h)))
         self._h = h
+
+    def set_aux_index(self, aux):
+        self._aux = aux  # keep it alive
+        check(lib().txq_session_set_aux_index(self._h, aux._h if aux is not None else None))
 
     def stage(self, blob, query_program=(), query_slot=()):
         al, size = _aligned(blob)

@@ -21,7 +21,8 @@ using ParallelFor = std::function<void(size_t, const std::function<void(size_t, 
 
 std::vector<uint8_t> make_blob(const std::vector<const std::vector<uint64_t>*>& kmer_tables, const std::vector<txq_program>& programs,
                                const std::vector<const std::vector<txq_op>*>& ops_of,
-                               const std::vector<const std::vector<uint32_t>*>& levels_of, const ParallelFor* par = nullptr) {
+                               const std::vector<const std::vector<uint32_t>*>& levels_of, const ParallelFor* par = nullptr,
+                               size_t n_aux_kmers = 0) {
     size_t n_kmers = 0;
     for (const auto* t : kmer_tables) n_kmers += t->size();
     if (n_kmers > 0xFFFFFFFEu) throw std::runtime_error("k-mer table overflow");
@@ -36,6 +37,7 @@ std::vector<uint8_t> make_blob(const std::vector<const std::vector<uint64_t>*>& 
     h.n_kmers = (uint32_t)n_kmers;
     h.n_ops = (uint32_t)n_ops;
     h.n_levels = (uint32_t)n_levels;
+    h.n_aux_kmers = n_aux_kmers;
     h.kmers_offset = sizeof(txq_blob_header_v2);
     h.programs_offset = h.kmers_offset + n_kmers * sizeof(uint64_t);
     h.ops_offset = h.programs_offset + programs.size() * sizeof(txq_program_v2);
@@ -73,13 +75,39 @@ std::vector<uint8_t> make_blob(const std::vector<const std::vector<uint64_t>*>& 
 
 static bool is_epsilon(int32_t label) { return label == KGraph::kGhost || label == KGraph::kSplit || label == '$'; }
 
-QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits)
-    : enc_(enc), g_(std::move(graph)), limits_(limits) {
+uint64_t dgram_residue_code(int symbol) {
+    static const uint8_t base[26] = {0, 2, 1, 2, 3, 4, 5, 6, 7, 9, 8, 9, 10, 11, 20, 12, 13, 14, 15, 16, 20, 17, 18, 20, 19, 3};
+    return (symbol >= 'A' && symbol <= 'Z') ? base[symbol - 'A'] : 0;
+}
+
+void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_gap, std::vector<uint64_t>& out) {
+    // only the 20 standard residues take part (include/dGramIndex.h:128-135,159-211)
+    auto code = [](char c) -> int {
+        static const char* alphabet = "ACDEFGHIKLMNPQRSTVWY";
+        const char* p = c ? std::strchr(alphabet, c) : nullptr;
+        return p ? (int)(p - alphabet) : -1;
+    };
+    if (seq.size() < min_gap + 7) return;
+    for (size_t i = 2; i + min_gap + 3 < seq.size(); ++i) {
+        const int a1 = code(seq[i - 2]), a2 = code(seq[i - 1]), a3 = code(seq[i]);
+        if (a1 < 0 || a2 < 0 || a3 < 0) continue;
+        for (uint64_t gap = min_gap; gap <= max_gap; ++gap) {
+            const size_t j = i + gap + 1;
+            if (j + 2 >= seq.size()) break;
+            const int b1 = code(seq[j]), b2 = code(seq[j + 1]), b3 = code(seq[j + 2]);
+            if (b1 < 0 || b2 < 0 || b3 < 0) continue;
+            out.push_back(gap * 64000000ULL + (uint64_t)a1 * 3200000ULL + (uint64_t)a2 * 160000ULL + (uint64_t)a3 * 8000ULL +
+                          (uint64_t)b1 * 400ULL + (uint64_t)b2 * 20ULL + (uint64_t)b3);
+        }
+    }
+}
+
+QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps)
+    : enc_(enc), g_(std::move(graph)), limits_(limits), gaps_(gaps) {
     if (enc_.k() < 2) throw std::runtime_error("k must be at least 2");
+    if (gaps_.augment) g_.augment();
     const int32_t n = n_nodes_ = g_.size();
     const std::vector<int32_t> topo = g_.topological_order();
-    for (int32_t v : topo)
-        if (g_.label[v] == KGraph::kGap) throw std::runtime_error("gap nodes (-a/-g) are not supported yet");
     // closure[v] of epsilon nodes, successors first
     std::vector<std::vector<int32_t>> closure(n);
     std::vector<uint8_t> hole(n, 0);
@@ -108,7 +136,7 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     for (int32_t u = 0; u <= n; ++u) {
         std::vector<int32_t> t;
         if (u == n) through(0, t, dangling_[u]);
-        else if (!is_epsilon(g_.label[u]) && g_.label[u] != KGraph::kMatch) through(g_.next_a[u], t, dangling_[u]);
+        else if (!is_epsilon(g_.label[u]) && g_.label[u] != KGraph::kMatch) through(g_.next_a[u], t, dangling_[u]);  // residues and gaps
         else continue;
         unique(t);
         if (t.empty()) continue;
@@ -145,7 +173,7 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     table_.resize(items);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
     std::vector<txq_op> none;
-    hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0}, none);
+    hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0, 0, 0, 0}, none);
 }
 
 // a state leaves item `from` (a residue node or the entry): to its join or only target
@@ -184,7 +212,10 @@ void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just
     // above them, so paths of different length < k-1 never share a key
     const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
-    const uint64_t key = (s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits));
+    // a state collecting the residues after a gap is identified by its partial d-gram and how many
+    // residues it has seen (bits 60-62 keep it apart from every ordinary state)
+    const uint64_t key = s.gapped ? (s.kmer | ((uint64_t)(4 + s.shift) << 60))
+                                  : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)));
     auto [where, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
     if (inserted) {
         s.asked = 0;
@@ -212,7 +243,7 @@ void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     }
 }
 
-void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op>& out) {
+void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op>& out, KmerTable* dgrams) {
     const unsigned k = enc_.k();
     const size_t start = out.size();
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
@@ -240,7 +271,49 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op
             }
             continue;
         }
+        if (lab == KGraph::kGap) {  // gap_procedure: restart the k-mer, or start a d-gram
+            const uint64_t gap = g_.gap[item];
+            for (State s : ns.items) {
+                if (s.shift < 3 || gap < gaps_.min_gap || gap > gaps_.max_gap) {
+                    s.kmer = 0;
+                    s.gapped = 0;
+                } else {
+                    s.kmer = gap * 64000000ULL + ((s.kmer >> 10) & 31) * 3200000ULL + ((s.kmer >> 5) & 31) * 160000ULL + (s.kmer & 31) * 8000ULL;
+                    s.gapped = 1;
+                }
+                s.shift = 0;
+                s.res1 = s.res2 = 0;
+                hand_on(item, s, out);
+            }
+            continue;
+        }
         for (State s : ns.items) {
+            if (s.gapped) {  // update_gapped: three residues complete the d-gram
+                if (s.shift == 0) { s.kmer += 400ULL * dgram_residue_code(lab); s.res1 = (uint8_t)lab; s.shift = 1; }
+                else if (s.shift == 1) { s.kmer += 20ULL * dgram_residue_code(lab); s.res2 = (uint8_t)lab; s.shift = 2; }
+                else {
+                    if (gaps_.dgram_loaded) {
+                        if (!dgrams) throw std::runtime_error("d-gram table missing");
+                        const uint32_t id = kDgramFlag | dgrams->intern(s.kmer + dgram_residue_code(lab));
+                        if (exclusive(s.slot)) emit(out, id, s.slot, s.slot, TXQ_SLOT_ZERO);
+                        else {
+                            const uint32_t d = fresh();
+                            emit(out, id, d, s.slot, TXQ_SLOT_ZERO);
+                            drop(s.slot);
+                            s.slot = d;
+                        }
+                    }
+                    s.kmer = 0;
+                    enc_.roll(s.res1, s.kmer);
+                    enc_.roll(s.res2, s.kmer);
+                    enc_.roll((unsigned char)lab, s.kmer);
+                    s.shift = 3 < k ? 3 : (uint8_t)k;
+                    s.gapped = 0;
+                    s.res1 = s.res2 = 0;
+                }
+                hand_on(item, s, out);
+                continue;
+            }
             const uint64_t probe = enc_.roll((unsigned char)lab, s.kmer);
             if (s.shift < k - 1) {
                 ++s.shift;
@@ -290,7 +363,8 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
-            ns.by_key.emplace((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)), i);
+            ns.by_key.emplace(s.gapped ? (s.kmer | ((uint64_t)(4 + s.shift) << 60))
+                                       : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits))), i);
         }
     }
 }
@@ -421,7 +495,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         try {
             if (bins <= 1) { passthrough[i] = 1; return; }  // include/query.h:265-272
             const std::string postfix = preprocess_query(regexes[i], enc);
-            q[i] = std::make_unique<QueryExpansion>(enc, build_kgraph(postfix, enc.k(), enc.alphabet() != Alphabet::Base), opt.limits);
+            q[i] = std::make_unique<QueryExpansion>(enc, build_kgraph(postfix, enc.k(), enc.alphabet() != Alphabet::Base), opt.limits, opt.gaps);
         } catch (const std::exception& e) {
             q[i].reset();
             st_local[i] = -1;
@@ -436,7 +510,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
     // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
     // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
-    std::vector<KmerTable> tables(n);
+    std::vector<KmerTable> tables(n), dgram_tables(n);
     std::vector<LevelScratch> scratch(threads);
     std::vector<std::vector<uint32_t>> levels(n);
     bool first = true;
@@ -445,12 +519,13 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         parallel_for([&](size_t i, int) {
             ops[i].clear();
             tables[i].clear();
+            dgram_tables[i].clear();
             if (first && passthrough[i]) ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
             if (!q[i] || q[i]->done()) return;
             if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
             try {
                 // a query that gains nothing from feedback runs on without pausing
-                q[i]->advance(q[i]->wants_feedback() ? opt.ops_per_query_per_stage : SIZE_MAX, tables[i], ops[i]);
+                q[i]->advance(q[i]->wants_feedback() ? opt.ops_per_query_per_stage : SIZE_MAX, tables[i], ops[i], &dgram_tables[i]);
             } catch (const std::exception& e) {
                 // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
                 // query is neutralised by not emitting anything further
@@ -467,21 +542,28 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
         if (!first && total.load() == 0 && !pending) break;
 
-        // the stage's k-mer table is the concatenation of the per-query tables
-        std::vector<uint32_t> base(n, 0);
-        std::vector<const std::vector<uint64_t>*> kmer_tables(n);
-        size_t stage_kmers = 0;
+        // the stage's table: the per-query k-mer tables, then the per-query d-gram tables (the
+        // device probes the last `stage_dgrams` entries on the auxiliary index)
+        std::vector<uint32_t> base(n, 0), dbase(n, 0);
+        std::vector<const std::vector<uint64_t>*> kmer_tables;
+        size_t stage_kmers = 0, stage_dgrams = 0;
         for (size_t i = 0; i < n; ++i) {
             base[i] = (uint32_t)stage_kmers;
             stage_kmers += tables[i].values().size();
-            kmer_tables[i] = &tables[i].values();
+            kmer_tables.push_back(&tables[i].values());
         }
-        if (stage_kmers > 0xFFFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
+        for (size_t i = 0; i < n; ++i) {
+            dbase[i] = (uint32_t)(stage_kmers + stage_dgrams);
+            stage_dgrams += dgram_tables[i].values().size();
+            kmer_tables.push_back(&dgram_tables[i].values());
+        }
+        if (stage_kmers + stage_dgrams > 0x7FFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
         parallel_for([&](size_t i, int t) {
-            const uint32_t add = base[i];
-            if (add)
-                for (txq_op& o : ops[i])
-                    if (o.kmer != TXQ_NO_KMER) o.kmer += add;
+            const uint32_t add = base[i], dadd = dbase[i];
+            for (txq_op& o : ops[i]) {
+                if (o.kmer == TXQ_NO_KMER) continue;
+                o.kmer = (o.kmer & kDgramFlag) ? (o.kmer & ~kDgramFlag) + dadd : o.kmer + add;
+            }
             levels[i] = schedule_levels(ops[i], slots[i], scratch[t]);
         });
 
@@ -503,7 +585,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        const std::vector<uint8_t> blob = make_blob(kmer_tables, programs, ops_of, levels_of, &par_any);
+        const std::vector<uint8_t> blob = make_blob(kmer_tables, programs, ops_of, levels_of, &par_any, stage_dgrams);
         st.expand_seconds += clock() - mark;
         mark = clock();
         exec.stage(blob, qp, qs, alive);
@@ -511,7 +593,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         mark = clock();
         ++st.stages;
         st.ops += total.load();
-        st.kmers += stage_kmers;
+        st.kmers += stage_kmers + stage_dgrams;
         st.feedback_queries += qp.size();
         // prune dead frontier states
         for (size_t a = 0; a < qp.size();) {

@@ -38,6 +38,24 @@ struct CompileLimits {
     size_t max_states = 8u << 20;  // per query
 };
 
+// -a / -g of `tetrex query` (reference include/arg_parse.h:64,68): bypass catastrophic sub-graphs
+// with Gap nodes, and filter across a gap with the d-gram index when one is loaded
+// (DGramIndex, include/dGramIndex.h; gap_procedure / update_gapped, include/otf_collector.h:216-245,290-312).
+struct GapOptions {
+    bool augment = false;
+    bool dgram_loaded = false;         // has_dibf_
+    uint64_t min_gap = 0, max_gap = 0; // DGramIndex::getMinGap / getMaxGap (0 / 0 without -g)
+};
+
+// residue code of the d-gram alphabet (DGramTools::aa_to_num): Base code for 'A'..'Z', else 0
+uint64_t dgram_residue_code(int symbol);
+// the d-gram codes one sequence record contributes (DGramIndex::process_sequence)
+void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_gap, std::vector<uint64_t>& out);
+
+// op.kmer of an op that ANDs with a d-gram mask: bit 31 set on the index into the d-gram table
+// (local to one expansion; run_staged rebases both kinds into the stage's single table, d-grams last)
+constexpr uint32_t kDgramFlag = 0x80000000u;
+
 struct QueryProgram {
     std::vector<txq_op> ops;  // k-mer field indexes the BATCH table
     uint32_t n_slots = TXQ_SLOT_FIRST_FREE;
@@ -65,12 +83,12 @@ class KmerTable {
 class QueryExpansion {
   public:
     using Intern = KmerTable&;
-    QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits);
+    QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps = {});
 
     bool done() const { return cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
-    void advance(size_t op_budget, Intern intern, std::vector<txq_op>& out);
+    void advance(size_t op_budget, Intern intern, std::vector<txq_op>& out, KmerTable* dgrams = nullptr);
     uint32_t n_slots() const { return high_water_; }
     // distinct non-constant slots of waiting states that were not asked about before (a waiting
     // state's mask only ever grows, so one answer per state is enough); marks them as asked
@@ -85,11 +103,12 @@ class QueryExpansion {
     uint64_t total_ops() const { return total_ops_; }
 
   private:
-    struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; };
+    struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; uint8_t gapped = 0; uint8_t res1 = 0, res2 = 0; };
     struct NodeStates { std::vector<State> items; FlatMap by_key; };
     const KmerEncoder& enc_;
     KGraph g_;
     CompileLimits limits_;
+    GapOptions gaps_;
     // Derived, epsilon-free graph.  Items 0..n-1 are the k-graph's nodes (only residue and Match
     // nodes are ever visited), item n is the entry, items > n are JOINS: one per distinct set of
     // >= 2 residue/Match nodes reachable through Ghost/Split/'$' nodes.  A state leaving a residue
@@ -137,6 +156,7 @@ struct StageExecutor {
 };
 
 struct StagedOptions {
+    GapOptions gaps;
     int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
     size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)

@@ -20,17 +20,32 @@ static void ensure_device(int device) {
     bound = device;
 }
 
-DeviceIndex::~DeviceIndex() {
-    if (ix_) txq_index_free(ix_);
-}
-
 static txq_ibf_desc describe(const IbfImage& f) {
     return txq_ibf_desc{f.bins, f.tech_bins, f.bin_size, f.hash_shift, f.bin_words, f.hash_funs, f.words.data()};
 }
 
+DeviceIndex::~DeviceIndex() {
+    if (aux_) txq_index_free(aux_);
+    if (ix_) txq_index_free(ix_);
+}
+
+void DeviceIndex::attach_dgram(const DgramImage& dgram) {
+    if (!ix_) throw std::runtime_error("index not uploaded");
+    if (dgram.ibf.bins != info_.user_bins) throw std::runtime_error("the d-gram index was built over a different number of bins");
+    if (aux_) { txq_index_free(aux_); aux_ = nullptr; }
+    txq_ibf_desc d = describe(dgram.ibf);
+    txq_index_desc desc{1, &d, nullptr, nullptr, dgram.ibf.bins};
+    txq_check(txq_index_upload(&desc, shard_rank_, n_shards_, &aux_), "txq_index_upload(d-gram)");
+    dgram_min_ = dgram.min_gap;
+    dgram_max_ = dgram.max_gap;
+}
+
 void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, int n_shards) {
     ensure_device(device);
+    if (aux_) { txq_index_free(aux_); aux_ = nullptr; }
     if (ix_) { txq_index_free(ix_); ix_ = nullptr; }
+    shard_rank_ = shard_rank;
+    n_shards_ = n_shards;
     enc_ = KmerEncoder(image.molecule == "na" ? Molecule::DNA : Molecule::Peptide, image.k, (Alphabet)image.reduction);
     if (!image.is_hibf) {
         txq_ibf_desc d = describe(image.ibf);
@@ -51,8 +66,16 @@ void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, in
     txq_check(txq_index_get_info(ix_, &info_), "txq_index_get_info");
 }
 
-TxqStageExecutor::TxqStageExecutor(txq_index* ix, size_t n_programs) {
+TxqStageExecutor::TxqStageExecutor(txq_index* ix, size_t n_programs, txq_index* aux) {
     txq_check(txq_session_begin(ix, n_programs, &session_), "txq_session_begin");
+    if (aux) {
+        const int rc = txq_session_set_aux_index(session_, aux);
+        if (rc != TXQ_OK) {
+            txq_session_end(session_, nullptr);
+            session_ = nullptr;
+            txq_check(rc, "txq_session_set_aux_index");
+        }
+    }
 }
 TxqStageExecutor::~TxqStageExecutor() {
     if (session_) txq_session_end(session_, nullptr);
@@ -73,14 +96,14 @@ void TxqStageExecutor::finish(uint64_t* masks) {
 
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                   std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
-                                  const StagedOptions* options) {
+                                  const StagedOptions* options, txq_index* aux) {
     txq_index_info info{};
     txq_check(txq_index_get_info(ix, &info), "txq_index_get_info");
     std::vector<uint64_t> masks(regexes.size() * info.shard_words);
     if (status) status->assign(regexes.size(), 0);
     if (messages) messages->assign(regexes.size(), std::string());
     if (regexes.empty()) return masks;
-    TxqStageExecutor exec(ix, regexes.size());
+    TxqStageExecutor exec(ix, regexes.size(), aux);
     const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, options ? *options : StagedOptions{}, status, messages);
     if (stats) *stats = st;
     exec.finish(masks.data());
@@ -90,7 +113,13 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
 std::vector<uint64_t> DeviceIndex::query_masks(const std::vector<std::string>& regexes, std::vector<int>* status,
                                                std::vector<std::string>* messages, StagedStats* stats, const StagedOptions* options) {
     if (!ix_) throw std::runtime_error("index not uploaded");
-    return run_queries(ix_, enc_, regexes, status, messages, stats, options);
+    StagedOptions opt = options ? *options : StagedOptions{};
+    if (aux_) {
+        opt.gaps.dgram_loaded = true;
+        opt.gaps.min_gap = dgram_min_;
+        opt.gaps.max_gap = dgram_max_;
+    }
+    return run_queries(ix_, enc_, regexes, status, messages, stats, &opt, aux_);
 }
 
 std::vector<uint64_t> set_bins(const uint64_t* mask, uint64_t bins) {
@@ -229,6 +258,28 @@ IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOpt
     }
     img.format = "hibf";
     return img;
+}
+
+DgramImage build_dgram_index(const std::vector<std::string>& bin_files, uint64_t min_gap, uint64_t max_gap, unsigned hash_count,
+                             float fpr, int device) {
+    if (bin_files.empty()) throw std::runtime_error("no input libraries");
+    if (min_gap > max_gap) throw std::runtime_error("lower gap bound above the upper bound");
+    ensure_device(device);
+    std::vector<std::vector<uint64_t>> values(bin_files.size());
+    for (size_t b = 0; b < bin_files.size(); ++b)
+        for_each_record(bin_files[b], [&](const FastaRecord& r) { dgram_record_values(r.seq, min_gap, max_gap, values[b]); });
+    std::vector<const std::vector<uint64_t>*> per_bin;
+    size_t most = 0;
+    for (auto& v : values) { per_bin.push_back(&v); most = std::max(most, v.size()); }
+    DgramImage d;
+    d.min_gap = min_gap;
+    d.max_gap = max_gap;
+    d.hash_count = (uint8_t)hash_count;
+    d.fpr = fpr;
+    d.bin_paths = bin_files;
+    d.ibf = build_flat(per_bin, std::max<uint64_t>(1, compute_bitcount(most, fpr)), hash_count);
+    d.format = "dgram";
+    return d;
 }
 
 }  // namespace tetrex

@@ -19,7 +19,7 @@ void txq_check(int rc, const char* what);
 // StageExecutor over a txq session: slot masks stay in HBM between stages.
 class TxqStageExecutor final : public StageExecutor {
   public:
-    TxqStageExecutor(txq_index* ix, size_t n_programs);
+    TxqStageExecutor(txq_index* ix, size_t n_programs, txq_index* aux = nullptr);
     ~TxqStageExecutor() override;
     void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& query_program,
                const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) override;
@@ -33,7 +33,7 @@ class TxqStageExecutor final : public StageExecutor {
 // Whole queries on an uploaded index: staged expansion + device execution.
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                   std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
-                                  const StagedOptions* options);
+                                  const StagedOptions* options, txq_index* aux = nullptr);
 
 class DeviceIndex {
   public:
@@ -55,9 +55,17 @@ class DeviceIndex {
     std::vector<uint64_t> query_masks(const std::vector<std::string>& regexes, std::vector<int>* status = nullptr,
                                       std::vector<std::string>* messages = nullptr, StagedStats* stats = nullptr,
                                       const StagedOptions* options = nullptr);
+    // `tetrex query -g`: upload the d-gram index next to the main index (same device, same shard)
+    void attach_dgram(const DgramImage& dgram);
+    bool has_dgram() const { return aux_ != nullptr; }
+    uint64_t dgram_min_gap() const { return dgram_min_; }
+    uint64_t dgram_max_gap() const { return dgram_max_; }
 
   private:
     txq_index* ix_ = nullptr;
+    txq_index* aux_ = nullptr;
+    uint64_t dgram_min_ = 0, dgram_max_ = 0;
+    int shard_rank_ = 0, n_shards_ = 1;
     txq_index_info info_{};
     KmerEncoder enc_;
 };
@@ -80,5 +88,8 @@ struct BuildOptions {
 };
 // `tetrex index`: FASTA files -> index image, bits set on the GPU (txq_emplace_device).
 IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOptions& opt, size_t* n_sequences = nullptr);
+// `tetrex track`: FASTA files -> d-gram index (reference src/dGramIndex.cpp:22-38, include/dGramIndex.h:105-157)
+DgramImage build_dgram_index(const std::vector<std::string>& bin_files, uint64_t min_gap, uint64_t max_gap, unsigned hash_count,
+                             float fpr, int device = 0);
 
 }  // namespace tetrex

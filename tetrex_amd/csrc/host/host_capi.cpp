@@ -114,8 +114,8 @@ struct CallbackExecutor final : StageExecutor {
 }  // namespace
 
 int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
-                   size_t ops_per_query_per_stage, size_t ops_per_stage, txh_stage_fn fn, void* user, int* status,
-                   uint64_t* stats6) {
+                   size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps, txh_stage_fn fn,
+                   void* user, int* status, uint64_t* stats6) {
     try {
         KmerEncoder enc = encoder(dna, k, reduction);
         std::vector<std::string> rx(regex, regex + n);
@@ -125,6 +125,7 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
         StagedOptions opt;
         if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
         if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
+        if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0, gaps->min_gap, gaps->max_gap};
         std::vector<int> st;
         std::vector<std::string> why;
         const StagedStats s = run_staged(enc, bins, rx, exec, opt, &st, &why);
@@ -139,6 +140,13 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
         }
         return failures;
     } catch (const std::exception& e) { return fail(e.what()); }
+}
+
+int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, size_t cap) {
+    std::vector<uint64_t> v;
+    dgram_record_values(std::string_view(seq, len), min_gap, max_gap, v);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    return (int64_t)v.size();
 }
 
 const void* txh_blob_data(const txh_blob* b, size_t* bytes) {

@@ -249,7 +249,55 @@ IndexImage parse_legacy(const uint8_t* p, size_t n) {
     return ix;  // trailing reduction name etc. are not needed on the query path
 }
 
+DgramImage parse_dgram(const uint8_t* p, size_t n, const Variant& v) {
+    In in(p, n);
+    DgramImage d;
+    d.min_gap = in.get<uint64_t>();
+    d.max_gap = in.get<uint64_t>();
+    d.pad = in.get<uint64_t>();
+    d.hash_count = in.get<uint8_t>();
+    d.fpr = in.get<float>();
+    if (d.min_gap > d.max_gap || d.max_gap > (1u << 20) || d.hash_count < 1 || d.hash_count > 5) throw ParseError("implausible d-gram header");
+    d.bin_paths = in.strs();
+    d.ibf = read_hibf_ibf(in, v);
+    const uint64_t bc = in.get<uint64_t>();
+    if (bc != d.bin_paths.size() || bc != d.ibf.bins || d.ibf.hash_funs != d.hash_count) throw ParseError("d-gram bin count mismatch");
+    // trailing `hits_` bit vector of bc bits, same container layout as the filter's data
+    const uint64_t words = (bc + 63) / 64, stored = v.pad512 ? ((words + 7) / 8) * 8 : words;
+    if (v.bit_vector == 0) { if (in.get<uint64_t>() != bc) throw ParseError("hits size"); }
+    else if (v.bit_vector == 1) { if (in.get<uint64_t>() != stored) throw ParseError("hits words"); }
+    else { if (in.get<uint64_t>() != bc || in.get<uint64_t>() != stored) throw ParseError("hits size"); }
+    for (uint64_t i = 0; i < stored; ++i) in.get<uint64_t>();
+    if (v.bit_vector == 1 && in.get<uint64_t>() != bc) throw ParseError("hits size");
+    if (in.left() != 0) throw ParseError("trailing bytes");
+    d.format = "cereal/" + v.name();
+    return d;
+}
+
 }  // namespace
+
+DgramImage parse_dgram_index(const std::vector<uint8_t>& bytes) {
+    std::string first_error;
+    for (int ibfver = 1; ibfver >= 0; --ibfver)
+        for (int bv = 0; bv < 3; ++bv)
+            for (int pad = 0; pad < 2; ++pad)
+                for (int occ = 0; occ < 3; ++occ) {
+                    const Variant v{ibfver != 0, bv, pad != 0, occ, false, false};
+                    try {
+                        return parse_dgram(bytes.data(), bytes.size(), v);
+                    } catch (const ParseError& e) {
+                        if (first_error.empty()) first_error = e.what();
+                    }
+                }
+    throw std::runtime_error("not a TetRex d-gram index (no known layout variant fits): " + first_error);
+}
+
+DgramImage read_dgram_index_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("Filepath " + path + " not valid");
+    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+    return parse_dgram_index(bytes);
+}
 
 IndexImage parse_index(const std::vector<uint8_t>& bytes) {
     std::string first_error;
@@ -362,6 +410,32 @@ std::vector<uint8_t> serialise_index(const IndexImage& ix) {
         o.raw(enc.reduce_table().data(), 256);
     }
     return std::move(o.buf);
+}
+
+std::vector<uint8_t> serialise_dgram_index(const DgramImage& d) {
+    Out o;
+    o.put<uint64_t>(d.min_gap);
+    o.put<uint64_t>(d.max_gap);
+    o.put<uint64_t>(d.pad);
+    o.put<uint8_t>(d.hash_count);
+    o.put<float>(d.fpr);
+    o.strs(d.bin_paths);
+    write_ibf(o, d.ibf);
+    o.put<uint64_t>(d.ibf.bins);
+    o.put<uint64_t>(d.ibf.bins);  // hits_: bit_vector {size in bits | words}, all set (include/dGramIndex.h:96)
+    for (uint64_t w = 0; w < (d.ibf.bins + 63) / 64; ++w) {
+        const uint64_t left = d.ibf.bins - w * 64;
+        o.put<uint64_t>(left >= 64 ? ~0ULL : ((1ULL << left) - 1ULL));
+    }
+    return std::move(o.buf);
+}
+
+void write_dgram_index_file(const std::string& path, const DgramImage& d) {
+    const std::vector<uint8_t> bytes = serialise_dgram_index(d);
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) throw std::runtime_error("cannot open " + path + " for writing");
+    f.write((const char*)bytes.data(), (std::streamsize)bytes.size());
+    if (!f) throw std::runtime_error("short write to " + path);
 }
 
 void write_index_file(const std::string& path, const IndexImage& ix) {

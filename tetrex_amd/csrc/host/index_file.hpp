@@ -55,6 +55,21 @@ struct IndexImage {
     uint64_t bin_count() const { return is_hibf ? hibf.user_bins : ibf.bins; }
 };
 
+// The d-gram index of `tetrex track` / `tetrex query -g` (reference include/dGramIndex.h:305-309):
+//   u64 min_gap | u64 max_gap | u64 pad | u8 hash_count | f32 fpr | vec<str> bins | <hibf IBF> | u64 bin_count | bit_vector hits
+struct DgramImage {
+    uint64_t min_gap = 3, max_gap = 21, pad = 1;
+    uint8_t hash_count = 3;
+    float fpr = 0.05f;
+    std::vector<std::string> bin_paths;
+    IbfImage ibf;
+    std::string format;
+};
+DgramImage parse_dgram_index(const std::vector<uint8_t>& bytes);
+DgramImage read_dgram_index_file(const std::string& path);
+std::vector<uint8_t> serialise_dgram_index(const DgramImage& d);
+void write_dgram_index_file(const std::string& path, const DgramImage& d);
+
 // Throws std::runtime_error with a descriptive message on malformed input.
 IndexImage read_index_file(const std::string& path);
 IndexImage parse_index(const std::vector<uint8_t>& bytes);

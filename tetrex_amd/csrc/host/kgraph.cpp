@@ -1,5 +1,6 @@
 #include "kgraph.hpp"
 
+#include <algorithm>
 #include <cctype>
 #include <stdexcept>
 
@@ -7,6 +8,7 @@ namespace tetrex {
 
 int32_t KGraph::add(int32_t lab) {
     label.push_back(lab);
+    gap.push_back(0);
     next_a.push_back(kNone);
     next_b.push_back(kNone);
     return size() - 1;
@@ -46,6 +48,69 @@ std::vector<int32_t> KGraph::topological_order() const {
     return order;
 }
 
+std::vector<int32_t> KGraph::reference_ranks() const {
+    const int32_t n = size();
+    std::vector<std::vector<int32_t>> out(n);
+    for (size_t a = 0; a < arc_src.size(); ++a) out[arc_src[a]].push_back(arc_dst[a]);
+    std::vector<int32_t> rank(n, 0), cursor(n, 0);
+    std::vector<uint8_t> seen(n, 0);
+    int32_t next = n;
+    for (int32_t root = n - 1; root >= 0; --root) {
+        if (seen[root]) continue;
+        std::vector<int32_t> stack{root};
+        seen[root] = 1;
+        while (!stack.empty()) {
+            const int32_t u = stack.back();
+            if (cursor[u] < (int32_t)out[u].size()) {
+                const int32_t v = out[u][out[u].size() - 1 - cursor[u]++];  // newest arc first
+                if (!seen[v]) { seen[v] = 1; stack.push_back(v); }
+            } else {
+                rank[u] = --next;
+                stack.pop_back();
+            }
+        }
+    }
+    return rank;
+}
+
+size_t KGraph::augment() {
+    if (catsites.empty()) return 0;
+    const std::vector<int32_t> rank = reference_ranks();
+    std::vector<CatSite> cats = catsites;
+    std::sort(cats.begin(), cats.end(), [&](const CatSite& a, const CatSite& b) { return rank[a.first] < rank[b.first]; });
+    // neighbouring regions (consecutive ranks) fuse; their gap sets add pairwise
+    std::vector<CatSite> merged;
+    for (const CatSite& c : cats) {
+        if (merged.empty() || rank[c.first] - 1 != rank[merged.back().last]) { merged.push_back(c); continue; }
+        CatSite& m = merged.back();
+        m.last = c.last;
+        std::set<uint64_t> sum;
+        for (uint64_t x : m.gaps) for (uint64_t y : c.gaps) sum.insert(x + y);
+        m.gaps.swap(sum);
+    }
+    size_t added = 0;
+    auto bypass = [&](int32_t from, int32_t to, uint64_t length) {
+        const int32_t g = add(kGap);
+        gap[g] = length;
+        link(from, g);
+        link(g, to);
+        ++added;
+    };
+    for (const CatSite& c : merged) {
+        const int32_t downstream = next_a[c.last];
+        if (downstream == kNone) throw std::runtime_error("catastrophic region without a successor");
+        if (c.gaps.size() == 1) { bypass(c.site, downstream, *c.gaps.begin()); continue; }
+        // several lengths: a guard Split/Ghost pair.  A Split has two successor slots and every arc
+        // after the first lands in the second (update_arc_map), so only the first and the last
+        // length survive — in the reference in hash-set order, here in ascending order.
+        const int32_t fork = add(kSplit), join = add(kGhost);
+        link(c.site, fork);
+        link(join, downstream);
+        for (uint64_t length : c.gaps) bypass(fork, join, length);
+    }
+    return added;
+}
+
 namespace {
 
 // A partially built piece of the graph: entry/exit node, or a symbol that the reduced builder
@@ -53,7 +118,22 @@ namespace {
 struct Fragment {
     int32_t entry = KGraph::kNone, exit = KGraph::kNone;
     bool pending = false;
+    uint64_t paths = 1;          // Subgraph::paths (include/construction_tools.h:76)
+    std::set<uint64_t> lengths;  // Subgraph::lengths
     bool single() const { return pending || entry == exit; }
+    static Fragment residue(int32_t node, bool pending) {
+        Fragment f;
+        f.entry = f.exit = node;
+        f.pending = pending;
+        f.lengths = {1};
+        return f;
+    }
+    static Fragment span(int32_t entry, int32_t exit) {
+        Fragment f;
+        f.entry = entry;
+        f.exit = exit;
+        return f;
+    }
 };
 
 class Builder {
@@ -133,16 +213,15 @@ class Builder {
         const int32_t s = waiting_symbol();
         symbols_.pop_back();
         const int32_t n = g_.add(s);
-        f = Fragment{n, n, false};
+        f = Fragment::residue(n, false);
     }
 
     void symbol(int32_t s) {
         if (reduced_) {
             symbols_.push_back(s);
-            stack_.push_back(Fragment{KGraph::kNone, KGraph::kNone, true});
+            stack_.push_back(Fragment::residue(KGraph::kNone, true));
         } else {
-            const int32_t n = g_.add(s);
-            stack_.push_back(Fragment{n, n, false});
+            stack_.push_back(Fragment::residue(g_.add(s), false));
         }
     }
 
@@ -151,7 +230,12 @@ class Builder {
         realise(right);
         realise(left);
         g_.link(left.exit, right.entry);
-        stack_.push_back(Fragment{left.entry, right.exit, false});
+        Fragment both = Fragment::span(left.entry, right.exit);
+        both.paths = left.paths * right.paths;
+        for (uint64_t x : left.lengths) for (uint64_t y : right.lengths) both.lengths.insert(x + y);
+        if (right.paths >= 15 || (both.paths >= 690000u && right.entry != right.exit))
+            g_.catsites.push_back(CatSite{left.exit, right.entry, right.exit, right.lengths});
+        stack_.push_back(both);
     }
 
     void alternate() {
@@ -174,7 +258,11 @@ class Builder {
         const int32_t join = g_.add(KGraph::kGhost);
         g_.link(left.exit, join);
         g_.link(right.exit, join);
-        stack_.push_back(Fragment{fork, join, false});
+        Fragment either = Fragment::span(fork, join);
+        either.paths = left.paths + right.paths;
+        either.lengths = left.lengths;
+        either.lengths.insert(right.lengths.begin(), right.lengths.end());
+        stack_.push_back(either);
     }
 
     void optional() {
@@ -185,14 +273,20 @@ class Builder {
         const int32_t join = g_.add(KGraph::kGhost);
         g_.link(fork, join);
         g_.link(body.exit, join);
-        stack_.push_back(Fragment{fork, join, false});
+        Fragment maybe = Fragment::span(fork, join);
+        maybe.paths = body.paths + 1;
+        maybe.lengths = body.lengths;
+        maybe.lengths.insert(0);
+        stack_.push_back(maybe);
     }
 
     // duplicate the sub-graph between f.entry and f.exit (nodes on some entry->exit path)
     Fragment duplicate(const Fragment& f) {
         if (f.single()) {
-            const int32_t n = g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]);
-            return Fragment{n, n, false};
+            Fragment copy = Fragment::residue(g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]), false);
+            copy.paths = f.paths;
+            copy.lengths = f.lengths;
+            return copy;
         }
         const int32_t n0 = g_.size();
         const size_t a0 = g_.arc_src.size();
@@ -206,7 +300,10 @@ class Builder {
             const int32_t u = g_.arc_src[a], v = g_.arc_dst[a];
             if (image[u] != KGraph::kNone && image[v] != KGraph::kNone) g_.link(image[u], image[v]);
         }
-        return Fragment{image[f.entry], image[f.exit], false};
+        Fragment copy = Fragment::span(image[f.entry], image[f.exit]);
+        copy.paths = f.paths;
+        copy.lengths = f.lengths;
+        return copy;
     }
     void flood(int32_t from, bool forward, std::vector<uint8_t>& mark, uint8_t bit) const {
         // adjacency (CSR) of the current arc list in the requested direction
@@ -249,7 +346,10 @@ class Builder {
             if (i == (int)depth - 2) { g_.link(copy.exit, join); break; }
             tail = copy.exit;
         }
-        stack_.push_back(Fragment{fork, join, false});
+        Fragment loop = Fragment::span(fork, join);
+        loop.paths = body.paths * depth;
+        for (uint64_t i = 0; i < depth; ++i) for (uint64_t l : body.lengths) loop.lengths.insert(i * l);
+        stack_.push_back(loop);
     }
 
     void plus() {
@@ -266,7 +366,7 @@ class Builder {
             if (i == (int)k_ - 2) { g_.link(copy.exit, join); break; }
             tail = copy.exit;
         }
-        stack_.push_back(Fragment{body.entry, join, false});
+        stack_.push_back(Fragment::span(body.entry, join));  // the reference records no path statistics for '+'
     }
 
     // X{lo} / X{lo,hi}; returns true when the following '-' of the postfix has been consumed

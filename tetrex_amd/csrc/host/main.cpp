@@ -112,7 +112,6 @@ int cmd_query(int argc, char** argv) {
     std::string input = a.pos[1];
     if (input == "-") std::cin >> input;
     if (a.has("draw")) std::cerr << "[WARNING] -d/--draw (graphviz dump) is not available in this build" << std::endl;
-    if (a.has("augment") || a.has("gibf")) std::cerr << "[WARNING] -a/--augment and -g/--gibf (d-gram index) are not available in this build; running the plain query" << std::endl;
 
     IndexImage image;
     try {
@@ -124,6 +123,9 @@ int cmd_query(int argc, char** argv) {
     }
     DeviceIndex dev;
     dev.upload(image, std::atoi(a.get("device", "0").c_str()));
+    if (a.has("gibf")) dev.attach_dgram(read_dgram_index_file(a.get("gibf", "")));  // include/query.h:259-264
+    StagedOptions sopt;
+    sopt.gaps.augment = a.has("augment");
     const KmerEncoder enc = dev.encoder();
     const uint64_t bins = dev.bins(), W = dev.info().shard_words;
     const VerifyOptions vopt{threads};
@@ -164,7 +166,7 @@ int cmd_query(int argc, char** argv) {
         const double t0 = now();
         std::vector<int> status;
         std::vector<std::string> why;
-        const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why);
+        const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why, nullptr, &sopt);
         const double batch = (now() - t0) / std::max<size_t>(1, motifs.size());
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
@@ -177,7 +179,7 @@ int cmd_query(int argc, char** argv) {
         const std::vector<std::string> queries = split(input, ':');
         if (queries.size() == 1) { std::cerr << "Did you use the correct delimiter (:)?" << std::endl; return 0; }
         const double t1 = now();
-        const std::vector<uint64_t> masks = dev.query_masks(queries);
+        const std::vector<uint64_t> masks = dev.query_masks(queries, nullptr, nullptr, nullptr, &sopt);
         std::vector<uint64_t> all(masks.begin(), masks.begin() + W);
         for (size_t q = 1; q < queries.size(); ++q)
             for (uint64_t w = 0; w < W; ++w) all[w] &= masks[q * W + w];
@@ -189,7 +191,7 @@ int cmd_query(int argc, char** argv) {
     const double t1 = now();
     std::vector<int> status;
     std::vector<std::string> why;
-    const std::vector<uint64_t> masks = dev.query_masks({input}, &status, &why);
+    const std::vector<uint64_t> masks = dev.query_masks({input}, &status, &why, nullptr, &sopt);
     if (status[0]) { std::cerr << "[Error] query not searchable: " << why[0] << std::endl; return 1; }
     run_one(input, masks.data(), dest, false, t1);
     return 0;
@@ -240,6 +242,34 @@ int cmd_index(int argc, char** argv) {
     return 0;
 }
 
+// tetrex track [-l lower] [-u upper] [-n] [-i] <name> <libs...>   (include/arg_parse.h:94-122, src/dGramIndex.cpp:22-38)
+int cmd_track(int argc, char** argv) {
+    const std::vector<OptSpec> spec = {{'l', "lower", true}, {'u', "upper", true}, {'n', "nucleic_acid", false}, {'i', "ibf", false},
+                                       {'D', "device", true}};
+    Args a;
+    try {
+        a = parse(argc, argv, 2, spec);
+        if (a.pos.size() < 2) throw std::runtime_error("expected <name> <libraries...>");
+    } catch (const std::exception& e) {
+        std::cerr << "[Error TetRex Dgram Indexing module " << e.what() << "\n";
+        return 0;
+    }
+    std::vector<std::string> files;
+    for (size_t i = 1; i < a.pos.size(); ++i) {
+        const std::filesystem::path p = a.pos[i];
+        if (p.extension() == ".lst") {
+            std::ifstream in(p);
+            if (!in) throw std::runtime_error("Could not open file " + p.string() + " for reading.");
+            for (std::string line; std::getline(in, line);) files.push_back(line);
+        } else files.push_back(std::filesystem::absolute(p).string());
+    }
+    const DgramImage d = build_dgram_index(files, std::strtoull(a.get("lower", "3").c_str(), nullptr, 10),
+                                           std::strtoull(a.get("upper", "21").c_str(), nullptr, 10), 3, 0.05f,
+                                           std::atoi(a.get("device", "0").c_str()));
+    write_dgram_index_file(a.pos[0], d);  // the reference writes the name as given, no extension
+    return 0;
+}
+
 int cmd_inspect(int argc, char** argv) {
     if (argc != 3) { std::cerr << "[Error TetRex Index Inspection module expected <index>\n"; return 0; }
     std::cerr << "Reading Index from Disk... ";
@@ -276,7 +306,7 @@ int main(int argc, char** argv) {
         if (sub == "query") return cmd_query(argc, argv);
         if (sub == "index") return cmd_index(argc, argv);
         if (sub == "inspect") return cmd_inspect(argc, argv);
-        if (sub == "track") { std::cerr << "[Error] the d-gram index (track) is not part of this build\n"; return -1; }
+        if (sub == "track") return cmd_track(argc, argv);
         std::cerr << "[Error] unknown sub-command " << sub << "\n";
         return -1;
     } catch (const std::exception& e) {

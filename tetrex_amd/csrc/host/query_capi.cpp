@@ -17,16 +17,24 @@ const char* txe_last_error(void) { return g_qerr.c_str(); }
 
 int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6) {
+    return txe_query_masks_gapped(handle, nullptr, nullptr, dna, k, reduction, regex, n, ops_per_query_per_stage, masks, status, stats6);
+}
+
+int txe_query_masks_gapped(void* handle, void* aux_handle, const txh_gap_options* gaps, int dna, unsigned k, unsigned reduction,
+                           const char* const* regex, size_t n, size_t ops_per_query_per_stage, uint64_t* masks, int* status,
+                           uint64_t* stats6) {
     try {
         txq_index* ix = static_cast<txq_index*>(handle);
+        txq_index* aux = static_cast<txq_index*>(aux_handle);
         const KmerEncoder enc(dna ? Molecule::DNA : Molecule::Peptide, k, (Alphabet)reduction);
         std::vector<std::string> rx(regex, regex + n);
         StagedOptions opt;
         if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
+        if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0 && aux != nullptr, gaps->min_gap, gaps->max_gap};
         std::vector<int> st;
         std::vector<std::string> why;
         StagedStats s;
-        const std::vector<uint64_t> out = run_queries(ix, enc, rx, &st, &why, &s, &opt);
+        const std::vector<uint64_t> out = run_queries(ix, enc, rx, &st, &why, &s, &opt, aux);
         std::copy(out.begin(), out.end(), masks);
         int failures = 0;
         for (size_t i = 0; i < n; ++i) {

@@ -328,6 +328,17 @@ int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out) {
     return TXQ_OK;
 }
 
+int txq_session_set_aux_index(txq_session* s, txq_index* aux) {
+    if (!s) return fail(TXQ_ERR_ARG, "null argument");
+    if (aux) {
+        if (aux->is_hibf) return fail(TXQ_ERR_ARG, "the auxiliary index must be a flat IBF");
+        if (aux->user_bins != s->ix->user_bins || aux->shard_word0 != s->ix->shard_word0 || aux->shard_words != s->ix->shard_words)
+            return fail(TXQ_ERR_ARG, "the auxiliary index must cover the same bins and the same shard as the main index");
+    }
+    s->aux = aux;
+    return TXQ_OK;
+}
+
 int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const uint32_t* query_program,
                       const uint32_t* query_slot, size_t n_queries, uint8_t* alive) {
     if (int rc = require_init()) return rc;

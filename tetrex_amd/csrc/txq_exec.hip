@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void gather_result_kernel(uint64_t* const* __r
 // normalises the program table.
 struct BlobView {
     uint32_t n_kmers = 0, n_ops = 0, n_levels = 0;
-    uint64_t kmers_offset = 0, ops_offset = 0, levels_offset = 0;
+    uint64_t kmers_offset = 0, ops_offset = 0, levels_offset = 0, n_aux_kmers = 0;
     std::vector<DevProgram> programs;
     std::vector<uint32_t> n_slots;
 };
@@ -187,6 +187,8 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     if (v2) {
         v.n_kmers = h2->n_kmers; v.n_ops = h2->n_ops; v.n_levels = h2->n_levels;
         v.kmers_offset = h2->kmers_offset; v.ops_offset = h2->ops_offset; v.levels_offset = h2->levels_offset;
+        v.n_aux_kmers = h2->n_aux_kmers;
+        if (v.n_aux_kmers > v.n_kmers) return fail(TXQ_ERR_PROGRAM, "more auxiliary k-mers than k-mers");
         programs_offset = h2->programs_offset;
         if (h2->n_programs != n_programs) return fail(TXQ_ERR_PROGRAM, "blob holds %u programs, caller says %zu", h2->n_programs, n_programs);
     } else {
@@ -372,14 +374,19 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
     }
     const uint64_t* d_kmers = (const uint64_t*)(s.d_blob + h->kmers_offset);
-    const size_t nk_ = h->n_kmers; (void)nk_;
-    if (nk) {
+    const size_t n_aux = (size_t)h->n_aux_kmers, n_main = nk - n_aux;
+    if (n_aux && !s.aux) return fail(TXQ_ERR_STATE, "the blob has auxiliary (d-gram) k-mers but the session has no auxiliary index");
+    if (n_main) {
         if (ix.is_hibf) {
-            if (int rc = hibf_probe(ix, d_kmers, nk, ix.scratch_masks, nullptr, st)) return rc;
+            if (int rc = hibf_probe(ix, d_kmers, n_main, ix.scratch_masks, nullptr, st)) return rc;
         } else {
-            hipError_t e = launch_probe(ix.ibf[0], d_kmers, nk, ix.scratch_masks, nullptr, st);
+            hipError_t e = launch_probe(ix.ibf[0], d_kmers, n_main, ix.scratch_masks, nullptr, st);
             if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
         }
+    }
+    if (n_aux) {  // d-grams: same bins, same column shard, their own flat IBF
+        hipError_t e = launch_probe(s.aux->ibf[0], d_kmers + n_main, n_aux, ix.scratch_masks + n_main * (size_t)W, nullptr, st);
+        if (e != hipSuccess) return fail_hip(e, "d-gram probe kernel launch");
     }
     if (h->n_ops) {
         int g = 1;

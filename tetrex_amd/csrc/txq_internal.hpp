@@ -44,6 +44,7 @@ struct DevProgram { uint32_t first_op, n_ops, first_level, n_levels; };
 // A batch of programs whose slot masks persist in HBM across stages (txq_exec.hip).
 struct Session {
     Index* ix = nullptr;
+    Index* aux = nullptr;  // optional d-gram index (flat IBF, same bins and shard as ix)
     size_t n_programs = 0;
     uint32_t W = 0;
     std::vector<uint64_t*> chunks;  // arena chunks

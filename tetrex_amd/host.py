@@ -91,13 +91,31 @@ STAGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.
                        C.POINTER(C.c_uint8))
 
 
-def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0):
+class GapOptions(C.Structure):
+    _fields_ = [("augment", C.c_int), ("dgram_loaded", C.c_int), ("min_gap", C.c_uint64), ("max_gap", C.c_uint64)]
+
+
+def dgram_values(seq, min_gap, max_gap):
+    L = lib()
+    L.txh_dgram_values.restype = C.c_int64
+    L.txh_dgram_values.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, u64p, C.c_size_t]
+    s = seq.encode() if isinstance(seq, str) else seq
+    cap = max(1, len(s) * (max_gap - min_gap + 1))
+    out = np.zeros(cap, dtype=np.uint64)
+    n = L.txh_dgram_values(s, len(s), min_gap, max_gap, out.ctypes.data_as(u64p), cap)
+    return out[:n].copy()
+
+
+def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0, gaps=None):
     """Drive the C++ staged expansion with a Python executor.
 
     stage(blob: bytes, query_program: list, query_slot: list) -> iterable of bool (alive)."""
     L = lib()
     L.txh_run_staged.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
-                                 C.c_size_t, STAGE_FN, C.c_void_p, C.POINTER(C.c_int), u64p]
+                                 C.c_size_t, C.POINTER(GapOptions), STAGE_FN, C.c_void_p, C.POINTER(C.c_int), u64p]
+    g = None
+    if gaps is not None:  # dict(augment=, dgram_loaded=, min_gap=, max_gap=)
+        g = GapOptions(int(gaps.get("augment", 0)), int(gaps.get("dgram_loaded", 0)), gaps.get("min_gap", 0), gaps.get("max_gap", 0))
     n = len(regexes)
     arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
     status = (C.c_int * n)()
@@ -114,8 +132,8 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
             err.append(e)
             return -1
 
-    rc = L.txh_run_staged(arr, n, int(dna), k, reduction, bins, ops_per_query_per_stage, ops_per_stage, STAGE_FN(cb), None,
-                          status, stats)
+    rc = L.txh_run_staged(arr, n, int(dna), k, reduction, bins, ops_per_query_per_stage, ops_per_stage,
+                          C.byref(g) if g is not None else None, STAGE_FN(cb), None, status, stats)
     if err:
         raise err[0]
     if rc < 0:
@@ -141,7 +159,7 @@ def parse_blob(blob):
         _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off = struct.unpack_from("<6I3Q", blob, 0)
         stride = 4
     else:
-        _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off, _ = struct.unpack_from("<6I4Q", blob, 0)
+        _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off, _, _ = struct.unpack_from("<6I5Q", blob, 0)
         stride = 6
     kmers = np.frombuffer(blob, dtype="<u8", count=n_kmers, offset=k_off)
     progs = np.frombuffer(blob, dtype="<u4", count=n_prog * stride, offset=p_off).reshape(n_prog, stride)
@@ -153,12 +171,18 @@ def parse_blob(blob):
     return kmers, out
 
 
+def blob_aux_kmers(blob):
+    """Number of trailing k-mer table entries that belong to the auxiliary (d-gram) index."""
+    magic, ver = struct.unpack_from("<2I", blob, 0)
+    return struct.unpack_from("<6I5Q", blob, 0)[-1] if ver == 2 else 0
+
+
 def blob_levels(blob):
     """Level tables of a version-2 blob: list of per-program end-index lists."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
     if ver != 2:
         return None
-    _, _, n_prog, n_kmers, n_ops, n_lv, k_off, p_off, o_off, l_off = struct.unpack_from("<6I4Q", blob, 0)
+    _, _, n_prog, n_kmers, n_ops, n_lv, k_off, p_off, o_off, l_off, _ = struct.unpack_from("<6I5Q", blob, 0)
     progs = np.frombuffer(blob, dtype="<u4", count=n_prog * 6, offset=p_off).reshape(n_prog, 6)
     lv = np.frombuffer(blob, dtype="<u4", count=n_lv, offset=l_off)
     return [list(int(x) for x in lv[int(r[3]):int(r[3]) + int(r[4])]) for r in progs]
