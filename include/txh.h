@@ -27,6 +27,9 @@ int txh_preprocess(const char* regex, int dna, unsigned k, unsigned reduction, c
 int txh_kgraph(const char* postfix, unsigned k, int reduced, int32_t* labels, int32_t* next_a, int32_t* next_b,
                int32_t cap);
 
+/* Graphviz text of the k-graph (`tetrex query -d`); augment != 0 applies -a first */
+int txh_kgraph_dot(const char* postfix, unsigned k, int reduced, int augment, char* out, size_t cap);
+
 /* Compile a batch of queries for an index with `bins` bins into one program blob.
  * status[i] receives 0 or a negative code for query i (a failed query becomes an empty program
  * whose result mask is zero); the blob is owned by the library until txh_blob_free. */

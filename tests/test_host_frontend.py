@@ -222,3 +222,18 @@ def test_level_schedule_is_race_free(host, oracle):
                 assert not reads.get(d), "accumulated slot read in the same level"
             begin = end
     assert deep >= 5
+
+
+def test_graphviz_dump_of_config1(host, golden):
+    """`tetrex query -d`: node shapes/labels as in the reference's print_graph and exactly the arcs of
+    the hand-traced config-1 graph."""
+    g = golden("kgraph_config1.json")
+    dot = host.kgraph_dot(g["postfix"], g["k"])
+    assert dot.startswith('digraph kGraph\n{\n\trankdir="LR";\n') and dot.endswith("}")
+    assert '\t0 [shape=point label=""];' in dot and '\t13 [shape=doublecircle label=""];' in dot
+    assert '\t1 [label="A"];' in dot and '\t12 [label="T"];' in dot and '\t4 [label="Ø"];' in dot and '\t3 [label="•"];' in dot
+    arcs = sorted(tuple(int(x) for x in line.strip(";\t").split("->")) for line in dot.splitlines() if "->" in line)
+    assert arcs == sorted(map(tuple, g["arcs"]))
+    # an augmented graph shows GAP nodes and hides the bypassed region
+    aug = host.kgraph_dot(host.translate("LMAEG.{4}WWYN"), 4, augment=True)
+    assert 'label="GAP"' in aug and aug.count("->") < host.kgraph_dot(host.translate("LMAEG.{4}WWYN"), 4).count("->")

@@ -64,6 +64,14 @@ int txh_kgraph(const char* postfix, unsigned k, int reduced, int32_t* labels, in
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int txh_kgraph_dot(const char* postfix, unsigned k, int reduced, int augment, char* out, size_t cap) {
+    try {
+        KGraph g = build_kgraph(postfix, k, reduced != 0);
+        if (augment) g.augment();
+        return put(g.to_graphviz(), out, cap);
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int txh_compile_batch(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
                       txh_blob** out, int* status) {
     try {

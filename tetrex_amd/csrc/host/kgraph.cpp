@@ -111,6 +111,35 @@ size_t KGraph::augment() {
     return added;
 }
 
+std::string KGraph::to_graphviz() const {
+    std::string out = "digraph kGraph\n{\n\trankdir=\"LR\";\n";
+    for (int32_t v = size() - 1; v >= 0; --v) {  // the reference lists nodes from the newest down
+        out += "\t" + std::to_string(v);
+        if (v == 0) out += " [shape=point label=\"\"];\n";
+        else if (label[v] == kSplit) out += " [label=\"\xC3\x98\"];\n";
+        else if (label[v] == kGhost) out += " [label=\"\xE2\x80\xA2\"];\n";
+        else if (label[v] == kMatch) out += " [shape=doublecircle label=\"\"];\n";
+        else if (label[v] == kGap) out += " [label=\"GAP\"];\n";
+        else out += std::string(" [label=\"") + (char)label[v] + "\"];\n";
+    }
+    // arcs that are still reachable through the successor slots (an augmented graph hides the bypassed ones)
+    std::vector<uint8_t> seen(size(), 0);
+    std::vector<int32_t> todo{0};
+    seen[0] = 1;
+    while (!todo.empty()) {
+        const int32_t u = todo.back();
+        todo.pop_back();
+        int32_t targets[2] = {next_a[u], next_b[u] != next_a[u] ? next_b[u] : kNone};
+        for (int32_t t : targets) {
+            if (t == kNone) continue;
+            out += "\t" + std::to_string(u) + "->" + std::to_string(t) + ";\n";
+            if (!seen[t]) { seen[t] = 1; todo.push_back(t); }
+        }
+    }
+    out += "}";
+    return out;
+}
+
 namespace {
 
 // A partially built piece of the graph: entry/exit node, or a symbol that the reduced builder

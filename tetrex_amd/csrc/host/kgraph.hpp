@@ -46,6 +46,9 @@ struct KGraph {
     // -a/--augment (reference include/otf_collector.h:395-493): bypass every (merged) catsite with
     // Gap nodes, one per possible length; returns the number of Gap nodes added
     size_t augment();
+    // -d/--draw: Graphviz text of the graph (reference print_graph, src/construction_tools.cpp:42-94:
+    // point for the start node, "Ø" splits, "•" ghosts, doublecircle match, "GAP" gaps, residue letters)
+    std::string to_graphviz() const;
 };
 
 // Builds the k-graph of `postfix` for k-mer size k.  reduced_alphabet selects the reduced

@@ -7,6 +7,7 @@
 // The candidate-bin masks come from the GPU (libtxq.so); there is no CPU probe path.
 #include "device_index.hpp"
 #include "index_file.hpp"
+#include "kgraph.hpp"
 #include "regex_front.hpp"
 #include "verify.hpp"
 
@@ -111,7 +112,6 @@ int cmd_query(int argc, char** argv) {
     std::string dest = a.get("output", "-");
     std::string input = a.pos[1];
     if (input == "-") std::cin >> input;
-    if (a.has("draw")) std::cerr << "[WARNING] -d/--draw (graphviz dump) is not available in this build" << std::endl;
 
     IndexImage image;
     try {
@@ -187,6 +187,15 @@ int cmd_query(int argc, char** argv) {
         if (popcount_mask(all.data(), W)) verify_conjunction(set_bins(all.data(), bins), image.bin_paths, queries, std::cout, vopt);
         if (verbose) std::cerr << "Query Time: " << (now() - t1) << std::endl;
         return 0;
+    }
+    if (a.has("draw")) {  // include/query.h:244: kgraph_visualizer.gv in the working directory
+        try {
+            KGraph g = build_kgraph(preprocess_query(input, enc), enc.k(), enc.alphabet() != Alphabet::Base);
+            if (sopt.gaps.augment) g.augment();
+            std::ofstream("kgraph_visualizer.gv") << g.to_graphviz();
+        } catch (const std::exception& e) {
+            std::cerr << "[WARNING] could not draw the k-graph: " << e.what() << std::endl;
+        }
     }
     const double t1 = now();
     std::vector<int> status;

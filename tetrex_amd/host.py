@@ -66,6 +66,15 @@ def kgraph(postfix, k, reduced=False):
     return dict(labels=list(lab[:n]), succ=list(zip(na[:n], nb[:n])))
 
 
+def kgraph_dot(postfix, k, reduced=False, augment=False):
+    L = lib()
+    L.txh_kgraph_dot.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(1 << 22)
+    if L.txh_kgraph_dot(postfix.encode(), k, int(reduced), int(augment), buf, len(buf)) < 0:
+        raise _err()
+    return buf.value.decode()
+
+
 def compile_batch(regexes, dna, k, reduction, bins):
     """Returns (blob bytes, status list, stats array [n,4] = ops, slots, states, probe ops)."""
     n = len(regexes)
