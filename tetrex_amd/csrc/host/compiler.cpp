@@ -162,6 +162,15 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     for (int32_t v = n; v < items; ++v) live[v] = 1;
     for (int32_t v = 0; v < items; ++v)
         if (live[v]) targets_of(v, [&](int32_t t) { ++indeg[t]; });
+    // A residue node's states have pairwise different keys, and rolling one residue into all of them
+    // can make keys collide; a join's states are already merged.  So only items fed by exactly one
+    // JOIN receive collision-free arrivals.
+    single_source_.assign(items, 0);
+    {
+        std::vector<int32_t> from_joins(items, 0);
+        for (int32_t j = n + 1; j < items; ++j) targets_of(j, [&](int32_t t) { ++from_joins[t]; });
+        for (int32_t v = 0; v < items; ++v) single_source_[v] = indeg[v] == 1 && from_joins[v] == 1;
+    }
     std::vector<int32_t> ready;
     for (int32_t v = 0; v < items; ++v)
         if (live[v] && indeg[v] == 0) ready.push_back(v);
@@ -209,6 +218,12 @@ void QueryExpansion::emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst,
 void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
+    if (single_source_[to]) {  // nothing to merge with: no table look-up
+        s.asked = 0;
+        ns.items.push_back(s);
+        if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+        return;
+    }
     // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just
     // above them, so paths of different length < k-1 never share a key
     const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
@@ -360,6 +375,7 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         }
         ns.items.swap(keep);
         ns.by_key.clear();
+        if (single_source_[order_[c]]) continue;
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;

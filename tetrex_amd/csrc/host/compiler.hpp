@@ -120,6 +120,7 @@ class QueryExpansion {
     std::vector<uint32_t> fan_first_; // per join (item - n - 1): CSR into fan_
     std::vector<int32_t> fan_;
     std::vector<uint8_t> dangling_;   // some path out of the item ends in a node without successor
+    std::vector<uint8_t> single_source_;  // item fed by exactly one item: its arrivals cannot collide
     int32_t n_nodes_ = 0;
     std::vector<NodeStates> table_;
     std::vector<uint32_t> refs_;

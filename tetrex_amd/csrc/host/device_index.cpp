@@ -82,11 +82,15 @@ TxqStageExecutor::~TxqStageExecutor() {
 }
 void TxqStageExecutor::stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
                              std::vector<uint8_t>& alive) {
-    std::vector<uint64_t> aligned((blob.size() + 7) / 8);  // txq wants an 8-byte aligned blob
-    std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
     alive.assign(qp.size(), 1);
-    txq_check(txq_session_stage(session_, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()),
-              "txq_session_stage");
+    const void* data = blob.data();
+    std::vector<uint64_t> aligned;
+    if (reinterpret_cast<uintptr_t>(data) % 8) {  // txq wants an 8-byte aligned blob (heap vectors already are)
+        aligned.resize((blob.size() + 7) / 8);
+        std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
+        data = aligned.data();
+    }
+    txq_check(txq_session_stage(session_, data, blob.size(), qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
 }
 void TxqStageExecutor::finish(uint64_t* masks) {
     txq_session* s = session_;

@@ -18,6 +18,9 @@
 // Format of a stage's op list: include/txq_program.h.
 #include "txq_internal.hpp"
 #include "../../include/txq_program.h"
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace txq {
@@ -244,7 +247,14 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     return TXQ_OK;
 }
 
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 Session::~Session() {
+    if (std::getenv("TXQ_TRACE"))
+        fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded; validate %.3f s, upload %.3f s, device+sync %.3f s\n",
+                n_programs, n_stages, bytes_uploaded / 1e6, t_validate, t_upload, t_device);
     for (uint64_t* c : chunks) (void)hipFree(c);
     for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
 }
@@ -287,7 +297,12 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     Index& ix = *s.ix;
     const unsigned char* blob = (const unsigned char*)blob_v;
     BlobView bv;
+    double t0 = now_s();
     if (int rc = validate_blob(blob, bytes, s.n_programs, &bv)) return rc;
+    s.t_validate += now_s() - t0;
+    t0 = now_s();
+    ++s.n_stages;
+    s.bytes_uploaded += bytes;
     const BlobView* h = &bv;
     const uint32_t W = s.W;
     for (size_t i = 0; i < n_q; ++i) {
@@ -367,6 +382,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // pageable host buffers: the copies above have left host memory once the stream drains;
     // `fresh`/`base` are locals, so drain before they go out of scope or are reused
     TXQ_HIP(hipStreamSynchronize(st));
+    s.t_upload += now_s() - t0;
+    t0 = now_s();
 
     if (!fresh.empty()) {
         size_t blocks = (fresh.size() * W + 255) / 256;
@@ -435,6 +452,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         TXQ_HIP(hipMemcpyAsync(alive, d_alive, n_q, hipMemcpyDeviceToHost, st));
         TXQ_HIP(hipStreamSynchronize(st));
     }
+    if (std::getenv("TXQ_TRACE")) { (void)hipStreamSynchronize(st); }
+    s.t_device += now_s() - t0;
     return TXQ_OK;
 }
 

@@ -54,6 +54,9 @@ struct Session {
     uint64_t** d_base = nullptr;
     unsigned char* d_blob = nullptr; size_t cap_blob = 0;
     unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+    // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
+    double t_validate = 0, t_upload = 0, t_device = 0;
+    size_t n_stages = 0, bytes_uploaded = 0;
     ~Session();
 };
 
