@@ -259,12 +259,8 @@ class Index:
     def emplace_device(self, d_values, d_bins_of, n, stream=None):
         check(lib().txq_emplace_device(self._h, d_values, d_bins_of, n, stream))
 
-    def download_words(self):
-        n = int(self.info.shard_words)
-        # rows are not part of txq_index_info; callers know bin_size
-        raise NotImplementedError("use download_words_rows(bin_size)")
-
     def download_words_rows(self, bin_size):
+        """The shard's bit matrix, row-major [bin_size][shard_words] (flat IBF only)."""
         out = np.zeros(bin_size * self.shard_words, dtype=np.uint64)
         check(lib().txq_index_download_words(self._h, out.ctypes.data_as(u64p), out.size))
         return out
