@@ -71,7 +71,7 @@ def pmc_traffic(args, n, W, h, m):
     if not files:
         return None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"]["void txq::probe_kernel<8, 3>"]
+        k = json.load(f)["kernels"]["void txq::probe_kernel<8, 3>"]  # same kernel, round-1 name before the unroll parameter
     return k["hbm_traffic_bytes_per_launch_corrected"]
 
 
@@ -252,7 +252,7 @@ def main():
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": "txq::probe_kernel<8,3>" if (W == 16 and h == 3) else "txq::probe_kernel",
+            "kernel": "txq::probe_kernel<8,3,2,false>" if (W == 16 and h == 3) else "txq::probe_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -10,11 +10,12 @@
 //     128-byte row (1024 bins) takes 8 lanes and a wave gathers 8 k-mers x h rows per step,
 //   * the row indices travel from the hashing lane to the gathering lane group by ds_bpermute
 //     (__shfl), no LDS allocation, no redundant 64-bit multiplies,
-//   * steps are processed in pairs so 2*h independent 16-byte gathers per lane are in flight
-//     before the first AND; output rows of one step are contiguous (coalesced 1-KiB stores),
+//   * two steps are in flight at a time (2*h independent 16-byte gathers per lane before the
+//     first AND, 8 waves/SIMD); output rows of one step are contiguous (coalesced 1-KiB stores),
 //   * `alive` (mask != 0, the collector's path_.none() test) falls out of one __ballot per step.
 // Algorithmic HBM bytes per probe: h*W*8 (rows) + W*8 (mask) + 8 (k-mer); W = shard_words.
 #include "txq_kernels.hpp"
+#include <cstdlib>
 
 namespace txq {
 
@@ -26,29 +27,19 @@ __device__ __forceinline__ void st16_stream(uint64_t* p, u32x4 v) {
 }
 __device__ __forceinline__ bool nonzero(u32x4 v) { return (v.x | v.y | v.z | v.w) != 0u; }
 
-// One gather step: k-mer `kidx` (valid iff kidx < n), rows r[0..H), this lane's 16-byte chunk `c`.
-template <int H>
-__device__ __forceinline__ u32x4 gather_and(const IbfDev& f, const uint32_t (&r)[H], uint32_t c) {
-    u32x4 v[H];
-#pragma unroll
-    for (int i = 0; i < H; ++i) v[i] = ld16(f.words + (size_t)r[i] * f.stride + 2u * c);
-    u32x4 acc = v[0];
-#pragma unroll
-    for (int i = 1; i < H; ++i) acc &= v[i];
-    return acc;
-}
-
 __device__ __forceinline__ void store_chunk(const IbfDev& f, uint64_t* masks, size_t kidx, uint32_t c, u32x4 acc) {
     uint64_t* dst = masks + kidx * f.shard_words + 2u * c;
     if (2u * c + 1u < f.shard_words) st16_stream(dst, acc);
     else __builtin_nontemporal_store(((uint64_t)acc.y << 32) | acc.x, dst);  // odd tail word
 }
 
-// LPK lanes per k-mer, H hash functions.  Requires bin_size < 2^32 and an even stride.
-template <int LPK, int H>
+// LPK lanes per k-mer, H hash functions, U steps in flight.  Requires bin_size < 2^32 and an even
+// stride.  U*H independent 16-byte gathers per lane are issued before the first AND.
+template <int LPK, int H, int U, bool NT>
 __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __restrict__ kmers, size_t n,
                                                     uint64_t* __restrict__ masks, uint64_t* __restrict__ alive) {
-    constexpr int KPS = 64 / LPK;  // k-mers per step
+    constexpr int KPS = 64 / LPK;          // k-mers per step
+    constexpr int UU = U < LPK ? U : LPK;  // a tile has LPK steps
     const int lane = threadIdx.x & 63;
     const int sub = lane % LPK, grp = lane / LPK;
     const uint32_t chunks = f.stride >> 1;
@@ -62,28 +53,42 @@ __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __
 #pragma unroll
         for (int i = 0; i < H; ++i) row[i] = (uint32_t)hash_row(v, kSeeds[i], f.hash_shift, f.bin_size);
         bool my_alive = false;
-        // steps in pairs: 2*H gathers in flight per lane
-        for (int s = 0; s < LPK; s += 2) {
-            const int src0 = s * KPS + grp, src1 = (s + 1) * KPS + grp;
-            uint32_t r0[H], r1[H];
+        for (int s = 0; s < LPK; s += UU) {
+            uint32_t r[UU][H];
 #pragma unroll
-            for (int i = 0; i < H; ++i) { r0[i] = __shfl(row[i], src0); r1[i] = __shfl(row[i], (LPK > 1) ? src1 : src0); }
-            bool nz0 = false, nz1 = false;
+            for (int u = 0; u < UU; ++u)
+#pragma unroll
+                for (int i = 0; i < H; ++i) r[u][i] = __shfl(row[i], (s + u) * KPS + grp);
+            bool nz[UU];
+#pragma unroll
+            for (int u = 0; u < UU; ++u) nz[u] = false;
             for (uint32_t c = sub; c < chunks; c += LPK) {
-                u32x4 a0 = gather_and<H>(f, r0, c);
-                u32x4 a1 = a0;
-                if (LPK > 1) a1 = gather_and<H>(f, r1, c);
-                if (base + src0 < n) store_chunk(f, masks, base + src0, c, a0);
-                if (LPK > 1 && base + src1 < n) store_chunk(f, masks, base + src1, c, a1);
-                nz0 |= nonzero(a0);
-                nz1 |= nonzero(a1);
+                u32x4 x[UU][H];
+#pragma unroll
+                for (int u = 0; u < UU; ++u)
+#pragma unroll
+                    for (int i = 0; i < H; ++i) {
+                        const uint64_t* p = f.words + (size_t)r[u][i] * f.stride + 2u * c;
+                        x[u][i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p)) : ld16(p);
+                    }
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    u32x4 acc = x[u][0];
+#pragma unroll
+                    for (int i = 1; i < H; ++i) acc &= x[u][i];
+                    const size_t kidx = base + (s + u) * KPS + grp;
+                    if (kidx < n) store_chunk(f, masks, kidx, c, acc);
+                    nz[u] |= nonzero(acc);
+                }
             }
             if (alive) {
                 const uint64_t gm = LPK == 64 ? ~0ULL : ((1ULL << LPK) - 1ULL);
-                const uint64_t b0 = __ballot(nz0), b1 = __ballot(nz1);
                 const int my_step = lane / KPS, my_grp = lane % KPS;
-                if (my_step == s) my_alive = ((b0 >> (my_grp * LPK)) & gm) != 0;
-                if (LPK > 1 && my_step == s + 1) my_alive = ((b1 >> (my_grp * LPK)) & gm) != 0;
+#pragma unroll
+                for (int u = 0; u < UU; ++u) {
+                    const uint64_t b = __ballot(nz[u]);
+                    if (my_step == s + u) my_alive = ((b >> (my_grp * LPK)) & gm) != 0;
+                }
             }
         }
         if (alive) {
@@ -174,12 +179,28 @@ static inline unsigned grid_for(size_t work_items, unsigned per_block) {
 template <int LPK>
 static hipError_t launch_lpk(const IbfDev& f, const uint64_t* k, size_t n, uint64_t* m, uint64_t* a, hipStream_t s) {
     const unsigned grid = grid_for((n + 63) / 64, 4);
+    // experiment knobs (round 1 tuning): steps in flight and non-temporal row loads
+    // (profiles/r1_probe_variants_ab.txt: 1/2/4/8 steps in flight differ by <= 2 % — occupancy already
+    // supplies the memory-level parallelism, and 4 steps cost 124 VGPRs = half the waves per SIMD;
+    // non-temporal ROW loads cost 20 % on a cache-resident matrix and gain nothing on an 8 GB one.
+    // Default: 2 steps in flight, 8 waves/SIMD, plain row loads.)
+    static const int unroll = std::getenv("TXQ_PROBE_UNROLL") ? std::atoi(std::getenv("TXQ_PROBE_UNROLL")) : 2;
+    static const bool nt = std::getenv("TXQ_PROBE_NT") != nullptr;
+    if (f.hash_funs == 3 && LPK == 8 && (unroll != 2 || nt)) {
+        if (unroll == 1 && !nt) probe_kernel<LPK, 3, 1, false><<<grid, 256, 0, s>>>(f, k, n, m, a);
+        else if (unroll == 4 && !nt) probe_kernel<LPK, 3, 4, false><<<grid, 256, 0, s>>>(f, k, n, m, a);
+        else if (unroll == 8 && !nt) probe_kernel<LPK, 3, 8, false><<<grid, 256, 0, s>>>(f, k, n, m, a);
+        else if (unroll == 2 && nt) probe_kernel<LPK, 3, 2, true><<<grid, 256, 0, s>>>(f, k, n, m, a);
+        else if (unroll == 4 && nt) probe_kernel<LPK, 3, 4, true><<<grid, 256, 0, s>>>(f, k, n, m, a);
+        else return hipErrorInvalidValue;
+        return hipGetLastError();
+    }
     switch (f.hash_funs) {
-        case 1: probe_kernel<LPK, 1><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
-        case 2: probe_kernel<LPK, 2><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
-        case 3: probe_kernel<LPK, 3><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
-        case 4: probe_kernel<LPK, 4><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
-        case 5: probe_kernel<LPK, 5><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
+        case 1: probe_kernel<LPK, 1, 2, false><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
+        case 2: probe_kernel<LPK, 2, 2, false><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
+        case 3: probe_kernel<LPK, 3, 2, false><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
+        case 4: probe_kernel<LPK, 4, 2, false><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
+        case 5: probe_kernel<LPK, 5, 2, false><<<grid, 256, 0, s>>>(f, k, n, m, a); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
