@@ -71,8 +71,11 @@ def pmc_traffic(args, n, W, h, m):
     if not files:
         return None
     with open(files[-1]) as f:
-        k = json.load(f)["kernels"]["void txq::probe_kernel<8, 3>"]  # same kernel, round-1 name before the unroll parameter
-    return k["hbm_traffic_bytes_per_launch_corrected"]
+        kernels = json.load(f)["kernels"]
+    for name, k in kernels.items():
+        if name.startswith("void txq::probe_kernel<8, 3") and "hbm_traffic_bytes_per_launch_corrected" in k:
+            return k["hbm_traffic_bytes_per_launch_corrected"]
+    return None
 
 
 def cpu_baseline(ix, m, h, bins_local, kmers, sample, threads):
