@@ -40,6 +40,13 @@ def splitmix64(seed, n, start=0):
         return z ^ (z >> np.uint64(31))
 
 
+def compute_bitcount(n, fpr):
+    """Rows of an IBF sized like the reference does (include/index_ibf.h:133-139):
+    ceil(-n ln p / ln^2 2) with ln p evaluated in float."""
+    import math
+    return int(math.ceil(-float(n) * float(np.log(np.float32(fpr))) / (math.log(2.0) ** 2)))
+
+
 def build_index(capi, torch, bins_total, bins_local, m, h, rank, world, per_bin, value_bits):
     """Device-side construction: per_bin uniform values into each of this rank's bins."""
     ix = capi.Index.create_ibf(bins_total, m, h, shard_rank=rank, n_shards=world)
@@ -179,13 +186,12 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from tetrex_amd import capi
-    import oracle as O  # only for compute_bitcount of the workload shape and the cpu_baseline leg
 
     capi.init(local_rank)
     h = args.hash
     bins_local = args.bins_per_gpu
     bins_total = bins_local * world
-    m = args.rows if args.rows > 0 else O.compute_bitcount(args.per_bin, 0.05)
+    m = args.rows if args.rows > 0 else compute_bitcount(args.per_bin, 0.05)
     value_bits = args.kmer_bits
 
     t_build = time.perf_counter()
