@@ -21,7 +21,7 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "liboracle.so")
+        so = os.environ.get("TETREX_ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # e.g. the ASan build
         if not os.path.exists(so):
             build()
         L = C.CDLL(so)

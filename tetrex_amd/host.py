@@ -6,7 +6,8 @@ import struct
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtetrex_host.so")
+# TETREX_HOST_LIB: load another build of the same library (e.g. an AddressSanitizer build on the CPU)
+LIB_PATH = os.environ.get("TETREX_HOST_LIB") or os.path.join(_HERE, "libtetrex_host.so")
 _LIB = None
 i32p = C.POINTER(C.c_int32)
 u64p = C.POINTER(C.c_uint64)
