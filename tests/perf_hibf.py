@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Secondary measurement (not the contract bench): HIBF descent rate on a BASELINE configs[4]-shaped
+"""Secondary measurement (not the contract bench; lives under tests/ because it builds its tree with
+the oracle and checks a sample against it): HIBF descent rate on a BASELINE configs[4]-shaped
 tree (65536 user bins, 256-wide root of merged bins over 256 children, h=2, Murphy k=5 values).
 Prints one JSON line.  Used with rocprofv3 for the per-kernel table in DESIGN.md."""
 import json
@@ -11,7 +12,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
 def main():
