@@ -98,6 +98,9 @@ void Index::release() {
     if (d_next) (void)hipFree(d_next);
     if (d_tb_user) (void)hipFree(d_tb_user);
     if (d_map_off) (void)hipFree(d_map_off);
+    for (void* p : {(void*)session_cache.chunk, (void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
+        if (p) (void)hipFree(p);
+    session_cache = SessionCache{};
     if (d_merged) (void)hipFree(d_merged);
     if (d_merged_off) (void)hipFree(d_merged_off);
     d_merged = d_merged_off = nullptr;

@@ -255,6 +255,17 @@ Session::~Session() {
     if (std::getenv("TXQ_TRACE"))
         fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded; validate %.3f s, upload %.3f s, device+sync %.3f s\n",
                 n_programs, n_stages, bytes_uploaded / 1e6, t_validate, t_upload, t_device);
+    if (owns_cache && ix) {  // hand the buffers back for the next session (keep only the first chunk)
+        Index::SessionCache& c = ix->session_cache;
+        for (size_t i = 1; i < chunks.size(); ++i) (void)hipFree(chunks[i]);
+        c.chunk = chunks.empty() ? nullptr : chunks[0];
+        c.chunk_cap = chunks.empty() ? 0 : first_chunk_cap;
+        c.d_base = d_base; c.cap_base = cap_base;
+        c.d_blob = d_blob; c.cap_blob = cap_blob;
+        c.d_aux = d_aux; c.cap_aux = cap_aux;
+        c.in_use = false;
+        return;
+    }
     for (uint64_t* c : chunks) (void)hipFree(c);
     for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
 }
@@ -262,10 +273,11 @@ Session::~Session() {
 // bump allocation of `words` 64-bit words of slot storage
 static int arena_alloc(Session& s, size_t words, uint64_t** out) {
     if (s.chunks.empty() || s.chunk_used + words > s.chunk_cap) {
-        size_t cap = (size_t)8 << 20;  // 64 MiB chunks
+        size_t cap = s.chunks.empty() ? (size_t)1 << 20 : (size_t)8 << 20;  // 8 MiB first, then 64 MiB chunks
         if (words > cap) cap = words;
         uint64_t* c = nullptr;
         TXQ_HIP(hipMalloc((void**)&c, cap * 8));
+        if (s.chunks.empty()) s.first_chunk_cap = cap;
         s.chunks.push_back(c);
         s.chunk_cap = cap;
         s.chunk_used = 0;
@@ -284,9 +296,24 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     s->W = (uint32_t)ix.shard_words;
     s->base.assign(n_programs, nullptr);
     s->cap.assign(n_programs, 0);
-    if (n_programs) {
+    Index::SessionCache& c = ix.session_cache;
+    if (!c.in_use) {  // adopt the previous session's buffers
+        c.in_use = true;
+        s->owns_cache = true;
+        if (c.chunk) { s->chunks.push_back(c.chunk); s->chunk_cap = s->first_chunk_cap = c.chunk_cap; s->chunk_used = 0; }
+        s->d_base = c.d_base; s->cap_base = c.cap_base;
+        s->d_blob = c.d_blob; s->cap_blob = c.cap_blob;
+        s->d_aux = c.d_aux; s->cap_aux = c.cap_aux;
+        c = Index::SessionCache{};
+        c.in_use = true;
+    }
+    if (n_programs > s->cap_base) {
+        if (s->d_base) (void)hipFree(s->d_base);
+        s->d_base = nullptr;
+        s->cap_base = 0;
         hipError_t e = hipMalloc((void**)&s->d_base, n_programs * sizeof(uint64_t*));
         if (e != hipSuccess) { delete s; return fail_hip(e, "hipMalloc(session)"); }
+        s->cap_base = n_programs;
     }
     *out = s;
     return TXQ_OK;

@@ -35,6 +35,16 @@ struct Index {
     uint64_t* scratch_slots = nullptr; size_t cap_slots = 0;
     uint64_t* scratch_final = nullptr; size_t cap_final = 0;
 
+    // Device buffers of the last session, kept for the next one: a single query must not pay
+    // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.
+    struct SessionCache {
+        uint64_t* chunk = nullptr; size_t chunk_cap = 0;  // first slot-arena chunk (words)
+        uint64_t** d_base = nullptr; size_t cap_base = 0;  // entries
+        unsigned char* d_blob = nullptr; size_t cap_blob = 0;
+        unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+        bool in_use = false;
+    } session_cache;
+
     void release();
 };
 
@@ -48,10 +58,11 @@ struct Session {
     size_t n_programs = 0;
     uint32_t W = 0;
     std::vector<uint64_t*> chunks;  // arena chunks
-    size_t chunk_used = 0, chunk_cap = 0;
+    size_t chunk_used = 0, chunk_cap = 0, first_chunk_cap = 0;
     std::vector<uint64_t*> base;    // per program: its slot region [cap][W]
     std::vector<uint32_t> cap;      // per program: slots allocated
-    uint64_t** d_base = nullptr;
+    uint64_t** d_base = nullptr; size_t cap_base = 0;
+    bool owns_cache = false;  // buffers came from / go back to ix->session_cache
     unsigned char* d_blob = nullptr; size_t cap_blob = 0;
     unsigned char* d_aux = nullptr; size_t cap_aux = 0;
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
