@@ -6,6 +6,7 @@
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -19,8 +20,8 @@ constexpr uint32_t kPinned = 0x7FFFFFFF;  // reference count of the constant slo
 
 using ParallelFor = std::function<void(size_t, const std::function<void(size_t, int)>&)>;
 
-std::vector<uint8_t> make_blob(const std::vector<const std::vector<uint64_t>*>& kmer_tables, const std::vector<txq_program>& programs,
-                               const std::vector<const std::vector<txq_op>*>& ops_of,
+std::vector<uint8_t> make_blob(const std::vector<const KmerVec*>& kmer_tables, const std::vector<txq_program>& programs,
+                               const std::vector<const OpVec*>& ops_of,
                                const std::vector<const std::vector<uint32_t>*>& levels_of, const ParallelFor* par = nullptr,
                                size_t n_aux_kmers = 0) {
     size_t n_kmers = 0;
@@ -181,12 +182,12 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     }
     table_.resize(items);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
-    std::vector<txq_op> none;
+    OpVec none;
     hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0, 0, 0, 0}, none);
 }
 
 // a state leaves item `from` (a residue node or the entry): to its join or only target
-void QueryExpansion::hand_on(int32_t from, State s, std::vector<txq_op>& out) {
+void QueryExpansion::hand_on(int32_t from, State s, OpVec& out) {
     if (dangling_[from]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
     if (forward_[from] == KGraph::kNone) { drop(s.slot); return; }
     arrive(forward_[from], s, out);
@@ -209,18 +210,20 @@ void QueryExpansion::drop(uint32_t s) {
 }
 bool QueryExpansion::exclusive(uint32_t s) const { return refs_[s] == 1; }
 
-void QueryExpansion::emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b) {
+void QueryExpansion::emit(OpVec& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b) {
     if (++total_ops_ > limits_.max_ops) throw std::runtime_error("query expands to too many mask operations");
     out.push_back(txq_op{kmer, dst, a, b});
 }
 
 // hand a state (owning one reference to its slot) to node `to`
-void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
+void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
+    if (ns.items.capacity() == 0) adopt_storage(ns);
     if (single_source_[to]) {  // nothing to merge with: no table look-up
         s.asked = 0;
         ns.items.push_back(s);
+        ++waiting_;
         if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         return;
     }
@@ -235,6 +238,7 @@ void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     if (inserted) {
         s.asked = 0;
         ns.items.push_back(s);
+        ++waiting_;
         if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         return;
     }
@@ -258,7 +262,12 @@ void QueryExpansion::arrive(int32_t to, State s, std::vector<txq_op>& out) {
     }
 }
 
-void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op>& out, KmerTable* dgrams) {
+void QueryExpansion::adopt_storage(NodeStates& ns) {
+    if (!spare_items_.empty()) { ns.items.swap(spare_items_.back()); spare_items_.pop_back(); }
+    if (ns.by_key.capacity() == 0 && !spare_maps_.empty()) { std::swap(ns.by_key, spare_maps_.back()); spare_maps_.pop_back(); }
+}
+
+void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams) {
     const unsigned k = enc_.k();
     const size_t start = out.size();
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
@@ -269,7 +278,16 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op
         const int32_t item = order_[cursor_++];
         NodeStates ns;
         ns.items.swap(table_[item].items);
-        table_[item].by_key.clear();
+        waiting_ -= ns.items.size();
+        if (table_[item].by_key.capacity()) {
+            table_[item].by_key.clear();
+            if (table_[item].by_key.capacity() && spare_maps_.size() < 64) { spare_maps_.emplace_back(); std::swap(spare_maps_.back(), table_[item].by_key); }
+        }
+        // the consumed vector's storage goes back to the pool when this item is finished
+        struct Recycle {
+            std::vector<StateVec>& pool; StateVec& v;
+            ~Recycle() { if (v.capacity() && pool.size() < 64) { v.clear(); pool.emplace_back(); pool.back().swap(v); } }
+        } recycle{spare_items_, ns.items};
         if (item > n_nodes_) {  // join: equal states were merged on arrival; fan out
             const uint32_t lo = fan_first_[item - n_nodes_ - 1], hi = fan_first_[item - n_nodes_];
             for (const State& s : ns.items) {
@@ -351,12 +369,13 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, std::vector<txq_op
 }
 
 void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) {
-    std::vector<uint8_t> seen(refs_.size(), 0);
+    if (seen_.size() < refs_.size()) seen_.resize(refs_.size(), 0);
+    if (++seen_epoch_ == 0) { std::fill(seen_.begin(), seen_.end(), 0); seen_epoch_ = 1; }
     for (size_t c = cursor_; c < order_.size(); ++c)
         for (State& s : table_[order_[c]].items) {
             if (s.asked) continue;
             s.asked = 1;
-            if (s.slot >= TXQ_SLOT_FIRST_FREE && !seen[s.slot]) { seen[s.slot] = 1; out.push_back(s.slot); ++asked_; }
+            if (s.slot >= TXQ_SLOT_FIRST_FREE && seen_[s.slot] != seen_epoch_) { seen_[s.slot] = seen_epoch_; out.push_back(s.slot); ++asked_; }
         }
 }
 
@@ -368,9 +387,9 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         for (const State& s : ns.items)
             if (s.slot < dead.size() && dead[s.slot]) { any = true; break; }
         if (!any) continue;
-        std::vector<State> keep;
+        StateVec keep;
         for (const State& s : ns.items) {
-            if (s.slot < dead.size() && dead[s.slot]) { drop(s.slot); ++pruned_; }
+            if (s.slot < dead.size() && dead[s.slot]) { drop(s.slot); ++pruned_; --waiting_; }
             else keep.push_back(s);
         }
         ns.items.swap(keep);
@@ -387,7 +406,8 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
 
 // ---- level scheduling ---------------------------------------------------------------------
 
-std::vector<uint32_t> schedule_levels(std::vector<txq_op>& ops, uint32_t n_slots, LevelScratch& sc) {
+std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, LevelScratch& sc, txq_op* dst,
+                                           uint32_t kmer_add, uint32_t dgram_add) {
     std::vector<uint32_t> ends;
     if (ops.empty()) return ends;
     if (sc.stamp.size() < n_slots) { sc.stamp.resize(n_slots, 0); sc.wr.resize(n_slots); sc.rd.resize(n_slots); sc.acc.resize(n_slots); }
@@ -425,15 +445,25 @@ std::vector<uint32_t> schedule_levels(std::vector<txq_op>& ops, uint32_t n_slots
         sc.level_of[i] = lvl;
         if (lvl > top) top = lvl;
     }
-    // stable counting sort by level
+    // stable counting sort by level, straight into dst
     ends.assign(top, 0);
     for (uint32_t l : sc.level_of) ++ends[l - 1];
-    std::vector<uint32_t> pos(top, 0);
-    for (uint32_t l = 1; l < top; ++l) pos[l] = pos[l - 1] + ends[l - 1];
-    sc.sorted.resize(ops.size());
-    for (size_t i = 0; i < ops.size(); ++i) sc.sorted[pos[sc.level_of[i] - 1]++] = ops[i];
-    ops.swap(sc.sorted);
+    sc.pos.assign(top, 0);
+    for (uint32_t l = 1; l < top; ++l) sc.pos[l] = sc.pos[l - 1] + ends[l - 1];
+    for (size_t i = 0; i < ops.size(); ++i) {
+        txq_op o = ops[i];
+        if (o.kmer != TXQ_NO_KMER) o.kmer = (o.kmer & kDgramFlag) ? (o.kmer & ~kDgramFlag) + dgram_add : o.kmer + kmer_add;
+        dst[sc.pos[sc.level_of[i] - 1]++] = o;
+    }
     for (uint32_t l = 1; l < top; ++l) ends[l] += ends[l - 1];
+    return ends;
+}
+
+std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch& sc) {
+    sc.sorted.resize(ops.size());
+    // the one-shot path has no d-gram ops: indexes pass through unchanged
+    std::vector<uint32_t> ends = schedule_levels_into(ops, n_slots, sc, sc.sorted.data(), 0, kDgramFlag);
+    ops.swap(sc.sorted);
     return ends;
 }
 
@@ -505,7 +535,6 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         }
     } pool(threads);
     auto parallel_for = [&](const std::function<void(size_t, int)>& body) { pool.run(n, body); };
-    const ParallelFor par_any = [&](size_t cnt, const std::function<void(size_t, int)>& body) { pool.run(cnt, body); };
 
     parallel_for([&](size_t i, int) {
         try {
@@ -521,31 +550,77 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
 
     StagedStats st;
     auto clock = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    // TETREX_TRACE=1: per-stage phase times on stderr
+    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
+    double lap_at = clock();
+    auto lap = [&](const char* what) {
+        if (!trace) return;
+        const double now = clock();
+        std::fprintf(stderr, "[tetrex] %-10s %8.2f ms\n", what, (now - lap_at) * 1e3);
+        lap_at = now;
+    };
+    lap("graphs");
     double mark = clock();
-    std::vector<std::vector<txq_op>> ops(n);
+    std::vector<OpVec> ops(n);
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
     // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
     // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
     std::vector<KmerTable> tables(n), dgram_tables(n);
     std::vector<LevelScratch> scratch(threads);
-    std::vector<std::vector<uint32_t>> levels(n);
+    std::vector<std::vector<uint8_t>> dead_scratch(threads);
+    std::vector<std::vector<uint32_t>> levels(n), asks(n);
+    std::vector<uint64_t> fin_states(n, 0), fin_pruned(n, 0);
+    std::vector<uint32_t> touched, act;  // queries with ops in the previous stage; unfinished queries
+    // the stage's blob is assembled in place, in storage that is reused from stage to stage
+    struct RawBuffer {
+        std::unique_ptr<uint64_t[]> words;
+        size_t cap = 0;
+        uint8_t* ensure(size_t bytes) {
+            if (bytes > cap) { cap = std::max(bytes, cap + cap / 2); words.reset(new uint64_t[(cap + 7) / 8]); }
+            return reinterpret_cast<uint8_t*>(words.get());
+        }
+    } blob_store;
     bool first = true;
     for (;;) {
+        for (uint32_t i : touched) {
+            if (q[i]) { ops[i].clear(); tables[i].clear(); dgram_tables[i].clear(); }
+            else { OpVec().swap(ops[i]); tables[i] = KmerTable(); dgram_tables[i] = KmerTable(); }  // finished: storage back to the cache
+            levels[i].clear();
+        }
+        touched.clear();
+        act.clear();
+        for (size_t i = 0; i < n; ++i) {
+            if (first && passthrough[i]) { ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT}); touched.push_back((uint32_t)i); }
+            if (q[i] && !q[i]->done()) act.push_back((uint32_t)i);
+        }
+        // largest first: a stage ends when its last task ends
+        {
+            std::vector<uint64_t> w(n, 0);
+            for (uint32_t i : act) w[i] = q[i]->weight();
+            std::stable_sort(act.begin(), act.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });
+        }
+        // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
+        size_t feedback_budget = act.empty() ? opt.ops_per_query_per_stage : opt.stage_target_ops / act.size();
+        if (feedback_budget < opt.ops_per_query_per_stage) feedback_budget = opt.ops_per_query_per_stage;
+        if (feedback_budget > opt.ops_per_task) feedback_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        const size_t run_on_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+
         std::atomic<size_t> total{0};
-        parallel_for([&](size_t i, int) {
-            ops[i].clear();
-            tables[i].clear();
-            dgram_tables[i].clear();
-            if (first && passthrough[i]) ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
-            if (!q[i] || q[i]->done()) return;
+        std::vector<double> busy(threads, 0.0);
+        pool.run(act.size(), [&](size_t at, int t) {
+            const size_t i = act[at];
+            const double t0 = trace ? clock() : 0.0;
+            struct Busy { double& acc; double t0; bool on; const decltype(clock)& clk; ~Busy() { if (on) acc += clk() - t0; } } busy_guard{busy[t], t0, trace, clock};
             if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
             try {
-                // a query that gains nothing from feedback runs on without pausing
-                q[i]->advance(q[i]->wants_feedback() ? opt.ops_per_query_per_stage : SIZE_MAX, tables[i], ops[i], &dgram_tables[i]);
+                // a query that gains nothing from feedback only pauses to keep the stage's tasks even
+                q[i]->advance(q[i]->wants_feedback() ? feedback_budget : run_on_budget, tables[i], ops[i], &dgram_tables[i]);
             } catch (const std::exception& e) {
                 // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
                 // query is neutralised by not emitting anything further
                 ops[i].clear();
+                tables[i].clear();
+                dgram_tables[i].clear();
                 q[i].reset();
                 st_local[i] = -1;
                 why[i] = e.what();
@@ -553,78 +628,134 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             }
             total.fetch_add(ops[i].size(), std::memory_order_relaxed);
             slots[i] = q[i]->n_slots();
+            if (q[i]->done()) {  // free the expansion's tables here, on the worker
+                fin_states[i] = q[i]->states();
+                fin_pruned[i] = q[i]->pruned();
+                q[i].reset();
+            }
         });
+        if (trace) {
+            double sum = 0, mx = 0;
+            for (double b : busy) { sum += b; if (b > mx) mx = b; }
+            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, total.load(), act.size());
+        }
+        lap("advance");
         bool pending = false;
-        for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
+        for (uint32_t i : act) {
+            pending |= q[i] && !q[i]->done();
+            if (!ops[i].empty() || !tables[i].values().empty()) touched.push_back(i);
+        }
         if (!first && total.load() == 0 && !pending) break;
 
-        // the stage's table: the per-query k-mer tables, then the per-query d-gram tables (the
-        // device probes the last `stage_dgrams` entries on the auxiliary index)
-        std::vector<uint32_t> base(n, 0), dbase(n, 0);
-        std::vector<const std::vector<uint64_t>*> kmer_tables;
-        size_t stage_kmers = 0, stage_dgrams = 0;
-        for (size_t i = 0; i < n; ++i) {
-            base[i] = (uint32_t)stage_kmers;
-            stage_kmers += tables[i].values().size();
-            kmer_tables.push_back(&tables[i].values());
+        // layout: header | k-mer tables of the touched queries, then their d-gram tables (the device
+        // probes the last `stage_dgrams` entries on the auxiliary index) | programs | ops | levels
+        std::sort(touched.begin(), touched.end());
+        std::vector<uint32_t> base(touched.size()), dbase(touched.size()), first_op(touched.size());
+        size_t stage_kmers = 0, stage_dgrams = 0, stage_ops = 0;
+        for (size_t j = 0; j < touched.size(); ++j) {
+            base[j] = (uint32_t)stage_kmers;
+            stage_kmers += tables[touched[j]].values().size();
+            first_op[j] = (uint32_t)stage_ops;
+            stage_ops += ops[touched[j]].size();
         }
-        for (size_t i = 0; i < n; ++i) {
-            dbase[i] = (uint32_t)(stage_kmers + stage_dgrams);
-            stage_dgrams += dgram_tables[i].values().size();
-            kmer_tables.push_back(&dgram_tables[i].values());
+        for (size_t j = 0; j < touched.size(); ++j) {
+            dbase[j] = (uint32_t)(stage_kmers + stage_dgrams);
+            stage_dgrams += dgram_tables[touched[j]].values().size();
         }
         if (stage_kmers + stage_dgrams > 0x7FFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
-        parallel_for([&](size_t i, int t) {
-            const uint32_t add = base[i], dadd = dbase[i];
-            for (txq_op& o : ops[i]) {
-                if (o.kmer == TXQ_NO_KMER) continue;
-                o.kmer = (o.kmer & kDgramFlag) ? (o.kmer & ~kDgramFlag) + dadd : o.kmer + add;
-            }
-            levels[i] = schedule_levels(ops[i], slots[i], scratch[t]);
+        if (stage_ops > 0xFFFFFFFFu) throw std::runtime_error("stage has more than 2^32 operations");
+        txq_blob_header_v2 h{};
+        h.magic = TXQ_PROGRAM_MAGIC;
+        h.version = TXQ_PROGRAM_VERSION_LEVELS;
+        h.n_programs = (uint32_t)n;
+        h.n_kmers = (uint32_t)(stage_kmers + stage_dgrams);
+        h.n_ops = (uint32_t)stage_ops;
+        h.n_aux_kmers = stage_dgrams;
+        h.kmers_offset = sizeof(txq_blob_header_v2);
+        h.programs_offset = h.kmers_offset + (stage_kmers + stage_dgrams) * sizeof(uint64_t);
+        h.ops_offset = h.programs_offset + n * sizeof(txq_program_v2);
+        h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
+        // a program has at most one level per op; the untouched tail of the reservation costs nothing
+        uint8_t* blob = blob_store.ensure(h.levels_offset + stage_ops * 4 + 8);
+        uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
+        txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
+        pool.run(touched.size(), [&](size_t j, int t) {
+            const uint32_t i = touched[j];
+            const auto& km = tables[i].values();
+            if (!km.empty()) std::memcpy(blob_kmers + base[j], km.data(), km.size() * 8);
+            const auto& dg = dgram_tables[i].values();
+            if (!dg.empty()) std::memcpy(blob_kmers + dbase[j], dg.data(), dg.size() * 8);
+            levels[i] = schedule_levels_into(ops[i], slots[i], scratch[t], blob_ops + first_op[j], base[j], dbase[j]);
         });
-
-        std::vector<txq_program> programs(n);
-        std::vector<const std::vector<txq_op>*> ops_of(n);
-        std::vector<const std::vector<uint32_t>*> levels_of(n);
-        uint32_t at = 0;
-        for (size_t i = 0; i < n; ++i) {
-            programs[i] = txq_program{at, (uint32_t)ops[i].size(), slots[i], 0};
-            at += (uint32_t)ops[i].size();
-            ops_of[i] = &ops[i];
-            levels_of[i] = &levels[i];
+        lap("levels");
+        txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob + h.programs_offset);
+        uint32_t* lv = reinterpret_cast<uint32_t*>(blob + h.levels_offset);
+        {
+            size_t j = 0;
+            uint32_t at_level = 0;
+            for (size_t i = 0; i < n; ++i) {
+                if (j < touched.size() && touched[j] == i) {
+                    const uint32_t nl = (uint32_t)levels[i].size();
+                    pr[i] = txq_program_v2{first_op[j], (uint32_t)ops[i].size(), slots[i], at_level, nl, 0};
+                    if (nl) std::memcpy(lv + at_level, levels[i].data(), (size_t)nl * 4);
+                    at_level += nl;
+                    ++j;
+                } else {
+                    pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots[i], at_level, 0, 0};
+                }
+            }
+            h.n_levels = at_level;
+            if (at_level & 1) lv[at_level] = 0;
         }
+        std::memcpy(blob, &h, sizeof h);
+        const size_t blob_bytes = h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7);
+        lap("blob");
+
+        // which waiting states does the device have to report on
+        std::vector<uint32_t> fb;
+        for (uint32_t i : act)
+            if (q[i] && !q[i]->done() && q[i]->wants_feedback()) fb.push_back(i);
+        pool.run(fb.size(), [&](size_t j, int) { asks[fb[j]].clear(); q[fb[j]]->frontier_slots(asks[fb[j]]); });
         std::vector<uint32_t> qp, qs;
-        for (size_t i = 0; i < n; ++i) {
-            if (!q[i] || q[i]->done() || !q[i]->wants_feedback()) continue;
-            const size_t before = qs.size();
-            q[i]->frontier_slots(qs);
-            qp.insert(qp.end(), qs.size() - before, (uint32_t)i);
+        std::vector<size_t> ask_first(fb.size() + 1, 0);
+        for (size_t j = 0; j < fb.size(); ++j) {
+            const auto& v = asks[fb[j]];
+            qs.insert(qs.end(), v.begin(), v.end());
+            qp.insert(qp.end(), v.size(), fb[j]);
+            ask_first[j + 1] = qs.size();
         }
         std::vector<uint8_t> alive(qp.size(), 1);
-        const std::vector<uint8_t> blob = make_blob(kmer_tables, programs, ops_of, levels_of, &par_any, stage_dgrams);
+        lap("frontier");
         st.expand_seconds += clock() - mark;
         mark = clock();
-        exec.stage(blob, qp, qs, alive);
+        exec.stage(blob, blob_bytes, qp, qs, alive);
         st.execute_seconds += clock() - mark;
         mark = clock();
+        lap("execute");
         ++st.stages;
         st.ops += total.load();
         st.kmers += stage_kmers + stage_dgrams;
         st.feedback_queries += qp.size();
         // prune dead frontier states
-        for (size_t a = 0; a < qp.size();) {
-            const uint32_t p = qp[a];
-            std::vector<uint8_t> dead(q[p]->n_slots(), 0);
+        pool.run(fb.size(), [&](size_t j, int t) {
             bool any = false;
-            for (; a < qp.size() && qp[a] == p; ++a)
-                if (!alive[a]) { dead[qs[a]] = 1; any = true; }
-            if (any) q[p]->prune(dead);
-        }
+            for (size_t a = ask_first[j]; a < ask_first[j + 1] && !any; ++a) any = !alive[a];
+            if (!any) return;
+            const uint32_t p = fb[j];
+            std::vector<uint8_t>& dead = dead_scratch[t];
+            dead.assign(q[p]->n_slots(), 0);
+            for (size_t a = ask_first[j]; a < ask_first[j + 1]; ++a)
+                if (!alive[a]) dead[qs[a]] = 1;
+            q[p]->prune(dead);
+        });
+        lap("prune");
         first = false;
         if (!pending) break;
     }
-    for (size_t i = 0; i < n; ++i)
+    for (size_t i = 0; i < n; ++i) {
         if (q[i]) { st.states += q[i]->states(); st.pruned += q[i]->pruned(); }
+        else { st.states += fin_states[i]; st.pruned += fin_pruned[i]; }
+    }
     if (status) *status = st_local;
     if (messages) *messages = why;
     return st;
@@ -657,9 +788,9 @@ size_t ProgramBatch::add(const KGraph& g) {
 
 std::vector<uint8_t> ProgramBatch::serialise() const {
     std::vector<txq_program> pr(programs_.size());
-    std::vector<std::vector<txq_op>> ops(programs_.size());
+    std::vector<OpVec> ops(programs_.size());
     std::vector<std::vector<uint32_t>> levels(programs_.size());
-    std::vector<const std::vector<txq_op>*> ops_of(programs_.size());
+    std::vector<const OpVec*> ops_of(programs_.size());
     std::vector<const std::vector<uint32_t>*> levels_of(programs_.size());
     LevelScratch scratch;
     uint32_t first = 0;

@@ -56,8 +56,11 @@ void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_ga
 // (local to one expansion; run_staged rebases both kinds into the stage's single table, d-grams last)
 constexpr uint32_t kDgramFlag = 0x80000000u;
 
+using OpVec = CachedVector<txq_op>;
+using KmerVec = CachedVector<uint64_t>;
+
 struct QueryProgram {
-    std::vector<txq_op> ops;  // k-mer field indexes the BATCH table
+    OpVec ops;  // k-mer field indexes the BATCH table
     uint32_t n_slots = TXQ_SLOT_FIRST_FREE;
     uint64_t states = 0, probes = 0;  // statistics
 };
@@ -72,12 +75,12 @@ class KmerTable {
         if (fresh) values_.push_back(value);
         return *slot;
     }
-    const std::vector<uint64_t>& values() const { return values_; }
+    const KmerVec& values() const { return values_; }
     void clear() { index_.clear(); values_.clear(); }
 
   private:
     FlatMap index_;
-    std::vector<uint64_t> values_;
+    KmerVec values_;
 };
 
 class QueryExpansion {
@@ -88,7 +91,7 @@ class QueryExpansion {
     bool done() const { return cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
-    void advance(size_t op_budget, Intern intern, std::vector<txq_op>& out, KmerTable* dgrams = nullptr);
+    void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr);
     uint32_t n_slots() const { return high_water_; }
     // distinct non-constant slots of waiting states that were not asked about before (a waiting
     // state's mask only ever grows, so one answer per state is enough); marks them as asked
@@ -101,10 +104,14 @@ class QueryExpansion {
     uint64_t probes() const { return probes_; }
     uint64_t pruned() const { return pruned_; }
     uint64_t total_ops() const { return total_ops_; }
+    // rough cost of running this query to its end (waiting states x remaining items): orders the
+    // tasks of a stage, largest first
+    uint64_t weight() const { return (uint64_t)(order_.size() - cursor_) * (waiting_ + 1); }
 
   private:
     struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; uint8_t gapped = 0; uint8_t res1 = 0, res2 = 0; };
-    struct NodeStates { std::vector<State> items; FlatMap by_key; };
+    using StateVec = CachedVector<State>;
+    struct NodeStates { StateVec items; FlatMap by_key; };
     const KmerEncoder& enc_;
     KGraph g_;
     CompileLimits limits_;
@@ -130,29 +137,39 @@ class QueryExpansion {
     std::vector<uint32_t> free_, parked_;
     size_t free_head_ = 0;
     uint32_t high_water_ = TXQ_SLOT_FIRST_FREE;
-    uint64_t states_ = 0, probes_ = 0, pruned_ = 0, total_ops_ = 0, asked_ = 0;
+    uint64_t states_ = 0, probes_ = 0, pruned_ = 0, total_ops_ = 0, asked_ = 0, waiting_ = 0;
+    // storage of consumed items, reused by the items that fill next (keeps the allocator out of the loop)
+    std::vector<StateVec> spare_items_;
+    std::vector<FlatMap> spare_maps_;
+    std::vector<uint32_t> seen_;  // frontier_slots: slot -> epoch
+    uint32_t seen_epoch_ = 0;
 
     uint32_t fresh();
     void share(uint32_t s);
     void drop(uint32_t s);
     bool exclusive(uint32_t s) const;
-    void arrive(int32_t to, State s, std::vector<txq_op>& out);
-    void hand_on(int32_t from, State s, std::vector<txq_op>& out);
-    void emit(std::vector<txq_op>& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b);
+    void arrive(int32_t to, State s, OpVec& out);
+    void adopt_storage(NodeStates& ns);
+    void hand_on(int32_t from, State s, OpVec& out);
+    void emit(OpVec& out, uint32_t kmer, uint32_t dst, uint32_t a, uint32_t b);
 };
 
 // Reorders `ops` (one program's ops of one stage, in a valid sequential order) into dependency
 // levels as defined in txq_program.h (version 2) and returns the end index of every level.
 // Scratch vectors are reused across calls (sized to n_slots).
-struct LevelScratch { std::vector<uint32_t> wr, rd, acc, stamp; uint32_t epoch = 0; std::vector<uint32_t> level_of; std::vector<txq_op> sorted; };
-std::vector<uint32_t> schedule_levels(std::vector<txq_op>& ops, uint32_t n_slots, LevelScratch& scratch);
+struct LevelScratch { std::vector<uint32_t> wr, rd, acc, stamp; uint32_t epoch = 0; std::vector<uint32_t> level_of, pos; OpVec sorted; };
+std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch& scratch);
+// Same, but leaves `ops` alone and writes the reordered ops to `dst` (room for ops.size()), adding
+// `kmer_add` to every k-mer index and `dgram_add` to every (flag-stripped) d-gram index on the way.
+std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, LevelScratch& scratch, txq_op* dst,
+                                           uint32_t kmer_add, uint32_t dgram_add);
 
 // What executes a stage: the GPU session (device_index.cpp) or a test double.
 struct StageExecutor {
     virtual ~StageExecutor() = default;
-    // Runs the NEW ops of every program (blob in txq_program.h format, all programs present) and
-    // answers alive[i] = slot query_slot[i] of program query_program[i] has a bit set.
-    virtual void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& query_program,
+    // Runs the NEW ops of every program (blob in txq_program.h format, all programs present,
+    // 8-byte aligned) and answers alive[i] = slot query_slot[i] of program query_program[i] has a bit set.
+    virtual void stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& query_program,
                        const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) = 0;
 };
 
@@ -161,6 +178,8 @@ struct StagedOptions {
     int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
     size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)
+    size_t ops_per_task = 256u << 10;        // no query runs longer than this in one stage (load balance)
+    size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
     CompileLimits limits;
 };
 
@@ -189,7 +208,7 @@ class ProgramBatch {
 
     size_t size() const { return programs_.size(); }
     size_t kmer_count() const { return table_.values().size(); }
-    const std::vector<uint64_t>& kmers() const { return table_.values(); }
+    const KmerVec& kmers() const { return table_.values(); }
     const QueryProgram& program(size_t i) const { return programs_[i]; }
     std::vector<uint8_t> serialise() const;
 

@@ -80,17 +80,10 @@ TxqStageExecutor::TxqStageExecutor(txq_index* ix, size_t n_programs, txq_index* 
 TxqStageExecutor::~TxqStageExecutor() {
     if (session_) txq_session_end(session_, nullptr);
 }
-void TxqStageExecutor::stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+void TxqStageExecutor::stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
                              std::vector<uint8_t>& alive) {
     alive.assign(qp.size(), 1);
-    const void* data = blob.data();
-    std::vector<uint64_t> aligned;
-    if (reinterpret_cast<uintptr_t>(data) % 8) {  // txq wants an 8-byte aligned blob (heap vectors already are)
-        aligned.resize((blob.size() + 7) / 8);
-        std::copy(blob.begin(), blob.end(), reinterpret_cast<uint8_t*>(aligned.data()));
-        data = aligned.data();
-    }
-    txq_check(txq_session_stage(session_, data, blob.size(), qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
+    txq_check(txq_session_stage(session_, blob, blob_bytes, qp.data(), qs.data(), qp.size(), alive.data()), "txq_session_stage");
 }
 void TxqStageExecutor::finish(uint64_t* masks) {
     txq_session* s = session_;

@@ -21,7 +21,7 @@ class TxqStageExecutor final : public StageExecutor {
   public:
     TxqStageExecutor(txq_index* ix, size_t n_programs, txq_index* aux = nullptr);
     ~TxqStageExecutor() override;
-    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& query_program,
+    void stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& query_program,
                const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) override;
     // copies every program's RESULT mask (n_programs x shard_words words) and ends the session
     void finish(uint64_t* masks);

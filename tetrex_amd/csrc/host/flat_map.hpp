@@ -3,6 +3,8 @@
 // collector's per-node state tables and the per-stage k-mer tables, where std::unordered_map's
 // node allocations dominated the expansion time.
 #pragma once
+#include "block_cache.hpp"
+
 #include <cstdint>
 #include <utility>
 #include <vector>
@@ -13,6 +15,7 @@ class FlatMap {
   public:
     FlatMap() = default;
     size_t size() const { return size_; }
+    size_t capacity() const { return cap_; }
     void clear() {
         if (size_ == 0) return;
         if (cap_ > 1024 && size_ * 8 < cap_) {  // shrink tables that were briefly huge
@@ -42,8 +45,8 @@ class FlatMap {
 
   private:
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;  // values must never be 0xFFFFFFFF
-    std::vector<uint64_t> keys_;
-    std::vector<uint32_t> vals_;
+    CachedVector<uint64_t> keys_;
+    CachedVector<uint32_t> vals_;
     size_t cap_ = 0, size_ = 0;
 
     static uint64_t mix(uint64_t x) {
@@ -54,8 +57,8 @@ class FlatMap {
     }
     void grow() {
         const size_t ncap = cap_ ? cap_ * 2 : 16;
-        std::vector<uint64_t> ok;
-        std::vector<uint32_t> ov;
+        CachedVector<uint64_t> ok;
+        CachedVector<uint32_t> ov;
         ok.swap(keys_);
         ov.swap(vals_);
         keys_.assign(ncap, 0);

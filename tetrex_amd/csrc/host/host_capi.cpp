@@ -110,12 +110,10 @@ namespace {
 struct CallbackExecutor final : StageExecutor {
     txh_stage_fn fn;
     void* user;
-    void stage(const std::vector<uint8_t>& blob, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+    void stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
                std::vector<uint8_t>& alive) override {
-        std::vector<uint64_t> aligned((blob.size() + 7) / 8);
-        std::memcpy(aligned.data(), blob.data(), blob.size());
         alive.assign(qp.size(), 1);
-        if (fn(user, aligned.data(), blob.size(), qp.data(), qs.data(), qp.size(), alive.data()) != 0)
+        if (fn(user, blob, blob_bytes, qp.data(), qs.data(), qp.size(), alive.data()) != 0)
             throw std::runtime_error("stage executor callback failed");
     }
 };
@@ -131,7 +129,8 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
         exec.fn = fn;
         exec.user = user;
         StagedOptions opt;
-        if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
+        // an explicit per-query budget is taken literally (no adaptive growth)
+        if (ops_per_query_per_stage) { opt.ops_per_query_per_stage = ops_per_query_per_stage; opt.stage_target_ops = 0; }
         if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
         if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0, gaps->min_gap, gaps->max_gap};
         std::vector<int> st;
