@@ -47,6 +47,16 @@ def compute_bitcount(n, fpr):
     return int(math.ceil(-float(n) * float(np.log(np.float32(fpr))) / (math.log(2.0) ** 2)))
 
 
+def workload_name(bins_local, m, args):
+    """SURVEY.md §8(d) names: S-IBF-1024 (the default), S-IBF-8192 (8192 bins x 62.5 M rows = 64 GB on
+    one GPU, BASELINE configs[3] unsharded); anything else spells its shape out."""
+    if bins_local == 1024 and args.rows == 0:
+        return "S-IBF-1024"
+    if bins_local == 8192 and m == 62500000:
+        return "S-IBF-8192"
+    return "S-IBF-%d-rows%d" % (bins_local, m)
+
+
 def build_index(capi, torch, bins_total, bins_local, m, h, rank, world, per_bin, value_bits):
     """Device-side construction: per_bin uniform values into each of this rank's bins."""
     ix = capi.Index.create_ibf(bins_total, m, h, shard_rank=rank, n_shards=world)
@@ -251,7 +261,7 @@ def main():
         "dtype": "u64",
         "data": "synthetic",
         "config": {
-            "workload": "S-IBF-1024" if args.rows == 0 else "S-IBF-1024-rows%d" % m,
+            "workload": workload_name(bins_local, m, args),
             "bins_per_gpu": bins_local, "bins_total": bins_total, "hash_funs": h, "bin_size_rows": m,
             "kmers_per_step": n, "kmer_bits": value_bits, "values_per_bin": args.per_bin,
             "matrix_bytes_per_gpu": int(ix.info.device_bytes), "mask_words": W,
