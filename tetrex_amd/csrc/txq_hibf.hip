@@ -10,6 +10,7 @@
 // "any bit of the run is set", so every set technical bin can be handled independently.
 // No host round trip between levels: each level kernel reads its item count from HBM.
 #include "txq_internal.hpp"
+#include <cstdlib>
 #include <deque>
 
 namespace txq {
@@ -22,6 +23,17 @@ struct HibfView {
     const uint64_t* merged;      // per IBF word: bit b set <=> technical bin 64w+b is a merged bin
     const uint64_t* merged_off;  // [n_ibf] offset of IBF i's words in `merged`
 };
+
+// loads through a pointer that was itself read from memory: tell the compiler it is global memory
+// (otherwise it emits flat loads, which also wait on the LDS counter)
+__device__ __forceinline__ uint64_t gload(const uint64_t* p) {
+    return *(const __attribute__((address_space(1))) uint64_t*)p;
+}
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 gload2(const uint64_t* p) {  // p is 16-byte aligned
+    const u64x2 q = *(const __attribute__((address_space(1))) u64x2*)p;
+    return ulonglong2{q.x, q.y};
+}
 
 // exclusive prefix sum of `v` over the 64 lanes of a wave; *total receives the wave sum
 __device__ __forceinline__ uint32_t wave_exclusive_scan(uint32_t v, uint32_t* total) {
@@ -64,15 +76,15 @@ __global__ __launch_bounds__(256) void hibf_level_kernel(HibfView t, const uint6
         const uint64_t v = live ? kmers[kidx] : 0;
         uint64_t row[5];
 #pragma unroll
-        for (uint32_t j = 0; j < 5; ++j) row[j] = j < f.hash_funs ? hash_row(v, kSeeds[j], f.hash_shift, f.bin_size) : 0;
+        for (uint32_t j = 0; j < 5; ++j) row[j] = (j == 0 || j < f.hash_funs) ? hash_row(v, kSeeds[j], f.hash_shift, f.bin_size) : row[j ? j - 1 : 0];
         for (uint32_t wi = 0; wi < w_iters; ++wi) {
             const uint32_t w = wi * G + sub;
             uint64_t acc = 0;
             if (live && w < f.shard_words) {
+                // all loads issue together: a hash function the IBF does not have repeats the last real row
                 acc = ~0ULL;
 #pragma unroll
-                for (uint32_t j = 0; j < 5; ++j)
-                    if (j < f.hash_funs) acc &= f.words[row[j] * f.stride + w];
+                for (uint32_t j = 0; j < 5; ++j) acc &= gload(f.words + row[j] * f.stride + w);
             }
             uint64_t kids = acc ? (acc & t.merged[moff + w]) : 0;
             uint64_t hits = acc & ~kids;
@@ -110,6 +122,157 @@ __global__ __launch_bounds__(256) void hibf_level_kernel(HibfView t, const uint6
                     atomicOr((unsigned long long*)(masks + (size_t)kidx * w_out + (word - word0)), 1ULL << (ub & 63));
             }
         }
+    }
+}
+
+constexpr uint32_t kRootEntry = 0xFFFFFFFFu;  // stack entry of the root IBF (every other entry is a technical-bin index)
+
+// value of `v` in lane `src` (wave-uniform src)
+__device__ __forceinline__ uint64_t read_lane(uint64_t v, int src) {
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// orders this wave's LDS traffic: everything before is visible to every lane after
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Whole descent of ONE k-mer per wave, no frontier in HBM: the wave keeps the k-mer's result row
+// (w_out words) and a stack of IBF ids in LDS, pops up to 64/G IBFs per round (G lanes each, FOUR
+// row words = two 16-byte loads per lane and hash function), pushes the children found and ORs
+// user-bin hits into the LDS row; the finished row is written once, coalesced.  HBM traffic per
+// k-mer is the row itself (w_out * 8 B) instead of a zero fill plus one read-modify-write per hit
+// word; the tree (tens of MB) is served from L2 / Infinity Cache, which makes the kernel
+// instruction-bound: hence few lanes per IBF (a 256-bin IBF is one lane) and only as many hash
+// evaluations as the tree's IBFs have (h_max, wave-uniform).  A k-mer visits every IBF at most
+// once (the IBFs form a tree), so a stack of n_ibf entries cannot overflow.
+// LDS per wave: w_out * 8 + stack_cap * 4 bytes (dynamic); launch: 64 * waves threads per block.
+template <int G>
+__global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint64_t* __restrict__ kmers, size_t n,
+                                                         uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0,
+                                                         uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
+                                                         uint32_t h_max, uint64_t* __restrict__ alive) {
+    extern __shared__ uint64_t lds[];
+    const uint32_t lane = threadIdx.x & 63;
+    uint64_t* row = lds + (size_t)(threadIdx.x >> 6) * wave_words;
+    uint32_t* stack = reinterpret_cast<uint32_t*>(row + w_out);
+    const uint32_t sub = lane % G, group = lane / G;
+    constexpr uint32_t kPerRound = 64 / G;
+    const size_t waves = ((size_t)gridDim.x * blockDim.x) >> 6;
+    const size_t first = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    uint64_t v_next = first < n ? kmers[first] : 0;
+    for (size_t i = first; i < n; i += waves) {
+        for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
+        if (lane == 0) stack[0] = kRootEntry;
+        const uint64_t v = v_next;
+        if (i + waves < n) v_next = kmers[i + waves];  // lands while this k-mer descends
+        uint32_t count = 1;  // wave-uniform
+        while (count) {
+            wave_sync();
+            const uint32_t take = count < kPerRound ? count : kPerRound;
+            count -= take;
+            const bool live = group < take;
+            // a stack entry is a technical-bin index; its child IBF is looked up when the entry is popped
+            const uint32_t entry = live ? stack[count + group] : kRootEntry;
+            const uint32_t id = entry == kRootEntry ? 0u : (uint32_t)gload(t.next + entry);
+            const IbfDev f = t.ibf[id];
+            const uint32_t off = (uint32_t)t.map_off[id];
+            const uint64_t moff = t.merged_off[id];
+            uint64_t r[5];
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) {
+                if (j >= h_max) { r[j] = 0; continue; }  // uniform: no IBF of this tree has more
+                // a hash function this IBF does not have repeats its last real row (AND is idempotent)
+                r[j] = (j == 0 || j < f.hash_funs) ? hash_row(v, kSeeds[j], f.hash_shift, f.bin_size) : r[j ? j - 1 : 0];
+            }
+            for (uint32_t wi = 0; wi < w_iters; ++wi) {
+                const uint32_t w0 = (wi * G + sub) * 4u;
+                uint64_t acc[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0};
+                if (live && w0 < f.shard_words) {  // every load of the round issues before the first is used
+                    if (f.stride == 1) {
+                        uint64_t x = ~0ULL;
+#pragma unroll
+                        for (uint32_t j = 0; j < 5; ++j)
+                            if (j < h_max) x &= gload(f.words + r[j]);
+                        acc[0] = x;
+                    } else {  // rows are padded to an even number of words, the padding is zero
+                        const bool upper = w0 + 2 < f.stride;
+                        ulonglong2 lo{~0ULL, ~0ULL}, hi{~0ULL, ~0ULL};
+#pragma unroll
+                        for (uint32_t j = 0; j < 5; ++j) {
+                            if (j >= h_max) continue;
+                            const uint64_t* p = f.words + r[j] * f.stride + w0;
+                            const ulonglong2 a = gload2(p);
+                            lo.x &= a.x; lo.y &= a.y;
+                            if (upper) { const ulonglong2 b = gload2(p + 2); hi.x &= b.x; hi.y &= b.y; }
+                        }
+                        acc[0] = lo.x; acc[1] = lo.y;
+                        if (upper) { acc[2] = hi.x; acc[3] = hi.y; }
+                    }
+                    // merged-bin masks are padded to 4 words per IBF
+                    const ulonglong2 m0 = gload2(t.merged + moff + w0), m1 = gload2(t.merged + moff + w0 + 2);
+                    mg[0] = m0.x; mg[1] = m0.y; mg[2] = m1.x; mg[3] = m1.y;
+                }
+                // Children and mapped user bins are expanded by the whole wave, one 64-bit word per step:
+                // lane L takes bit L, so a word costs the same whether 1 or 64 of its bits are set.
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const uint64_t kids = acc[q] & mg[q];
+                    const uint32_t first_tb = off + (w0 + (uint32_t)q) * 64u;
+                    uint64_t owners = __ballot(kids != 0);
+                    while (owners) {  // wave-uniform
+                        const int src = __builtin_ctzll(owners);
+                        owners &= owners - 1;
+                        const uint64_t word = read_lane(kids, src);
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)first_tb, src);
+                        if ((word >> lane) & 1) {
+                            const uint32_t pos = count + (uint32_t)__builtin_popcountll(word & ((1ULL << lane) - 1));
+                            if (pos < stack_cap) stack[pos] = base + lane;
+                        }
+                        count += (uint32_t)__builtin_popcountll(word);
+                        if (count > stack_cap) count = stack_cap;  // unreachable for a tree; keeps the indexes in range
+                    }
+                    uint64_t hits = acc[q] & ~mg[q];
+                    const uint32_t w = w0 + (uint32_t)q;
+                    if (hits && f.ident_word != kNoIdent) {  // the row word is a mask word
+                        const uint64_t word = (uint64_t)f.ident_word + w;
+                        if (word >= word0 && word < (uint64_t)word0 + w_out) atomicOr((unsigned long long*)(row + (word - word0)), hits);
+                        hits = 0;
+                    }
+                    // padding bits are never set; this guards the map look-up
+                    if (w * 64u + 63u >= f.bins) hits &= f.bins > w * 64u ? (~0ULL >> (63u - ((f.bins - 1u) & 63u))) : 0;
+                    owners = __ballot(hits != 0);
+                    while (owners) {
+                        const int src = __builtin_ctzll(owners);
+                        owners &= owners - 1;
+                        const uint64_t word = read_lane(hits, src);
+                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)first_tb, src);
+                        if ((word >> lane) & 1) {
+                            const uint64_t ub = gload(t.tb_user + base + lane);
+                            const uint64_t mw = ub >> 6;
+                            if (mw >= word0 && mw < (uint64_t)word0 + w_out) atomicOr((unsigned long long*)(row + (mw - word0)), 1ULL << (ub & 63));
+                        }
+                    }
+                }
+            }
+        }
+        wave_sync();
+        uint64_t any = 0;
+        uint64_t* out = masks + i * (size_t)w_out;
+        for (uint32_t j = lane; j < w_out; j += 64) {
+            const uint64_t x = row[j];
+            any |= x;
+            __builtin_nontemporal_store(x, out + j);
+        }
+        if (alive) {
+            const uint64_t some = __ballot(any != 0);
+            if (lane == 0 && some) atomicOr((unsigned long long*)(alive + (i >> 6)), 1ULL << (i & 63));
+        }
+        wave_sync();  // the next k-mer reuses the row
     }
 }
 
@@ -176,6 +339,7 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     for (uint64_t i = 0; i < n; ++i)
         if (level[i] < 0) return fail(TXQ_ERR_ARG, "IBF %llu is unreachable from the root", (unsigned long long)i);
     ix.depth = (uint32_t)width.size();
+    ix.hibf_total_tbs = off[n];
     ix.max_level_width = 1;
     for (uint64_t w : width) if (w > ix.max_level_width) ix.max_level_width = w;
 
@@ -202,7 +366,8 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     TXQ_HIP(hipMalloc((void**)&ix.d_map_off, n * 8));
     // merged-bin bitmasks, one 64-bit word per row word of every IBF
     std::vector<uint64_t> moff(n + 1, 0);
-    for (uint64_t i = 0; i < n; ++i) moff[i + 1] = moff[i] + desc.ibf[i].bin_words;
+    // (padded to 4 words per IBF: the fused kernel reads them as two 16-byte loads)
+    for (uint64_t i = 0; i < n; ++i) moff[i + 1] = moff[i] + ((desc.ibf[i].bin_words + 3) & ~(uint64_t)3);
     std::vector<uint64_t> merged(moff[n], 0);
     for (uint64_t i = 0; i < n; ++i)
         for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
@@ -227,9 +392,67 @@ static hipError_t launch_level(unsigned grid, hipStream_t s, HibfView t, const u
     return hipGetLastError();
 }
 
+template <int G>
+static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes, hipStream_t s, HibfView t, const uint64_t* kmers, size_t n,
+                               uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
+                               uint32_t h_max, uint64_t* alive) {
+    hibf_fused_kernel<G><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive);
+    return hipGetLastError();
+}
+
+// fused descent (hibf_fused_kernel) when a k-mer's row and IBF stack fit the LDS; returns false if not
+// (TXQ_HIBF_LEVELS=1 forces the level-synchronous path, for A/B runs and for testing both)
+static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s, int* rc) {
+    const uint32_t w_out = (uint32_t)ix.shard_words;
+    const uint32_t stack_cap = (uint32_t)ix.ibf.size();
+    const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2;
+    const size_t wave_bytes = wave_words * 8;
+    const size_t lds_budget = 64u << 10;
+    const char* force = std::getenv("TXQ_HIBF_LEVELS");
+    if (!w_out || wave_bytes > lds_budget || ix.hibf_total_tbs >= kRootEntry || (force && force[0] == '1')) return false;
+    unsigned waves = 4;
+    while (waves > 1 && wave_bytes * waves > lds_budget) waves >>= 1;
+    // about 16 waves per CU are resident where the LDS allows it (TXQ_HIBF_WAVES overrides the total)
+    size_t want_waves = (size_t)256 * 16;
+    if (const char* e = std::getenv("TXQ_HIBF_WAVES")) want_waves = std::atoll(e) > 0 ? (size_t)std::atoll(e) : want_waves;
+    const size_t total_waves = n < want_waves ? n : want_waves;
+    const unsigned grid = (unsigned)((total_waves + waves - 1) / waves);
+    const uint32_t quads = (ix.max_stride + 3) / 4;  // a lane owns four row words
+    int g = 1;
+    while (g < 64 && (uint32_t)g < quads) g <<= 1;
+    const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged_off};
+    uint32_t h_max = 1;
+    for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
+    *rc = TXQ_OK;
+    if (d_alive) {
+        hipError_t e = hipMemsetAsync(d_alive, 0, ((n + 63) / 64) * 8, s);
+        if (e != hipSuccess) { *rc = fail_hip(e, "hipMemsetAsync(alive)"); return true; }
+    }
+    hipError_t e;
+#define TXQ_FUSED(G) e = launch_fused<G>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_masks, w_out, (uint32_t)ix.shard_word0, w_iters, \
+                                         stack_cap, (uint32_t)wave_words, h_max, d_alive)
+    switch (g) {
+        case 1: TXQ_FUSED(1); break;
+        case 2: TXQ_FUSED(2); break;
+        case 4: TXQ_FUSED(4); break;
+        case 8: TXQ_FUSED(8); break;
+        case 16: TXQ_FUSED(16); break;
+        case 32: TXQ_FUSED(32); break;
+        default: TXQ_FUSED(64); break;
+    }
+#undef TXQ_FUSED
+    if (e != hipSuccess) *rc = fail_hip(e, "hibf fused kernel launch");
+    return true;
+}
+
 int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     if (n == 0) return TXQ_OK;
+    {
+        int rc = TXQ_OK;
+        if (hibf_probe_fused(ix, d_kmers, n, d_masks, d_alive, s, &rc)) return rc;
+    }
     if (w_out) TXQ_HIP(hipMemsetAsync(d_masks, 0, n * w_out * 8, s));
     // Frontier bound: a (k-mer, IBF) pair occurs at most once, so level l holds at most
     // chunk * (#IBFs on level l) items.  Choose the chunk so that this always fits.

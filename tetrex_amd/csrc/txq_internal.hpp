@@ -23,6 +23,7 @@ struct Index {
     uint64_t* d_merged = nullptr;    // merged-bin bitmask words of every IBF, flattened
     uint64_t* d_merged_off = nullptr;
     uint32_t depth = 1;              // levels of the tree
+    uint64_t hibf_total_tbs = 0;     // technical bins over all IBFs of the tree
     uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
     uint32_t max_stride = 1;         // widest row over all IBFs (words)
 
