@@ -168,6 +168,33 @@ def test_hibf_sharded_masks_and_wide_tree(capi, oracle):
             ix.free()
 
 
+@pytest.mark.parametrize("shape", [dict(user_bins=40, tmax=32, levels=2), dict(user_bins=300, tmax=128, levels=3),
+                                   dict(user_bins=2500, tmax=2048, levels=3, n_values=8), dict(user_bins=700, tmax=200, levels=5, n_values=12)])
+def test_hibf_fused_and_level_synchronous_kernels_agree(capi, oracle, shape, monkeypatch):
+    """The same tree through both descent kernels (txq_hibf.hip: hibf_fused_kernel is the default,
+    TXQ_HIBF_LEVELS=1 selects hibf_level_kernel): masks and alive bits equal the oracle's, whatever
+    the row width (one word, a lane's four words, several lanes), the depth and the shard."""
+    ox, descs, values = random_hibf(oracle, 31, **shape)
+    ub = shape["user_bins"]
+    kmers = np.concatenate([np.concatenate([v[:3] for v in values]), splitmix64(8, 1500) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    for R, r in ((1, 0), (2, 1)):
+        ix = capi.Index.upload_hibf(ub, descs, shard_rank=r, n_shards=R)
+        lo, nw = int(ix.info.shard_word0), ix.shard_words
+        dk = capi.DeviceBuffer.from_numpy(kmers)
+        for levels in ("0", "1"):
+            monkeypatch.setenv("TXQ_HIBF_LEVELS", levels)
+            dm = capi.DeviceBuffer(kmers.size * nw * 8)
+            da = capi.DeviceBuffer(((kmers.size + 63) // 64) * 8)
+            ix.probe_device(dk.ptr, kmers.size, dm.ptr, da.ptr)
+            capi.synchronize()
+            got = dm.to_numpy(np.uint64, (kmers.size, nw))
+            assert np.array_equal(got, want[:, lo:lo + nw]), (shape, R, levels)
+            alive = np.unpackbits(da.to_numpy(np.uint8, (((kmers.size + 63) // 64) * 8,)), bitorder="little")[:kmers.size]
+            assert np.array_equal(alive.astype(bool), got.any(axis=1)), (shape, R, levels)
+        ix.free()
+
+
 def test_full_size_swissprot_shape_properties(capi, oracle):
     """BASELINE configs[1] shape (1024 bins, h=3, m=1,247,045 rows, 160 MB): size-independent
     properties at full size, and a sampled bit-exact comparison against the oracle."""
