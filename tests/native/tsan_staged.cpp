@@ -1,0 +1,55 @@
+// ThreadSanitizer driver for the staged expansion (run by tools/tsan_cpu_test.sh): expands a batch of
+// wildcard-rich motifs on 8 threads against an executor that declares every 7th frontier state dead,
+// so the thread pool, the block cache and the parallel frontier/prune passes all run under TSan.
+#include "../../tetrex_amd/csrc/host/compiler.hpp"
+
+#include <cstdio>
+#include <string>
+#include <vector>
+
+using namespace tetrex;
+
+struct FakeExecutor final : StageExecutor {
+    size_t stages = 0, bytes = 0;
+    void stage(const uint8_t*, size_t blob_bytes, const std::vector<uint32_t>& qp, const std::vector<uint32_t>&,
+               std::vector<uint8_t>& alive) override {
+        alive.assign(qp.size(), 1);
+        for (size_t i = 0; i < alive.size(); i += 7) alive[i] = 0;
+        ++stages;
+        bytes += blob_bytes;
+    }
+};
+
+int main() {
+    const char* residues = "ACDEFGHIKLMNPQRSTVWY";
+    std::vector<std::string> motifs;
+    uint64_t x = 12345;
+    auto next = [&]() { x ^= x << 13; x ^= x >> 7; x ^= x << 17; return x; };
+    for (int i = 0; i < 96; ++i) {
+        std::string m;
+        const int len = 5 + (int)(next() % 8);
+        for (int j = 0; j < len; ++j) {
+            const uint64_t r = next() % 10;
+            if (r == 0) m += '.';
+            else if (r == 1) m += ".{1,3}";
+            else if (r == 2) { m += '['; for (int c = 0; c < 3; ++c) m += residues[next() % 20]; m += ']'; }
+            else m += residues[next() % 20];
+        }
+        motifs.push_back(m);
+    }
+    KmerEncoder enc(Molecule::Peptide, 4, Alphabet::Base);
+    FakeExecutor exec;
+    StagedOptions opt;
+    opt.threads = 8;
+    opt.ops_per_query_per_stage = 512;
+    opt.ops_per_task = 4096;
+    opt.stage_target_ops = 1 << 16;
+    std::vector<int> status;
+    std::vector<std::string> why;
+    const StagedStats st = run_staged(enc, 1024, motifs, exec, opt, &status, &why);
+    size_t failed = 0;
+    for (int s : status) failed += s != 0;
+    std::printf("stages %zu ops %llu states %llu pruned %llu failed %zu blob bytes %zu\n", st.stages, (unsigned long long)st.ops,
+                (unsigned long long)st.states, (unsigned long long)st.pruned, failed, exec.bytes);
+    return st.stages > 1 && st.pruned > 0 ? 0 : 1;
+}
