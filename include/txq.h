@@ -109,7 +109,10 @@ int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, i
 /* Copy the shard's bit matrix back, row-major [bin_size][shard_words]. */
 int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_words);
 
-/* Batched bulk_contains: masks[i * shard_words + w] for k-mer i.  Host buffers; synchronous. */
+/* Batched bulk_contains: masks[i * shard_words + w] for k-mer i.  Host buffers; synchronous.
+ * Chunks are pipelined (probe of chunk c+1 overlaps the copy-back of chunk c); a `masks` buffer
+ * from txq_host_alloc (pinned) receives the device copies directly, any other one goes through a
+ * pinned bounce buffer. */
 int txq_probe(txq_index* ix, const uint64_t* kmers, size_t n, uint64_t* masks);
 /* Same on device-resident buffers, asynchronous on `stream`.  d_alive may be NULL; otherwise it
  * receives ceil(n/64) words, bit i set iff mask i has any bit set in this shard
@@ -152,6 +155,9 @@ int txq_free(void* dptr);
 int txq_memcpy_h2d(void* dst, const void* src, size_t bytes);
 int txq_memcpy_d2h(void* dst, const void* src, size_t bytes);
 int txq_synchronize(void);
+/* Page-locked host memory (hipHostMalloc): fastest source/destination of the host-buffer entry points. */
+int txq_host_alloc(void** ptr, size_t bytes);
+int txq_host_free(void* ptr);
 
 #ifdef __cplusplus
 }

@@ -195,6 +195,43 @@ def test_hibf_fused_and_level_synchronous_kernels_agree(capi, oracle, shape, mon
         ix.free()
 
 
+def test_host_buffer_probe_pipelines_chunks_into_pageable_and_pinned_memory(capi, oracle):
+    """txq_probe (host buffers) cuts the batch into chunks and overlaps probe and copy-back; the
+    result is the same in pageable and in pinned (txq_host_alloc) output memory, for a flat IBF
+    (3 chunks) and an HIBF (2 chunks), and equals the oracle on a sample."""
+    bins, m = 1024, 50021
+    words = random_words(bins, m, 0.3, 77)
+    ix = capi.Index.upload_ibf(bins, m, 3, words)
+    n = 700000
+    kmers = splitmix64(21, n) >> np.uint64(40)
+    got = ix.probe(kmers)
+    pinned = capi.HostBuffer((n, 16))
+    ix.probe(kmers, out=pinned.array)
+    assert np.array_equal(got, pinned.array)
+    dk = capi.DeviceBuffer.from_numpy(kmers)
+    dm = capi.DeviceBuffer(n * 16 * 8)
+    ix.probe_device(dk.ptr, n, dm.ptr)
+    capi.synchronize()
+    assert np.array_equal(got, dm.to_numpy(np.uint64, (n, 16)))
+    idx = np.arange(0, n, 997)
+    assert np.array_equal(got[idx], oracle_ibf_from_words(oracle, bins, m, 3, words).probe(kmers[idx]))
+    pinned.free()
+    ix.free()
+
+    ox, descs, values = random_hibf(oracle, 5, user_bins=300, levels=3)
+    hx = capi.Index.upload_hibf(300, descs)
+    n = (1 << 20) + 12345
+    kmers = np.resize(np.concatenate([np.concatenate([v[:4] for v in values]), splitmix64(9, 5000) >> np.uint64(44)]), n)
+    got = hx.probe(kmers)
+    dk = capi.DeviceBuffer.from_numpy(kmers)
+    dm = capi.DeviceBuffer(n * hx.shard_words * 8)
+    hx.probe_device(dk.ptr, n, dm.ptr)
+    capi.synchronize()
+    assert np.array_equal(got, dm.to_numpy(np.uint64, (n, hx.shard_words)))
+    assert np.array_equal(got[:6200], ox.probe(kmers[:6200]))
+    hx.free()
+
+
 def test_full_size_swissprot_shape_properties(capi, oracle):
     """BASELINE configs[1] shape (1024 bins, h=3, m=1,247,045 rows, 160 MB): size-independent
     properties at full size, and a sampled bit-exact comparison against the oracle."""

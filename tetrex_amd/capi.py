@@ -23,7 +23,7 @@ SYMBOLS = [
     "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
     "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_set_aux_index", "txq_session_stage", "txq_session_end",
-    "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize",
+    "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize", "txq_host_alloc", "txq_host_free",
 ]
 
 
@@ -82,6 +82,8 @@ def lib():
         L.txq_free.argtypes = [C.c_void_p]
         L.txq_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
         L.txq_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+        L.txq_host_alloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        L.txq_host_free.argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -133,6 +135,23 @@ def device_count_safe():
 
 def synchronize():
     check(lib().txq_synchronize())
+
+
+class HostBuffer:
+    """Page-locked host memory from txq_host_alloc, viewed as a numpy array."""
+
+    def __init__(self, shape, dtype=np.uint64):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        check(lib().txq_host_alloc(C.byref(p), self.nbytes))
+        self.ptr = p.value
+        self.array = np.frombuffer((C.c_uint8 * self.nbytes).from_address(self.ptr), dtype=dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            check(lib().txq_host_free(self.ptr))
+            self.ptr = None
 
 
 class DeviceBuffer:
@@ -246,10 +265,13 @@ class Index:
     def shard_words(self):
         return int(self.info.shard_words)
 
-    def probe(self, kmers):
-        """Host-buffer batched bulk_contains: (n, shard_words) uint64."""
+    def probe(self, kmers, out=None):
+        """Host-buffer batched bulk_contains: (n, shard_words) uint64.  `out` may be a preallocated
+        C-contiguous uint64 array of that shape (e.g. HostBuffer.array: pinned, no bounce copy)."""
         k = np.ascontiguousarray(kmers, dtype=np.uint64)
-        out = np.zeros((k.size, self.shard_words), dtype=np.uint64)
+        if out is None:
+            out = np.zeros((k.size, self.shard_words), dtype=np.uint64)
+        assert out.dtype == np.uint64 and out.flags.c_contiguous and out.size == k.size * self.shard_words
         check(lib().txq_probe(self._h, k.ctypes.data_as(u64p), k.size, out.ctypes.data_as(u64p)))
         return out
 

@@ -98,6 +98,14 @@ void Index::release() {
     if (d_next) (void)hipFree(d_next);
     if (d_tb_user) (void)hipFree(d_tb_user);
     if (d_map_off) (void)hipFree(d_map_off);
+    for (int i = 0; i < 2; ++i) {
+        if (host_pipe.stream[i]) (void)hipStreamDestroy(host_pipe.stream[i]);
+        if (host_pipe.done[i]) (void)hipEventDestroy(host_pipe.done[i]);
+        if (host_pipe.d_kmers[i]) (void)hipFree(host_pipe.d_kmers[i]);
+        if (host_pipe.d_masks[i]) (void)hipFree(host_pipe.d_masks[i]);
+        if (host_pipe.bounce[i]) (void)hipHostFree(host_pipe.bounce[i]);
+    }
+    host_pipe = HostPipe{};
     for (void* p : {(void*)session_cache.chunk, (void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
@@ -278,21 +286,76 @@ int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t*
     return TXQ_OK;
 }
 
+// Host-buffer probe: chunks are pipelined over two streams — while chunk c's masks travel back
+// (device -> pinned bounce buffer -> caller's memory, or straight into the caller's memory when
+// that is pinned, e.g. from txq_host_alloc), chunk c+1 is probed.
 int txq_probe(txq_index* ix, const uint64_t* kmers, size_t n, uint64_t* masks) {
     if (int rc = require_init()) return rc;
     if (!ix || (n && (!kmers || !masks))) return fail(TXQ_ERR_ARG, "null argument");
     const size_t W = ix->shard_words;
     if (W == 0 || n == 0) return TXQ_OK;
-    // bounded staging: chunks of <= 2^20 k-mers
-    const size_t chunk = n < ((size_t)1 << 20) ? n : ((size_t)1 << 20);
-    if (int rc = ensure((void**)&ix->scratch_kmers, &ix->cap_kmers, chunk * 8)) return rc;
-    if (int rc = ensure((void**)&ix->scratch_masks, &ix->cap_masks, chunk * W * 8)) return rc;
-    for (size_t off = 0; off < n; off += chunk) {
-        const size_t m = n - off < chunk ? n - off : chunk;
-        TXQ_HIP(hipMemcpy(ix->scratch_kmers, kmers + off, m * 8, hipMemcpyHostToDevice));
-        if (int rc = txq_probe_device(ix, ix->scratch_kmers, m, ix->scratch_masks, nullptr, nullptr)) return rc;
-        TXQ_HIP(hipMemcpy(masks + off * W, ix->scratch_masks, m * W * 8, hipMemcpyDeviceToHost));
+    // chunk: about 32 MiB of masks, at most 2^20 k-mers
+    size_t chunk = ((size_t)32 << 20) / (W * 8);
+    if (chunk > ((size_t)1 << 20)) chunk = (size_t)1 << 20;
+    if (chunk < 1024) chunk = 1024;
+    if (chunk > n) chunk = n;
+    Index::HostPipe& hp = ix->host_pipe;
+    for (int i = 0; i < 2; ++i) {
+        if (!hp.stream[i]) TXQ_HIP(hipStreamCreateWithFlags(&hp.stream[i], hipStreamNonBlocking));
+        if (!hp.done[i]) TXQ_HIP(hipEventCreateWithFlags(&hp.done[i], hipEventDisableTiming));
+        if (int rc = ensure((void**)&hp.d_kmers[i], &hp.cap_kmers[i], chunk * 8)) return rc;
+        if (int rc = ensure((void**)&hp.d_masks[i], &hp.cap_masks[i], chunk * W * 8)) return rc;
     }
+    hipPointerAttribute_t attr{};
+    const bool pinned_out = hipPointerGetAttributes(&attr, masks) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();  // an unregistered pointer is reported as an error: not one of ours
+    if (!pinned_out) {
+        for (int i = 0; i < 2; ++i) {
+            if (hp.cap_bounce[i] < chunk * W * 8) {
+                if (hp.bounce[i]) (void)hipHostFree(hp.bounce[i]);
+                hp.bounce[i] = nullptr;
+                hp.cap_bounce[i] = 0;
+                TXQ_HIP(hipHostMalloc((void**)&hp.bounce[i], chunk * W * 8, hipHostMallocDefault));
+                hp.cap_bounce[i] = chunk * W * 8;
+            }
+        }
+    }
+    size_t pending_off[2] = {0, 0}, pending_m[2] = {0, 0};
+    auto drain = [&](int b) -> int {  // wait for buffer b's chunk and hand it to the caller
+        if (!pending_m[b]) return TXQ_OK;
+        TXQ_HIP(hipEventSynchronize(hp.done[b]));
+        if (!pinned_out) std::memcpy(masks + pending_off[b] * W, hp.bounce[b], pending_m[b] * W * 8);
+        pending_m[b] = 0;
+        return TXQ_OK;
+    };
+    int b = 0;
+    for (size_t off = 0; off < n; off += chunk, b ^= 1) {
+        const size_t m = n - off < chunk ? n - off : chunk;
+        if (int rc = drain(b)) return rc;  // this buffer's previous chunk
+        // the HIBF descent has per-index scratch (frontiers): its chunks share one stream
+        hipStream_t st = hp.stream[ix->is_hibf ? 0 : b];
+        TXQ_HIP(hipMemcpyAsync(hp.d_kmers[b], kmers + off, m * 8, hipMemcpyHostToDevice, st));
+        if (int rc = txq_probe_device(ix, hp.d_kmers[b], m, hp.d_masks[b], nullptr, st)) return rc;
+        TXQ_HIP(hipMemcpyAsync(pinned_out ? (void*)(masks + off * W) : (void*)hp.bounce[b], hp.d_masks[b], m * W * 8, hipMemcpyDeviceToHost, st));
+        TXQ_HIP(hipEventRecord(hp.done[b], st));
+        pending_off[b] = off;
+        pending_m[b] = m;
+    }
+    if (int rc = drain(b)) return rc;
+    if (int rc = drain(b ^ 1)) return rc;
+    return TXQ_OK;
+}
+
+int txq_host_alloc(void** ptr, size_t bytes) {
+    if (int rc = require_init()) return rc;
+    if (!ptr) return fail(TXQ_ERR_ARG, "null argument");
+    TXQ_HIP(hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return TXQ_OK;
+}
+
+int txq_host_free(void* ptr) {
+    if (!ptr) return TXQ_OK;
+    TXQ_HIP(hipHostFree(ptr));
     return TXQ_OK;
 }
 

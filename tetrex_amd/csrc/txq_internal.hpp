@@ -46,6 +46,15 @@ struct Index {
         bool in_use = false;
     } session_cache;
 
+    // txq_probe (host buffers): two streams with their device and pinned bounce buffers
+    struct HostPipe {
+        hipStream_t stream[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        uint64_t* d_kmers[2] = {nullptr, nullptr}; size_t cap_kmers[2] = {0, 0};
+        uint64_t* d_masks[2] = {nullptr, nullptr}; size_t cap_masks[2] = {0, 0};
+        uint64_t* bounce[2] = {nullptr, nullptr}; size_t cap_bounce[2] = {0, 0};
+    } host_pipe;
+
     void release();
 };
 
