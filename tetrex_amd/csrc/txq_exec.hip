@@ -17,6 +17,9 @@
 // Most queries finish in one stage; txq_run_programs is exactly that case.
 // Format of a stage's op list: include/txq_program.h.
 #include "txq_internal.hpp"
+#include <algorithm>
+#include <thread>
+#include <atomic>
 #include "../../include/txq_program.h"
 #include <chrono>
 #include <cstdio>
@@ -235,13 +238,41 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             }
             if (prev != d.n_ops) return fail(TXQ_ERR_PROGRAM, "program %u: levels do not cover the ops", p);
         }
-        for (uint32_t i = 0; i < d.n_ops; ++i) {
-            const txq_op& o = ops[d.first_op + i];
-            if (o.dst >= n_slots || o.a >= n_slots || o.b >= n_slots) return fail(TXQ_ERR_PROGRAM, "program %u op %u: slot out of range", p, i);
-            if (o.dst == TXQ_SLOT_ZERO || o.dst == TXQ_SLOT_ONES) return fail(TXQ_ERR_PROGRAM, "program %u op %u: writes a constant slot", p, i);
-            if (o.kmer != TXQ_NO_KMER && o.kmer >= v.n_kmers) return fail(TXQ_ERR_PROGRAM, "program %u op %u: k-mer index out of range", p, i);
-        }
         v.programs[p] = d;
+    }
+    // every op of every program: operands inside the program's slot region, k-mer inside the table.
+    // Large stages (hundreds of MB of ops) are checked by several threads, each taking whole programs.
+    struct Bad { uint32_t program = 0xFFFFFFFFu, op = 0; int kind = 0; };
+    auto check_program = [&](uint32_t p, Bad& bad) {
+        const DevProgram& d = v.programs[p];
+        const uint32_t n_slots = v.n_slots[p];
+        const txq_op* o = ops + d.first_op;
+        for (uint32_t i = 0; i < d.n_ops; ++i) {
+            int kind = 0;
+            if (o[i].dst >= n_slots || o[i].a >= n_slots || o[i].b >= n_slots) kind = 1;
+            else if (o[i].dst == TXQ_SLOT_ZERO || o[i].dst == TXQ_SLOT_ONES) kind = 2;
+            else if (o[i].kmer != TXQ_NO_KMER && o[i].kmer >= v.n_kmers) kind = 3;
+            if (kind) { if (p < bad.program) bad = Bad{p, i, kind}; return; }
+        }
+    };
+    Bad bad;
+    unsigned n_threads = v.n_ops >= (1u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+    if (n_threads <= 1) {
+        for (uint32_t p = 0; p < n_programs && bad.program == 0xFFFFFFFFu; ++p) check_program(p, bad);
+    } else {
+        std::vector<Bad> found(n_threads);
+        std::atomic<uint32_t> next{0};
+        std::vector<std::thread> workers;
+        for (unsigned t = 0; t < n_threads; ++t)
+            workers.emplace_back([&, t]() {
+                for (uint32_t p; (p = next.fetch_add(1)) < n_programs;) check_program(p, found[t]);
+            });
+        for (auto& w : workers) w.join();
+        for (const Bad& b : found) if (b.program < bad.program) bad = b;
+    }
+    if (bad.program != 0xFFFFFFFFu) {
+        static const char* const what[] = {"", "slot out of range", "writes a constant slot", "k-mer index out of range"};
+        return fail(TXQ_ERR_PROGRAM, "program %u op %u: %s", bad.program, bad.op, what[bad.kind]);
     }
     *out = std::move(v);
     return TXQ_OK;
