@@ -110,6 +110,8 @@ void Index::release() {
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
     if (d_merged) (void)hipFree(d_merged);
+    if (d_descend) (void)hipFree(d_descend);
+    d_descend = nullptr;
     if (d_merged_off) (void)hipFree(d_merged_off);
     d_merged = d_merged_off = nullptr;
     for (void* p : {(void*)scratch_kmers, (void*)scratch_masks, (void*)frontier[0], (void*)frontier[1], (void*)d_counts,

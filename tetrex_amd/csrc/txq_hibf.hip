@@ -12,6 +12,7 @@
 #include "txq_internal.hpp"
 #include <cstdlib>
 #include <deque>
+#include <utility>
 
 namespace txq {
 
@@ -21,7 +22,8 @@ struct HibfView {
     const uint64_t* tb_user;
     const uint64_t* map_off;
     const uint64_t* merged;      // per IBF word: bit b set <=> technical bin 64w+b is a merged bin
-    const uint64_t* merged_off;  // [n_ibf] offset of IBF i's words in `merged`
+    const uint64_t* descend;     // same layout: the merged bins whose sub-tree holds user bins of THIS shard's mask columns
+    const uint64_t* merged_off;  // [n_ibf] offset of IBF i's words in `merged` / `descend`
 };
 
 // loads through a pointer that was itself read from memory: tell the compiler it is global memory
@@ -86,8 +88,8 @@ __global__ __launch_bounds__(256) void hibf_level_kernel(HibfView t, const uint6
 #pragma unroll
                 for (uint32_t j = 0; j < 5; ++j) acc &= gload(f.words + row[j] * f.stride + w);
             }
-            uint64_t kids = acc ? (acc & t.merged[moff + w]) : 0;
-            uint64_t hits = acc & ~kids;
+            uint64_t kids = acc ? (acc & t.descend[moff + w]) : 0;
+            uint64_t hits = acc ? (acc & ~t.merged[moff + w]) : 0;
             // children -> next frontier, one atomic per wave
             uint32_t total;
             const uint32_t mine = (uint32_t)__builtin_popcountll(kids);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
             }
             for (uint32_t wi = 0; wi < w_iters; ++wi) {
                 const uint32_t w0 = (wi * G + sub) * 4u;
-                uint64_t acc[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0};
+                uint64_t acc[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
                 if (live && w0 < f.shard_words) {  // every load of the round issues before the first is used
                     if (f.stride == 1) {
                         uint64_t x = ~0ULL;
@@ -215,13 +217,15 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                     }
                     // merged-bin masks are padded to 4 words per IBF
                     const ulonglong2 m0 = gload2(t.merged + moff + w0), m1 = gload2(t.merged + moff + w0 + 2);
+                    const ulonglong2 d0 = gload2(t.descend + moff + w0), d1 = gload2(t.descend + moff + w0 + 2);
                     mg[0] = m0.x; mg[1] = m0.y; mg[2] = m1.x; mg[3] = m1.y;
+                    dn[0] = d0.x; dn[1] = d0.y; dn[2] = d1.x; dn[3] = d1.y;
                 }
                 // Children and mapped user bins are expanded by the whole wave, one 64-bit word per step:
                 // lane L takes bit L, so a word costs the same whether 1 or 64 of its bits are set.
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint64_t kids = acc[q] & mg[q];
+                    const uint64_t kids = acc[q] & dn[q];  // children outside this shard's columns are not visited
                     const uint32_t first_tb = off + (w0 + (uint32_t)q) * 64u;
                     uint64_t owners = __ballot(kids != 0);
                     while (owners) {  // wave-uniform
@@ -372,6 +376,40 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     for (uint64_t i = 0; i < n; ++i)
         for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
             if (desc.tb_to_user_bin[i][b] == TXQ_MERGED_BIN) merged[moff[i] + (b >> 6)] |= 1ULL << (b & 63);
+    // Sub-tree pruning for column shards: a merged bin is only descended into when its sub-tree
+    // holds a user bin whose mask word belongs to this shard (span[i] = mask-word range under IBF i).
+    std::vector<std::pair<uint64_t, uint64_t>> span(n, {UINT64_MAX, 0});
+    {
+        std::vector<uint64_t> order;  // parents before children (BFS order from the tree walk above)
+        order.reserve(n);
+        std::deque<uint64_t> bfs{0};
+        while (!bfs.empty()) {
+            const uint64_t i = bfs.front();
+            bfs.pop_front();
+            order.push_back(i);
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+                if (tbu[off[i] + b] == TXQ_MERGED_BIN) bfs.push_back(next[off[i] + b]);
+        }
+        for (size_t at = order.size(); at-- > 0;) {
+            const uint64_t i = order[at];
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b) {
+                const uint64_t ub = tbu[off[i] + b];
+                std::pair<uint64_t, uint64_t> r = ub == TXQ_MERGED_BIN ? span[next[off[i] + b]] : std::make_pair(ub >> 6, ub >> 6);
+                if (r.first < span[i].first) span[i].first = r.first;
+                if (r.first != UINT64_MAX && r.second > span[i].second) span[i].second = r.second;
+            }
+        }
+    }
+    std::vector<uint64_t> descend(moff[n], 0);
+    const uint64_t shard_lo = ix.shard_word0, shard_hi = ix.shard_word0 + ix.shard_words;  // [lo, hi)
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t b = 0; b < desc.ibf[i].bins; ++b) {
+            if (tbu[off[i] + b] != TXQ_MERGED_BIN) continue;
+            const auto& r = span[next[off[i] + b]];
+            if (r.first != UINT64_MAX && r.first < shard_hi && r.second >= shard_lo) descend[moff[i] + (b >> 6)] |= 1ULL << (b & 63);
+        }
+    TXQ_HIP(hipMalloc((void**)&ix.d_descend, (moff[n] ? moff[n] : 1) * 8));
+    TXQ_HIP(hipMemcpy(ix.d_descend, descend.data(), moff[n] * 8, hipMemcpyHostToDevice));
     TXQ_HIP(hipMalloc((void**)&ix.d_merged, (moff[n] ? moff[n] : 1) * 8));
     TXQ_HIP(hipMalloc((void**)&ix.d_merged_off, n * 8));
     TXQ_HIP(hipMemcpy(ix.d_merged, merged.data(), moff[n] * 8, hipMemcpyHostToDevice));
@@ -421,7 +459,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     int g = 1;
     while (g < 64 && (uint32_t)g < quads) g <<= 1;
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged_off};
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off};
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
     *rc = TXQ_OK;
@@ -467,7 +505,7 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
     }
     if (int rc = ensure((void**)&ix.d_counts, &ix.cap_counts, ((size_t)ix.depth + 2) * 4)) return rc;
     uint32_t* overflow = ix.d_counts + ix.depth + 1;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged_off};
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off};
     int g = 1;
     while (g < 64 && (uint32_t)g < ix.max_stride) g <<= 1;
     const uint32_t w_iters = (ix.max_stride + (uint32_t)g - 1) / (uint32_t)g;
