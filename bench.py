@@ -120,36 +120,54 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     from tetrex_amd.dist import gather_final_masks
     k = 4
     single = "LMA(E|Q)GLYN"  # BASELINE configs[1] motif
-    ix.query_masks([single], False, k)  # warm-up (library load, first launches)
-    lat = []
-    for _ in range(20):
-        t0 = time.perf_counter()
-        ix.query_masks([single], False, k)
-        lat.append(time.perf_counter() - t0)
+    motifs = random_prosite_motifs(args.motifs, 6)
     # a batch without gaps/wildcards (literal residues and residue classes only) for contrast
     plain = random_prosite_motifs(args.motifs, 7, wildcard=0.0, classes=0.3, ranges=0.0)
-    ix.query_masks(plain[:10], False, k)
-    tp = time.perf_counter()
-    _, plain_status, plain_stats = ix.query_masks(plain, False, k)
-    plain_s = time.perf_counter() - tp
-    motifs = random_prosite_motifs(args.motifs, 6)
+    err = None
+    local = {}
+    try:  # rank-local work first: a failure here must not leave the other ranks waiting in a collective
+        ix.query_masks([single], False, k)  # warm-up (library load, first launches)
+        lat = []
+        for _ in range(20):
+            t0 = time.perf_counter()
+            ix.query_masks([single], False, k)
+            lat.append(time.perf_counter() - t0)
+        ix.query_masks(plain[:10], False, k)
+        tp = time.perf_counter()
+        _, plain_status, plain_stats = ix.query_masks(plain, False, k)
+        plain_s = time.perf_counter() - tp
+        local = {"lat": lat, "plain_status": plain_status, "plain_stats": plain_stats, "plain_s": plain_s}
+    except Exception as e:  # noqa: BLE001 - reported in the JSON line
+        err = repr(e)
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    masks, status, stats = ix.query_masks(motifs, False, k)
+    masks = status = stats = None
+    if err is None:
+        try:
+            masks, status, stats = ix.query_masks(motifs, False, k)
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
     t1 = time.perf_counter()
     gather_s = 0.0
+    total = t1 - t0
     if world > 1:
-        local = torch.from_numpy(masks.view(np.int64)).cuda()
-        full = gather_final_masks(local, ix.info.mask_words)
-        torch.cuda.synchronize()
-        gather_s = time.perf_counter() - t1
-        t = torch.tensor([t1 - t0 + gather_s], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        total = float(t.item())
-        assert full.shape == (len(motifs), int(ix.info.mask_words))
-    else:
-        total = t1 - t0
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=args.coll_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            err = err or "another rank failed"
+        else:
+            loc = torch.from_numpy(masks.view(np.int64)).to(args.coll_device)
+            full = gather_final_masks(loc, ix.info.mask_words)
+            torch.cuda.synchronize()
+            gather_s = time.perf_counter() - t1
+            t = torch.tensor([t1 - t0 + gather_s], dtype=torch.float64, device=args.coll_device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            total = float(t.item())
+            assert full.shape == (len(motifs), int(ix.info.mask_words))
+    if err is not None:
+        return {"error": err}
+    lat, plain_status, plain_stats, plain_s = local["lat"], local["plain_status"], local["plain_stats"], local["plain_s"]
     return {
         "metric": "end-to-end queries/sec (regex -> candidate-bin mask, verification excluded)",
         "batch_queries_per_s": len(motifs) / total,
@@ -177,6 +195,9 @@ def main():
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
     ap.add_argument("--kmer-bits", type=int, default=20)
+    ap.add_argument("--rehearse-single-device", action="store_true",
+                    help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host "
+                         "tensors (RCCL refuses two ranks on one device); numbers from such a run are not bench results")
     args = ap.parse_args()
 
     import torch
@@ -190,10 +211,16 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.rehearse_single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
+    args.coll_device = "cpu" if args.rehearse_single_device else "cuda"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.rehearse_single_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from tetrex_amd import capi
 
@@ -237,7 +264,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
@@ -259,7 +286,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64",
-        "data": "synthetic",
+        "data": "synthetic" if not args.rehearse_single_device else "synthetic (REHEARSAL: all ranks on one device, gloo collectives; not a bench result)",
         "config": {
             "workload": workload_name(bins_local, m, args),
             "bins_per_gpu": bins_local, "bins_total": bins_total, "hash_funs": h, "bin_size_rows": m,

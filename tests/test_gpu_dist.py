@@ -71,3 +71,26 @@ def test_two_shards_on_one_gpu_gather_to_the_oracle_masks():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_bench_two_rank_rehearsal_prints_one_contract_line():
+    """bench.py's N>1 path (shard build per rank, barriers, max-over-ranks timing, final-mask
+    all-gather) rehearsed with two ranks on the one GPU of this box (gloo collectives; RCCL needs one
+    device per rank).  Checks the JSON contract, not the numbers."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--kmers", str(1 << 18), "--per-bin", "2000", "--motifs", "40", "--rehearse-single-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["bins_total"] == 2048
+    assert "error" not in out["end_to_end"], out["end_to_end"]
+    assert out["end_to_end"]["batch"]["failed"] == 0
