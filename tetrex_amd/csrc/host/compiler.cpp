@@ -181,6 +181,8 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
         targets_of(v, [&](int32_t t) { if (--indeg[t] == 0) ready.push_back(t); });
     }
     table_.resize(items);
+    input_of_.assign(items, KGraph::kNone);
+    readers_.assign(join_of.size(), 0);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
     OpVec none;
     hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0, 0, 0, 0}, none);
@@ -290,15 +292,55 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         } recycle{spare_items_, ns.items};
         if (item > n_nodes_) {  // join: equal states were merged on arrival; fan out
             const uint32_t lo = fan_first_[item - n_nodes_ - 1], hi = fan_first_[item - n_nodes_];
+            // A target fed by this join alone reads the join's list in place when its turn comes
+            // (no copy per target); a target with other sources gets its copies now, to merge them.
+            uint32_t readers = 0;
+            for (uint32_t i = lo; i < hi; ++i) readers += single_source_[fan_[i]];
             for (const State& s : ns.items) {
-                for (uint32_t i = lo + 1; i < hi; ++i) share(s.slot);
-                for (uint32_t i = lo; i < hi; ++i) arrive(fan_[i], s, out);
+                if (refs_[s.slot] != kPinned) refs_[s.slot] += hi - lo - 1;
+                for (uint32_t i = lo; i < hi; ++i)
+                    if (!single_source_[fan_[i]]) arrive(fan_[i], s, out);
+            }
+            if (readers && !ns.items.empty()) {
+                for (uint32_t i = lo; i < hi; ++i)
+                    if (single_source_[fan_[i]]) input_of_[fan_[i]] = item;
+                readers_[item - n_nodes_ - 1] = readers;
+                waiting_ += (uint64_t)ns.items.size() * readers;
+                table_[item].items.swap(ns.items);  // stays until the last reader is done
+                open_joins_.push_back(item);
             }
             continue;
         }
+        // the states to process: this item's own arrivals, or the list of the join that feeds it
+        const StateVec* input = &ns.items;
+        struct Release {  // the last reader of a join's list recycles it
+            QueryExpansion& q; int32_t join;
+            ~Release() {
+                if (join == KGraph::kNone) return;
+                if (--q.readers_[join - q.n_nodes_ - 1] != 0) return;
+                StateVec& v = q.table_[join].items;
+                if (v.capacity() && q.spare_items_.size() < 64) { v.clear(); q.spare_items_.emplace_back(); q.spare_items_.back().swap(v); }
+                else StateVec().swap(v);
+                for (size_t i = 0; i < q.open_joins_.size(); ++i)
+                    if (q.open_joins_[i] == join) { q.open_joins_[i] = q.open_joins_.back(); q.open_joins_.pop_back(); break; }
+            }
+        } release{*this, input_of_[item]};
+        if (input_of_[item] != KGraph::kNone) {
+            input = &table_[input_of_[item]].items;
+            input_of_[item] = KGraph::kNone;
+            waiting_ -= input->size();
+            states_ += input->size();
+            if (states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+        }
         const int32_t lab = g_.label[item];
+        if (forward_[item] != KGraph::kNone && !single_source_[forward_[item]] && input->size() > 8) {
+            // the merging table of the receiver grows once, not by repeated doubling and re-hashing
+            NodeStates& next = table_[forward_[item]];
+            if (next.items.capacity() == 0) adopt_storage(next);
+            next.by_key.reserve(next.items.size() + input->size());
+        }
         if (lab == KGraph::kMatch) {
-            for (const State& s : ns.items) {
+            for (const State& s : *input) {
                 emit(out, TXQ_NO_KMER, TXQ_SLOT_RESULT, s.slot, TXQ_SLOT_RESULT);
                 drop(s.slot);
             }
@@ -306,7 +348,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         }
         if (lab == KGraph::kGap) {  // gap_procedure: restart the k-mer, or start a d-gram
             const uint64_t gap = g_.gap[item];
-            for (State s : ns.items) {
+            for (State s : *input) {
                 if (s.shift < 3 || gap < gaps_.min_gap || gap > gaps_.max_gap) {
                     s.kmer = 0;
                     s.gapped = 0;
@@ -320,7 +362,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             }
             continue;
         }
-        for (State s : ns.items) {
+        for (State s : *input) {
             if (s.gapped) {  // update_gapped: three residues complete the d-gram
                 if (s.shift == 0) { s.kmer += 400ULL * dgram_residue_code(lab); s.res1 = (uint8_t)lab; s.shift = 1; }
                 else if (s.shift == 1) { s.kmer += 20ULL * dgram_residue_code(lab); s.res2 = (uint8_t)lab; s.shift = 2; }
@@ -371,28 +413,40 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
 void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) {
     if (seen_.size() < refs_.size()) seen_.resize(refs_.size(), 0);
     if (++seen_epoch_ == 0) { std::fill(seen_.begin(), seen_.end(), 0); seen_epoch_ = 1; }
-    for (size_t c = cursor_; c < order_.size(); ++c)
-        for (State& s : table_[order_[c]].items) {
+    auto ask = [&](StateVec& items) {
+        for (State& s : items) {
             if (s.asked) continue;
             s.asked = 1;
             if (s.slot >= TXQ_SLOT_FIRST_FREE && seen_[s.slot] != seen_epoch_) { seen_[s.slot] = seen_epoch_; out.push_back(s.slot); ++asked_; }
         }
+    };
+    for (size_t c = cursor_; c < order_.size(); ++c) ask(table_[order_[c]].items);
+    for (int32_t j : open_joins_) ask(table_[j].items);  // lists that wait for their readers
 }
 
 void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    auto is_dead = [&](const State& s) { return s.slot < dead.size() && dead[s.slot]; };
+    // `holders` = how many readers still hold a reference to every state of the list
+    auto sweep = [&](StateVec& items, uint32_t holders) -> bool {
+        bool any = false;
+        for (const State& s : items)
+            if (is_dead(s)) { any = true; break; }
+        if (!any) return false;
+        StateVec keep;
+        for (const State& s : items) {
+            if (is_dead(s)) {
+                for (uint32_t h = 0; h < holders; ++h) drop(s.slot);
+                ++pruned_;
+                waiting_ -= holders;
+            } else keep.push_back(s);
+        }
+        items.swap(keep);
+        return true;
+    };
     for (size_t c = cursor_; c < order_.size(); ++c) {
         NodeStates& ns = table_[order_[c]];
-        bool any = false;
-        for (const State& s : ns.items)
-            if (s.slot < dead.size() && dead[s.slot]) { any = true; break; }
-        if (!any) continue;
-        StateVec keep;
-        for (const State& s : ns.items) {
-            if (s.slot < dead.size() && dead[s.slot]) { drop(s.slot); ++pruned_; --waiting_; }
-            else keep.push_back(s);
-        }
-        ns.items.swap(keep);
+        if (!sweep(ns.items, 1)) continue;
         ns.by_key.clear();
         if (single_source_[order_[c]]) continue;
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
@@ -402,6 +456,7 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
                                        : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits))), i);
         }
     }
+    for (int32_t j : open_joins_) sweep(table_[j].items, readers_[j - n_nodes_ - 1]);
 }
 
 // ---- level scheduling ---------------------------------------------------------------------
@@ -410,37 +465,41 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
                                            uint32_t kmer_add, uint32_t dgram_add) {
     std::vector<uint32_t> ends;
     if (ops.empty()) return ends;
-    if (sc.stamp.size() < n_slots) { sc.stamp.resize(n_slots, 0); sc.wr.resize(n_slots); sc.rd.resize(n_slots); sc.acc.resize(n_slots); }
-    if (++sc.epoch == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0); sc.epoch = 1; }
-    auto touch = [&](uint32_t s) {
-        if (sc.stamp[s] != sc.epoch) { sc.stamp[s] = sc.epoch; sc.wr[s] = sc.rd[s] = sc.acc[s] = 0; }
+    if (sc.slot.size() < n_slots) sc.slot.resize(n_slots, LevelScratch::Slot{0, 0, 0, 0});
+    if (++sc.epoch == 0) { for (auto& s : sc.slot) s.stamp = 0; sc.epoch = 1; }
+    auto touch = [&](uint32_t s) -> LevelScratch::Slot& {
+        LevelScratch::Slot& x = sc.slot[s];
+        if (x.stamp != sc.epoch) x = LevelScratch::Slot{sc.epoch, 0, 0, 0};
+        return x;
     };
     // level of op = smallest level that respects every hazard against earlier ops (levels from 1)
     sc.level_of.resize(ops.size());
     uint32_t top = 0;
     for (size_t i = 0; i < ops.size(); ++i) {
         const txq_op& o = ops[i];
-        touch(o.dst); touch(o.a); touch(o.b);
+        LevelScratch::Slot& sd = touch(o.dst);
+        LevelScratch::Slot& sa = touch(o.a);
+        LevelScratch::Slot& sb = touch(o.b);
         const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
         uint32_t lvl = 1;
         auto after = [&](uint32_t l) { if (l + 1 > lvl) lvl = l + 1; };
         if (accumulate) {
-            const uint32_t src = o.dst == o.a ? o.b : o.a;
-            after(sc.wr[src]); after(sc.acc[src]);   // RAW on the source
-            after(sc.wr[o.dst]); after(sc.rd[o.dst]); // after the last full write and every earlier reader
-            if (sc.acc[o.dst] > lvl) lvl = sc.acc[o.dst];  // may share a level with other accumulations
-            if (sc.rd[src] < lvl) sc.rd[src] = lvl;
-            sc.acc[o.dst] = lvl;
+            LevelScratch::Slot& src = o.dst == o.a ? sb : sa;
+            after(src.wr); after(src.acc);   // RAW on the source
+            after(sd.wr); after(sd.rd);      // after the last full write and every earlier reader
+            if (sd.acc > lvl) lvl = sd.acc;  // may share a level with other accumulations
+            if (src.rd < lvl) src.rd = lvl;
+            sd.acc = lvl;
         } else {
-            after(sc.wr[o.a]); after(sc.acc[o.a]);
-            after(sc.wr[o.b]); after(sc.acc[o.b]);
+            after(sa.wr); after(sa.acc);
+            after(sb.wr); after(sb.acc);
             // WAR / WAW on dst; an in-place op (dst == a or b) reads its own old value, which is fine
-            after(sc.wr[o.dst]); after(sc.acc[o.dst]);
-            const uint32_t rd_dst = sc.rd[o.dst];
+            after(sd.wr); after(sd.acc);
+            const uint32_t rd_dst = sd.rd;
             after(rd_dst);
-            if (sc.rd[o.a] < lvl) sc.rd[o.a] = lvl;
-            if (sc.rd[o.b] < lvl) sc.rd[o.b] = lvl;
-            sc.wr[o.dst] = lvl;
+            if (sa.rd < lvl) sa.rd = lvl;
+            if (sb.rd < lvl) sb.rd = lvl;
+            sd.wr = lvl;
         }
         sc.level_of[i] = lvl;
         if (lvl > top) top = lvl;
@@ -565,7 +624,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
     // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
     // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
-    std::vector<KmerTable> tables(n), dgram_tables(n);
+    std::vector<KmerTable> tables(n, KmerTable(false)), dgram_tables(n, KmerTable(false));
     std::vector<LevelScratch> scratch(threads);
     std::vector<std::vector<uint8_t>> dead_scratch(threads);
     std::vector<std::vector<uint32_t>> levels(n), asks(n);
@@ -584,7 +643,7 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     for (;;) {
         for (uint32_t i : touched) {
             if (q[i]) { ops[i].clear(); tables[i].clear(); dgram_tables[i].clear(); }
-            else { OpVec().swap(ops[i]); tables[i] = KmerTable(); dgram_tables[i] = KmerTable(); }  // finished: storage back to the cache
+            else { OpVec().swap(ops[i]); tables[i] = KmerTable(false); dgram_tables[i] = KmerTable(false); }  // finished: storage back to the cache
             levels[i].clear();
         }
         touched.clear();

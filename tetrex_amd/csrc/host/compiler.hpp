@@ -70,16 +70,34 @@ struct QueryProgram {
 // k-mer value -> dense index, in first-seen order (one per stage and per expansion thread)
 class KmerTable {
   public:
+    // exact: every value gets one index (hash map).  Otherwise duplicates are only caught by a small
+    // direct-mapped cache: a repeated k-mer may get a second entry and is then simply probed twice,
+    // which costs the device less than an exact look-up costs the host (a wildcard position of a
+    // peptide query yields 160 000 mostly distinct k-mers).
+    explicit KmerTable(bool exact = true) : exact_(exact) {}
     uint32_t intern(uint64_t value) {
-        auto [slot, fresh] = index_.emplace(value, (uint32_t)values_.size());
-        if (fresh) values_.push_back(value);
-        return *slot;
+        if (exact_) {
+            auto [slot, fresh] = index_.emplace(value, (uint32_t)values_.size());
+            if (fresh) values_.push_back(value);
+            return *slot;
+        }
+        if (recent_.empty()) recent_.assign(kRecent, 0);
+        uint64_t h = value * 0x9E3779B97F4A7C15ULL;
+        uint32_t& id = recent_[h >> (64 - kRecentBits)];
+        if (id < values_.size() && values_[id] == value) return id;  // entries left by an earlier stage fail this check
+        id = (uint32_t)values_.size();
+        values_.push_back(value);
+        return id;
     }
     const KmerVec& values() const { return values_; }
     void clear() { index_.clear(); values_.clear(); }
 
   private:
+    static constexpr unsigned kRecentBits = 13;
+    static constexpr size_t kRecent = (size_t)1 << kRecentBits;
+    bool exact_;
     FlatMap index_;
+    CachedVector<uint32_t> recent_;
     KmerVec values_;
 };
 
@@ -130,6 +148,12 @@ class QueryExpansion {
     std::vector<uint8_t> single_source_;  // item fed by exactly one item: its arrivals cannot collide
     int32_t n_nodes_ = 0;
     std::vector<NodeStates> table_;
+    // A join's merged list is read in place by the targets it alone feeds (instead of one copy per
+    // target): input_of_[target] = that join while the target waits, readers_[join] = targets still to
+    // read the list, open_joins_ = joins whose list is kept for readers.
+    std::vector<int32_t> input_of_;
+    std::vector<uint32_t> readers_;
+    std::vector<int32_t> open_joins_;
     std::vector<uint32_t> refs_;
     // Freed slots are recycled oldest-first and only after the node item that freed them is
     // finished: immediate (LIFO) reuse would chain unrelated ops through write-after-read
@@ -157,7 +181,13 @@ class QueryExpansion {
 // Reorders `ops` (one program's ops of one stage, in a valid sequential order) into dependency
 // levels as defined in txq_program.h (version 2) and returns the end index of every level.
 // Scratch vectors are reused across calls (sized to n_slots).
-struct LevelScratch { std::vector<uint32_t> wr, rd, acc, stamp; uint32_t epoch = 0; std::vector<uint32_t> level_of, pos; OpVec sorted; };
+struct LevelScratch {
+    struct Slot { uint32_t stamp, wr, rd, acc; };  // last full write / last read / last accumulation level of a slot, valid when stamp == epoch
+    std::vector<Slot> slot;
+    uint32_t epoch = 0;
+    std::vector<uint32_t> level_of, pos;
+    OpVec sorted;
+};
 std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch& scratch);
 // Same, but leaves `ops` alone and writes the reordered ops to `dst` (room for ops.size()), adding
 // `kmer_add` to every k-mer index and `dgram_add` to every (flag-stripped) d-gram index on the way.

@@ -19,11 +19,10 @@ class FlatMap {
     void clear() {
         if (size_ == 0) return;
         if (cap_ > 1024 && size_ * 8 < cap_) {  // shrink tables that were briefly huge
-            keys_.clear(); keys_.shrink_to_fit();
-            vals_.clear(); vals_.shrink_to_fit();
+            slots_.clear(); slots_.shrink_to_fit();
             cap_ = 0;
         } else {
-            std::fill(vals_.begin(), vals_.end(), kEmpty);
+            for (Slot& s : slots_) s.val = kEmpty;
         }
         size_ = 0;
     }
@@ -32,21 +31,28 @@ class FlatMap {
         if ((size_ + 1) * 4 > cap_ * 3) grow();
         size_t i = mix(key) & (cap_ - 1);
         for (;;) {
-            if (vals_[i] == kEmpty) {
-                keys_[i] = key;
-                vals_[i] = value;
+            Slot& s = slots_[i];
+            if (s.val == kEmpty) {
+                s.key = key;
+                s.val = value;
                 ++size_;
-                return {&vals_[i], true};
+                return {&s.val, true};
             }
-            if (keys_[i] == key) return {&vals_[i], false};
+            if (s.key == key) return {&s.val, false};
             i = (i + 1) & (cap_ - 1);
         }
+    }
+    // room for `n` entries without growing
+    void reserve(size_t n) {
+        size_t want = 16;
+        while (want * 3 < n * 4) want <<= 1;
+        if (want > cap_) grow(want);
     }
 
   private:
     static constexpr uint32_t kEmpty = 0xFFFFFFFFu;  // values must never be 0xFFFFFFFF
-    CachedVector<uint64_t> keys_;
-    CachedVector<uint32_t> vals_;
+    struct Slot { uint64_t key; uint32_t val; uint32_t pad; };  // key and value share a cache line: one miss per probe
+    CachedVector<Slot> slots_;
     size_t cap_ = 0, size_ = 0;
 
     static uint64_t mix(uint64_t x) {
@@ -55,19 +61,15 @@ class FlatMap {
         x ^= x >> 33;
         return x;
     }
-    void grow() {
-        const size_t ncap = cap_ ? cap_ * 2 : 16;
-        CachedVector<uint64_t> ok;
-        CachedVector<uint32_t> ov;
-        ok.swap(keys_);
-        ov.swap(vals_);
-        keys_.assign(ncap, 0);
-        vals_.assign(ncap, kEmpty);
-        const size_t ocap = cap_;
+    void grow(size_t to = 0) {
+        const size_t ncap = to ? to : (cap_ ? cap_ * 2 : 16);
+        CachedVector<Slot> old;
+        old.swap(slots_);
+        slots_.assign(ncap, Slot{0, kEmpty, 0});
         cap_ = ncap;
         size_ = 0;
-        for (size_t i = 0; i < ocap; ++i)
-            if (ov[i] != kEmpty) emplace(ok[i], ov[i]);
+        for (const Slot& s : old)
+            if (s.val != kEmpty) emplace(s.key, s.val);
     }
 };
 
