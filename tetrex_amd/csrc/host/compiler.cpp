@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <future>
 #include <mutex>
 #include <cstdio>
 #include <cstdlib>
@@ -640,34 +641,22 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         }
     } blob_store;
     bool first = true;
-    for (;;) {
-        for (uint32_t i : touched) {
-            if (q[i]) { ops[i].clear(); tables[i].clear(); dgram_tables[i].clear(); }
-            else { OpVec().swap(ops[i]); tables[i] = KmerTable(false); dgram_tables[i] = KmerTable(false); }  // finished: storage back to the cache
-            levels[i].clear();
-        }
-        touched.clear();
-        act.clear();
-        for (size_t i = 0; i < n; ++i) {
-            if (first && passthrough[i]) { ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT}); touched.push_back((uint32_t)i); }
-            if (q[i] && !q[i]->done()) act.push_back((uint32_t)i);
-        }
-        // largest first: a stage ends when its last task ends
+    // While the device executes stage s, the queries that do not wait for its feedback are already
+    // expanded for stage s+1 (`ahead`); `carried` = the ops that produced.
+    const bool overlap = !(std::getenv("TETREX_NO_OVERLAP") && std::getenv("TETREX_NO_OVERLAP")[0] == '1');
+    std::vector<uint8_t> ahead(n, 0);
+    size_t carried = 0;
+    std::vector<double> busy(threads, 0.0);
+    // expands the queries of `set` (largest first) until each has used its budget; returns the ops emitted
+    auto advance_set = [&](std::vector<uint32_t>& set, size_t already, size_t feedback_budget, size_t run_on_budget) -> size_t {
         {
             std::vector<uint64_t> w(n, 0);
-            for (uint32_t i : act) w[i] = q[i]->weight();
-            std::stable_sort(act.begin(), act.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });
+            for (uint32_t i : set) w[i] = q[i]->weight();
+            std::stable_sort(set.begin(), set.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });  // a stage ends when its last task ends
         }
-        // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
-        size_t feedback_budget = act.empty() ? opt.ops_per_query_per_stage : opt.stage_target_ops / act.size();
-        if (feedback_budget < opt.ops_per_query_per_stage) feedback_budget = opt.ops_per_query_per_stage;
-        if (feedback_budget > opt.ops_per_task) feedback_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
-        const size_t run_on_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
-
-        std::atomic<size_t> total{0};
-        std::vector<double> busy(threads, 0.0);
-        pool.run(act.size(), [&](size_t at, int t) {
-            const size_t i = act[at];
+        std::atomic<size_t> total{already};
+        pool.run(set.size(), [&](size_t at, int t) {
+            const size_t i = set[at];
             const double t0 = trace ? clock() : 0.0;
             struct Busy { double& acc; double t0; bool on; const decltype(clock)& clk; ~Busy() { if (on) acc += clk() - t0; } } busy_guard{busy[t], t0, trace, clock};
             if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
@@ -693,18 +682,41 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
                 q[i].reset();
             }
         });
+        return total.load() - already;
+    };
+    for (;;) {
+        touched.clear();
+        act.clear();
+        size_t unfinished = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (first && passthrough[i]) { ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT}); touched.push_back((uint32_t)i); }
+            if (ahead[i]) {  // expanded during the previous execution
+                ahead[i] = 0;
+                if (!ops[i].empty() || !tables[i].values().empty()) touched.push_back((uint32_t)i);
+                unfinished += q[i] && !q[i]->done();
+                continue;
+            }
+            if (q[i] && !q[i]->done()) { act.push_back((uint32_t)i); ++unfinished; }
+        }
+        // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
+        size_t feedback_budget = unfinished ? opt.stage_target_ops / unfinished : opt.ops_per_query_per_stage;
+        if (feedback_budget < opt.ops_per_query_per_stage) feedback_budget = opt.ops_per_query_per_stage;
+        if (feedback_budget > opt.ops_per_task) feedback_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        const size_t run_on_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        std::fill(busy.begin(), busy.end(), 0.0);
+        const size_t stage_total = carried + advance_set(act, carried, feedback_budget, run_on_budget);
+        carried = 0;
         if (trace) {
             double sum = 0, mx = 0;
             for (double b : busy) { sum += b; if (b > mx) mx = b; }
-            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, total.load(), act.size());
+            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, stage_total, act.size());
         }
         lap("advance");
         bool pending = false;
-        for (uint32_t i : act) {
-            pending |= q[i] && !q[i]->done();
+        for (uint32_t i : act)
             if (!ops[i].empty() || !tables[i].values().empty()) touched.push_back(i);
-        }
-        if (!first && total.load() == 0 && !pending) break;
+        for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
+        if (!first && stage_total == 0 && !pending) break;
 
         // layout: header | k-mer tables of the touched queries, then their d-gram tables (the device
         // probes the last `stage_dgrams` entries on the auxiliary index) | programs | ops | levels
@@ -770,10 +782,20 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         const size_t blob_bytes = h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7);
         lap("blob");
 
+        // the blob holds the stage now: the per-query buffers are free for the next one
+        for (uint32_t i : touched) {
+            if (q[i]) { ops[i].clear(); tables[i].clear(); dgram_tables[i].clear(); }
+            else { OpVec().swap(ops[i]); tables[i] = KmerTable(false); dgram_tables[i] = KmerTable(false); }  // finished: storage back to the cache
+            levels[i].clear();
+        }
+
         // which waiting states does the device have to report on
-        std::vector<uint32_t> fb;
-        for (uint32_t i : act)
-            if (q[i] && !q[i]->done() && q[i]->wants_feedback()) fb.push_back(i);
+        std::vector<uint32_t> fb, run_on;
+        for (size_t i = 0; i < n; ++i) {
+            if (!q[i] || q[i]->done()) continue;
+            if (q[i]->wants_feedback()) fb.push_back((uint32_t)i);
+            else run_on.push_back((uint32_t)i);
+        }
         pool.run(fb.size(), [&](size_t j, int) { asks[fb[j]].clear(); q[fb[j]]->frontier_slots(asks[fb[j]]); });
         std::vector<uint32_t> qp, qs;
         std::vector<size_t> ask_first(fb.size() + 1, 0);
@@ -787,12 +809,31 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         lap("frontier");
         st.expand_seconds += clock() - mark;
         mark = clock();
-        exec.stage(blob, blob_bytes, qp, qs, alive);
-        st.execute_seconds += clock() - mark;
+        if (overlap && !run_on.empty()) {
+            // the device runs this stage while the queries that do not wait for its answer go on
+            std::future<void> running = std::async(std::launch::async, [&]() { exec.stage(blob, blob_bytes, qp, qs, alive); });
+            std::fill(busy.begin(), busy.end(), 0.0);
+            try {
+                carried = advance_set(run_on, 0, run_on_budget, run_on_budget);
+            } catch (...) {
+                running.wait();
+                throw;
+            }
+            for (uint32_t i : run_on) ahead[i] = 1;
+            const double ahead_s = clock() - mark;
+            lap("ahead");
+            running.get();
+            const double both = clock() - mark;
+            st.expand_seconds += ahead_s;
+            st.execute_seconds += both - ahead_s;  // what the device added beyond the overlapped expansion
+        } else {
+            exec.stage(blob, blob_bytes, qp, qs, alive);
+            st.execute_seconds += clock() - mark;
+        }
         mark = clock();
         lap("execute");
         ++st.stages;
-        st.ops += total.load();
+        st.ops += stage_total;
         st.kmers += stage_kmers + stage_dgrams;
         st.feedback_queries += qp.size();
         // prune dead frontier states

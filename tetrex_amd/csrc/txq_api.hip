@@ -30,6 +30,14 @@ int fail_hip(hipError_t e, const char* what) {
 }
 int require_init() {
     if (g_device < 0) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
+    // the HIP device is a per-thread setting: a thread other than the one that called txq_init
+    // (e.g. the host's stage-submission thread) would otherwise talk to device 0
+    static thread_local int t_device = -1;
+    if (t_device != g_device) {
+        hipError_t e = hipSetDevice(g_device);
+        if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
+        t_device = g_device;
+    }
     return TXQ_OK;
 }
 
