@@ -16,6 +16,9 @@ independent), so scaling is "weak".  A probe is one k-mer tested against one 102
 Output: ONE JSON line on rank 0 (contract in the task description), including
   roofline     — algorithmic bytes of the probe kernel / its HIP-event duration vs 8 TB/s HBM,
   cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host.
+Two further legs report the other BASELINE figures without touching `value`:
+  end_to_end   — queries/s, regex -> candidate-bin mask, on the same index;
+  hibf         — k-mers/s of the HIBF descent on a 65536-user-bin tree (BASELINE configs[4] shape).
 """
 import argparse
 import json
@@ -180,6 +183,87 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     }
 
 
+def hibf_descent(capi, torch, args, rank, world):
+    """Third figure (BASELINE configs[4] shape, SURVEY.md §8d S-HIBF-65536): k-mers/s of the HIBF
+    descent — root IBF of 256 merged bins over 256 child IBFs of 256 user bins each, h = 2, sizes from
+    compute_bitcount at fpr 0.05, values from a 10-letter k = 5 universe (10^5 k-mers).  Every IBF is
+    filled on the device with the real hash and uploaded as a tree; with N ranks the 65536 mask columns
+    are sharded (each rank descends only into sub-trees of its own columns).  Runs after the timed
+    probe steps; it does not touch `value`."""
+    user_bins, children, per_bin, h = 65536, 256, args.hibf_per_bin, 2
+    per_child = user_bins // children
+    rng = np.random.default_rng(5)
+    shifts = np.uint64(5) * np.arange(4, -1, -1, dtype=np.uint64)
+
+    def values(count):
+        return (rng.integers(0, 10, size=(count, 5)).astype(np.uint64) << shifts).sum(axis=1).astype(np.uint64)
+
+    def filled(bins, rows, vals, bins_of):
+        ix = capi.Index.create_ibf(bins, rows, h)
+        dv = torch.from_numpy(vals.view(np.int64)).cuda()
+        db = torch.from_numpy(bins_of.astype(np.uint32).view(np.int32)).cuda()
+        ix.emplace_device(dv.data_ptr(), db.data_ptr(), vals.size, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        words = ix.download_words_rows(rows)
+        ix.free()
+        return words
+
+    t0 = time.perf_counter()
+    m_child = compute_bitcount(per_bin, 0.05)
+    m_root = compute_bitcount(per_bin * per_child, 0.05)
+    tb_of = np.repeat(np.arange(per_child, dtype=np.uint32), per_bin)
+    descs = [None]
+    root_vals, root_bins, sample = [], [], []
+    for c in range(children):
+        v = values(per_child * per_bin)
+        descs.append(dict(bins=per_child, bin_size=m_child, hash_funs=h, words=filled(per_child, m_child, v, tb_of),
+                          next_ibf_id=np.zeros(per_child, dtype=np.uint64),
+                          tb_to_user=np.arange(c * per_child, (c + 1) * per_child, dtype=np.uint64)))
+        root_vals.append(v)
+        root_bins.append(np.full(v.size, c, dtype=np.uint32))
+        sample.append((v[::997], c * per_child + tb_of[::997]))
+    descs[0] = dict(bins=children, bin_size=m_root, hash_funs=h,
+                    words=filled(children, m_root, np.concatenate(root_vals), np.concatenate(root_bins)),
+                    next_ibf_id=np.arange(1, children + 1, dtype=np.uint64),
+                    tb_to_user=np.full(children, 0xFFFFFFFFFFFFFFFF, dtype=np.uint64))
+    ix = capi.Index.upload_hibf(user_bins, descs, shard_rank=rank, n_shards=world)
+    build_s = time.perf_counter() - t0
+    W = ix.shard_words
+    n = args.hibf_kmers
+    present = np.concatenate([v for v, _ in sample])
+    kmers = np.concatenate([np.resize(present, n // 2), values(n - n // 2)])
+    rng.shuffle(kmers)
+    dk = torch.from_numpy(kmers.view(np.int64)).cuda()
+    dm = torch.empty((n, W), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+    for _ in range(2):
+        ix.probe_device(dk.data_ptr(), n, dm.data_ptr(), None, stream.cuda_stream)
+    torch.cuda.synchronize()
+    reps = 5
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(stream)
+    for _ in range(reps):
+        ix.probe_device(dk.data_ptr(), n, dm.data_ptr(), None, stream.cuda_stream)
+    b.record(stream)
+    torch.cuda.synchronize()
+    dt = a.elapsed_time(b) / 1e3 / reps
+    # size-independent check: an inserted value is found in its own user bin (no false negatives)
+    pv = np.concatenate([v for v, _ in sample])[:4096]
+    pb = np.concatenate([u for _, u in sample])[:4096].astype(np.int64)
+    got = ix.probe(pv)
+    lo = int(ix.info.shard_word0)
+    mine = (pb // 64 >= lo) & (pb // 64 < lo + W)
+    bits = (got[np.arange(pv.size)[mine], (pb[mine] // 64 - lo)] >> (pb[mine] % 64).astype(np.uint64)) & np.uint64(1)
+    if not bool(bits.all()):
+        raise SystemExit("bench: HIBF descent lost an inserted value")
+    out = {"workload": "S-HIBF-65536", "user_bins": user_bins, "n_ibf": children + 1, "hash_funs": h, "values_per_bin": per_bin,
+           "kmers": n, "kmers_per_s_per_gpu": n / dt, "seconds_per_batch": dt, "mask_bytes_per_kmer": W * 8,
+           "mask_write_GBps": n * W * 8 / dt / 1e9, "column_shards": world, "tree_bytes": int(ix.info.device_bytes),
+           "index_build_s": round(build_s, 1), "checked_present_values": int(mine.sum())}
+    ix.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -193,6 +277,9 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-queries", action="store_true", help="skip the end-to-end queries/s leg")
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
+    ap.add_argument("--no-hibf", action="store_true", help="skip the HIBF descent leg")
+    ap.add_argument("--hibf-kmers", type=int, default=1 << 20)
+    ap.add_argument("--hibf-per-bin", type=int, default=300)
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
     ap.add_argument("--kmer-bits", type=int, default=20)
     ap.add_argument("--rehearse-single-device", action="store_true",
@@ -332,6 +419,11 @@ def main():
         out["end_to_end"] = end_to_end_queries(ix, torch, dist, world, rank, args)
 
     ix.free()
+    if not args.no_hibf:
+        try:
+            out["hibf"] = hibf_descent(capi, torch, args, rank, world)
+        except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
+            out["hibf"] = {"error": repr(e)}
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

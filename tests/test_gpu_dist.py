@@ -82,7 +82,7 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--kmers", str(1 << 18), "--per-bin", "2000", "--motifs", "40", "--rehearse-single-device"]
+           "--kmers", str(1 << 18), "--per-bin", "2000", "--motifs", "40", "--hibf-kmers", str(1 << 16), "--rehearse-single-device"]
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -94,3 +94,5 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["bins_total"] == 2048
     assert "error" not in out["end_to_end"], out["end_to_end"]
     assert out["end_to_end"]["batch"]["failed"] == 0
+    assert "error" not in out["hibf"], out["hibf"]
+    assert out["hibf"]["column_shards"] == 2 and out["hibf"]["mask_bytes_per_kmer"] == 4096
