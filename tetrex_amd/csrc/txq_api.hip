@@ -119,6 +119,8 @@ void Index::release() {
     session_cache = SessionCache{};
     if (d_merged) (void)hipFree(d_merged);
     if (d_descend) (void)hipFree(d_descend);
+    if (d_nodes) (void)hipFree(d_nodes);
+    d_nodes = nullptr;
     d_descend = nullptr;
     if (d_merged_off) (void)hipFree(d_merged_off);
     d_merged = d_merged_off = nullptr;

@@ -11,6 +11,7 @@
 // No host round trip between levels: each level kernel reads its item count from HBM.
 #include "txq_internal.hpp"
 #include <cstdlib>
+#include <cstring>
 #include <deque>
 #include <utility>
 
@@ -24,7 +25,27 @@ struct HibfView {
     const uint64_t* merged;      // per IBF word: bit b set <=> technical bin 64w+b is a merged bin
     const uint64_t* descend;     // same layout: the merged bins whose sub-tree holds user bins of THIS shard's mask columns
     const uint64_t* merged_off;  // [n_ibf] offset of IBF i's words in `merged` / `descend`
+    // fused kernel: everything about the child IBF behind merged technical bin e in ONE 32-byte
+    // record, nodes[e] (no next_ibf_id -> descriptor chain); nodes[total technical bins] is the root
+    const struct HibfNode* nodes;
+    uint32_t root_entry;
 };
+
+struct HibfNode {  // 32 bytes = two 16-byte loads per lane
+    uint64_t words;       // device pointer to the IBF's rows
+    uint32_t bin_size;    // rows (< 2^32: the fused kernel is not used for larger IBFs)
+    uint32_t packed;      // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | has merged bins (29)
+    uint32_t off;         // first entry of the IBF's technical bins in the flattened maps
+    uint32_t moff;        // first word of the IBF in `merged` / `descend`
+    uint32_t ident_word;  // see IbfDev::ident_word
+    uint32_t bins;        // technical bins
+    __host__ __device__ uint32_t stride() const { return packed & 0xFFFFFu; }
+    __host__ __device__ uint32_t hash_shift() const { return (packed >> 20) & 63u; }
+    __host__ __device__ uint32_t hash_funs() const { return (packed >> 26) & 7u; }
+    __host__ __device__ bool has_merged() const { return (packed >> 29) & 1u; }
+    __host__ __device__ uint32_t words_per_row() const { return (bins + 63u) >> 6; }
+};
+static_assert(sizeof(HibfNode) == 32, "two 16-byte pieces per node");
 
 // loads through a pointer that was itself read from memory: tell the compiler it is global memory
 // (otherwise it emits flat loads, which also wait on the LDS counter)
@@ -169,45 +190,51 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
     uint64_t v_next = first < n ? kmers[first] : 0;
     for (size_t i = first; i < n; i += waves) {
         for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
-        if (lane == 0) stack[0] = kRootEntry;
-        const uint64_t v = v_next;
+        if (lane == 0) stack[0] = t.root_entry;
+        // the k-mer is the same in every lane: make that visible, so that the seed products are
+        // computed once per k-mer on the scalar unit instead of per IBF on the vector unit
+        const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v_next >> 32)) << 32) |
+                           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v_next);
         if (i + waves < n) v_next = kmers[i + waves];  // lands while this k-mer descends
+        uint64_t seeded[5];
+#pragma unroll
+        for (uint32_t j = 0; j < 5; ++j) seeded[j] = v * kSeeds[j];
         uint32_t count = 1;  // wave-uniform
         while (count) {
             wave_sync();
             const uint32_t take = count < kPerRound ? count : kPerRound;
             count -= take;
             const bool live = group < take;
-            // a stack entry is a technical-bin index; its child IBF is looked up when the entry is popped
-            const uint32_t entry = live ? stack[count + group] : kRootEntry;
-            const uint32_t id = entry == kRootEntry ? 0u : (uint32_t)gload(t.next + entry);
-            const IbfDev f = t.ibf[id];
-            const uint32_t off = (uint32_t)t.map_off[id];
-            const uint64_t moff = t.merged_off[id];
+            // a stack entry is a technical-bin index; everything about the IBF behind it is one record
+            const HibfNode nd = t.nodes[live ? stack[count + group] : t.root_entry];
+            const uint32_t stride = nd.stride(), words_per_row = nd.words_per_row();
             uint64_t r[5];
 #pragma unroll
             for (uint32_t j = 0; j < 5; ++j) {
                 if (j >= h_max) { r[j] = 0; continue; }  // uniform: no IBF of this tree has more
                 // a hash function this IBF does not have repeats its last real row (AND is idempotent)
-                r[j] = (j == 0 || j < f.hash_funs) ? hash_row(v, kSeeds[j], f.hash_shift, f.bin_size) : r[j ? j - 1 : 0];
+                r[j] = (j == 0 || j < nd.hash_funs()) ? hash_row_seeded32(seeded[j], nd.hash_shift(), nd.bin_size) : r[j ? j - 1 : 0];
             }
+            // most rounds only meet leaves: then nothing is loaded or done for merged bins
+            const bool any_merged = __ballot(live && nd.has_merged()) != 0;
             for (uint32_t wi = 0; wi < w_iters; ++wi) {
                 const uint32_t w0 = (wi * G + sub) * 4u;
                 uint64_t acc[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
-                if (live && w0 < f.shard_words) {  // every load of the round issues before the first is used
-                    if (f.stride == 1) {
+                if (live && w0 < words_per_row) {  // every load of the round issues before the first is used
+                    const uint64_t* words = (const uint64_t*)nd.words;
+                    if (stride == 1) {
                         uint64_t x = ~0ULL;
 #pragma unroll
                         for (uint32_t j = 0; j < 5; ++j)
-                            if (j < h_max) x &= gload(f.words + r[j]);
+                            if (j < h_max) x &= gload(words + r[j]);
                         acc[0] = x;
                     } else {  // rows are padded to an even number of words, the padding is zero
-                        const bool upper = w0 + 2 < f.stride;
+                        const bool upper = w0 + 2 < stride;
                         ulonglong2 lo{~0ULL, ~0ULL}, hi{~0ULL, ~0ULL};
 #pragma unroll
                         for (uint32_t j = 0; j < 5; ++j) {
                             if (j >= h_max) continue;
-                            const uint64_t* p = f.words + r[j] * f.stride + w0;
+                            const uint64_t* p = words + r[j] * stride + w0;
                             const ulonglong2 a = gload2(p);
                             lo.x &= a.x; lo.y &= a.y;
                             if (upper) { const ulonglong2 b = gload2(p + 2); hi.x &= b.x; hi.y &= b.y; }
@@ -215,41 +242,45 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                         acc[0] = lo.x; acc[1] = lo.y;
                         if (upper) { acc[2] = hi.x; acc[3] = hi.y; }
                     }
-                    // merged-bin masks are padded to 4 words per IBF
-                    const ulonglong2 m0 = gload2(t.merged + moff + w0), m1 = gload2(t.merged + moff + w0 + 2);
-                    const ulonglong2 d0 = gload2(t.descend + moff + w0), d1 = gload2(t.descend + moff + w0 + 2);
-                    mg[0] = m0.x; mg[1] = m0.y; mg[2] = m1.x; mg[3] = m1.y;
-                    dn[0] = d0.x; dn[1] = d0.y; dn[2] = d1.x; dn[3] = d1.y;
+                    if (nd.has_merged()) {  // merged-bin masks are padded to 4 words per IBF
+                        const uint64_t moff = nd.moff;
+                        const ulonglong2 m0 = gload2(t.merged + moff + w0), m1 = gload2(t.merged + moff + w0 + 2);
+                        const ulonglong2 d0 = gload2(t.descend + moff + w0), d1 = gload2(t.descend + moff + w0 + 2);
+                        mg[0] = m0.x; mg[1] = m0.y; mg[2] = m1.x; mg[3] = m1.y;
+                        dn[0] = d0.x; dn[1] = d0.y; dn[2] = d1.x; dn[3] = d1.y;
+                    }
                 }
                 // Children and mapped user bins are expanded by the whole wave, one 64-bit word per step:
                 // lane L takes bit L, so a word costs the same whether 1 or 64 of its bits are set.
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const uint64_t kids = acc[q] & dn[q];  // children outside this shard's columns are not visited
-                    const uint32_t first_tb = off + (w0 + (uint32_t)q) * 64u;
-                    uint64_t owners = __ballot(kids != 0);
-                    while (owners) {  // wave-uniform
-                        const int src = __builtin_ctzll(owners);
-                        owners &= owners - 1;
-                        const uint64_t word = read_lane(kids, src);
-                        const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)first_tb, src);
-                        if ((word >> lane) & 1) {
-                            const uint32_t pos = count + (uint32_t)__builtin_popcountll(word & ((1ULL << lane) - 1));
-                            if (pos < stack_cap) stack[pos] = base + lane;
+                    const uint32_t first_tb = nd.off + (w0 + (uint32_t)q) * 64u;
+                    if (any_merged) {
+                        const uint64_t kids = acc[q] & dn[q];  // children outside this shard's columns are not visited
+                        uint64_t owners = __ballot(kids != 0);
+                        while (owners) {  // wave-uniform
+                            const int src = __builtin_ctzll(owners);
+                            owners &= owners - 1;
+                            const uint64_t word = read_lane(kids, src);
+                            const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)first_tb, src);
+                            if ((word >> lane) & 1) {
+                                const uint32_t pos = count + (uint32_t)__builtin_popcountll(word & ((1ULL << lane) - 1));
+                                if (pos < stack_cap) stack[pos] = base + lane;
+                            }
+                            count += (uint32_t)__builtin_popcountll(word);
+                            if (count > stack_cap) count = stack_cap;  // unreachable for a tree; keeps the indexes in range
                         }
-                        count += (uint32_t)__builtin_popcountll(word);
-                        if (count > stack_cap) count = stack_cap;  // unreachable for a tree; keeps the indexes in range
                     }
                     uint64_t hits = acc[q] & ~mg[q];
                     const uint32_t w = w0 + (uint32_t)q;
-                    if (hits && f.ident_word != kNoIdent) {  // the row word is a mask word
-                        const uint64_t word = (uint64_t)f.ident_word + w;
+                    if (hits && nd.ident_word != kNoIdent) {  // the row word is a mask word
+                        const uint64_t word = (uint64_t)nd.ident_word + w;
                         if (word >= word0 && word < (uint64_t)word0 + w_out) atomicOr((unsigned long long*)(row + (word - word0)), hits);
                         hits = 0;
                     }
                     // padding bits are never set; this guards the map look-up
-                    if (w * 64u + 63u >= f.bins) hits &= f.bins > w * 64u ? (~0ULL >> (63u - ((f.bins - 1u) & 63u))) : 0;
-                    owners = __ballot(hits != 0);
+                    if (w * 64u + 63u >= nd.bins) hits &= nd.bins > w * 64u ? (~0ULL >> (63u - ((nd.bins - 1u) & 63u))) : 0;
+                    uint64_t owners = __ballot(hits != 0);
                     while (owners) {
                         const int src = __builtin_ctzll(owners);
                         owners &= owners - 1;
@@ -419,6 +450,34 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     TXQ_HIP(hipMemcpy(ix.d_tb_user, tbu.data(), off[n] * 8, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_map_off, off.data(), n * 8, hipMemcpyHostToDevice));
     ix.device_bytes += n * sizeof(IbfDev) + off[n] * 16 + n * 8;
+    // node records by technical bin for the fused kernel (skipped for trees too large for it)
+    bool compact = off[n] < kRootEntry && moff[n] < 0xFFFFFFFFull && off[n] <= ((size_t)256 << 20) / sizeof(HibfNode);
+    for (const IbfDev& f : ix.ibf) compact = compact && !(f.bin_size >> 32) && f.stride < (1u << 20) && f.hash_shift < 64 && f.hash_funs < 8;
+    if (compact) {
+        std::vector<HibfNode> nodes(off[n] + 1);
+        std::memset(nodes.data(), 0, nodes.size() * sizeof(HibfNode));
+        auto node_of = [&](uint64_t i) {
+            const IbfDev& f = ix.ibf[i];
+            bool has_merged = false;
+            for (uint64_t w = moff[i]; w < moff[i + 1]; ++w) has_merged = has_merged || merged[w] != 0;
+            HibfNode nd{};
+            nd.words = (uint64_t)(uintptr_t)f.words;
+            nd.bin_size = (uint32_t)f.bin_size;
+            nd.packed = f.stride | (f.hash_shift << 20) | (f.hash_funs << 26) | ((uint32_t)has_merged << 29);
+            nd.off = (uint32_t)off[i];
+            nd.moff = (uint32_t)moff[i];
+            nd.ident_word = f.ident_word;
+            nd.bins = f.bins;
+            return nd;
+        };
+        for (uint64_t i = 0; i < n; ++i)
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+                if (tbu[off[i] + b] == TXQ_MERGED_BIN) nodes[off[i] + b] = node_of(next[off[i] + b]);
+        nodes[off[n]] = node_of(0);
+        TXQ_HIP(hipMalloc((void**)&ix.d_nodes, nodes.size() * sizeof(HibfNode)));
+        TXQ_HIP(hipMemcpy(ix.d_nodes, nodes.data(), nodes.size() * sizeof(HibfNode), hipMemcpyHostToDevice));
+        ix.device_bytes += nodes.size() * sizeof(HibfNode);
+    }
     return TXQ_OK;
 }
 
@@ -447,7 +506,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     const size_t wave_bytes = wave_words * 8;
     const size_t lds_budget = 64u << 10;
     const char* force = std::getenv("TXQ_HIBF_LEVELS");
-    if (!w_out || wave_bytes > lds_budget || ix.hibf_total_tbs >= kRootEntry || (force && force[0] == '1')) return false;
+    if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || (force && force[0] == '1')) return false;
     unsigned waves = 4;
     while (waves > 1 && wave_bytes * waves > lds_budget) waves >>= 1;
     // about 16 waves per CU are resident where the LDS allows it (TXQ_HIBF_WAVES overrides the total)
@@ -459,7 +518,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     int g = 1;
     while (g < 64 && (uint32_t)g < quads) g <<= 1;
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off};
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
     *rc = TXQ_OK;
@@ -505,7 +564,7 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
     }
     if (int rc = ensure((void**)&ix.d_counts, &ix.cap_counts, ((size_t)ix.depth + 2) * 4)) return rc;
     uint32_t* overflow = ix.d_counts + ix.depth + 1;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off};
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
     int g = 1;
     while (g < 64 && (uint32_t)g < ix.max_stride) g <<= 1;
     const uint32_t w_iters = (ix.max_stride + (uint32_t)g - 1) / (uint32_t)g;

@@ -21,6 +21,7 @@ struct Index {
     uint64_t* d_tb_user = nullptr;   // flattened tb_to_user_bin (TXQ_MERGED_BIN for merged)
     uint64_t* d_map_off = nullptr;   // [n_ibf] offset of IBF i's maps in the flattened arrays
     uint64_t* d_merged = nullptr;    // merged-bin bitmask words of every IBF, flattened
+    void* d_nodes = nullptr;         // HibfNode[total technical bins + 1] for the fused descent (txq_hibf.hip)
     uint64_t* d_descend = nullptr;   // same layout: merged bins worth descending into for this shard
     uint64_t* d_merged_off = nullptr;
     uint32_t depth = 1;              // levels of the tree

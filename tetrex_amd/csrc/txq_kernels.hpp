@@ -35,12 +35,31 @@ struct IbfDev {
 };
 static constexpr uint32_t kNoIdent = 0xFFFFFFFFu;
 
-// row index of `v` under hash function i: fastrange of the mixed hash onto [0, bin_size)
-__device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t shift, uint64_t bin_size) {
-    v *= seed;
+// floor(x * n / 2^64) for n < 2^32 (every IBF with fewer than 4 G rows): two 32-bit multiplies
+__device__ __forceinline__ uint64_t fastrange32(uint64_t x, uint32_t n) {
+    return ((uint64_t)(uint32_t)(x >> 32) * (uint64_t)n + (uint64_t)__umulhi((uint32_t)x, n)) >> 32;
+}
+__device__ __forceinline__ uint64_t fastrange(uint64_t x, uint64_t n) {
+    return (n >> 32) ? __umul64hi(x, n) : fastrange32(x, (uint32_t)n);
+}
+
+// second half of hash_row for a value that is already multiplied by its seed
+__device__ __forceinline__ uint64_t hash_row_seeded(uint64_t v, uint32_t shift, uint64_t bin_size) {
     v ^= v >> shift;
     v *= kGolden;
-    return __umul64hi(v, bin_size);
+    return fastrange(v, bin_size);
+}
+// the same when the caller knows that bin_size < 2^32 (saves evaluating both fastrange variants
+// where bin_size differs from lane to lane)
+__device__ __forceinline__ uint64_t hash_row_seeded32(uint64_t v, uint32_t shift, uint32_t bin_size) {
+    v ^= v >> shift;
+    v *= kGolden;
+    return fastrange32(v, bin_size);
+}
+
+// row index of `v` under hash function i: fastrange of the mixed hash onto [0, bin_size)
+__device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t shift, uint64_t bin_size) {
+    return hash_row_seeded(v * seed, shift, bin_size);
 }
 
 }  // namespace txq
