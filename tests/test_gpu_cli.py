@@ -126,3 +126,15 @@ def test_bad_index_path_and_bad_query(toy):
     assert "Filepath to (H)IBF Index not valid" in se
     rc, so, se = run("query", toy["ibf"], "A{2,}")
     assert rc != 0 and "not searchable" in se
+
+
+def test_stats_flag_prints_one_json_line(toy):
+    """-S/--stats (an extension of this build): the candidate-mask stage in numbers, on stderr."""
+    import json
+    rc, so, se = run("query", "-S", toy["ibf"], "A(C+|G+)T")
+    assert rc == 0, se
+    lines = [ln for ln in se.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, se
+    st = json.loads(lines[0])
+    assert st["queries"] == 1 and st["bins"] == 5 and st["stages"] >= 1 and st["ops"] > 0 and st["kmer_probes"] > 0
+    assert st["mask_seconds"] >= st["execute_seconds"] >= 0

@@ -97,7 +97,7 @@ size_t popcount_mask(const uint64_t* m, uint64_t words) {
 int cmd_query(int argc, char** argv) {
     const std::vector<OptSpec> spec = {{'d', "draw", false}, {'v', "verbose", false}, {'f', "file", false}, {'c', "conj", false},
                                        {'a', "augment", false}, {'t', "threads", true}, {'o', "output", true}, {'g', "gibf", true},
-                                       {'D', "device", true}};
+                                       {'D', "device", true}, {'S', "stats", false}};
     Args a;
     try {
         a = parse(argc, argv, 2, spec);
@@ -129,6 +129,14 @@ int cmd_query(int argc, char** argv) {
     const KmerEncoder enc = dev.encoder();
     const uint64_t bins = dev.bins(), W = dev.info().shard_words;
     const VerifyOptions vopt{threads};
+    // -S/--stats (not in the reference): one JSON line on stderr about the candidate-mask stage
+    auto print_stats = [&](const StagedStats& st, size_t queries, double seconds) {
+        if (!a.has("stats")) return;
+        std::cerr << "{\"queries\": " << queries << ", \"mask_seconds\": " << seconds << ", \"stages\": " << st.stages
+                  << ", \"ops\": " << st.ops << ", \"kmer_probes\": " << st.kmers << ", \"states\": " << st.states
+                  << ", \"pruned_states\": " << st.pruned << ", \"expand_seconds\": " << st.expand_seconds
+                  << ", \"execute_seconds\": " << st.execute_seconds << ", \"bins\": " << bins << "}" << std::endl;
+    };
 
     auto run_one = [&](const std::string& rx, const uint64_t* mask, const std::string& destination, bool log_file_mode, double t1) {
         const size_t narrowed = popcount_mask(mask, W);
@@ -166,7 +174,9 @@ int cmd_query(int argc, char** argv) {
         const double t0 = now();
         std::vector<int> status;
         std::vector<std::string> why;
-        const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why, nullptr, &sopt);
+        StagedStats st;
+        const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why, &st, &sopt);
+        print_stats(st, motifs.size(), now() - t0);
         const double batch = (now() - t0) / std::max<size_t>(1, motifs.size());
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
@@ -179,7 +189,9 @@ int cmd_query(int argc, char** argv) {
         const std::vector<std::string> queries = split(input, ':');
         if (queries.size() == 1) { std::cerr << "Did you use the correct delimiter (:)?" << std::endl; return 0; }
         const double t1 = now();
-        const std::vector<uint64_t> masks = dev.query_masks(queries, nullptr, nullptr, nullptr, &sopt);
+        StagedStats st;
+        const std::vector<uint64_t> masks = dev.query_masks(queries, nullptr, nullptr, &st, &sopt);
+        print_stats(st, queries.size(), now() - t1);
         std::vector<uint64_t> all(masks.begin(), masks.begin() + W);
         for (size_t q = 1; q < queries.size(); ++q)
             for (uint64_t w = 0; w < W; ++w) all[w] &= masks[q * W + w];
@@ -200,7 +212,9 @@ int cmd_query(int argc, char** argv) {
     const double t1 = now();
     std::vector<int> status;
     std::vector<std::string> why;
-    const std::vector<uint64_t> masks = dev.query_masks({input}, &status, &why, nullptr, &sopt);
+    StagedStats st;
+    const std::vector<uint64_t> masks = dev.query_masks({input}, &status, &why, &st, &sopt);
+    print_stats(st, 1, now() - t1);
     if (status[0]) { std::cerr << "[Error] query not searchable: " << why[0] << std::endl; return 1; }
     run_one(input, masks.data(), dest, false, t1);
     return 0;
