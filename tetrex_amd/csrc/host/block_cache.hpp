@@ -13,6 +13,8 @@
 #include <new>
 #include <vector>
 
+#include <sys/mman.h>
+
 namespace tetrex {
 
 class BlockCache {
@@ -30,9 +32,7 @@ class BlockCache {
                 return p;
             }
         }
-        void* p = std::malloc((size_t)1 << cls);
-        if (!p) throw std::bad_alloc();
-        return p;
+        return fresh((size_t)1 << cls);
     }
     static void give(void* p, int cls) {
         const size_t bytes = (size_t)1 << cls;
@@ -55,6 +55,20 @@ class BlockCache {
         }
     }
     static size_t cached_bytes() { return cached().load(); }
+    // new memory from the system; blocks of 2 MiB and more ask for transparent huge pages (one page
+    // fault per 2 MiB instead of 512: the first touch of a GB of ops is otherwise ~250 000 faults)
+    static void* fresh(size_t bytes) {
+        void* p = nullptr;
+        if (bytes >= kHuge) {
+            if (posix_memalign(&p, kHuge, bytes) != 0) throw std::bad_alloc();
+            (void)madvise(p, bytes, MADV_HUGEPAGE);
+        } else {
+            p = std::malloc(bytes);
+            if (!p) throw std::bad_alloc();
+        }
+        return p;
+    }
+    static constexpr size_t kHuge = (size_t)2 << 20;
 
   private:
     struct Class { std::mutex m; std::vector<void*> free; };

@@ -633,11 +633,19 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     std::vector<uint32_t> touched, act;  // queries with ops in the previous stage; unfinished queries
     // the stage's blob is assembled in place, in storage that is reused from stage to stage
     struct RawBuffer {
-        std::unique_ptr<uint64_t[]> words;
+        uint8_t* data = nullptr;
         size_t cap = 0;
-        uint8_t* ensure(size_t bytes) {
-            if (bytes > cap) { cap = std::max(bytes, cap + cap / 2); words.reset(new uint64_t[(cap + 7) / 8]); }
-            return reinterpret_cast<uint8_t*>(words.get());
+        ~RawBuffer() { std::free(data); }
+        // the first large request reserves the most a stage can need: untouched pages cost nothing,
+        // and a buffer that never moves is faulted in once instead of once per growth step
+        uint8_t* ensure(size_t bytes, size_t ceiling) {
+            if (bytes > cap) {
+                std::free(data);
+                data = nullptr;
+                cap = bytes > ((size_t)64 << 20) ? std::max(bytes + bytes / 2, ceiling) : bytes + bytes / 2;
+                data = static_cast<uint8_t*>(BlockCache::fresh(cap));
+            }
+            return data;
         }
     } blob_store;
     bool first = true;
@@ -747,7 +755,9 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
         h.ops_offset = h.programs_offset + n * sizeof(txq_program_v2);
         h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
         // a program has at most one level per op; the untouched tail of the reservation costs nothing
-        uint8_t* blob = blob_store.ensure(h.levels_offset + stage_ops * 4 + 8);
+        // per op: the op, a level entry at worst, a k-mer at worst
+        const size_t most_ops = opt.ops_per_stage + (size_t)threads * std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        uint8_t* blob = blob_store.ensure(h.levels_offset + stage_ops * 4 + 8, sizeof(txq_blob_header_v2) + n * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
         uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
         txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
         pool.run(touched.size(), [&](size_t j, int t) {
