@@ -16,6 +16,8 @@ int main(int argc, char** argv) {
     std::vector<std::string> motifs; std::ifstream in(argv[1]); std::string l; while (std::getline(in, l)) if (!l.empty()) motifs.push_back(l);
     KmerEncoder enc(Molecule::Peptide, 4, Alphabet::Base);
     StagedOptions opt; opt.threads = argc > 2 ? atoi(argv[2]) : 1;
+    if (argc > 3) opt.ops_per_task = (size_t)atol(argv[3]);
+    if (argc > 4) opt.ops_per_stage = (size_t)atol(argv[4]);
     for (int rep = 0; rep < 5; ++rep) {
         Fake exec; std::vector<int> st; std::vector<std::string> why;
         auto t0 = std::chrono::steady_clock::now();
