@@ -121,7 +121,7 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     Runs after the timed probe steps; it does not touch `value`."""
     from motifs import random_prosite_motifs
     from tetrex_amd.dist import gather_final_masks
-    k = 4
+    k = max(2, args.kmer_bits // 5)  # peptide k-mers, 5 bits per residue (4 for the default 20-bit values)
     single = "LMA(E|Q)GLYN"  # BASELINE configs[1] motif
     motifs = random_prosite_motifs(args.motifs, 6)
     # a batch without gaps/wildcards (literal residues and residue classes only) for contrast

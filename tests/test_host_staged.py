@@ -42,7 +42,7 @@ def _run(host, ox, queries, dna, k, per_query, per_stage=0):
     return checked, stats, sim
 
 
-@pytest.mark.parametrize("per_query", [1, 7, 64, 4096, 1 << 30])
+@pytest.mark.parametrize("per_query", [0, 1, 7, 64, 4096, 1 << 30])  # 0 = the product's default policy
 def test_every_stage_budget_gives_the_oracle_masks(host, oracle, per_query):
     ox = _index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
     qs = [q for q in PEPTIDE_QUERIES if "{2,4}C" not in q] + random_prosite_motifs(25, 3, wildcard=0.05, ranges=0.0)

@@ -270,10 +270,22 @@ void QueryExpansion::adopt_storage(NodeStates& ns) {
     if (ns.by_key.capacity() == 0 && !spare_maps_.empty()) { std::swap(ns.by_key, spare_maps_.back()); spare_maps_.pop_back(); }
 }
 
-void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams) {
+void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams, bool verified_only) {
     const unsigned k = enc_.k();
     const size_t start = out.size();
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
+        if (verified_only) {
+            // Expand only what the device has confirmed alive: an item whose input still holds a state
+            // created since the last feedback waits for the next stage.  This is the reference's
+            // immediate `none()` pruning at the granularity of one DP level per stage — without it a
+            // sparse index makes the host expand (and the device probe) whole sub-trees of dead states.
+            const int32_t next = order_[cursor_];
+            const StateVec& waiting = input_of_[next] != KGraph::kNone ? table_[input_of_[next]].items : table_[next].items;
+            bool unverified = false;
+            for (const State& s : waiting)
+                if (!s.asked && s.slot >= TXQ_SLOT_FIRST_FREE) { unverified = true; break; }
+            if (unverified) break;
+        }
         if (!parked_.empty()) {  // slots freed by the previous item become reusable now
             free_.insert(free_.end(), parked_.begin(), parked_.end());
             parked_.clear();
@@ -651,6 +663,8 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
     bool first = true;
     // While the device executes stage s, the queries that do not wait for its feedback are already
     // expanded for stage s+1 (`ahead`); `carried` = the ops that produced.
+    bool verified_levels = opt.verified_levels;
+    if (const char* e = std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels = e[0] == '1';  // A/B knob
     const bool overlap = !(std::getenv("TETREX_NO_OVERLAP") && std::getenv("TETREX_NO_OVERLAP")[0] == '1');
     std::vector<uint8_t> ahead(n, 0);
     size_t carried = 0;
@@ -670,7 +684,8 @@ StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<
             if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
             try {
                 // a query that gains nothing from feedback only pauses to keep the stage's tasks even
-                q[i]->advance(q[i]->wants_feedback() ? feedback_budget : run_on_budget, tables[i], ops[i], &dgram_tables[i]);
+                const bool fb = q[i]->wants_feedback();
+                q[i]->advance(fb ? feedback_budget : run_on_budget, tables[i], ops[i], &dgram_tables[i], fb && verified_levels && q[i]->mostly_dying());
             } catch (const std::exception& e) {
                 // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
                 // query is neutralised by not emitting anything further

@@ -109,13 +109,18 @@ class QueryExpansion {
     bool done() const { return cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
-    void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr);
+    // verified_only: stop before the first item that would consume a state the device has not yet
+    // reported on (see frontier_slots / prune).
+    void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr, bool verified_only = false);
     uint32_t n_slots() const { return high_water_; }
     // distinct non-constant slots of waiting states that were not asked about before (a waiting
     // state's mask only ever grows, so one answer per state is enough); marks them as asked
     void frontier_slots(std::vector<uint32_t>& out);
     // feedback is pointless where (almost) nothing dies: stop asking after enough evidence
     bool wants_feedback() const { return asked_ < 2048 || pruned_ * 50 >= asked_; }
+    // where a quarter or more of the states die, expanding an unconfirmed state is mostly wasted work:
+    // such a query only expands what the device has confirmed alive (advance(..., verified_only))
+    bool mostly_dying() const { return asked_ >= 64 && pruned_ * 4 >= asked_; }
     // drop every waiting state whose slot is listed as dead (dead[slot] != 0)
     void prune(const std::vector<uint8_t>& dead_by_slot);
     uint64_t states() const { return states_; }
@@ -210,6 +215,7 @@ struct StagedOptions {
     size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)
     size_t ops_per_task = 256u << 10;        // no query runs longer than this in one stage (load balance)
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
+    bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;
 };
 

@@ -129,8 +129,8 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
         exec.fn = fn;
         exec.user = user;
         StagedOptions opt;
-        // an explicit per-query budget is taken literally (no adaptive growth)
-        if (ops_per_query_per_stage) { opt.ops_per_query_per_stage = ops_per_query_per_stage; opt.stage_target_ops = 0; }
+        // an explicit per-query budget is taken literally (no adaptive growth, no waiting for verified states)
+        if (ops_per_query_per_stage) { opt.ops_per_query_per_stage = ops_per_query_per_stage; opt.stage_target_ops = 0; opt.verified_levels = false; }
         if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
         if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0, gaps->min_gap, gaps->max_gap};
         std::vector<int> st;
