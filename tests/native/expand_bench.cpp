@@ -14,7 +14,7 @@ struct Fake final : StageExecutor {
 };
 int main(int argc, char** argv) {
     std::vector<std::string> motifs; std::ifstream in(argv[1]); std::string l; while (std::getline(in, l)) if (!l.empty()) motifs.push_back(l);
-    KmerEncoder enc(Molecule::Peptide, 4, Alphabet::Base);
+    KmerEncoder enc(Molecule::Peptide, getenv("EB_K") ? (unsigned)atoi(getenv("EB_K")) : 4u, Alphabet::Base);
     StagedOptions opt; opt.threads = argc > 2 ? atoi(argv[2]) : 1;
     if (argc > 3) opt.ops_per_task = (size_t)atol(argv[3]);
     if (argc > 4) opt.ops_per_stage = (size_t)atol(argv[4]);
