@@ -1,7 +1,7 @@
 // Native timing harness for the staged expansion (no GPU, no Python): expands the motifs of a text file
 // against an executor that keeps every state alive and prints the time of five repetitions.
 //   g++ -O3 -march=native -std=c++20 -pthread -o /tmp/expand_bench tests/native/expand_bench.cpp \
-//       tetrex_amd/csrc/host/{encoder,regex_front,kgraph,compiler}.cpp && /tmp/expand_bench motifs.txt 16
+//       tetrex_amd/csrc/host/{encoder,regex_front,kgraph,compiler,staged}.cpp && /tmp/expand_bench motifs.txt 16
 #include "../../tetrex_amd/csrc/host/compiler.hpp"
 #include <chrono>
 #include <cstdio>

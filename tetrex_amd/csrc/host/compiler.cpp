@@ -2,16 +2,9 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <condition_variable>
-#include <future>
-#include <mutex>
-#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
-#include <thread>
 #include <stdexcept>
 
 namespace tetrex {
@@ -537,353 +530,6 @@ std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch
     std::vector<uint32_t> ends = schedule_levels_into(ops, n_slots, sc, sc.sorted.data(), 0, kDgramFlag);
     ops.swap(sc.sorted);
     return ends;
-}
-
-// ---- staged driver ------------------------------------------------------------------------
-
-StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
-                       const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages) {
-    const size_t n = regexes.size();
-    std::vector<int> st_local(n, 0);
-    std::vector<std::string> why(n);
-    std::vector<std::unique_ptr<QueryExpansion>> q(n);
-    std::vector<uint8_t> passthrough(n, 0);
-    // default: the hardware threads, but at most 16 — one GPU's CPU share on a multi-GPU node
-    // (override with StagedOptions::threads or the TETREX_THREADS environment variable)
-    int threads = opt.threads;
-    if (threads <= 0) {
-        if (const char* env = std::getenv("TETREX_THREADS")) threads = std::atoi(env);
-    }
-    if (threads <= 0) {
-        threads = (int)std::thread::hardware_concurrency();
-        if (threads > 16) threads = 16;
-    }
-    if (threads < 1) threads = 1;
-    if ((size_t)threads > n) threads = n ? (int)n : 1;
-
-    // every query is expanded by one thread at a time; threads own disjoint queries.
-    // A small persistent pool: workers pull indexes of the current job from an atomic counter.
-    struct Pool {
-        std::vector<std::thread> workers;
-        std::mutex m;
-        std::condition_variable wake, done;
-        const std::function<void(size_t, int)>* job = nullptr;
-        size_t count = 0, generation = 0, running = 0;
-        std::atomic<size_t> next{0};
-        bool stop = false;
-        explicit Pool(int n) {
-            for (int t = 1; t < n; ++t)
-                workers.emplace_back([this, t]() {
-                    size_t seen = 0;
-                    for (;;) {
-                        std::unique_lock<std::mutex> lk(m);
-                        wake.wait(lk, [&] { return stop || generation != seen; });
-                        if (stop) return;
-                        seen = generation;
-                        const auto* fn = job;
-                        const size_t cnt = count;
-                        lk.unlock();
-                        for (size_t i; (i = next.fetch_add(1)) < cnt;) (*fn)(i, t);
-                        lk.lock();
-                        if (--running == 0) done.notify_one();
-                    }
-                });
-        }
-        ~Pool() {
-            { std::lock_guard<std::mutex> lk(m); stop = true; }
-            wake.notify_all();
-            for (auto& w : workers) w.join();
-        }
-        void run(size_t cnt, const std::function<void(size_t, int)>& fn) {
-            if (workers.empty() || cnt < 2) { for (size_t i = 0; i < cnt; ++i) fn(i, 0); return; }
-            {
-                std::lock_guard<std::mutex> lk(m);
-                job = &fn; count = cnt; next.store(0); running = workers.size(); ++generation;
-            }
-            wake.notify_all();
-            for (size_t i; (i = next.fetch_add(1)) < cnt;) fn(i, 0);
-            std::unique_lock<std::mutex> lk(m);
-            done.wait(lk, [&] { return running == 0; });
-        }
-    } pool(threads);
-    auto parallel_for = [&](const std::function<void(size_t, int)>& body) { pool.run(n, body); };
-
-    parallel_for([&](size_t i, int) {
-        try {
-            if (bins <= 1) { passthrough[i] = 1; return; }  // include/query.h:265-272
-            const std::string postfix = preprocess_query(regexes[i], enc);
-            q[i] = std::make_unique<QueryExpansion>(enc, build_kgraph(postfix, enc.k(), enc.alphabet() != Alphabet::Base), opt.limits, opt.gaps);
-        } catch (const std::exception& e) {
-            q[i].reset();
-            st_local[i] = -1;
-            why[i] = e.what();
-        }
-    });
-
-    StagedStats st;
-    auto clock = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    // TETREX_TRACE=1: per-stage phase times on stderr
-    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
-    double lap_at = clock();
-    auto lap = [&](const char* what) {
-        if (!trace) return;
-        const double now = clock();
-        std::fprintf(stderr, "[tetrex] %-10s %8.2f ms\n", what, (now - lap_at) * 1e3);
-        lap_at = now;
-    };
-    lap("graphs");
-    double mark = clock();
-    std::vector<OpVec> ops(n);
-    std::vector<uint32_t> slots(n, TXQ_SLOT_FIRST_FREE);
-    // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
-    // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
-    std::vector<KmerTable> tables(n, KmerTable(false)), dgram_tables(n, KmerTable(false));
-    std::vector<LevelScratch> scratch(threads);
-    std::vector<std::vector<uint8_t>> dead_scratch(threads);
-    std::vector<std::vector<uint32_t>> levels(n), asks(n);
-    std::vector<uint64_t> fin_states(n, 0), fin_pruned(n, 0);
-    std::vector<uint32_t> touched, act;  // queries with ops in the previous stage; unfinished queries
-    // the stage's blob is assembled in place, in storage that is reused from stage to stage
-    struct RawBuffer {
-        uint8_t* data = nullptr;
-        size_t cap = 0;
-        ~RawBuffer() { std::free(data); }
-        // the first large request reserves the most a stage can need: untouched pages cost nothing,
-        // and a buffer that never moves is faulted in once instead of once per growth step
-        uint8_t* ensure(size_t bytes, size_t ceiling) {
-            if (bytes > cap) {
-                std::free(data);
-                data = nullptr;
-                cap = bytes > ((size_t)64 << 20) ? std::max(bytes + bytes / 2, ceiling) : bytes + bytes / 2;
-                data = static_cast<uint8_t*>(BlockCache::fresh(cap));
-            }
-            return data;
-        }
-    } blob_store;
-    bool first = true;
-    // While the device executes stage s, the queries that do not wait for its feedback are already
-    // expanded for stage s+1 (`ahead`); `carried` = the ops that produced.
-    bool verified_levels = opt.verified_levels;
-    if (const char* e = std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels = e[0] == '1';  // A/B knob
-    const bool overlap = !(std::getenv("TETREX_NO_OVERLAP") && std::getenv("TETREX_NO_OVERLAP")[0] == '1');
-    std::vector<uint8_t> ahead(n, 0);
-    size_t carried = 0;
-    std::vector<double> busy(threads, 0.0);
-    // expands the queries of `set` (largest first) until each has used its budget; returns the ops emitted
-    auto advance_set = [&](std::vector<uint32_t>& set, size_t already, size_t feedback_budget, size_t run_on_budget) -> size_t {
-        {
-            std::vector<uint64_t> w(n, 0);
-            for (uint32_t i : set) w[i] = q[i]->weight();
-            std::stable_sort(set.begin(), set.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });  // a stage ends when its last task ends
-        }
-        std::atomic<size_t> total{already};
-        pool.run(set.size(), [&](size_t at, int t) {
-            const size_t i = set[at];
-            const double t0 = trace ? clock() : 0.0;
-            struct Busy { double& acc; double t0; bool on; const decltype(clock)& clk; ~Busy() { if (on) acc += clk() - t0; } } busy_guard{busy[t], t0, trace, clock};
-            if (total.load(std::memory_order_relaxed) >= opt.ops_per_stage) return;  // waits for a later stage
-            try {
-                // a query that gains nothing from feedback only pauses to keep the stage's tasks even
-                const bool fb = q[i]->wants_feedback();
-                q[i]->advance(fb ? feedback_budget : run_on_budget, tables[i], ops[i], &dgram_tables[i], fb && verified_levels && q[i]->mostly_dying());
-            } catch (const std::exception& e) {
-                // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned
-                // query is neutralised by not emitting anything further
-                ops[i].clear();
-                tables[i].clear();
-                dgram_tables[i].clear();
-                q[i].reset();
-                st_local[i] = -1;
-                why[i] = e.what();
-                return;
-            }
-            total.fetch_add(ops[i].size(), std::memory_order_relaxed);
-            slots[i] = q[i]->n_slots();
-            if (q[i]->done()) {  // free the expansion's tables here, on the worker
-                fin_states[i] = q[i]->states();
-                fin_pruned[i] = q[i]->pruned();
-                q[i].reset();
-            }
-        });
-        return total.load() - already;
-    };
-    for (;;) {
-        touched.clear();
-        act.clear();
-        size_t unfinished = 0;
-        for (size_t i = 0; i < n; ++i) {
-            if (first && passthrough[i]) { ops[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT}); touched.push_back((uint32_t)i); }
-            if (ahead[i]) {  // expanded during the previous execution
-                ahead[i] = 0;
-                if (!ops[i].empty() || !tables[i].values().empty()) touched.push_back((uint32_t)i);
-                unfinished += q[i] && !q[i]->done();
-                continue;
-            }
-            if (q[i] && !q[i]->done()) { act.push_back((uint32_t)i); ++unfinished; }
-        }
-        // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
-        size_t feedback_budget = unfinished ? opt.stage_target_ops / unfinished : opt.ops_per_query_per_stage;
-        if (feedback_budget < opt.ops_per_query_per_stage) feedback_budget = opt.ops_per_query_per_stage;
-        if (feedback_budget > opt.ops_per_task) feedback_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
-        const size_t run_on_budget = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
-        std::fill(busy.begin(), busy.end(), 0.0);
-        const size_t stage_total = carried + advance_set(act, carried, feedback_budget, run_on_budget);
-        carried = 0;
-        if (trace) {
-            double sum = 0, mx = 0;
-            for (double b : busy) { sum += b; if (b > mx) mx = b; }
-            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, stage_total, act.size());
-        }
-        lap("advance");
-        bool pending = false;
-        for (uint32_t i : act)
-            if (!ops[i].empty() || !tables[i].values().empty()) touched.push_back(i);
-        for (size_t i = 0; i < n; ++i) pending |= q[i] && !q[i]->done();
-        if (!first && stage_total == 0 && !pending) break;
-
-        // layout: header | k-mer tables of the touched queries, then their d-gram tables (the device
-        // probes the last `stage_dgrams` entries on the auxiliary index) | programs | ops | levels
-        std::sort(touched.begin(), touched.end());
-        std::vector<uint32_t> base(touched.size()), dbase(touched.size()), first_op(touched.size());
-        size_t stage_kmers = 0, stage_dgrams = 0, stage_ops = 0;
-        for (size_t j = 0; j < touched.size(); ++j) {
-            base[j] = (uint32_t)stage_kmers;
-            stage_kmers += tables[touched[j]].values().size();
-            first_op[j] = (uint32_t)stage_ops;
-            stage_ops += ops[touched[j]].size();
-        }
-        for (size_t j = 0; j < touched.size(); ++j) {
-            dbase[j] = (uint32_t)(stage_kmers + stage_dgrams);
-            stage_dgrams += dgram_tables[touched[j]].values().size();
-        }
-        if (stage_kmers + stage_dgrams > 0x7FFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
-        if (stage_ops > 0xFFFFFFFFu) throw std::runtime_error("stage has more than 2^32 operations");
-        txq_blob_header_v2 h{};
-        h.magic = TXQ_PROGRAM_MAGIC;
-        h.version = TXQ_PROGRAM_VERSION_LEVELS;
-        h.n_programs = (uint32_t)n;
-        h.n_kmers = (uint32_t)(stage_kmers + stage_dgrams);
-        h.n_ops = (uint32_t)stage_ops;
-        h.n_aux_kmers = stage_dgrams;
-        h.kmers_offset = sizeof(txq_blob_header_v2);
-        h.programs_offset = h.kmers_offset + (stage_kmers + stage_dgrams) * sizeof(uint64_t);
-        h.ops_offset = h.programs_offset + n * sizeof(txq_program_v2);
-        h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
-        // a program has at most one level per op; the untouched tail of the reservation costs nothing
-        // per op: the op, a level entry at worst, a k-mer at worst
-        const size_t most_ops = opt.ops_per_stage + (size_t)threads * std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
-        uint8_t* blob = blob_store.ensure(h.levels_offset + stage_ops * 4 + 8, sizeof(txq_blob_header_v2) + n * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
-        uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
-        txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
-        pool.run(touched.size(), [&](size_t j, int t) {
-            const uint32_t i = touched[j];
-            const auto& km = tables[i].values();
-            if (!km.empty()) std::memcpy(blob_kmers + base[j], km.data(), km.size() * 8);
-            const auto& dg = dgram_tables[i].values();
-            if (!dg.empty()) std::memcpy(blob_kmers + dbase[j], dg.data(), dg.size() * 8);
-            levels[i] = schedule_levels_into(ops[i], slots[i], scratch[t], blob_ops + first_op[j], base[j], dbase[j]);
-        });
-        lap("levels");
-        txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob + h.programs_offset);
-        uint32_t* lv = reinterpret_cast<uint32_t*>(blob + h.levels_offset);
-        {
-            size_t j = 0;
-            uint32_t at_level = 0;
-            for (size_t i = 0; i < n; ++i) {
-                if (j < touched.size() && touched[j] == i) {
-                    const uint32_t nl = (uint32_t)levels[i].size();
-                    pr[i] = txq_program_v2{first_op[j], (uint32_t)ops[i].size(), slots[i], at_level, nl, 0};
-                    if (nl) std::memcpy(lv + at_level, levels[i].data(), (size_t)nl * 4);
-                    at_level += nl;
-                    ++j;
-                } else {
-                    pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots[i], at_level, 0, 0};
-                }
-            }
-            h.n_levels = at_level;
-            if (at_level & 1) lv[at_level] = 0;
-        }
-        std::memcpy(blob, &h, sizeof h);
-        const size_t blob_bytes = h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7);
-        lap("blob");
-
-        // the blob holds the stage now: the per-query buffers are free for the next one
-        for (uint32_t i : touched) {
-            if (q[i]) { ops[i].clear(); tables[i].clear(); dgram_tables[i].clear(); }
-            else { OpVec().swap(ops[i]); tables[i] = KmerTable(false); dgram_tables[i] = KmerTable(false); }  // finished: storage back to the cache
-            levels[i].clear();
-        }
-
-        // which waiting states does the device have to report on
-        std::vector<uint32_t> fb, run_on;
-        for (size_t i = 0; i < n; ++i) {
-            if (!q[i] || q[i]->done()) continue;
-            if (q[i]->wants_feedback()) fb.push_back((uint32_t)i);
-            else run_on.push_back((uint32_t)i);
-        }
-        pool.run(fb.size(), [&](size_t j, int) { asks[fb[j]].clear(); q[fb[j]]->frontier_slots(asks[fb[j]]); });
-        std::vector<uint32_t> qp, qs;
-        std::vector<size_t> ask_first(fb.size() + 1, 0);
-        for (size_t j = 0; j < fb.size(); ++j) {
-            const auto& v = asks[fb[j]];
-            qs.insert(qs.end(), v.begin(), v.end());
-            qp.insert(qp.end(), v.size(), fb[j]);
-            ask_first[j + 1] = qs.size();
-        }
-        std::vector<uint8_t> alive(qp.size(), 1);
-        lap("frontier");
-        st.expand_seconds += clock() - mark;
-        mark = clock();
-        if (overlap && !run_on.empty()) {
-            // the device runs this stage while the queries that do not wait for its answer go on
-            std::future<void> running = std::async(std::launch::async, [&]() { exec.stage(blob, blob_bytes, qp, qs, alive); });
-            std::fill(busy.begin(), busy.end(), 0.0);
-            try {
-                carried = advance_set(run_on, 0, run_on_budget, run_on_budget);
-            } catch (...) {
-                running.wait();
-                throw;
-            }
-            for (uint32_t i : run_on) ahead[i] = 1;
-            const double ahead_s = clock() - mark;
-            lap("ahead");
-            running.get();
-            const double both = clock() - mark;
-            st.expand_seconds += ahead_s;
-            st.execute_seconds += both - ahead_s;  // what the device added beyond the overlapped expansion
-        } else {
-            exec.stage(blob, blob_bytes, qp, qs, alive);
-            st.execute_seconds += clock() - mark;
-        }
-        mark = clock();
-        lap("execute");
-        ++st.stages;
-        st.ops += stage_total;
-        st.kmers += stage_kmers + stage_dgrams;
-        st.feedback_queries += qp.size();
-        // prune dead frontier states
-        pool.run(fb.size(), [&](size_t j, int t) {
-            bool any = false;
-            for (size_t a = ask_first[j]; a < ask_first[j + 1] && !any; ++a) any = !alive[a];
-            if (!any) return;
-            const uint32_t p = fb[j];
-            std::vector<uint8_t>& dead = dead_scratch[t];
-            dead.assign(q[p]->n_slots(), 0);
-            for (size_t a = ask_first[j]; a < ask_first[j + 1]; ++a)
-                if (!alive[a]) dead[qs[a]] = 1;
-            q[p]->prune(dead);
-        });
-        lap("prune");
-        first = false;
-        if (!pending) break;
-    }
-    for (size_t i = 0; i < n; ++i) {
-        if (q[i]) { st.states += q[i]->states(); st.pruned += q[i]->pruned(); }
-        else { st.states += fin_states[i]; st.pruned += fin_pruned[i]; }
-    }
-    if (status) *status = st_local;
-    if (messages) *messages = why;
-    return st;
 }
 
 // ---- one-shot batches ----------------------------------------------------------------------

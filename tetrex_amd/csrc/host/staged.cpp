@@ -1,0 +1,406 @@
+// Host side: the staged driver — a batch of queries is expanded piecewise (QueryExpansion,
+// compiler.cpp), every piece is shipped as one blob to a StageExecutor (the device session), and the
+// executor's answers about waiting states prune the frontier before it fans out (product code).
+//
+// One stage:
+//   advance   every unfinished query emits ops until its budget is used (thread pool, largest first);
+//             queries that no longer ask for feedback were already advanced while the previous stage
+//             executed (`ahead`)
+//   assemble  the stage's ops are ordered into dependency levels straight into the blob
+//             (header | k-mer tables | programs | ops | levels, include/txq_program.h)
+//   frontier  the waiting states of the queries that still ask for feedback
+//   execute   StageExecutor::stage on a helper thread, overlapped with the next `ahead` expansion
+//   prune     dead waiting states are dropped
+#include "compiler.hpp"
+#include "regex_front.hpp"
+#include "thread_pool.hpp"
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <future>
+#include <memory>
+#include <stdexcept>
+#include <thread>
+
+namespace tetrex {
+
+namespace {
+
+double now_seconds() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+bool env_is(const char* name, char value) {
+    const char* e = std::getenv(name);
+    return e && e[0] == value;
+}
+
+// default: the hardware threads, but at most 16 — one GPU's CPU share on a multi-GPU node
+// (override with StagedOptions::threads or the TETREX_THREADS environment variable)
+int expansion_threads(const StagedOptions& opt, size_t n_queries) {
+    int threads = opt.threads;
+    if (threads <= 0) {
+        if (const char* env = std::getenv("TETREX_THREADS")) threads = std::atoi(env);
+    }
+    if (threads <= 0) {
+        threads = (int)std::thread::hardware_concurrency();
+        if (threads > 16) threads = 16;
+    }
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > n_queries) threads = n_queries ? (int)n_queries : 1;
+    return threads;
+}
+
+// The stage's blob is assembled in place, in storage that is reused from stage to stage.  The first
+// large request reserves the most a stage can need: untouched pages cost nothing, and a buffer that
+// never moves is faulted in once instead of once per growth step.
+struct BlobStore {
+    uint8_t* data = nullptr;
+    size_t cap = 0;
+    ~BlobStore() { std::free(data); }
+    uint8_t* ensure(size_t bytes, size_t ceiling) {
+        if (bytes > cap) {
+            std::free(data);
+            data = nullptr;
+            cap = bytes > ((size_t)64 << 20) ? std::max(bytes + bytes / 2, ceiling) : bytes + bytes / 2;
+            data = static_cast<uint8_t*>(BlockCache::fresh(cap));
+        }
+        return data;
+    }
+};
+
+class StagedRun {
+  public:
+    StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
+        : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
+          status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
+          dgram_tables_(n_, KmerTable(false)), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
+          fin_pruned_(n_, 0), ahead_(n_, 0), busy_(threads_, 0.0) {
+        trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
+        verified_levels_ = opt.verified_levels;
+        if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
+        overlap_ = !env_is("TETREX_NO_OVERLAP", '1');
+        run_on_budget_ = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+    }
+
+    StagedStats run(std::vector<int>* status, std::vector<std::string>* messages) {
+        lap_at_ = now_seconds();
+        build_expansions();
+        lap("graphs");
+        double mark = now_seconds();
+        for (bool first = true;; first = false) {
+            const size_t stage_ops = advance_stage(first);
+            bool pending = false;
+            for (size_t i = 0; i < n_; ++i) pending |= q_[i] && !q_[i]->done();
+            if (!first && stage_ops == 0 && !pending) break;
+            const Blob blob = assemble();
+            Frontier fr = collect_frontier();
+            st_.expand_seconds += now_seconds() - mark;
+            mark = now_seconds();
+            execute(blob, fr);
+            mark = now_seconds();
+            ++st_.stages;
+            st_.ops += stage_ops;
+            st_.kmers += blob.kmers;
+            st_.feedback_queries += fr.program.size();
+            prune(fr);
+            if (!pending) break;
+        }
+        for (size_t i = 0; i < n_; ++i) {
+            if (q_[i]) { st_.states += q_[i]->states(); st_.pruned += q_[i]->pruned(); }
+            else { st_.states += fin_states_[i]; st_.pruned += fin_pruned_[i]; }
+        }
+        if (status) *status = status_;
+        if (messages) *messages = why_;
+        return st_;
+    }
+
+  private:
+    struct Blob { const uint8_t* data; size_t bytes; size_t kmers; };
+    struct Frontier {
+        std::vector<uint32_t> queries;         // the queries that asked, in the order of the questions
+        std::vector<size_t> first;             // [queries.size() + 1] range of each query's questions
+        std::vector<uint32_t> program, slot;   // the questions: is slot `slot[a]` of program `program[a]` alive?
+        std::vector<uint8_t> alive;            // the answers
+        std::vector<uint32_t> run_on;          // unfinished queries that did not ask
+    };
+
+    void lap(const char* what) {
+        if (!trace_) return;
+        const double now = now_seconds();
+        std::fprintf(stderr, "[tetrex] %-10s %8.2f ms\n", what, (now - lap_at_) * 1e3);
+        lap_at_ = now;
+    }
+
+    void build_expansions() {
+        pool_.run(n_, [&](size_t i, int) {
+            try {
+                if (bins_ <= 1) { passthrough_[i] = 1; return; }  // include/query.h:265-272
+                const std::string postfix = preprocess_query(regexes_[i], enc_);
+                q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps);
+            } catch (const std::exception& e) {
+                fail(i, e);
+            }
+        });
+    }
+
+    // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned query is
+    // neutralised by not emitting anything further
+    void fail(size_t i, const std::exception& e) {
+        ops_[i].clear();
+        tables_[i].clear();
+        dgram_tables_[i].clear();
+        q_[i].reset();
+        status_[i] = -1;
+        why_[i] = e.what();
+    }
+
+    // expands the queries of `set` (largest first) until each has used its budget; returns the ops emitted
+    size_t advance_set(std::vector<uint32_t>& set, size_t already, size_t feedback_budget) {
+        {
+            std::vector<uint64_t> w(n_, 0);
+            for (uint32_t i : set) w[i] = q_[i]->weight();
+            std::stable_sort(set.begin(), set.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });  // a stage ends when its last task ends
+        }
+        std::fill(busy_.begin(), busy_.end(), 0.0);
+        std::atomic<size_t> total{already};
+        pool_.run(set.size(), [&](size_t at, int t) {
+            const size_t i = set[at];
+            const double t0 = trace_ ? now_seconds() : 0.0;
+            if (total.load(std::memory_order_relaxed) >= opt_.ops_per_stage) return;  // waits for a later stage
+            try {
+                // a query that gains nothing from feedback only pauses to keep the stage's tasks even
+                const bool asks = q_[i]->wants_feedback();
+                q_[i]->advance(asks ? feedback_budget : run_on_budget_, tables_[i], ops_[i], &dgram_tables_[i],
+                               asks && verified_levels_ && q_[i]->mostly_dying());
+            } catch (const std::exception& e) {
+                fail(i, e);
+                return;
+            }
+            total.fetch_add(ops_[i].size(), std::memory_order_relaxed);
+            slots_[i] = q_[i]->n_slots();
+            if (q_[i]->done()) {  // free the expansion's tables here, on the worker
+                fin_states_[i] = q_[i]->states();
+                fin_pruned_[i] = q_[i]->pruned();
+                q_[i].reset();
+            }
+            if (trace_) busy_[t] += now_seconds() - t0;
+        });
+        if (trace_) {
+            double sum = 0, mx = 0;
+            for (double b : busy_) { sum += b; if (b > mx) mx = b; }
+            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, total.load(), set.size());
+        }
+        return total.load() - already;
+    }
+
+    // advance: fills touched_ (queries with something for this stage) and returns the stage's op count
+    size_t advance_stage(bool first) {
+        touched_.clear();
+        std::vector<uint32_t> act;
+        size_t unfinished = 0;
+        for (size_t i = 0; i < n_; ++i) {
+            if (first && passthrough_[i]) {
+                ops_[i].push_back(txq_op{TXQ_NO_KMER, TXQ_SLOT_RESULT, TXQ_SLOT_ONES, TXQ_SLOT_RESULT});
+                touched_.push_back((uint32_t)i);
+            }
+            if (ahead_[i]) {  // expanded during the previous execution
+                ahead_[i] = 0;
+                if (!ops_[i].empty() || !tables_[i].values().empty()) touched_.push_back((uint32_t)i);
+                unfinished += q_[i] && !q_[i]->done();
+                continue;
+            }
+            if (q_[i] && !q_[i]->done()) { act.push_back((uint32_t)i); ++unfinished; }
+        }
+        // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
+        size_t feedback_budget = unfinished ? opt_.stage_target_ops / unfinished : opt_.ops_per_query_per_stage;
+        if (feedback_budget < opt_.ops_per_query_per_stage) feedback_budget = opt_.ops_per_query_per_stage;
+        if (feedback_budget > opt_.ops_per_task) feedback_budget = run_on_budget_;
+        const size_t total = carried_ + advance_set(act, carried_, feedback_budget);
+        carried_ = 0;
+        for (uint32_t i : act)
+            if (!ops_[i].empty() || !tables_[i].values().empty()) touched_.push_back(i);
+        std::sort(touched_.begin(), touched_.end());
+        lap("advance");
+        return total;
+    }
+
+    // layout: header | k-mer tables of the touched queries, then their d-gram tables (the device
+    // probes the last `stage_dgrams` entries on the auxiliary index) | programs | ops | levels
+    Blob assemble() {
+        const size_t m = touched_.size();
+        std::vector<uint32_t> base(m), dbase(m), first_op(m);
+        size_t stage_kmers = 0, stage_dgrams = 0, stage_ops = 0;
+        for (size_t j = 0; j < m; ++j) {
+            base[j] = (uint32_t)stage_kmers;
+            stage_kmers += tables_[touched_[j]].values().size();
+            first_op[j] = (uint32_t)stage_ops;
+            stage_ops += ops_[touched_[j]].size();
+        }
+        for (size_t j = 0; j < m; ++j) {
+            dbase[j] = (uint32_t)(stage_kmers + stage_dgrams);
+            stage_dgrams += dgram_tables_[touched_[j]].values().size();
+        }
+        if (stage_kmers + stage_dgrams > 0x7FFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
+        if (stage_ops > 0xFFFFFFFFu) throw std::runtime_error("stage has more than 2^32 operations");
+        txq_blob_header_v2 h{};
+        h.magic = TXQ_PROGRAM_MAGIC;
+        h.version = TXQ_PROGRAM_VERSION_LEVELS;
+        h.n_programs = (uint32_t)n_;
+        h.n_kmers = (uint32_t)(stage_kmers + stage_dgrams);
+        h.n_ops = (uint32_t)stage_ops;
+        h.n_aux_kmers = stage_dgrams;
+        h.kmers_offset = sizeof(txq_blob_header_v2);
+        h.programs_offset = h.kmers_offset + (stage_kmers + stage_dgrams) * sizeof(uint64_t);
+        h.ops_offset = h.programs_offset + n_ * sizeof(txq_program_v2);
+        h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
+        // a program has at most one level per op, and per op at worst one k-mer: the ceiling of the reservation
+        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * run_on_budget_;
+        uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
+                                           sizeof(txq_blob_header_v2) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
+        uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
+        txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
+        pool_.run(m, [&](size_t j, int t) {
+            const uint32_t i = touched_[j];
+            const KmerVec& km = tables_[i].values();
+            if (!km.empty()) std::memcpy(blob_kmers + base[j], km.data(), km.size() * 8);
+            const KmerVec& dg = dgram_tables_[i].values();
+            if (!dg.empty()) std::memcpy(blob_kmers + dbase[j], dg.data(), dg.size() * 8);
+            levels_[i] = schedule_levels_into(ops_[i], slots_[i], scratch_[t], blob_ops + first_op[j], base[j], dbase[j]);
+        });
+        lap("levels");
+        txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob + h.programs_offset);
+        uint32_t* lv = reinterpret_cast<uint32_t*>(blob + h.levels_offset);
+        size_t j = 0;
+        uint32_t at_level = 0;
+        for (size_t i = 0; i < n_; ++i) {
+            if (j < m && touched_[j] == i) {
+                const uint32_t nl = (uint32_t)levels_[i].size();
+                pr[i] = txq_program_v2{first_op[j], (uint32_t)ops_[i].size(), slots_[i], at_level, nl, 0};
+                if (nl) std::memcpy(lv + at_level, levels_[i].data(), (size_t)nl * 4);
+                at_level += nl;
+                ++j;
+            } else {
+                pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, 0};
+            }
+        }
+        h.n_levels = at_level;
+        if (at_level & 1) lv[at_level] = 0;
+        std::memcpy(blob, &h, sizeof h);
+        // the blob holds the stage now: the per-query buffers are free for the next one
+        for (uint32_t i : touched_) {
+            if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
+            else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); }  // finished: storage back to the cache
+            levels_[i].clear();
+        }
+        lap("blob");
+        return Blob{blob, h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7), stage_kmers + stage_dgrams};
+    }
+
+    // which waiting states does the device have to report on
+    Frontier collect_frontier() {
+        Frontier fr;
+        for (size_t i = 0; i < n_; ++i) {
+            if (!q_[i] || q_[i]->done()) continue;
+            (q_[i]->wants_feedback() ? fr.queries : fr.run_on).push_back((uint32_t)i);
+        }
+        pool_.run(fr.queries.size(), [&](size_t j, int) {
+            const uint32_t i = fr.queries[j];
+            asks_[i].clear();
+            q_[i]->frontier_slots(asks_[i]);
+        });
+        fr.first.assign(fr.queries.size() + 1, 0);
+        for (size_t j = 0; j < fr.queries.size(); ++j) {
+            const std::vector<uint32_t>& v = asks_[fr.queries[j]];
+            fr.slot.insert(fr.slot.end(), v.begin(), v.end());
+            fr.program.insert(fr.program.end(), v.size(), fr.queries[j]);
+            fr.first[j + 1] = fr.slot.size();
+        }
+        fr.alive.assign(fr.program.size(), 1);
+        lap("frontier");
+        return fr;
+    }
+
+    // The device runs the stage; meanwhile the queries that do not wait for its answer go on
+    // (`ahead`; their ops are carried into the next stage).
+    void execute(const Blob& blob, Frontier& fr) {
+        const double start = now_seconds();
+        if (overlap_ && !fr.run_on.empty()) {
+            std::future<void> running = std::async(std::launch::async, [&]() { exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive); });
+            try {
+                carried_ = advance_set(fr.run_on, 0, run_on_budget_);
+            } catch (...) {
+                running.wait();
+                throw;
+            }
+            for (uint32_t i : fr.run_on) ahead_[i] = 1;
+            const double ahead_s = now_seconds() - start;
+            lap("ahead");
+            running.get();
+            st_.expand_seconds += ahead_s;
+            st_.execute_seconds += now_seconds() - start - ahead_s;  // what the device added beyond the overlapped expansion
+        } else {
+            exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive);
+            st_.execute_seconds += now_seconds() - start;
+        }
+        lap("execute");
+    }
+
+    void prune(const Frontier& fr) {
+        pool_.run(fr.queries.size(), [&](size_t j, int t) {
+            bool any = false;
+            for (size_t a = fr.first[j]; a < fr.first[j + 1] && !any; ++a) any = !fr.alive[a];
+            if (!any) return;
+            const uint32_t p = fr.queries[j];
+            std::vector<uint8_t>& dead = dead_scratch_[t];
+            dead.assign(q_[p]->n_slots(), 0);
+            for (size_t a = fr.first[j]; a < fr.first[j + 1]; ++a)
+                if (!fr.alive[a]) dead[fr.slot[a]] = 1;
+            q_[p]->prune(dead);
+        });
+        lap("prune");
+    }
+
+    const KmerEncoder& enc_;
+    const uint64_t bins_;
+    const std::vector<std::string>& regexes_;
+    StageExecutor& exec_;
+    const StagedOptions& opt_;
+    const size_t n_;
+    const int threads_;
+    ThreadPool pool_;  // every query is expanded by one thread at a time; threads own disjoint queries
+
+    std::vector<int> status_;
+    std::vector<std::string> why_;
+    std::vector<std::unique_ptr<QueryExpansion>> q_;  // null: failed, finished or a pass-through
+    std::vector<uint8_t> passthrough_;
+    std::vector<OpVec> ops_;       // per query: the ops of the stage being built
+    std::vector<uint32_t> slots_;  // per query: slots in use (what the device sizes the slot region by)
+    // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
+    // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
+    std::vector<KmerTable> tables_, dgram_tables_;
+    std::vector<LevelScratch> scratch_;               // per thread
+    std::vector<std::vector<uint8_t>> dead_scratch_;  // per thread
+    std::vector<std::vector<uint32_t>> levels_, asks_;
+    std::vector<uint64_t> fin_states_, fin_pruned_;   // statistics of the queries freed early
+    std::vector<uint32_t> touched_;                   // queries with ops or k-mers in the stage being built, ascending
+    std::vector<uint8_t> ahead_;                      // advanced while the previous stage executed
+    size_t carried_ = 0;                              // ops those produced
+    std::vector<double> busy_;
+    BlobStore blob_store_;
+    StagedStats st_;
+    size_t run_on_budget_ = 0;
+    bool trace_ = false, verified_levels_ = true, overlap_ = true;
+    double lap_at_ = 0;
+};
+
+}  // namespace
+
+StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
+                       const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages) {
+    return StagedRun(enc, bins, regexes, exec, opt).run(status, messages);
+}
+
+}  // namespace tetrex
