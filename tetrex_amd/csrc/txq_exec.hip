@@ -350,6 +350,53 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     return TXQ_OK;
 }
 
+// (re)size the programs' slot regions to what the stage needs; a grown region keeps its contents
+static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, hipStream_t st) {
+    bool moved = false;
+    for (size_t p = 0; p < s.n_programs; ++p) {
+        const uint32_t need = bv.n_slots[p];
+        if (need <= s.cap[p]) continue;
+        uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
+        if (cap < need) cap = need;
+        uint64_t* region = nullptr;
+        if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
+        if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
+        else fresh->push_back((uint32_t)p);
+        s.base[p] = region;
+        s.cap[p] = cap;
+        moved = true;
+    }
+    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
+    return TXQ_OK;
+}
+
+// Big level-scheduled programs leave the one-workgroup-per-program kernel: their ops are cut into
+// units per dependency level (units of level l, all programs, are contiguous in `units`) and every
+// level becomes one launch over the whole GPU.  Returns the number of programs left to exec_kernel.
+static size_t plan_units(BlobView& bv, const uint32_t* levels_host, std::vector<ExecUnit>* units, std::vector<size_t>* level_units) {
+    std::vector<std::vector<ExecUnit>> per_level;
+    size_t n_small = 0;
+    for (size_t p = 0; p < bv.programs.size(); ++p) {
+        DevProgram& d = bv.programs[p];
+        if (d.n_levels == 0 || d.n_ops < 2048) { n_small += d.n_ops != 0; continue; }
+        if (per_level.size() < d.n_levels) per_level.resize(d.n_levels);
+        uint32_t begin = 0;
+        for (uint32_t l = 0; l < d.n_levels; ++l) {
+            const uint32_t end = levels_host[d.first_level + l];
+            for (uint32_t at = begin; at < end; at += kUnitOps)
+                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < kUnitOps ? end : at + kUnitOps)});
+            begin = end;
+        }
+        d.n_ops = 0;  // the per-program kernel skips it
+    }
+    level_units->resize(per_level.size());
+    for (size_t l = 0; l < per_level.size(); ++l) {
+        (*level_units)[l] = per_level[l].size();
+        units->insert(units->end(), per_level[l].begin(), per_level[l].end());
+    }
+    return n_small;
+}
+
 int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
                   uint8_t* alive, hipStream_t st) {
     Index& ix = *s.ix;
@@ -371,48 +418,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         for (size_t i = 0; i < n_q; ++i) alive[i] = 0;
         return TXQ_OK;
     }
-    // (re)size slot regions; a grown region keeps its contents
-    std::vector<uint32_t> fresh;
-    bool moved = false;
-    for (size_t p = 0; p < s.n_programs; ++p) {
-        const uint32_t need = bv.n_slots[p];
-        if (need <= s.cap[p]) continue;
-        uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
-        if (cap < need) cap = need;
-        uint64_t* region = nullptr;
-        if (int rc = arena_alloc(s, (size_t)cap * W, &region)) return rc;
-        if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * W * 8, hipMemcpyDeviceToDevice, st));
-        else fresh.push_back((uint32_t)p);
-        s.base[p] = region;
-        s.cap[p] = cap;
-        moved = true;
-    }
-    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
+    std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
+    if (int rc = grow_slot_regions(s, bv, &fresh, st)) return rc;
 
-    // Big level-scheduled programs leave the one-workgroup-per-program kernel: their ops are cut
-    // into units per dependency level and every level becomes one launch over the whole GPU.
     const uint32_t* levels_host = h->n_levels ? (const uint32_t*)(blob + h->levels_offset) : nullptr;
-    std::vector<std::vector<ExecUnit>> per_level;
-    size_t n_small = 0;
-    for (size_t p = 0; p < s.n_programs; ++p) {
-        DevProgram& d = bv.programs[p];
-        if (d.n_levels == 0 || d.n_ops < 2048) { n_small += d.n_ops != 0; continue; }
-        if (per_level.size() < d.n_levels) per_level.resize(d.n_levels);
-        uint32_t begin = 0;
-        for (uint32_t l = 0; l < d.n_levels; ++l) {
-            const uint32_t end = levels_host[d.first_level + l];
-            for (uint32_t at = begin; at < end; at += kUnitOps)
-                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < kUnitOps ? end : at + kUnitOps)});
-            begin = end;
-        }
-        d.n_ops = 0;  // the per-program kernel skips it
-    }
     std::vector<ExecUnit> units;
-    std::vector<size_t> level_units(per_level.size());
-    for (size_t l = 0; l < per_level.size(); ++l) {
-        level_units[l] = per_level[l].size();
-        units.insert(units.end(), per_level[l].begin(), per_level[l].end());
-    }
+    std::vector<size_t> level_units;
+    const size_t n_small = plan_units(bv, levels_host, &units, &level_units);
 
     // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
