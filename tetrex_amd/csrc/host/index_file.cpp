@@ -292,11 +292,20 @@ DgramImage parse_dgram_index(const std::vector<uint8_t>& bytes) {
     throw std::runtime_error("not a TetRex d-gram index (no known layout variant fits): " + first_error);
 }
 
-DgramImage read_dgram_index_file(const std::string& path) {
-    std::ifstream f(path, std::ios::binary);
+// the whole file in one sized read (an index is hundreds of MB: no byte-wise stream iteration)
+static std::vector<uint8_t> read_whole_file(const std::string& path) {
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
     if (!f) throw std::runtime_error("Filepath " + path + " not valid");
-    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    return parse_dgram_index(bytes);
+    const std::streamoff size = f.tellg();
+    if (size < 0) throw std::runtime_error("Filepath " + path + " not valid");
+    std::vector<uint8_t> bytes((size_t)size);
+    f.seekg(0);
+    if (size && !f.read(reinterpret_cast<char*>(bytes.data()), size)) throw std::runtime_error("could not read " + path);
+    return bytes;
+}
+
+DgramImage read_dgram_index_file(const std::string& path) {
+    return parse_dgram_index(read_whole_file(path));
 }
 
 IndexImage parse_index(const std::vector<uint8_t>& bytes) {
@@ -322,10 +331,7 @@ IndexImage parse_index(const std::vector<uint8_t>& bytes) {
 }
 
 IndexImage read_index_file(const std::string& path) {
-    std::ifstream f(path, std::ios::binary);
-    if (!f) throw std::runtime_error("Filepath " + path + " not valid");
-    std::vector<uint8_t> bytes((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
-    return parse_index(bytes);
+    return parse_index(read_whole_file(path));
 }
 
 void peek_index_params(const std::vector<uint8_t>& bytes, uint8_t& k, std::string& molecule, bool& is_hibf) {

@@ -12,6 +12,7 @@
 #include "verify.hpp"
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <filesystem>
 #include <fstream>
@@ -113,6 +114,8 @@ int cmd_query(int argc, char** argv) {
     std::string input = a.pos[1];
     if (input == "-") std::cin >> input;
 
+    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
+    const double t_start = now();
     IndexImage image;
     try {
         image = read_index_file(a.pos[0]);
@@ -121,8 +124,10 @@ int cmd_query(int argc, char** argv) {
         std::cerr << e.what() << '\n';
         return 0;
     }
+    const double t_read = now();
     DeviceIndex dev;
     dev.upload(image, std::atoi(a.get("device", "0").c_str()));
+    if (trace) std::cerr << "[tetrex] index read+parse " << (t_read - t_start) << " s, device init+upload " << (now() - t_read) << " s" << std::endl;
     if (a.has("gibf")) dev.attach_dgram(read_dgram_index_file(a.get("gibf", "")));  // include/query.h:259-264
     StagedOptions sopt;
     sopt.gaps.augment = a.has("augment");
