@@ -58,7 +58,7 @@ __device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, const uint64
     }
 }
 
-// One workgroup per program.  G lanes per op (pow2 >= W, <= 64); lane `sub` owns words sub, sub+G, ...
+// One workgroup per program.  G lanes per op (pow2 >= W, at most the workgroup); lane `sub` owns words sub, sub+G, ...
 // A level's ops are dealt round-robin to the workgroup's lane groups; __syncthreads() separates
 // levels.  Programs without a level table run in op order on lane group 0.
 template <int G>
@@ -90,11 +90,12 @@ __global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict
 }
 
 // Big programs: one launch per dependency level, the level's ops of ALL big programs cut into
-// units of <= kUnitOps ops; one workgroup per unit, G lanes per op.  The kernel boundary is the
+// units of <= unit_ops(W) ops; one workgroup per unit, G lanes per op (up to the whole workgroup for wide masks).  The kernel boundary is the
 // barrier between levels, so slot words are plain loads/stores; concurrent accumulations use
 // agent-scope atomics (units of one program may run on different XCDs).
 struct ExecUnit { uint32_t program, begin, end; };
-static constexpr uint32_t kUnitOps = 128;
+static constexpr uint32_t kUnitWords = 2048;  // mask words one unit moves per operand: 128 ops of a 1024-bin index, 2 ops at 65536 bins
+static inline uint32_t unit_ops(uint32_t W) { return W >= kUnitWords ? 1u : kUnitWords / W; }
 
 template <int G>
 __global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
@@ -373,18 +374,20 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
 // Big level-scheduled programs leave the one-workgroup-per-program kernel: their ops are cut into
 // units per dependency level (units of level l, all programs, are contiguous in `units`) and every
 // level becomes one launch over the whole GPU.  Returns the number of programs left to exec_kernel.
-static size_t plan_units(BlobView& bv, const uint32_t* levels_host, std::vector<ExecUnit>* units, std::vector<size_t>* level_units) {
+static size_t plan_units(BlobView& bv, const uint32_t* levels_host, uint32_t W, std::vector<ExecUnit>* units, std::vector<size_t>* level_units) {
+    const uint32_t per_unit = unit_ops(W);
     std::vector<std::vector<ExecUnit>> per_level;
     size_t n_small = 0;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
         DevProgram& d = bv.programs[p];
-        if (d.n_levels == 0 || d.n_ops < 2048) { n_small += d.n_ops != 0; continue; }
+        // small = less work than a unit launch is worth: 2048 ops of a 1024-bin index, 32 ops at 65536 bins
+        if (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u) { n_small += d.n_ops != 0; continue; }
         if (per_level.size() < d.n_levels) per_level.resize(d.n_levels);
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
-            for (uint32_t at = begin; at < end; at += kUnitOps)
-                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < kUnitOps ? end : at + kUnitOps)});
+            for (uint32_t at = begin; at < end; at += per_unit)
+                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < per_unit ? end : at + per_unit)});
             begin = end;
         }
         d.n_ops = 0;  // the per-program kernel skips it
@@ -424,7 +427,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const uint32_t* levels_host = h->n_levels ? (const uint32_t*)(blob + h->levels_offset) : nullptr;
     std::vector<ExecUnit> units;
     std::vector<size_t> level_units;
-    const size_t n_small = plan_units(bv, levels_host, &units, &level_units);
+    const size_t n_small = plan_units(bv, levels_host, W, &units, &level_units);
 
     // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
@@ -476,8 +479,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (e != hipSuccess) return fail_hip(e, "d-gram probe kernel launch");
     }
     if (h->n_ops) {
+        // lanes per op: the mask width rounded up to a power of two, at most the whole workgroup
+        // (a 65536-bin mask is 1024 words: one word per thread of exec_kernel, four per thread of a unit)
         int g = 1;
-        while (g < 64 && (uint32_t)g < W) g <<= 1;
+        while (g < 1024 && (uint32_t)g < W) g <<= 1;
+        const int g_units = g < 256 ? g : 256;
         const txq_op* d_ops = (const txq_op*)(s.d_blob + h->ops_offset);
         const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(s.d_blob + h->levels_offset) : nullptr;
         if (n_small) {
@@ -490,7 +496,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 case 8: TXQ_EXEC(8); break;
                 case 16: TXQ_EXEC(16); break;
                 case 32: TXQ_EXEC(32); break;
-                default: TXQ_EXEC(64); break;
+                case 64: TXQ_EXEC(64); break;
+                case 128: TXQ_EXEC(128); break;
+                case 256: TXQ_EXEC(256); break;
+                case 512: TXQ_EXEC(512); break;
+                default: TXQ_EXEC(1024); break;
             }
 #undef TXQ_EXEC
         }
@@ -499,14 +509,16 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             const size_t cnt = level_units[l];
             if (cnt == 0) continue;
 #define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, ix.scratch_masks, W)
-            switch (g) {
+            switch (g_units) {
                 case 1: TXQ_UNITS(1); break;
                 case 2: TXQ_UNITS(2); break;
                 case 4: TXQ_UNITS(4); break;
                 case 8: TXQ_UNITS(8); break;
                 case 16: TXQ_UNITS(16); break;
                 case 32: TXQ_UNITS(32); break;
-                default: TXQ_UNITS(64); break;
+                case 64: TXQ_UNITS(64); break;
+                case 128: TXQ_UNITS(128); break;
+                default: TXQ_UNITS(256); break;
             }
 #undef TXQ_UNITS
             first += cnt;
