@@ -160,6 +160,15 @@ def record_values(seq, k, dna=True, reduction=0, wraparound=False):
     return [int(x) for x in out[:n]]
 
 
+def record_values_array(seq, k, dna=True, reduction=0, wraparound=False):
+    """record_values as a uint64 numpy array (no per-value Python objects: for whole sequences)."""
+    s = seq.encode() if isinstance(seq, str) else seq
+    cap = len(s) + 2
+    out = np.zeros(cap, dtype=np.uint64)
+    n = lib().txh_record_values(int(dna), k, reduction, s, len(s), int(wraparound), out.ctypes.data_as(u64p), cap)
+    return out[:n].copy()
+
+
 def parse_blob(blob):
     """Decode a txq_program.h blob (version 1 or 2): (kmers uint64[], [(n_slots, ops array [n,4] =
     kmer,dst,a,b)]).  Version-2 ops are in level order, which is also a valid sequential order."""
