@@ -368,6 +368,22 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             }
             continue;
         }
+        constexpr size_t kBatch = 16;
+        State pending[kBatch];
+        size_t n_pending = 0;
+        const int32_t receiver = forward_[item];
+        const bool batching = receiver != KGraph::kNone && !dangling_[item] && !single_source_[receiver] && input->size() >= 4 * kBatch;
+        auto flush = [&]() {
+            const FlatMap& keys = table_[receiver].by_key;
+            const unsigned bits = enc_.bits_per_symbol();
+            for (size_t i = 0; i < n_pending; ++i) {
+                const State& t = pending[i];
+                const unsigned phase = t.shift < k - 1 ? t.shift : k - 1;
+                keys.prefetch(t.gapped ? (t.kmer | ((uint64_t)(4 + t.shift) << 60)) : ((t.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits))));
+            }
+            for (size_t i = 0; i < n_pending; ++i) arrive(receiver, pending[i], out);
+            n_pending = 0;
+        };
         for (State s : *input) {
             if (s.gapped) {  // update_gapped: three residues complete the d-gram
                 if (s.shift == 0) { s.kmer += 400ULL * dgram_residue_code(lab); s.res1 = (uint8_t)lab; s.shift = 1; }
@@ -411,8 +427,17 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 }
                 s.shift = (uint8_t)k;
             }
-            hand_on(item, s, out);
+            // Arrivals of one node all go to the same receiver; with millions of keys (k = 6 peptides)
+            // its merge table lives in DRAM, so the table lines of a batch of arrivals are requested
+            // before the first of them is merged.
+            if (batching) {
+                pending[n_pending++] = s;
+                if (n_pending == kBatch) flush();
+            } else {
+                hand_on(item, s, out);
+            }
         }
+        if (n_pending) flush();
     }
 }
 

@@ -213,7 +213,8 @@ struct StagedOptions {
     int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
     size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)
-    size_t ops_per_task = 256u << 10;        // no query runs longer than this in one stage (load balance)
+    size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it doubles with every further stage the query
+                                             // needs (up to 32x), so a skewed batch is not held to many stages by its heaviest query
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;

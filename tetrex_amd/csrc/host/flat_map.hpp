@@ -42,6 +42,10 @@ class FlatMap {
             i = (i + 1) & (cap_ - 1);
         }
     }
+    // pulls the cache line a later emplace(key, ...) will look at first
+    void prefetch(uint64_t key) const {
+        if (cap_) __builtin_prefetch(&slots_[mix(key) & (cap_ - 1)]);
+    }
     // room for `n` entries without growing
     void reserve(size_t n) {
         size_t want = 16;

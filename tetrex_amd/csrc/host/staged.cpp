@@ -77,7 +77,7 @@ class StagedRun {
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
           dgram_tables_(n_, KmerTable(false)), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
-          fin_pruned_(n_, 0), ahead_(n_, 0), busy_(threads_, 0.0) {
+          fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
@@ -173,7 +173,10 @@ class StagedRun {
             try {
                 // a query that gains nothing from feedback only pauses to keep the stage's tasks even
                 const bool asks = q_[i]->wants_feedback();
-                q_[i]->advance(asks ? feedback_budget : run_on_budget_, tables_[i], ops_[i], &dgram_tables_[i],
+                // a feedback-free query that keeps coming back doubles its budget each time (256 k, 512 k, ... 8 M)
+                const size_t grown = run_on_budget_ << std::min<uint32_t>(run_on_stages_[i], 5);
+                if (!asks) ++run_on_stages_[i];
+                q_[i]->advance(asks ? feedback_budget : grown, tables_[i], ops_[i], &dgram_tables_[i],
                                asks && verified_levels_ && q_[i]->mostly_dying());
             } catch (const std::exception& e) {
                 fail(i, e);
@@ -257,7 +260,7 @@ class StagedRun {
         h.ops_offset = h.programs_offset + n_ * sizeof(txq_program_v2);
         h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
         // a program has at most one level per op, and per op at worst one k-mer: the ceiling of the reservation
-        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * run_on_budget_;
+        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 5, opt_.limits.max_ops);
         uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
                                            sizeof(txq_blob_header_v2) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
         uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
@@ -387,6 +390,7 @@ class StagedRun {
     std::vector<uint64_t> fin_states_, fin_pruned_;   // statistics of the queries freed early
     std::vector<uint32_t> touched_;                   // queries with ops or k-mers in the stage being built, ascending
     std::vector<uint8_t> ahead_;                      // advanced while the previous stage executed
+    std::vector<uint32_t> run_on_stages_;             // per query: stages it has run without asking for feedback
     size_t carried_ = 0;                              // ops those produced
     std::vector<double> busy_;
     BlobStore blob_store_;
