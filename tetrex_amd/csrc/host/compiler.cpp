@@ -2,6 +2,7 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -216,7 +217,7 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
     if (ns.items.capacity() == 0) adopt_storage(ns);
-    if (single_source_[to]) {  // nothing to merge with: no table look-up
+    if (single_source_[to] || ns.append_only) {  // nothing to merge with, or merging does not pay: no table look-up
         s.asked = 0;
         ns.items.push_back(s);
         ++waiting_;
@@ -258,6 +259,29 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
     }
 }
 
+// Will the arrivals that a union of residue nodes makes out of `list` merge at the node after it?  Two
+// of them merge exactly when their states agree in everything but the oldest symbol of the key, so the
+// answer is in the list itself: a sample taken BY KEY (one sixteenth of the key space, so both partners
+// of a pair are in or out together) counts how many states have such a partner.
+bool QueryExpansion::merging_pays(const StateVec& list) {
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    const uint64_t rest_mask = enc_.suffix_mask() >> bits;
+    if (!rest_mask) return true;
+    FlatMap seen;
+    if (!spare_maps_.empty()) { std::swap(seen, spare_maps_.back()); spare_maps_.pop_back(); }
+    uint32_t sampled = 0, partners = 0;
+    for (const State& s : list) {
+        if (s.gapped || s.shift < k - 1) { sampled = 0; break; }  // not the uniform case: keep merging
+        const uint64_t rest = s.kmer & rest_mask;
+        if ((rest * 0x9E3779B97F4A7C15ULL) >> 60) continue;
+        ++sampled;
+        if (!seen.emplace(rest, 0).second) ++partners;
+    }
+    seen.clear();
+    if (seen.capacity() && spare_maps_.size() < 64) { spare_maps_.emplace_back(); std::swap(spare_maps_.back(), seen); }
+    return sampled < 64 || partners * 4 >= sampled;  // a quarter or more of the states would be absorbed
+}
+
 void QueryExpansion::adopt_storage(NodeStates& ns) {
     if (!spare_items_.empty()) { ns.items.swap(spare_items_.back()); spare_items_.pop_back(); }
     if (ns.by_key.capacity() == 0 && !spare_maps_.empty()) { std::swap(ns.by_key, spare_maps_.back()); spare_maps_.pop_back(); }
@@ -287,6 +311,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         NodeStates ns;
         ns.items.swap(table_[item].items);
         waiting_ -= ns.items.size();
+        table_[item].append_only = false;
         if (table_[item].by_key.capacity()) {
             table_[item].by_key.clear();
             if (table_[item].by_key.capacity() && spare_maps_.size() < 64) { spare_maps_.emplace_back(); std::swap(spare_maps_.back(), table_[item].by_key); }
@@ -308,6 +333,11 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     if (!single_source_[fan_[i]]) arrive(fan_[i], s, out);
             }
             if (readers && !ns.items.empty()) {
+                if (ns.items.size() >= kMergeSample && !merging_pays(ns.items))
+                    for (uint32_t i = lo; i < hi; ++i) {  // the readers' receivers will just append
+                        const int32_t reader = fan_[i], recv = single_source_[reader] ? forward_[reader] : KGraph::kNone;
+                        if (recv != KGraph::kNone && !single_source_[recv] && table_[recv].items.empty()) table_[recv].append_only = true;
+                    }
                 for (uint32_t i = lo; i < hi; ++i)
                     if (single_source_[fan_[i]]) input_of_[fan_[i]] = item;
                 readers_[item - n_nodes_ - 1] = readers;
@@ -343,7 +373,8 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             // the merging table of the receiver grows once, not by repeated doubling and re-hashing
             NodeStates& next = table_[forward_[item]];
             if (next.items.capacity() == 0) adopt_storage(next);
-            next.by_key.reserve(next.items.size() + input->size());
+            if (next.append_only) next.items.reserve(next.items.size() + input->size());
+            else next.by_key.reserve(next.items.size() + input->size());
         }
         if (lab == KGraph::kMatch) {
             for (const State& s : *input) {
@@ -479,7 +510,7 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         NodeStates& ns = table_[order_[c]];
         if (!sweep(ns.items, 1)) continue;
         ns.by_key.clear();
-        if (single_source_[order_[c]]) continue;
+        if (single_source_[order_[c]] || ns.append_only) continue;
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;

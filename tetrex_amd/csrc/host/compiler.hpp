@@ -134,7 +134,14 @@ class QueryExpansion {
   private:
     struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; uint8_t gapped = 0; uint8_t res1 = 0, res2 = 0; };
     using StateVec = CachedVector<State>;
-    struct NodeStates { StateVec items; FlatMap by_key; };
+    // by_key merges arrivals with equal keys (the collector's absorb).  Merging is an optimisation, not a
+    // requirement: two unmerged states with one key just do the same work twice and OR the same bits into
+    // RESULT.  Where a join's list shows that (almost) none of the arrivals made from it can merge —
+    // sparse state sets, typical at k = 6 — the receiver gets no table and just appends (`append_only`):
+    // its look-ups, growth and initialisation were a third of the expansion time there.
+    struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; };
+    static constexpr uint32_t kMergeSample = 4096;  // lists shorter than this are not worth the question
+    bool merging_pays(const StateVec& list);
     const KmerEncoder& enc_;
     KGraph g_;
     CompileLimits limits_;
@@ -213,8 +220,8 @@ struct StagedOptions {
     int threads = 0;                         // expansion threads (0 = all hardware threads)
     size_t ops_per_query_per_stage = 4096;   // pause a query for feedback after this many new ops
     size_t ops_per_stage = 16u << 20;        // bound on one stage's blob (256 MiB of ops)
-    size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it doubles with every further stage the query
-                                             // needs (up to 32x), so a skewed batch is not held to many stages by its heaviest query
+    size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it quadruples with every further stage the query
+                                             // needs (up to 16x), so a skewed batch is not held to many stages by its heaviest query
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;

@@ -83,6 +83,7 @@ class StagedRun {
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
         overlap_ = !env_is("TETREX_NO_OVERLAP", '1');
         run_on_budget_ = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
     }
 
     StagedStats run(std::vector<int>* status, std::vector<std::string>* messages) {
@@ -173,8 +174,8 @@ class StagedRun {
             try {
                 // a query that gains nothing from feedback only pauses to keep the stage's tasks even
                 const bool asks = q_[i]->wants_feedback();
-                // a feedback-free query that keeps coming back doubles its budget each time (256 k, 512 k, ... 8 M)
-                const size_t grown = run_on_budget_ << std::min<uint32_t>(run_on_stages_[i], 5);
+                // a feedback-free query that keeps coming back quadruples its budget each time (256 k, 1 M, 4 M)
+                const size_t grown = run_on_budget_ << (2 * std::min<uint32_t>(run_on_stages_[i], 2));
                 if (!asks) ++run_on_stages_[i];
                 q_[i]->advance(asks ? feedback_budget : grown, tables_[i], ops_[i], &dgram_tables_[i],
                                asks && verified_levels_ && q_[i]->mostly_dying());
@@ -260,7 +261,7 @@ class StagedRun {
         h.ops_offset = h.programs_offset + n_ * sizeof(txq_program_v2);
         h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
         // a program has at most one level per op, and per op at worst one k-mer: the ceiling of the reservation
-        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 5, opt_.limits.max_ops);
+        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 4, opt_.limits.max_ops);
         uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
                                            sizeof(txq_blob_header_v2) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
         uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
