@@ -83,3 +83,23 @@ def test_one_bin_index_and_failed_queries(host, oracle):
     status, _ = host.run_staged(["LMAEG", "A{2,}", "LMAE"], False, 4, 0, 100, sim.stage)
     assert status[0] == 0 and status[1] != 0 and status[2] == 0
     assert np.array_equal(sim.result(0), ox.query("LMAEG")) and not sim.result(1).any()
+
+
+def test_default_policy_on_sparse_and_dense_indexes_at_k5(host, oracle):
+    """The product's default policy (adaptive budgets, expansion of confirmed states only where most
+    states die, no merge table where a join's list has no mergeable pair) against the oracle at k = 5:
+    a SPARSE index, where wildcard frontiers mostly die, and a DENSE one (every bit set: nothing dies,
+    the lists after a wildcard run reach 20^4 states and beyond the merge-sample threshold)."""
+    qs = ["LMA..E[DE]GLY", "WK.{1,2}[LIVM]D.F", "AC.DE.GH", "M[KR]..S[ST].L", "LMAEGLYN", "C.{2}C.H"]
+    sparse = _index(oracle, bins=96, m=80021, h=3, k=5, dna=False, per_bin=300, seed=8)
+    checked, stats, sim = _run(host, sparse, qs, False, 5, 0)
+    assert checked == len(qs)
+    wide = ["L...M...K", "A.{3}C.{2}DE", "W....[DE]K"]  # thousands of paths each: several stages, most states die
+    checked, stats, sim = _run(host, sparse, wide, False, 5, 0)
+    assert checked == len(wide) and stats["pruned"] > 0 and stats["stages"] >= 2
+    dense = oracle.Index.ibf(64, 257, 3, dna=False, k=5)
+    dense.set_words(np.full(257 * 1, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64))
+    checked, stats, sim = _run(host, dense, qs, False, 5, 0)
+    assert checked == len(qs) and stats["pruned"] == 0
+    for i in range(len(qs)):
+        assert int(sim.result(i)[0]) == 0xFFFFFFFFFFFFFFFF
