@@ -273,7 +273,7 @@ def main():
     ap.add_argument("--bins-per-gpu", type=int, default=1024)
     ap.add_argument("--per-bin", type=int, default=200000, help="values inserted per bin")
     ap.add_argument("--hash", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=1 << 23, help="k-mers timed on the CPU oracle (rank 0, N=1)")
+    ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="k-mers timed on the CPU oracle (rank 0, N=1); default: the whole batch")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-queries", action="store_true", help="skip the end-to-end queries/s leg")
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
