@@ -17,7 +17,8 @@ Output: ONE JSON line on rank 0 (contract in the task description), including
   roofline     — algorithmic bytes of the probe kernel / its HIP-event duration vs 8 TB/s HBM,
   cpu_baseline — the CPU oracle (oracle/, a port of the reference path) timed on this host.
 Two further legs report the other BASELINE figures without touching `value`:
-  end_to_end   — queries/s, regex -> candidate-bin mask, on the same index;
+  end_to_end   — queries/s, regex -> candidate-bin mask, on the same index, with its own cpu_baseline
+                 (the oracle's single-threaded query(), ~10 s, masks compared bit for bit);
   hibf         — k-mers/s of the HIBF descent on a 65536-user-bin tree (BASELINE configs[4] shape).
 """
 import argparse
@@ -113,6 +114,33 @@ def cpu_baseline(ix, m, h, bins_local, kmers, sample, threads):
     return out, q.size / dt, dt
 
 
+def cpu_query_baseline(ix, m, h, bins_local, k, motifs, gpu_masks, budget_s):
+    """cpu_baseline of the end-to-end leg: the oracle's query() (restatement of preprocess ->
+    construct_kgraph -> OTFCollector::collect with immediate pruning, one thread like the reference) on
+    the first motifs of the same batch, for about `budget_s` seconds, on the device-built matrix.  The
+    masks double as a parity check of the GPU result."""
+    import oracle as O
+    ox = O.Index.ibf(bins_local, m, h, dna=False, k=k)
+    ox.set_words(ix.download_words_rows(m))
+    done, compared, t0 = 0, 0, time.perf_counter()
+    for i, rx in enumerate(motifs):
+        try:
+            mask, st = ox.query(rx, with_stats=True)
+        except Exception:  # noqa: BLE001 - a motif the reference path cannot search either
+            done += 1
+            continue
+        done += 1
+        if st["quirk_merges"] == 0:  # the reference's result is well defined
+            if not np.array_equal(mask, gpu_masks[i]):
+                raise SystemExit("bench: the candidate-bin mask of %r differs from the CPU oracle" % rx)
+            compared += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": done / dt, "unit": "queries/s", "cores": 1, "kind": "port",
+            "sample": "first %d motifs of the same batch, single thread, %.1f s" % (done, dt), "masks_compared": compared}
+
+
 def end_to_end_queries(ix, torch, dist, world, rank, args):
     """Second headline metric (BASELINE.json): end-to-end queries/s = regex -> candidate-bin mask.
     Host: C++ front-end (regex -> k-graph -> staged frontier expansion); device: probe + mask-DAG
@@ -171,7 +199,11 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     if err is not None:
         return {"error": err}
     lat, plain_status, plain_stats, plain_s = local["lat"], local["plain_status"], local["plain_stats"], local["plain_s"]
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_query_baseline(ix, args.m_rows, args.hash, args.bins_per_gpu, k, motifs, masks, args.cpu_query_seconds)
     return {
+        **({"cpu_baseline": cpu} if cpu else {}),
         "metric": "end-to-end queries/sec (regex -> candidate-bin mask, verification excluded)",
         "batch_queries_per_s": len(motifs) / total,
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
@@ -275,6 +307,7 @@ def main():
     ap.add_argument("--hash", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=1 << 24, help="k-mers timed on the CPU oracle (rank 0, N=1); default: the whole batch")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--cpu-query-seconds", type=float, default=10.0, help="CPU oracle time spent on the end-to-end leg's baseline")
     ap.add_argument("--no-queries", action="store_true", help="skip the end-to-end queries/s leg")
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--no-hibf", action="store_true", help="skip the HIBF descent leg")
@@ -416,6 +449,7 @@ def main():
         out["parity_checked_probes"] = int(sample)
 
     if not args.no_queries:
+        args.m_rows = m
         out["end_to_end"] = end_to_end_queries(ix, torch, dist, world, rank, args)
 
     ix.free()
