@@ -96,3 +96,26 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert out["end_to_end"]["batch"]["failed"] == 0
     assert "error" not in out["hibf"], out["hibf"]
     assert out["hibf"]["column_shards"] == 2 and out["hibf"]["mask_bytes_per_kmer"] == 4096
+
+
+def test_bench_single_gpu_contract_line_with_all_legs():
+    """`python bench.py` at N=1 (small sizes): one JSON line with the contract keys, the roofline and
+    cpu_baseline objects, and the two extra legs without errors."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--kmers", str(1 << 18), "--per-bin", "2000",
+           "--motifs", "40", "--hibf-kmers", str(1 << 16), "--cpu-query-seconds", "1"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["metric"] == "k-mer IBF probes/sec" and out["unit"] == "probes/s" and out["n_gpus"] == 1 and out["vs_baseline"] is None
+    assert out["higher_is_better"] is True and out["dtype"] == "u64" and out["config"]["workload"].startswith("S-IBF-1024")
+    roof = out["roofline"]
+    assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["frac"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    cpu = out["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and out["parity_checked_probes"] == 1 << 18
+    e2e = out["end_to_end"]
+    assert "error" not in e2e and e2e["batch"]["failed"] == 0 and e2e["cpu_baseline"]["masks_compared"] > 0
+    assert "error" not in out["hibf"] and out["hibf"]["checked_present_values"] > 0
