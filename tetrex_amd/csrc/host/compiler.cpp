@@ -263,6 +263,15 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
 // of them merge exactly when their states agree in everything but the oldest symbol of the key, so the
 // answer is in the list itself: a sample taken BY KEY (one sixteenth of the key space, so both partners
 // of a pair are in or out together) counts how many states have such a partner.
+// lists shorter than this are not worth the question (TETREX_MERGE_SAMPLE lowers it so that small tests reach the code)
+size_t QueryExpansion::merge_sample_threshold() {
+    static const size_t v = [] {
+        const char* e = std::getenv("TETREX_MERGE_SAMPLE");
+        return e && std::atoll(e) > 0 ? (size_t)std::atoll(e) : (size_t)kMergeSample;
+    }();
+    return v;
+}
+
 bool QueryExpansion::merging_pays(const StateVec& list) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     const uint64_t rest_mask = enc_.suffix_mask() >> bits;
@@ -279,7 +288,8 @@ bool QueryExpansion::merging_pays(const StateVec& list) {
     }
     seen.clear();
     if (seen.capacity() && spare_maps_.size() < 64) { spare_maps_.emplace_back(); std::swap(spare_maps_.back(), seen); }
-    return sampled < 64 || partners * 4 >= sampled;  // a quarter or more of the states would be absorbed
+    const uint32_t enough = merge_sample_threshold() < kMergeSample ? 1 : 64;
+    return sampled < enough || partners * 4 >= sampled;  // a quarter or more of the states would be absorbed
 }
 
 void QueryExpansion::adopt_storage(NodeStates& ns) {
@@ -333,7 +343,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     if (!single_source_[fan_[i]]) arrive(fan_[i], s, out);
             }
             if (readers && !ns.items.empty()) {
-                if (ns.items.size() >= kMergeSample && !merging_pays(ns.items))
+                if (ns.items.size() >= merge_sample_threshold() && !merging_pays(ns.items))
                     for (uint32_t i = lo; i < hi; ++i) {  // the readers' receivers will just append
                         const int32_t reader = fan_[i], recv = single_source_[reader] ? forward_[reader] : KGraph::kNone;
                         if (recv != KGraph::kNone && !single_source_[recv] && table_[recv].items.empty()) table_[recv].append_only = true;

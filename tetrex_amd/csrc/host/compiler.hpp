@@ -142,6 +142,7 @@ class QueryExpansion {
     struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; };
     static constexpr uint32_t kMergeSample = 4096;  // lists shorter than this are not worth the question
     bool merging_pays(const StateVec& list);
+    static size_t merge_sample_threshold();
     const KmerEncoder& enc_;
     KGraph g_;
     CompileLimits limits_;
