@@ -176,6 +176,8 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
         targets_of(v, [&](int32_t t) { if (--indeg[t] == 0) ready.push_back(t); });
     }
     table_.resize(items);
+    // state keys are (k-1) symbols plus the length marker bit: small enough for a directly indexed merge table?
+    direct_key_bits_ = (enc_.k() - 1) * enc_.bits_per_symbol() + 1 <= 20 ? (enc_.k() - 1) * enc_.bits_per_symbol() + 1 : 0;
     input_of_.assign(items, KGraph::kNone);
     readers_.assign(join_of.size(), 0);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
@@ -231,6 +233,7 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
     // residues it has seen (bits 60-62 keep it apart from every ordinary state)
     const uint64_t key = s.gapped ? (s.kmer | ((uint64_t)(4 + s.shift) << 60))
                                   : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)));
+    ns.by_key.want_direct(direct_key_bits_);
     auto [where, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
     if (inserted) {
         s.asked = 0;

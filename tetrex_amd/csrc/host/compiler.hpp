@@ -167,6 +167,7 @@ class QueryExpansion {
     std::vector<int32_t> input_of_;
     std::vector<uint32_t> readers_;
     std::vector<int32_t> open_joins_;
+    unsigned direct_key_bits_ = 0;    // FlatMap::want_direct for the merge tables (0: keys too wide)
     std::vector<uint32_t> refs_;
     // Freed slots are recycled oldest-first and only after the node item that freed them is
     // finished: immediate (LIFO) reuse would chain unrelated ops through write-after-read
