@@ -81,9 +81,14 @@ class KmerTable {
             if (fresh) values_.push_back(value);
             return *slot;
         }
-        if (recent_.empty()) recent_.assign(kRecent, 0);
+        // the cache starts small (most queries of a large batch need a few dozen k-mers) and grows with the table
+        if (values_.size() >= ((size_t)2 << recent_bits_) && recent_bits_ < kRecentBits) {
+            recent_bits_ = recent_bits_ + 2 > kRecentBits ? kRecentBits : recent_bits_ + 2;
+            recent_.assign((size_t)1 << recent_bits_, 0);  // forgetting the old entries only costs a few repeats
+        }
+        if (recent_.empty()) recent_.assign((size_t)1 << recent_bits_, 0);
         uint64_t h = value * 0x9E3779B97F4A7C15ULL;
-        uint32_t& id = recent_[h >> (64 - kRecentBits)];
+        uint32_t& id = recent_[h >> (64 - recent_bits_)];
         if (id < values_.size() && values_[id] == value) return id;  // entries left by an earlier stage fail this check
         id = (uint32_t)values_.size();
         values_.push_back(value);
@@ -94,7 +99,7 @@ class KmerTable {
 
   private:
     static constexpr unsigned kRecentBits = 13;
-    static constexpr size_t kRecent = (size_t)1 << kRecentBits;
+    unsigned recent_bits_ = 5;
     bool exact_;
     FlatMap index_;
     CachedVector<uint32_t> recent_;
