@@ -509,8 +509,9 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || (force && force[0] == '1')) return false;
     unsigned waves = 4;
     while (waves > 1 && wave_bytes * waves > lds_budget) waves >>= 1;
-    // about 16 waves per CU are resident where the LDS allows it (TXQ_HIBF_WAVES overrides the total)
-    size_t want_waves = (size_t)256 * 16;
+    // 64 waves per CU are launched: with an 8 KiB row the LDS keeps 16 of them resident and the rest queue up,
+    // with the short rows of a column shard more are resident and the finer grain is worth 14 % (TXQ_HIBF_WAVES overrides)
+    size_t want_waves = (size_t)256 * 64;
     if (const char* e = std::getenv("TXQ_HIBF_WAVES")) want_waves = std::atoll(e) > 0 ? (size_t)std::atoll(e) : want_waves;
     const size_t total_waves = n < want_waves ? n : want_waves;
     const unsigned grid = (unsigned)((total_waves + waves - 1) / waves);
