@@ -22,16 +22,18 @@ def main():
     n_probe = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 22
     per_bin = int(sys.argv[2]) if len(sys.argv) > 2 else 300
     n_shards = int(sys.argv[3]) if len(sys.argv) > 3 else 1  # >1: time shard 0 of a column-sharded upload (one rank's work)
+    user_bins = int(sys.argv[4]) if len(sys.argv) > 4 else 65536
+    children = int(sys.argv[5]) if len(sys.argv) > 5 else 256
     rng = np.random.default_rng(5)
     shifts = np.uint64(5) * np.arange(4, -1, -1, dtype=np.uint64)
 
     def vals(b):
         return (rng.integers(0, 10, size=(per_bin, 5)).astype(np.uint64) << shifts).sum(axis=1).astype(np.uint64)
     t0 = time.perf_counter()
-    ox, descs, values = regular_hibf(O, 65536, 256, per_bin, vals, h=2, k=5, reduction=1)
+    ox, descs, values = regular_hibf(O, user_bins, children, per_bin, vals, h=2, k=5, reduction=1)
     t_build = time.perf_counter() - t0
     capi.init(0)
-    ix = capi.Index.upload_hibf(65536, descs, shard_rank=0, n_shards=n_shards)
+    ix = capi.Index.upload_hibf(user_bins, descs, shard_rank=0, n_shards=n_shards)
     W = ix.shard_words
     # half of the probes are inserted values (they descend to a leaf), half are random (mostly stop at the root)
     present = np.concatenate([v[:8] for v in values[::8]])
@@ -51,7 +53,7 @@ def main():
     sample = 2000
     got = dm.to_numpy(np.uint64, (n_probe, W))[:sample]
     assert np.array_equal(got, ox.probe(kmers[:sample])[:, :W]), "HIBF masks differ from the oracle"
-    print(json.dumps({"workload": "S-HIBF-65536", "n_shards": n_shards, "user_bins": 65536, "n_ibf": int(ix.info.n_ibf), "kmers": n_probe,
+    print(json.dumps({"workload": "S-HIBF-%d" % user_bins, "n_shards": n_shards, "user_bins": user_bins, "n_ibf": int(ix.info.n_ibf), "kmers": n_probe,
                       "seconds_per_batch": dt, "kmers_per_s": n_probe / dt, "mask_bytes_per_kmer": W * 8,
                       "mask_zero_fill_GBps": n_probe * W * 8 / dt / 1e9, "device_bytes": int(ix.info.device_bytes),
                       "index_build_s": round(t_build, 1), "parity_sample": sample}))
