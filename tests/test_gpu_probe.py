@@ -171,7 +171,8 @@ def test_hibf_sharded_masks_and_wide_tree(capi, oracle):
 @pytest.mark.parametrize("shape", [dict(user_bins=40, tmax=32, levels=2), dict(user_bins=300, tmax=128, levels=3),
                                    dict(user_bins=2500, tmax=2048, levels=3, n_values=8), dict(user_bins=700, tmax=200, levels=5, n_values=12)])
 def test_hibf_fused_and_level_synchronous_kernels_agree(capi, oracle, shape, monkeypatch):
-    """The same tree through both descent kernels (txq_hibf.hip: hibf_fused_kernel is the default,
+    """The same tree through all descent kernels (txq_hibf.hip: hibf_small_kernel for small trees and
+    hibf_fused_kernel otherwise are the default, TXQ_HIBF_SMALL=0 keeps small trees on the fused kernel,
     TXQ_HIBF_LEVELS=1 selects hibf_level_kernel): masks and alive bits equal the oracle's, whatever
     the row width (one word, a lane's four words, several lanes), the depth and the shard."""
     ox, descs, values = random_hibf(oracle, 31, **shape)
@@ -182,16 +183,18 @@ def test_hibf_fused_and_level_synchronous_kernels_agree(capi, oracle, shape, mon
         ix = capi.Index.upload_hibf(ub, descs, shard_rank=r, n_shards=R)
         lo, nw = int(ix.info.shard_word0), ix.shard_words
         dk = capi.DeviceBuffer.from_numpy(kmers)
-        for levels in ("0", "1"):
+        # small kernel (lane per k-mer, where the tree qualifies) / wave-per-k-mer kernel / level-synchronous
+        for levels, small in (("0", "1"), ("0", "0"), ("1", "1")):
             monkeypatch.setenv("TXQ_HIBF_LEVELS", levels)
+            monkeypatch.setenv("TXQ_HIBF_SMALL", small)
             dm = capi.DeviceBuffer(kmers.size * nw * 8)
             da = capi.DeviceBuffer(((kmers.size + 63) // 64) * 8)
             ix.probe_device(dk.ptr, kmers.size, dm.ptr, da.ptr)
             capi.synchronize()
             got = dm.to_numpy(np.uint64, (kmers.size, nw))
-            assert np.array_equal(got, want[:, lo:lo + nw]), (shape, R, levels)
+            assert np.array_equal(got, want[:, lo:lo + nw]), (shape, R, levels, small)
             alive = np.unpackbits(da.to_numpy(np.uint8, (((kmers.size + 63) // 64) * 8,)), bitorder="little")[:kmers.size]
-            assert np.array_equal(alive.astype(bool), got.any(axis=1)), (shape, R, levels)
+            assert np.array_equal(alive.astype(bool), got.any(axis=1)), (shape, R, levels, small)
         ix.free()
 
 

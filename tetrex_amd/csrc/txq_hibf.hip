@@ -311,6 +311,98 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
     }
 }
 
+// Small trees (every IBF at most 128 technical bins, at most 32 IBFs, at most 16 mask words — the
+// Swissprot-HIBF shape): ONE LANE per k-mer instead of one wave.  A lane keeps its k-mer's row and its
+// stack of technical-bin indexes in LDS columns ([word][lane], [entry][lane]: conflict-free), visits its IBFs
+// one after the other (a k-mer of such a tree visits two or three) and the workgroup writes its 256 rows
+// out together, coalesced.  The tree (about a MB) is L2-resident; 64 independent descents per wave
+// supply the memory-level parallelism that the wave-per-k-mer kernel gets from 64 IBFs per round.
+constexpr uint32_t kSmallThreads = 256, kSmallStack = 32, kSmallPitch = kSmallThreads + 1;
+
+__global__ __launch_bounds__(256) void hibf_small_kernel(HibfView t, const uint64_t* __restrict__ kmers, size_t n,
+                                                         uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0,
+                                                         uint32_t h_max, uint64_t* __restrict__ alive) {
+    extern __shared__ uint64_t lds[];
+    uint64_t* rows = lds;                                                          // [w_out][kSmallPitch]
+    uint16_t* stacks = reinterpret_cast<uint16_t*>(rows + (size_t)w_out * kSmallPitch);  // [kSmallStack][kSmallThreads]; a technical-bin index fits 16 bits here
+    const uint32_t tid = threadIdx.x;
+    for (size_t base = (size_t)blockIdx.x * kSmallThreads; base < n; base += (size_t)gridDim.x * kSmallThreads) {
+        const size_t i = base + tid;
+        const bool live = i < n;
+        const uint64_t v = live ? kmers[i] : 0;
+        for (uint32_t w = 0; w < w_out; ++w) rows[w * kSmallPitch + tid] = 0;
+        stacks[tid] = (uint16_t)t.root_entry;
+        uint32_t count = live ? 1u : 0u;
+        while (count) {  // lanes leave the loop one by one
+            const HibfNode nd = t.nodes[stacks[--count * kSmallThreads + tid]];
+            const uint32_t stride = nd.stride(), words_per_row = nd.words_per_row();
+            const uint64_t* words = (const uint64_t*)nd.words;
+            uint64_t acc[2] = {~0ULL, stride > 1 ? ~0ULL : 0ULL};
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) {
+                if (j >= h_max) continue;
+                const uint32_t jj = j < nd.hash_funs() ? j : nd.hash_funs() - 1;  // a missing hash function repeats the last real row
+                const uint64_t r = hash_row_seeded32(v * kSeeds[jj], nd.hash_shift(), nd.bin_size);
+                if (stride == 1) {
+                    acc[0] &= gload(words + r);
+                } else {
+                    const ulonglong2 a = gload2(words + r * 2);
+                    acc[0] &= a.x;
+                    acc[1] &= a.y;
+                }
+            }
+            uint64_t mg[2] = {0, 0}, dn[2] = {0, 0};
+            if (nd.has_merged()) {  // merged-bin masks are padded to 4 words per IBF
+                const ulonglong2 m = gload2(t.merged + nd.moff), d = gload2(t.descend + nd.moff);
+                mg[0] = m.x; mg[1] = m.y;
+                dn[0] = d.x; dn[1] = d.y;
+            }
+#pragma unroll
+            for (uint32_t w = 0; w < 2; ++w) {
+                if (w >= words_per_row) continue;
+                uint64_t kids = acc[w] & dn[w];  // children outside this shard's columns are not visited
+                while (kids) {
+                    const uint32_t tb = w * 64u + (uint32_t)__builtin_ctzll(kids);
+                    kids &= kids - 1;
+                    if (count < kSmallStack) stacks[count++ * kSmallThreads + tid] = (uint16_t)(nd.off + tb);
+                }
+                uint64_t hits = acc[w] & ~mg[w];
+                if (!hits) continue;
+                if (nd.ident_word != kNoIdent) {  // the row word is a mask word
+                    const uint64_t word = (uint64_t)nd.ident_word + w;
+                    if (word >= word0 && word < (uint64_t)word0 + w_out) rows[(word - word0) * kSmallPitch + tid] |= hits;
+                    continue;
+                }
+                // padding bits are never set; this guards the map look-up
+                if (w * 64u + 63u >= nd.bins) hits &= nd.bins > w * 64u ? (~0ULL >> (63u - ((nd.bins - 1u) & 63u))) : 0;
+                while (hits) {
+                    const uint32_t tb = w * 64u + (uint32_t)__builtin_ctzll(hits);
+                    hits &= hits - 1;
+                    const uint64_t ub = gload(t.tb_user + nd.off + tb);
+                    const uint64_t mw = ub >> 6;
+                    if (mw >= word0 && mw < (uint64_t)word0 + w_out) rows[(mw - word0) * kSmallPitch + tid] |= 1ULL << (ub & 63);
+                }
+            }
+        }
+        if (alive) {  // base is a multiple of 256: every wave owns whole alive words
+            uint64_t any = 0;
+            for (uint32_t w = 0; w < w_out; ++w) any |= rows[w * kSmallPitch + tid];
+            const uint64_t bits = __ballot(live && any != 0);
+            if ((tid & 63) == 0 && base + (tid & ~63u) < n) alive[(base + tid) >> 6] = bits;
+        }
+        __syncthreads();
+        // the workgroup's rows are one contiguous piece of the output: element e = row e / w_out, word e % w_out
+        const size_t rows_here = n - base < kSmallThreads ? n - base : kSmallThreads;
+        const size_t elems = rows_here * w_out;
+        uint64_t* out = masks + base * w_out;
+        for (size_t e = tid; e < elems; e += kSmallThreads) {
+            const uint32_t r = (uint32_t)(e / w_out), w = (uint32_t)(e % w_out);
+            __builtin_nontemporal_store(rows[w * kSmallPitch + r], out + e);
+        }
+        __syncthreads();  // the next chunk reuses the rows
+    }
+}
+
 // the frontier count of a level can exceed the capacity only through a bug; clamp for the reader
 __global__ void hibf_clamp_kernel(uint32_t* count, uint32_t cap) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && *count > cap) *count = cap;
@@ -507,6 +599,21 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     const size_t lds_budget = 64u << 10;
     const char* force = std::getenv("TXQ_HIBF_LEVELS");
     if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || (force && force[0] == '1')) return false;
+    uint32_t h_max = 1;
+    for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
+    *rc = TXQ_OK;
+    // small trees: one lane per k-mer (TXQ_HIBF_SMALL=0 keeps them on the wave-per-k-mer kernel, for A/B runs)
+    const char* small = std::getenv("TXQ_HIBF_SMALL");
+    if (ix.max_stride <= 2 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && !(small && small[0] == '0')) {
+        const size_t lds_bytes = (size_t)w_out * kSmallPitch * 8 + (size_t)kSmallStack * kSmallThreads * 2;
+        size_t blocks = (n + kSmallThreads - 1) / kSmallThreads;
+        if (blocks > 256 * 8) blocks = 256 * 8;
+        hibf_small_kernel<<<(unsigned)blocks, kSmallThreads, lds_bytes, s>>>(t, d_kmers, n, d_masks, w_out, (uint32_t)ix.shard_word0, h_max, d_alive);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) *rc = fail_hip(e, "hibf small-tree kernel launch");
+        return true;
+    }
     unsigned waves = 4;
     while (waves > 1 && wave_bytes * waves > lds_budget) waves >>= 1;
     // 64 waves per CU are launched: with an 8 KiB row the LDS keeps 16 of them resident and the rest queue up,
@@ -519,10 +626,6 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     int g = 1;
     while (g < 64 && (uint32_t)g < quads) g <<= 1;
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
-    uint32_t h_max = 1;
-    for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
-    *rc = TXQ_OK;
     if (d_alive) {
         hipError_t e = hipMemsetAsync(d_alive, 0, ((n + 63) / 64) * 8, s);
         if (e != hipSuccess) { *rc = fail_hip(e, "hipMemsetAsync(alive)"); return true; }
