@@ -19,7 +19,8 @@ Output: ONE JSON line on rank 0 (contract in the task description), including
 Two further legs report the other BASELINE figures without touching `value`:
   end_to_end   — queries/s, regex -> candidate-bin mask, on the same index, with its own cpu_baseline
                  (the oracle's single-threaded query(), ~10 s, masks compared bit for bit);
-  hibf         — k-mers/s of the HIBF descent on a 65536-user-bin tree (BASELINE configs[4] shape).
+  hibf         — k-mers/s of the HIBF descent on a 65536-user-bin tree (BASELINE configs[4] shape);
+  hibf_1024    — the same on a 1024-user-bin tree (the Swissprot-HIBF shape of BASELINE configs[2]).
 """
 import argparse
 import json
@@ -215,14 +216,14 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     }
 
 
-def hibf_descent(capi, torch, args, rank, world):
+def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
     """Third figure (BASELINE configs[4] shape, SURVEY.md §8d S-HIBF-65536): k-mers/s of the HIBF
     descent — root IBF of 256 merged bins over 256 child IBFs of 256 user bins each, h = 2, sizes from
     compute_bitcount at fpr 0.05, values from a 10-letter k = 5 universe (10^5 k-mers).  Every IBF is
     filled on the device with the real hash and uploaded as a tree; with N ranks the 65536 mask columns
     are sharded (each rank descends only into sub-trees of its own columns).  Runs after the timed
     probe steps; it does not touch `value`."""
-    user_bins, children, per_bin, h = 65536, 256, args.hibf_per_bin, 2
+    per_bin, h = args.hibf_per_bin, 2
     per_child = user_bins // children
     rng = np.random.default_rng(5)
     shifts = np.uint64(5) * np.arange(4, -1, -1, dtype=np.uint64)
@@ -288,7 +289,7 @@ def hibf_descent(capi, torch, args, rank, world):
     bits = (got[np.arange(pv.size)[mine], (pb[mine] // 64 - lo)] >> (pb[mine] % 64).astype(np.uint64)) & np.uint64(1)
     if not bool(bits.all()):
         raise SystemExit("bench: HIBF descent lost an inserted value")
-    out = {"workload": "S-HIBF-65536", "user_bins": user_bins, "n_ibf": children + 1, "hash_funs": h, "values_per_bin": per_bin,
+    out = {"workload": "S-HIBF-%d" % user_bins, "user_bins": user_bins, "n_ibf": children + 1, "hash_funs": h, "values_per_bin": per_bin,
            "kmers": n, "kmers_per_s_per_gpu": n / dt, "seconds_per_batch": dt, "mask_bytes_per_kmer": W * 8,
            "mask_write_GBps": n * W * 8 / dt / 1e9, "column_shards": world, "tree_bytes": int(ix.info.device_bytes),
            "index_build_s": round(build_s, 1), "checked_present_values": int(mine.sum())}
@@ -456,8 +457,11 @@ def main():
     if not args.no_hibf:
         try:
             out["hibf"] = hibf_descent(capi, torch, args, rank, world)
+            # the Swissprot-HIBF shape (BASELINE configs[2]): 1024 user bins, 16 children of 64 bins
+            out["hibf_1024"] = hibf_descent(capi, torch, args, rank, world, user_bins=1024, children=16)
         except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
-            out["hibf"] = {"error": repr(e)}
+            out.setdefault("hibf", {"error": repr(e)})
+            out.setdefault("hibf_1024", {"error": repr(e)})
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -119,3 +119,4 @@ def test_bench_single_gpu_contract_line_with_all_legs():
     e2e = out["end_to_end"]
     assert "error" not in e2e and e2e["batch"]["failed"] == 0 and e2e["cpu_baseline"]["masks_compared"] > 0
     assert "error" not in out["hibf"] and out["hibf"]["checked_present_values"] > 0
+    assert "error" not in out["hibf_1024"] and out["hibf_1024"]["user_bins"] == 1024
