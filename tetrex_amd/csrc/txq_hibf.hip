@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
     }
 }
 
-// Small trees (every IBF at most 128 technical bins, at most 32 IBFs, at most 16 mask words — the
+// Small trees (every IBF at most 256 technical bins, at most 32 IBFs, at most 16 mask words — the
 // Swissprot-HIBF shape): ONE LANE per k-mer instead of one wave.  A lane keeps its k-mer's row and its
 // stack of technical-bin indexes in LDS columns ([word][lane], [entry][lane]: conflict-free), visits its IBFs
 // one after the other (a k-mer of such a tree visits two or three) and the workgroup writes its 256 rows
@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void hibf_small_kernel(HibfView t, const uint6
             const HibfNode nd = t.nodes[stacks[--count * kSmallThreads + tid]];
             const uint32_t stride = nd.stride(), words_per_row = nd.words_per_row();
             const uint64_t* words = (const uint64_t*)nd.words;
-            uint64_t acc[2] = {~0ULL, stride > 1 ? ~0ULL : 0ULL};
+            uint64_t acc[4] = {~0ULL, stride > 1 ? ~0ULL : 0ULL, stride > 2 ? ~0ULL : 0ULL, stride > 2 ? ~0ULL : 0ULL};
 #pragma unroll
             for (uint32_t j = 0; j < 5; ++j) {
                 if (j >= h_max) continue;
@@ -345,20 +345,26 @@ __global__ __launch_bounds__(256) void hibf_small_kernel(HibfView t, const uint6
                 const uint64_t r = hash_row_seeded32(v * kSeeds[jj], nd.hash_shift(), nd.bin_size);
                 if (stride == 1) {
                     acc[0] &= gload(words + r);
-                } else {
-                    const ulonglong2 a = gload2(words + r * 2);
+                } else {  // rows are padded to an even number of words, the padding is zero
+                    const ulonglong2 a = gload2(words + r * stride);
                     acc[0] &= a.x;
                     acc[1] &= a.y;
+                    if (stride > 2) {
+                        const ulonglong2 b = gload2(words + r * stride + 2);
+                        acc[2] &= b.x;
+                        acc[3] &= b.y;
+                    }
                 }
             }
-            uint64_t mg[2] = {0, 0}, dn[2] = {0, 0};
+            uint64_t mg[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
             if (nd.has_merged()) {  // merged-bin masks are padded to 4 words per IBF
-                const ulonglong2 m = gload2(t.merged + nd.moff), d = gload2(t.descend + nd.moff);
-                mg[0] = m.x; mg[1] = m.y;
-                dn[0] = d.x; dn[1] = d.y;
+                const ulonglong2 m0 = gload2(t.merged + nd.moff), m1 = gload2(t.merged + nd.moff + 2);
+                const ulonglong2 d0 = gload2(t.descend + nd.moff), d1 = gload2(t.descend + nd.moff + 2);
+                mg[0] = m0.x; mg[1] = m0.y; mg[2] = m1.x; mg[3] = m1.y;
+                dn[0] = d0.x; dn[1] = d0.y; dn[2] = d1.x; dn[3] = d1.y;
             }
 #pragma unroll
-            for (uint32_t w = 0; w < 2; ++w) {
+            for (uint32_t w = 0; w < 4; ++w) {
                 if (w >= words_per_row) continue;
                 uint64_t kids = acc[w] & dn[w];  // children outside this shard's columns are not visited
                 while (kids) {
@@ -605,7 +611,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     *rc = TXQ_OK;
     // small trees: one lane per k-mer (TXQ_HIBF_SMALL=0 keeps them on the wave-per-k-mer kernel, for A/B runs)
     const char* small = std::getenv("TXQ_HIBF_SMALL");
-    if (ix.max_stride <= 2 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && !(small && small[0] == '0')) {
+    if (ix.max_stride <= 4 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && !(small && small[0] == '0')) {
         const size_t lds_bytes = (size_t)w_out * kSmallPitch * 8 + (size_t)kSmallStack * kSmallThreads * 2;
         size_t blocks = (n + kSmallThreads - 1) / kSmallThreads;
         if (blocks > 256 * 8) blocks = 256 * 8;
