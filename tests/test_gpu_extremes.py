@@ -127,3 +127,25 @@ def test_full_size_8192_bin_shard_properties(capi):
     fresh = splitmix64(13, 30000) >> np.uint64(24)
     assert np.array_equal(iy.probe(q), g1) and np.array_equal(iy.probe(fresh), ix.probe(fresh))
     ix.free(); iy.free()
+
+
+def test_more_than_two_to_the_32_rows(capi, oracle):
+    """bin_size >= 2^32 takes its own probe kernel (probe_bigrows_kernel) and the 64-bit branch of
+    fastrange; 40 bins x (2^32 + 12345) rows = one word per row, 34 GB on the device and in the oracle.
+    Values are inserted on both sides with their own emplace and the probes must agree bit for bit."""
+    bins, m, h = 40, (1 << 32) + 12345, 3
+    ox = oracle.Index.ibf(bins, m, h, dna=False, k=4)
+    ix = capi.Index.create_ibf(bins, m, h)
+    vals = splitmix64(11, 4000)
+    bins_of = (splitmix64(12, 4000) % np.uint64(bins)).astype(np.uint32)
+    for b in range(bins):
+        ox.emplace(vals[bins_of == b], b)
+    dv, db = capi.DeviceBuffer.from_numpy(vals), capi.DeviceBuffer.from_numpy(bins_of)
+    ix.emplace_device(dv.ptr, db.ptr, vals.size)
+    capi.synchronize()
+    probes = np.concatenate([vals, splitmix64(13, 4000)])
+    got, want = ix.probe(probes), ox.probe(probes)
+    assert np.array_equal(got, want)
+    assert all((int(got[i, 0]) >> int(bins_of[i])) & 1 for i in range(vals.size))  # no false negatives
+    assert int(np.count_nonzero(got[vals.size:])) == 0  # 12000 bits in 2^32 rows: a random probe finds nothing
+    ix.free()
