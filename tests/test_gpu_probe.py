@@ -235,6 +235,38 @@ def test_host_buffer_probe_pipelines_chunks_into_pageable_and_pinned_memory(capi
     hx.free()
 
 
+def test_hibf_with_a_different_hash_count_per_ibf(capi, oracle, monkeypatch):
+    """The reference's HIBF uses one hash count for the whole tree, the descriptor allows one per IBF:
+    root h = 3, children h = 1 / 2 / 3 / 4.  An IBF with fewer hash functions than the tree's maximum
+    repeats its last row in the kernels; all three descent kernels must agree with the oracle."""
+    from helpers import MERGED
+    rng = np.random.default_rng(12)
+    hs, per_child, user_bins = [1, 2, 3, 4], 70, 280
+    vals = [rng.integers(0, 1 << 20, size=30, dtype=np.uint64) for _ in range(user_bins)]
+    ox = oracle.Index.hibf(user_bins, dna=False, k=4)
+    nxt, tbu = np.arange(1, 5, dtype=np.uint64), np.full(4, MERGED, dtype=np.uint64)
+    descs = [dict(bins=4, bin_size=20011, hash_funs=3, next_ibf_id=nxt, tb_to_user=tbu)]
+    ox.add_ibf(4, 20011, 3, nxt, tbu)
+    for c, h in enumerate(hs):
+        ox.hibf_emplace(0, np.concatenate(vals[c * per_child:(c + 1) * per_child]), c)
+    for c, h in enumerate(hs):
+        tb = np.arange(c * per_child, (c + 1) * per_child, dtype=np.uint64)
+        i = ox.add_ibf(per_child, 1009, h, np.zeros(per_child, dtype=np.uint64), tb)
+        for t in range(per_child):
+            ox.hibf_emplace(i, vals[c * per_child + t], t)
+        descs.append(dict(bins=per_child, bin_size=1009, hash_funs=h, next_ibf_id=np.zeros(per_child, dtype=np.uint64), tb_to_user=tb))
+    for i, d in enumerate(descs):
+        d["words"] = ox.hibf_words(i)
+    kmers = np.concatenate([np.concatenate([v[:3] for v in vals]), splitmix64(14, 3000) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    ix = capi.Index.upload_hibf(user_bins, descs)
+    for levels, small in (("0", "1"), ("0", "0"), ("1", "1")):
+        monkeypatch.setenv("TXQ_HIBF_LEVELS", levels)
+        monkeypatch.setenv("TXQ_HIBF_SMALL", small)
+        assert np.array_equal(ix.probe(kmers), want), (levels, small)
+    ix.free()
+
+
 def test_full_size_swissprot_shape_properties(capi, oracle):
     """BASELINE configs[1] shape (1024 bins, h=3, m=1,247,045 rows, 160 MB): size-independent
     properties at full size, and a sampled bit-exact comparison against the oracle."""
