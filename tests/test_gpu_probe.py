@@ -298,3 +298,29 @@ def test_full_size_swissprot_shape_properties(capi, oracle):
     w_sub = sub.words()
     assert np.array_equal(w_sub & words, w_sub)  # every bit the oracle sets is set on the device
     ix.free()
+
+
+def test_shards_without_mask_words_and_empty_batches(capi, oracle):
+    """More shards than mask words: a rank that owns no column answers with zero-width masks (probes and
+    whole queries, flat and hierarchical); empty batches are no-ops."""
+    w = random_words(5, 101, 0.3, 1)
+    for r, width in ((0, 1), (1, 0)):
+        ix = capi.Index.upload_ibf(5, 101, 3, w, shard_rank=r, n_shards=2)
+        assert ix.shard_words == width and ix.probe(splitmix64(1, 100) >> np.uint64(58)).shape == (100, width)
+        masks, status, _ = ix.query_masks(["ACG", "A.T"], True, 3)
+        assert masks.shape == (2, width) and status == [0, 0]
+        ix.free()
+    ox, descs, values = random_hibf(oracle, 3, user_bins=40, tmax=32, levels=2)
+    kmers = np.concatenate([v[:2] for v in values])
+    for r, width in ((0, 1), (1, 0), (2, 0)):
+        hx = capi.Index.upload_hibf(40, descs, shard_rank=r, n_shards=3)
+        got = hx.probe(kmers)
+        assert got.shape == (kmers.size, width)
+        if width:
+            assert np.array_equal(got, ox.probe(kmers))
+        masks, status, _ = hx.query_masks(["LMAEG"], False, 4)
+        assert masks.shape == (1, width) and status == [0]
+        hx.free()
+    ix = capi.Index.upload_ibf(5, 101, 3, w)
+    assert ix.probe(np.zeros(0, dtype=np.uint64)).shape == (0, 1) and ix.query_masks([], True, 3)[0].shape == (0, 1)
+    ix.free()
