@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void emplace_kernel(IbfDev f, const uint64_t* 
 static inline unsigned grid_for(size_t work_items, unsigned per_block) {
     size_t blocks = (work_items + per_block - 1) / per_block;
     // Up to 256 blocks per CU before the kernels start to grid-stride: letting the dispatcher hand out
-    // short blocks balances better than 8 long ones per CU (1024-bin index: +0.6 % cache-resident, +2.8 %
-    // on the 8 GB matrix).  TXQ_PROBE_BLOCKS_PER_CU is the A/B knob.
+    // short blocks balances slightly better than 8 long ones per CU (1024-bin index: +0.6 % cache-resident,
+    // within the noise on matrices that miss the Infinity Cache).  TXQ_PROBE_BLOCKS_PER_CU is the A/B knob.
     static const size_t per_cu = std::getenv("TXQ_PROBE_BLOCKS_PER_CU") ? (size_t)std::atoi(std::getenv("TXQ_PROBE_BLOCKS_PER_CU")) : 256;
     const size_t cap = 256u * (per_cu ? per_cu : 1);
     if (blocks > cap) blocks = cap;
