@@ -72,7 +72,16 @@ class BlockCache {
 
   private:
     struct Class { std::mutex m; std::vector<void*> free; };
-    static Class* classes() { static Class c[64]; return c; }
+    struct Registry {  // the cached blocks go back to the system when the process (or the library) goes away
+        Class c[64];
+        ~Registry() {
+            for (Class& k : c) {
+                for (void* p : k.free) std::free(p);
+                k.free.clear();
+            }
+        }
+    };
+    static Class* classes() { static Registry r; return r.c; }
     static std::atomic<size_t>& cached() { static std::atomic<size_t> v{0}; return v; }
     // TETREX_CACHE_MB: upper bound on memory kept for reuse (default 4096)
     static size_t limit() {
