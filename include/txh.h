@@ -58,6 +58,16 @@ typedef int (*txh_stage_fn)(void* user, const void* blob, size_t bytes, const ui
 int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
                    size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps, txh_stage_fn fn,
                    void* user, int* status, uint64_t* stats6);
+/* The same with dense DP steps switched on (include/txq_program.h version 3): the executor then receives
+ * version-3 blobs.  min_states / sparse_below: 0 = the product's defaults; slot_bytes: bytes of one mask. */
+typedef struct {
+    int enabled;
+    uint32_t min_states, sparse_below, max_blocks;
+    uint64_t slot_bytes, pool_bytes;
+} txh_dense_options;
+int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
+                         size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps,
+                         const txh_dense_options* dense, txh_stage_fn fn, void* user, int* status, uint64_t* stats6);
 /* the d-gram codes one record contributes (DGramIndex::process_sequence, include/dGramIndex.h:159-211) */
 int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, size_t cap);
 
@@ -72,6 +82,8 @@ int txe_query_masks_gapped(void* txq_index_handle, void* aux_index_handle, const
                            unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,
                            uint64_t* masks, int* status, uint64_t* stats6);
 const char* txe_last_error(void);
+/* dense DP ops (include/txq_program.h version 3) the calling thread's last txe_query_masks* run sent to the device */
+uint64_t txe_last_dense_ops(void);
 
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,

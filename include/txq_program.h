@@ -97,4 +97,52 @@ typedef struct {
     uint32_t reserved;
 } txq_program_v2;
 
+/* Version 3 — dense DP steps (blob version TXQ_PROGRAM_VERSION_DENSE; a superset of version 2).
+ *
+ * Where a query's state set saturates (a run of wildcards or residue classes makes every (k-1)-symbol
+ * suffix a live state: 20^(k-1) states, and 20 times as many ops for the next wildcard) the host stops
+ * enumerating states.  It keeps such a state set as a DENSE BLOCK: N = A^(k-1) consecutive slots of the
+ * program's dense region (A = number of residue codes of the index's alphabet), the slot of suffix
+ * (y1 .. y_{k-1}), y1 oldest, at index  sum_j code(y_j) * A^(k-1-j).  Absent states are zero masks.
+ * One DENSE STEP then does the collector's whole update_path/absorb round for a set R of residues
+ * (reference include/otf_collector.h:247-278,190-208) on the device:
+ *     dst[(x1 .. x_{k-2}, r)] |= OR over a in shape[0] of  src[(a, x1 .. x_{k-2})] & M[kmer(a, x1 .. x_{k-2}, r)]
+ * for every r in R and every (x1 .. x_{k-2}) in shape[1] x .. x shape[k-2]; M[.] is bulk_contains of the
+ * (for DNA: canonical) k-mer, evaluated inside the kernel — these masks never touch HBM.
+ *
+ * Slots with TXQ_DENSE_SLOT_BIT set address the dense region: slot = BIT | (block * N + index).  Ordinary ops
+ * may read and write them (scattering enumerated states into a block, copying block entries out).
+ * A dense op sits in the op stream as  { kmer = TXQ_DENSE_OP, dst = index into the dense table, a = b = 0 }
+ * and obeys the level rules with its blocks as operands (a step reads all of src, reads and writes all of dst).
+ * Flat-IBF sessions only. */
+#define TXQ_PROGRAM_VERSION_DENSE 3u
+#define TXQ_DENSE_OP 0xFFFFFFFEu
+#define TXQ_DENSE_SLOT_BIT 0x40000000u
+#define TXQ_DENSE_MAX_POSITIONS 11u /* k - 1 <= 11 */
+
+enum { TXQ_DENSE_ZERO = 0,   /* dst block := 0                                                        */
+       TXQ_DENSE_STEP = 1,   /* see above                                                             */
+       TXQ_DENSE_REDUCE = 2  /* slot dst |= OR of the src entries inside shape[0] x .. x shape[k-2]   */ };
+
+typedef struct {
+    uint32_t kind;
+    uint32_t dst;     /* ZERO, STEP: first slot of the block (dense slot id); REDUCE: any writable slot   */
+    uint32_t src;     /* STEP, REDUCE: first slot of the block read                                         */
+    uint32_t r_mask;  /* STEP: bit c set <=> residue code c is rolled in                                    */
+    uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; /* per suffix position (oldest first): codes worth visiting    */
+    uint32_t reserved;
+} txq_dense_op; /* 64 bytes */
+
+typedef struct {
+    txq_blob_header_v2 v2;   /* version = TXQ_PROGRAM_VERSION_DENSE; txq_program_v2.reserved = the program's
+                                dense slots (a multiple of N)                                              */
+    uint64_t dense_offset;   /* txq_dense_op[n_dense]                                                       */
+    uint32_t n_dense;
+    uint32_t k;              /* k-mer length                                                                */
+    uint32_t bits;           /* bits per residue code in a k-mer value (5 peptides, 2 DNA)                  */
+    uint32_t alphabet;       /* A: residue codes are 0 .. A-1                                               */
+    uint32_t canonical;      /* 1: probe min(forward, reverse complement) (DNA, code ^ 2 = complement)      */
+    uint32_t reserved;
+} txq_blob_header_v3;
+
 #endif /* TXQ_PROGRAM_H */

@@ -140,7 +140,11 @@ def ones_mask(user_bins, word0=0, words=None):
 
 class SessionSimulator:
     """CPU stand-in for a txq session (test double): keeps every program's slot masks, runs a
-    stage's ops with numpy over oracle-probed masks and answers the alive questions."""
+    stage's ops with numpy over oracle-probed masks and answers the alive questions.  Understands
+    version-3 blobs (dense DP steps, include/txq_program.h): a program's dense region is one array."""
+
+    DENSE_OP = 0xFFFFFFFE
+    DENSE_BIT = 0x40000000
 
     def __init__(self, oracle_index, n_programs, dgram_index=None):
         from tetrex_amd import host
@@ -150,18 +154,94 @@ class SessionSimulator:
         self.W = oracle_index.words_per_mask
         self.ones = ones_mask(oracle_index.bins)
         self.slots = [dict() for _ in range(n_programs)]
+        self.dense = [np.zeros((0, self.W), dtype=np.uint64) for _ in range(n_programs)]
         self.stages = 0
+        self.dense_steps = 0
+        self.dense_kinds = [0, 0, 0]  # ZERO, STEP, REDUCE ops seen
 
     def _get(self, p, s):
+        if s & self.DENSE_BIT:
+            return self.dense[p][s & ~self.DENSE_BIT]
         if s == 0:
             return np.zeros(self.W, dtype=np.uint64)
         if s == 1:
             return self.ones
         return self.slots[p].get(s, np.zeros(self.W, dtype=np.uint64) if s == 2 else None)
 
+    def _set(self, p, s, v):
+        if s & self.DENSE_BIT:
+            self.dense[p][s & ~self.DENSE_BIT] = v
+        else:
+            self.slots[p][s] = v
+
+    @staticmethod
+    def _codes(mask):
+        return [c for c in range(32) if (mask >> c) & 1]
+
+    def _canonical(self, fwd, k):
+        rc = np.zeros_like(fwd)
+        f = fwd.copy()
+        for _ in range(k):
+            rc = (rc << np.uint64(2)) | ((f & np.uint64(3)) ^ np.uint64(2))
+            f >>= np.uint64(2)
+        return np.minimum(fwd, rc)
+
+    def _dense_op(self, p, par, row):
+        kind, dst, src, r_mask = (int(x) for x in row[:4])
+        k, bits, A = par["k"], par["bits"], par["alphabet"]
+        pos = k - 1
+        N = A ** pos
+        D = self.dense[p]
+        self.dense_kinds[kind] += 1
+        if kind == 0:  # ZERO
+            b = dst & ~self.DENSE_BIT
+            assert b % N == 0 and b + N <= D.shape[0]
+            D[b:b + N] = 0
+            return
+        sb = src & ~self.DENSE_BIT
+        assert (src & self.DENSE_BIT) and sb % N == 0 and sb + N <= D.shape[0]
+        shape = [self._codes(int(row[4 + j])) for j in range(pos)]
+        assert all(c < A for cs in shape for c in cs)
+        if kind == 2:  # REDUCE: slot dst |= OR of the entries inside the shape
+            idx = np.zeros(1, dtype=np.int64)
+            for cs in shape:
+                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
+            acc = np.bitwise_or.reduce(D[sb + idx], axis=0) if idx.size else np.zeros(self.W, dtype=np.uint64)
+            cur = self._get(p, dst)
+            assert cur is not None
+            self._set(p, dst, cur | acc)
+            return
+        assert kind == 1
+        self.dense_steps += 1
+        db = dst & ~self.DENSE_BIT
+        assert (dst & self.DENSE_BIT) and db % N == 0 and db + N <= D.shape[0] and db != sb
+        mid = np.zeros(1, dtype=np.int64)   # block index of (x1 .. x_{k-2})
+        midv = np.zeros(1, dtype=np.uint64)  # its k-mer bits
+        for cs in shape[1:]:
+            c = np.array(cs, dtype=np.int64)
+            mid = (mid[:, None] * A + c[None, :]).reshape(-1)
+            midv = ((midv[:, None] << np.uint64(bits)) | c.astype(np.uint64)[None, :]).reshape(-1)
+        if mid.size == 0 or not shape[0]:
+            return
+        a = np.array(shape[0], dtype=np.int64)
+        for r in self._codes(r_mask):
+            assert r < A
+            acc = np.zeros((mid.size, self.W), dtype=np.uint64)
+            for ai in a:
+                fwd = (np.uint64(ai) << np.uint64(bits * (k - 1))) | (midv << np.uint64(bits)) | np.uint64(r)
+                val = self._canonical(fwd, k) if par["canonical"] else fwd
+                acc |= D[sb + ai * A ** (pos - 1) + mid] & self.ox.probe(val)
+            D[db + mid * A + r] |= acc
+
     def stage(self, blob, qp, qs):
         kmers, progs = self.host.parse_blob(blob)
         assert len(progs) == len(self.slots)
+        dense = self.host.blob_dense(blob)
+        if dense is not None:
+            for p, want in enumerate(dense[2]):
+                have = self.dense[p].shape[0]
+                if want > have:
+                    self.dense[p] = np.concatenate([self.dense[p], np.zeros((want - have, self.W), dtype=np.uint64)])
         n_aux = self.host.blob_aux_kmers(blob)
         n_main = kmers.size - n_aux
         M = self.ox.probe(kmers[:n_main]) if n_main else np.zeros((0, self.W), dtype=np.uint64)
@@ -170,6 +250,10 @@ class SessionSimulator:
             M = np.concatenate([M, self.dg.probe(kmers[n_main:])])
         for p, (n_slots, ops) in enumerate(progs):
             for k, d, a, b in ops:
+                if k == self.DENSE_OP:
+                    assert dense is not None
+                    self._dense_op(p, dense[0], dense[1][int(d)])
+                    continue
                 x = self._get(p, int(a))
                 assert x is not None, "slot read before written"
                 x = x.copy()
@@ -177,8 +261,8 @@ class SessionSimulator:
                     x &= M[k]
                 y = self._get(p, int(b))
                 assert y is not None
-                assert int(d) < n_slots and int(d) >= 2
-                self.slots[p][int(d)] = x | y
+                assert (int(d) & self.DENSE_BIT) or (int(d) < n_slots and int(d) >= 2)
+                self._set(p, int(d), x | y)
         self.stages += 1
         out = []
         for p, s in zip(qp, qs):

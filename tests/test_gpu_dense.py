@@ -1,0 +1,140 @@
+"""Dense DP steps on the GPU (csrc/txq_exec.hip dense_kernel; host/compiler.cpp densify / dense_step): whole
+queries through the C++ host (libtetrex_query.so -> txq session), with the thresholds forced so low that nearly
+every list becomes a dense block, against the CPU oracle's collect() (reference
+include/otf_collector.h:341-393 over bulk_contains).  Bit-exact, on several mask widths, shards and both molecules."""
+import numpy as np
+import pytest
+
+from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from tetrex_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _oracle_index(oracle, bins, m, h, k, dna, per_bin, seed, reduction=0):
+    ox = oracle.Index.ibf(bins, m, h, dna=dna, k=k, reduction=reduction)
+    rng = np.random.default_rng(seed)
+    bits = (2 if dna else 5) * k
+    for b in range(bins):
+        ox.emplace(rng.integers(0, 1 << min(bits, 62), size=per_bin, dtype=np.uint64), b)
+    return ox
+
+
+def _wants(ox, queries):
+    out = []
+    for q in queries:
+        try:
+            m, st = ox.query(q, with_stats=True)
+            out.append(None if st["quirk_merges"] else m)
+        except Exception:
+            out.append(False)  # the reference path cannot search it either
+    return out
+
+
+def _check(capi, ox, queries, dna, k, reduction=0, shards=(1,), wants=None, per_query=0):
+    sh = ox.shape()
+    wants = wants if wants is not None else _wants(ox, queries)
+    checked, dense_ops = 0, 0
+    for R in shards:
+        for r in range(R):
+            ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=R)
+            lo, nw = int(ix.info.shard_word0), ix.shard_words
+            got, status, stats = ix.query_masks(queries, dna, k, reduction, per_query)
+            dense_ops += stats["dense_ops"]
+            for q, g, w, st in zip(queries, got, wants, status):
+                if w is False:
+                    assert st != 0, q
+                    continue
+                assert st == 0, q
+                if w is not None:
+                    assert np.array_equal(g, w[lo:lo + nw]), (q, R, r)
+                    checked += 1
+            ix.free()
+    return checked, dense_ops
+
+
+@pytest.mark.parametrize("knobs", [("1", "0"), ("2", "2"), ("24", "8"), (None, None)], ids=["everything", "2/2", "24/8", "defaults"])
+def test_peptide_queries_dense_vs_oracle(capi, oracle, monkeypatch, knobs):
+    if knobs[0]:
+        monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
+        monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
+    ox = _oracle_index(oracle, bins=1024, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
+    qs = PEPTIDE_QUERIES + random_prosite_motifs(60, 7, wildcard=0.1, ranges=0.05)
+    wants = _wants(ox, qs)
+    checked, dense_ops = _check(capi, ox, qs, False, 4, shards=(1, 4), wants=wants)
+    assert checked > 300 and dense_ops > 50
+    # and the same batch with dense steps switched off gives the same masks (A/B of the two paths)
+    monkeypatch.setenv("TETREX_DENSE", "0")
+    checked2, none = _check(capi, ox, qs, False, 4, wants=wants)
+    assert checked2 * 5 == checked and none == 0
+
+
+def test_dense_on_odd_and_wide_masks(capi, oracle, monkeypatch):
+    """Mask widths that take the other lane layouts of dense_kernel: 1 word, an odd number of words (8-byte lanes),
+    130 words (more 16-byte chunks than lanes per suffix)."""
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]", "LMA(E|Q)GLYN"]
+    for bins, per_bin in ((40, 700), (64 * 3 - 5, 700), (64 * 7, 500), (8300, 120)):
+        ox = _oracle_index(oracle, bins=bins, m=2053, h=3, k=4, dna=False, per_bin=per_bin, seed=bins)
+        checked, dense_ops = _check(capi, ox, qs, False, 4, shards=(1, 3) if bins > 200 else (1,))
+        assert checked >= 5 and dense_ops > 20, bins
+
+
+def test_dna_and_reduced_alphabets_dense(capi, oracle, monkeypatch):
+    monkeypatch.setenv("TETREX_DENSE_MIN", "1")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "0")
+    for bins, m, k, per_bin, h in ((70, 257, 3, 8, 3), (300, 4099, 5, 300, 2), (128, 8191, 7, 900, 4)):
+        ox = _oracle_index(oracle, bins=bins, m=m, h=h, k=k, dna=True, per_bin=per_bin, seed=bins)
+        qs = DNA_QUERIES + ["ACG..T.GA", "A.{2,4}CGT.A", "AC[GT]..[AC]CGT"]
+        checked, dense_ops = _check(capi, ox, qs, True, k)
+        assert checked > 8 and dense_ops > 10
+    for red in (1, 2):
+        ox = _oracle_index(oracle, bins=256, m=8191, h=2, k=5, dna=False, per_bin=1500, seed=red, reduction=red)
+        qs = ["LMA(E|Q)GLYN", "LMAEGLYNK", "W[LIVM]D.FYLK", "LMAE(GL|YN)K.DE", "KRDEG..NLMA"]
+        checked, dense_ops = _check(capi, ox, qs, False, 5, red)
+        assert checked >= 3 and dense_ops > 5
+
+
+def test_dense_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
+    """Tiny per-query stage budgets: blocks are written in one stage and read in the next; regions grow while they
+    hold live blocks (device-to-device copy) and blocks are recycled."""
+    monkeypatch.setenv("TETREX_DENSE_MIN", "3")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    ox = _oracle_index(oracle, bins=512, m=2053, h=3, k=4, dna=False, per_bin=800, seed=5)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "CLM.{2,4}C...[LIVMFYWC]", "LMK.{0,2}C.{0,2}D.{0,2}EK"]
+    for per_query in (3, 40):
+        checked, dense_ops = _check(capi, ox, qs, False, 4, per_query=per_query)
+        assert checked == len(qs) and dense_ops > 30
+
+
+def test_saturated_motifs_cost_few_host_ops(capi, oracle):
+    """Defaults: the wildcard-rich motifs of the bench batch.  Masks equal the oracle's and the host emits a small
+    fraction of the ops it needs without dense steps."""
+    import os
+    ox = _oracle_index(oracle, bins=1024, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=9)
+    qs = [q for q in random_prosite_motifs(300, 6) if "." in q][:40]
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    got, status, stats = ix.query_masks(qs, False, 4)
+    os.environ["TETREX_DENSE"] = "0"
+    try:
+        got0, status0, stats0 = ix.query_masks(qs, False, 4)
+    finally:
+        del os.environ["TETREX_DENSE"]
+    ix.free()
+    assert status == status0 and np.array_equal(got, got0)
+    assert stats["dense_ops"] > 0 and stats0["dense_ops"] == 0 and stats["ops"] * 10 < stats0["ops"]
+    compared = 0
+    for q, g, st in zip(qs[:12], got, status):
+        m, ost = ox.query(q, with_stats=True)
+        if st == 0 and not ost["quirk_merges"]:
+            assert np.array_equal(g, m), q
+            compared += 1
+    assert compared >= 6

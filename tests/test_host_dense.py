@@ -1,0 +1,119 @@
+"""CPU tests of the dense DP steps (include/txq_program.h version 3; host/compiler.cpp densify / dense_step /
+materialise, level scheduling with block hazards in schedule_levels_into).  The device session is replaced by
+the numpy simulator (helpers.SessionSimulator), which evaluates DENSE_ZERO / STEP / REDUCE from their
+definition over oracle-probed masks; the final masks must equal the oracle's collect()
+(reference include/otf_collector.h:341-393) whatever the thresholds that decide where lists go dense."""
+import numpy as np
+import pytest
+
+from helpers import SessionSimulator
+from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
+
+
+@pytest.fixture(scope="module")
+def host():
+    from tetrex_amd import host as H
+    H.lib()
+    return H
+
+
+def _index(oracle, bins, m, h, k, dna, per_bin, seed, reduction=0):
+    ox = oracle.Index.ibf(bins, m, h, dna=dna, k=k, reduction=reduction)
+    rng = np.random.default_rng(seed)
+    bits = (2 if dna else 5) * k
+    for b in range(bins):
+        ox.emplace(rng.integers(0, 1 << min(bits, 62), size=per_bin, dtype=np.uint64), b)
+    return ox
+
+
+def _run(host, ox, queries, dna, k, dense, per_query=0, gaps=None, reduction=0, augment=False):
+    sim = SessionSimulator(ox, len(queries))
+    status, stats = host.run_staged(queries, dna, k, reduction, ox.bins, sim.stage, per_query, 0, gaps=gaps, dense=dense)
+    checked = 0
+    for i, q in enumerate(queries):
+        try:
+            want, ost = ox.query_aug(q, augment=True) if augment else ox.query(q, with_stats=True)
+        except Exception:
+            assert status[i] != 0
+            continue
+        assert status[i] == 0, q
+        if ost["quirk_merges"]:
+            continue
+        assert np.array_equal(sim.result(i), want), q
+        checked += 1
+    return checked, stats, sim
+
+
+THRESHOLDS = [dict(min_states=1, sparse_below=1), dict(min_states=2, sparse_below=3), dict(min_states=20, sparse_below=9), dict()]
+
+
+@pytest.mark.parametrize("dense", THRESHOLDS, ids=["everything", "2/2", "20/8", "defaults"])
+def test_peptide_queries_with_dense_steps(host, oracle, dense):
+    ox = _index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
+    qs = [q for q in PEPTIDE_QUERIES if "{2,4}C" not in q] + random_prosite_motifs(25, 3, wildcard=0.1, ranges=0.05)
+    checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+    assert checked >= len(qs) - 8
+    assert sim.dense_steps > 100 and sim.dense_kinds[0] > 0
+    if dense.get("sparse_below") == 1:
+        assert sim.dense_kinds[2] > 10  # blocks reach the Match node: DENSE_REDUCE into RESULT
+
+
+@pytest.mark.parametrize("per_query", [1, 7, 64])
+def test_blocks_persist_across_stages(host, oracle, per_query):
+    """A stage budget of a few ops cuts the queries between dense steps: blocks written in one stage are read,
+    zeroed and recycled in later ones."""
+    ox = _index(oracle, bins=130, m=2053, h=3, k=4, dna=False, per_bin=800, seed=2)
+    # three literal residues first: the oracle's result is then well defined (no quirk merges)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]"]
+    checked, stats, sim = _run(host, ox, qs, False, 4, dict(min_states=4, sparse_below=3), per_query=per_query)
+    assert checked == len(qs) and stats["stages"] >= 2 and sim.dense_steps > 20
+
+
+def test_dna_dense_steps_probe_canonical_kmers(host, oracle):
+    ox = _index(oracle, bins=70, m=257, h=3, k=3, dna=True, per_bin=8, seed=3)
+    checked, stats, sim = _run(host, ox, DNA_QUERIES + ["A..T.G", "AC.{1,3}GT", "[AC]..[GT]A"], True, 3, dict(min_states=1, sparse_below=1))
+    assert checked >= 12 and sim.dense_steps > 20
+    ox = _index(oracle, bins=64, m=1021, h=2, k=5, dna=True, per_bin=60, seed=4)
+    checked, stats, sim = _run(host, ox, ["ACG..T.GA", "A.{2,4}CGT.A", "GATTACA", "AC[GT]..[AC]CGT"], True, 5, dict(min_states=3, sparse_below=3))
+    assert checked >= 3 and sim.dense_steps > 5
+
+
+def test_reduced_alphabet_k5(host, oracle):
+    ox = _index(oracle, bins=96, m=2053, h=2, k=5, dna=False, per_bin=500, seed=5, reduction=1)
+    qs = ["LMA..E[DE]GLY", "WK.{1,2}[LIVM]D.F", "AC.DE.GH", "M[KR]..S[ST].L", "LMAEGLYN"]
+    checked, stats, sim = _run(host, ox, qs, False, 5, dict(min_states=2, sparse_below=3), reduction=1)
+    assert checked >= 4 and sim.dense_steps > 5
+
+
+def test_no_block_left_falls_back_to_enumerated_states(host, oracle):
+    """With room for a single block (or a pool too small for even one) the steps out of a block have nowhere to
+    accumulate: the block is enumerated again and the query goes on with ordinary ops — same masks."""
+    ox = _index(oracle, bins=100, m=2053, h=3, k=4, dna=False, per_bin=700, seed=6)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH"]
+    for dense in (dict(min_states=2, sparse_below=1, max_blocks=1), dict(min_states=2, sparse_below=1, max_blocks=2),
+                  dict(min_states=2, sparse_below=1, pool_bytes=1)):
+        checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+        assert checked == len(qs)
+
+
+def test_gap_nodes_reduce_a_block(host, oracle):
+    """-a without a d-gram index: a state crossing a Gap node restarts its k-mer, so a whole block collapses
+    into one state (DENSE_REDUCE into an ordinary slot)."""
+    ox = _index(oracle, bins=100, m=2053, h=3, k=4, dna=False, per_bin=700, seed=7)
+    # residue classes (too few paths to be bypassed) make the list dense, the wildcard run behind them becomes Gap nodes
+    qs = ["LMK[DE][KR][ST][LIV].{3,6}FK", "WKL[LIVM][DE][FY].{2,4}GH[KR]K", "CLMAC[DE][ST].{2,3}GH[LIV]K"]
+    gaps = dict(augment=1)
+    checked, stats, sim = _run(host, ox, qs, False, 4, dict(min_states=2, sparse_below=1), gaps=gaps, augment=True)
+    assert checked >= 2 and sim.dense_steps >= 6 and sim.dense_kinds[2] >= 2
+
+
+def test_dense_cuts_the_host_work_of_a_saturated_motif(host, oracle):
+    """The point of it all: a wildcard run saturates the state list (20^3 states at k = 4); enumerated, every further
+    residue class costs an op per state and residue; as a block it costs one op."""
+    ox = oracle.Index.ibf(64, 257, 3, dna=False, k=4)
+    ox.set_words(np.full(257, np.uint64(0xFFFFFFFFFFFFFFFF), dtype=np.uint64))
+    qs = ["LMA.{3,5}[DE]..[LIVM]GK.H"]
+    _, plain, _ = _run(host, ox, qs, False, 4, None)
+    _, dense, sim = _run(host, ox, qs, False, 4, dict())
+    assert plain["ops"] > 200000 and dense["ops"] < plain["ops"] / 50
+    assert int(sim.result(0)[0]) == 0xFFFFFFFFFFFFFFFF

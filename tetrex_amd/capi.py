@@ -20,7 +20,7 @@ TXQ_MERGED_BIN = 0xFFFFFFFFFFFFFFFF
 # every symbol include/txq.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
-    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_create_ibf",
+    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_supports_dense", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
     "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_set_aux_index", "txq_session_stage", "txq_session_end",
     "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize", "txq_host_alloc", "txq_host_free",
@@ -309,7 +309,8 @@ class Index:
         if rc < 0:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
         keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
-        return masks, list(status), dict(zip(keys, (int(x) for x in stats)))
+        Lq.txe_last_dense_ops.restype = C.c_uint64
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
 
     def query_masks(self, regexes, dna, k, reduction=0, ops_per_query_per_stage=0):
         """Whole queries on this GPU-resident index through the C++ host (libtetrex_query.so):
@@ -325,7 +326,8 @@ class Index:
         if rc < 0:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
         keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
-        return masks, list(status), dict(zip(keys, (int(x) for x in stats)))
+        Lq.txe_last_dense_ops.restype = C.c_uint64
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
 
     def run_programs(self, blob, n_programs):
         buf = np.frombuffer(blob, dtype=np.uint8)

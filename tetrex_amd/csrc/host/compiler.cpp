@@ -98,9 +98,30 @@ void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_ga
     }
 }
 
-QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps)
-    : enc_(enc), g_(std::move(graph)), limits_(limits), gaps_(gaps) {
+QueryExpansion::~QueryExpansion() = default;
+
+uint64_t dense_block_slots(const KmerEncoder& enc, const DenseOptions& opt) {
+    const unsigned pos = enc.k() - 1;
+    if (!opt.enabled || enc.k() < 2 || pos > TXQ_DENSE_MAX_POSITIONS || opt.max_blocks == 0) return 0;
+    const uint64_t slot_bytes = opt.slot_bytes ? opt.slot_bytes : 128;
+    uint64_t n = 1;
+    for (unsigned j = 1; j <= pos; ++j) {
+        n *= enc.alphabet_size();
+        if (n > (1u << 22) || n * slot_bytes > opt.max_block_bytes) return 0;
+    }
+    return n * opt.max_blocks < TXQ_DENSE_SLOT_BIT ? n : 0;
+}
+
+QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps, DenseOptions dense)
+    : enc_(enc), g_(std::move(graph)), limits_(limits), gaps_(gaps), dense_(dense) {
     if (enc_.k() < 2) throw std::runtime_error("k must be at least 2");
+    // dense blocks: the d-gram filter needs three residues of history per state, which a (k-1)-suffix block does not keep
+    dense_pos_ = enc_.k() - 1;
+    dense_a_ = enc_.alphabet_size();
+    if (const uint64_t n = gaps_.dgram_loaded ? 0 : tetrex::dense_block_slots(enc_, dense_)) {
+        dense_ok_ = true;
+        dense_n_ = n;
+    }
     if (gaps_.augment) g_.augment();
     const int32_t n = n_nodes_ = g_.size();
     const std::vector<int32_t> topo = g_.topological_order();
@@ -300,9 +321,173 @@ void QueryExpansion::adopt_storage(NodeStates& ns) {
     if (ns.by_key.capacity() == 0 && !spare_maps_.empty()) { std::swap(ns.by_key, spare_maps_.back()); spare_maps_.pop_back(); }
 }
 
-void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams, bool verified_only) {
+// ---- dense blocks (include/txq_program.h, version 3) -----------------------------------------
+
+uint64_t QueryExpansion::dense_index(uint64_t kmer) const {
+    const unsigned bits = enc_.bits_per_symbol();
+    const uint64_t sym = enc_.symbol_mask();
+    uint64_t idx = 0;
+    for (unsigned j = 0; j < dense_pos_; ++j) idx = idx * dense_a_ + ((kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
+    return idx;
+}
+
+uint64_t QueryExpansion::shape_entries(const DenseRef& r) const {
+    uint64_t n = 1;
+    for (unsigned j = 0; j < dense_pos_; ++j) n *= (uint64_t)__builtin_popcount(r.shape[j]);
+    return n;
+}
+
+// makes sure the next `n` new_block() calls succeed (blocks come from the free list or extend the region)
+bool QueryExpansion::can_take_blocks(size_t n) {
+    const size_t available = free_blocks_.size() - free_block_head_;
+    if (n <= available) return true;
+    const size_t more = n - available;
+    if (n_blocks_ + more > dense_.max_blocks) return false;
+    const int64_t bytes = (int64_t)(more * dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128));
+    if (dense_.pool) {
+        if (dense_.pool->fetch_sub(bytes, std::memory_order_relaxed) - bytes < 0) {
+            dense_.pool->fetch_add(bytes, std::memory_order_relaxed);
+            return false;
+        }
+        pool_taken_ += (uint64_t)bytes;  // the device keeps the region until the session ends: nothing is handed back
+    }
+    for (size_t i = 0; i < more; ++i) {
+        free_blocks_.push_back((uint32_t)n_blocks_++);
+        block_refs_.push_back(0);
+    }
+    return true;
+}
+
+uint32_t QueryExpansion::new_block(OpVec& out) {
+    if (free_block_head_ >= free_blocks_.size()) throw std::logic_error("dense block taken without a reservation");
+    const uint32_t b = free_blocks_[free_block_head_++];
+    if (free_block_head_ == free_blocks_.size()) { free_blocks_.clear(); free_block_head_ = 0; }
+    block_refs_[b] = 1;
+    txq_dense_op z{};
+    z.kind = TXQ_DENSE_ZERO;
+    z.dst = dense_slot(b, 0);
+    emit_dense(out, z);
+    return b;
+}
+
+void QueryExpansion::release_block(uint32_t block) {
+    if (--block_refs_[block] == 0) parked_blocks_.push_back(block);  // reusable once the current item is finished
+}
+
+void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d) {
+    if (!dense_out_) throw std::logic_error("dense op without a dense table");
+    dense_out_->push_back(d);
+    emit(out, TXQ_DENSE_OP, (uint32_t)(dense_out_->size() - 1), 0, 0);
+    if (d.kind == TXQ_DENSE_STEP) ++dense_steps_;
+}
+
+// the block this list accumulates into (created on first use; the caller has reserved it)
+QueryExpansion::DenseRef* QueryExpansion::owned_block(NodeStates& ns, OpVec& out) {
+    for (DenseRef& r : ns.dense)
+        if (r.owned) return &r;
+    DenseRef r{};
+    r.block = new_block(out);
+    r.owned = 1;
+    ns.dense.push_back(r);
+    return &ns.dense.back();
+}
+
+// a list with many full-length states becomes (part of) a block: one scatter op per state now instead of
+// one op per state and residue at every later step
+void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
+    if (!dense_ok_ || ns.items.size() < dense_.min_states) return;
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    size_t full = 0;
+    for (const State& s : ns.items) full += !s.gapped && s.shift >= k - 1;
+    if (full < dense_.min_states) return;
+    bool has_own = false;
+    for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
+    if (!has_own && !can_take_blocks(1)) return;
+    DenseRef* own = owned_block(ns, out);
+    const uint64_t sym = enc_.symbol_mask();
+    size_t kept = 0;
+    for (size_t i = 0; i < ns.items.size(); ++i) {
+        const State s = ns.items[i];
+        if (s.gapped || s.shift < k - 1) { ns.items[kept++] = s; continue; }
+        const uint32_t e = dense_slot(own->block, dense_index(s.kmer));
+        emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
+        drop(s.slot);
+        for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
+    }
+    ns.items.resize(kept);
+}
+
+// blocks of `item` whose shape has shrunk to a few entries (or all of them, when no block can be had for
+// their successors) go back to enumerated states: one copy op per entry of the shape
+void QueryExpansion::materialise(int32_t item, OpVec& out, bool all) {
+    NodeStates& ns = table_[item];
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    std::vector<DenseRef> keep, take;
+    for (const DenseRef& r : ns.dense) (all || small_enough(r) ? take : keep).push_back(r);
+    if (take.empty()) return;
+    ns.dense.swap(keep);
+    for (const DenseRef& r : take) {
+        // odometer over shape[0] x .. x shape[k-2]
+        unsigned code[TXQ_DENSE_MAX_POSITIONS];
+        bool empty = false;
+        for (unsigned j = 0; j < dense_pos_; ++j) {
+            if (!r.shape[j]) { empty = true; break; }
+            code[j] = (unsigned)__builtin_ctz(r.shape[j]);
+        }
+        while (!empty) {
+            uint64_t idx = 0, kmer = 0;
+            for (unsigned j = 0; j < dense_pos_; ++j) { idx = idx * dense_a_ + code[j]; kmer = (kmer << bits) | code[j]; }
+            const uint32_t d = fresh();
+            emit(out, TXQ_NO_KMER, d, dense_slot(r.block, idx), TXQ_SLOT_ZERO);
+            arrive(item, State{kmer, d, (uint8_t)k, 0, 0, 0, 0}, out);
+            unsigned j = dense_pos_;
+            for (;;) {
+                if (j == 0) { empty = true; break; }
+                --j;
+                const uint32_t higher = r.shape[j] & ~((2u << code[j]) - 1u);
+                if (higher) { code[j] = (unsigned)__builtin_ctz(higher); break; }
+                code[j] = (unsigned)__builtin_ctz(r.shape[j]);
+            }
+        }
+        release_block(r.block);
+    }
+}
+
+// one collector round for all states of `src` and the residues of r_mask, accumulated into the receiver's block
+void QueryExpansion::dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out) {
+    if (receiver == KGraph::kNone || !r_mask) return;
+    NodeStates& rs = table_[receiver];
+    DenseRef* own = owned_block(rs, out);
+    txq_dense_op d{};
+    d.kind = TXQ_DENSE_STEP;
+    d.dst = dense_slot(own->block, 0);
+    d.src = dense_slot(src.block, 0);
+    d.r_mask = r_mask;
+    for (unsigned j = 0; j < dense_pos_; ++j) d.shape[j] = src.shape[j];
+    emit_dense(out, d);
+    for (unsigned j = 0; j + 1 < dense_pos_; ++j) own->shape[j] |= src.shape[j + 1];
+    own->shape[dense_pos_ - 1] |= r_mask;
+}
+
+// the lists that dense steps out of `item` accumulate into
+void QueryExpansion::dense_receivers(int32_t item, std::vector<int32_t>& out) const {
+    out.clear();
+    auto add = [&](int32_t r) {
+        if (r != KGraph::kNone && std::find(out.begin(), out.end(), r) == out.end()) out.push_back(r);
+    };
+    if (item > n_nodes_) {
+        for (uint32_t i = fan_first_[item - n_nodes_ - 1]; i < fan_first_[item - n_nodes_]; ++i) {
+            const int32_t t = fan_[i];
+            if (g_.label[t] < 256 && single_source_[t]) add(forward_[t]);
+        }
+    } else if (g_.label[item] < 256) add(forward_[item]);
+}
+
+void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams, bool verified_only, DenseVec* dense) {
     const unsigned k = enc_.k();
     const size_t start = out.size();
+    dense_out_ = dense;
+    const bool go_dense = dense_ok_ && dense != nullptr;
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
         if (verified_only) {
             // Expand only what the device has confirmed alive: an item whose input still holds a state
@@ -320,10 +505,39 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             free_.insert(free_.end(), parked_.begin(), parked_.end());
             parked_.clear();
         }
+        if (!parked_blocks_.empty()) {
+            free_blocks_.insert(free_blocks_.end(), parked_blocks_.begin(), parked_blocks_.end());
+            parked_blocks_.clear();
+        }
+        bool densify_here = false;
+        if (dense_ok_) {
+            // Dense part of this item's input: shapes that have shrunk to a few entries are enumerated again; so is
+            // everything when the blocks its steps would accumulate into cannot be had (budget), or when this call
+            // has nowhere to put dense ops.  A list that is about to be densified needs those blocks as well.
+            const int32_t next = order_[cursor_];
+            NodeStates& cur = table_[next];
+            const bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
+            if (!cur.dense.empty() || may_densify) {
+                dense_receivers(next, receivers_scratch_);
+                size_t need = 0;
+                for (int32_t r : receivers_scratch_) {
+                    bool has = false;
+                    for (const DenseRef& d : table_[r].dense) has |= d.owned != 0;
+                    need += !has;
+                }
+                bool own = false;
+                for (const DenseRef& d : cur.dense) own |= d.owned != 0;
+                const bool ok = go_dense && can_take_blocks(need + (may_densify && !own ? 1 : 0));
+                densify_here = ok && may_densify;
+                if (!cur.dense.empty()) materialise(next, out, !ok);
+            }
+        }
         const int32_t item = order_[cursor_++];
         NodeStates ns;
         ns.items.swap(table_[item].items);
+        ns.dense.swap(table_[item].dense);
         waiting_ -= ns.items.size();
+        if (densify_here) densify(ns, out);
         table_[item].append_only = false;
         if (table_[item].by_key.capacity()) {
             table_[item].by_key.clear();
@@ -344,6 +558,34 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 if (refs_[s.slot] != kPinned) refs_[s.slot] += hi - lo - 1;
                 for (uint32_t i = lo; i < hi; ++i)
                     if (!single_source_[fan_[i]]) arrive(fan_[i], s, out);
+            }
+            if (!ns.dense.empty()) {
+                // one step per receiver for all the residue nodes that only this join feeds; a target with other
+                // sources (or a Match / Gap node) takes a reference to the block and deals with it on its turn
+                struct Group { int32_t receiver; uint32_t r_mask; };
+                std::vector<Group> groups;
+                for (uint32_t i = lo; i < hi; ++i) {
+                    const int32_t t = fan_[i];
+                    if (g_.label[t] < 256 && single_source_[t]) {
+                        if (dangling_[t]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
+                        if (forward_[t] == KGraph::kNone) continue;
+                        const uint32_t bit = 1u << enc_.code((unsigned char)g_.label[t]);
+                        bool found = false;
+                        for (Group& g : groups)
+                            if (g.receiver == forward_[t]) { g.r_mask |= bit; found = true; }
+                        if (!found) groups.push_back(Group{forward_[t], bit});
+                    } else {
+                        for (DenseRef r : ns.dense) {
+                            r.owned = 0;
+                            ++block_refs_[r.block];
+                            table_[t].dense.push_back(r);
+                        }
+                    }
+                }
+                for (const Group& g : groups)
+                    for (const DenseRef& r : ns.dense) dense_step(r, g.r_mask, g.receiver, out);
+                for (const DenseRef& r : ns.dense) release_block(r.block);
+                ns.dense.clear();
             }
             if (readers && !ns.items.empty()) {
                 if (ns.items.size() >= merge_sample_threshold() && !merging_pays(ns.items))
@@ -382,6 +624,32 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             if (states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         }
         const int32_t lab = g_.label[item];
+        for (const DenseRef& r : ns.dense) {
+            if (lab == KGraph::kMatch) {
+                txq_dense_op d{};
+                d.kind = TXQ_DENSE_REDUCE;
+                d.dst = TXQ_SLOT_RESULT;
+                d.src = dense_slot(r.block, 0);
+                for (unsigned j = 0; j < dense_pos_; ++j) d.shape[j] = r.shape[j];
+                emit_dense(out, d);
+            } else if (lab == KGraph::kGap) {
+                // gap_procedure without a d-gram index: every state restarts its k-mer, i.e. they all merge into one
+                const uint32_t acc = fresh();
+                emit(out, TXQ_NO_KMER, acc, TXQ_SLOT_ZERO, TXQ_SLOT_ZERO);
+                txq_dense_op d{};
+                d.kind = TXQ_DENSE_REDUCE;
+                d.dst = acc;
+                d.src = dense_slot(r.block, 0);
+                for (unsigned j = 0; j < dense_pos_; ++j) d.shape[j] = r.shape[j];
+                emit_dense(out, d);
+                hand_on(item, State{0, acc, 0, 0, 0, 0, 0}, out);
+            } else {
+                if (dangling_[item]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
+                dense_step(r, 1u << enc_.code((unsigned char)lab), forward_[item], out);
+            }
+            release_block(r.block);
+        }
+        ns.dense.clear();
         if (forward_[item] != KGraph::kNone && !single_source_[forward_[item]] && input->size() > 8) {
             // the merging table of the receiver grows once, not by repeated doubling and re-hashing
             NodeStates& next = table_[forward_[item]];
@@ -537,45 +805,100 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
 // ---- level scheduling ---------------------------------------------------------------------
 
 std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, LevelScratch& sc, txq_op* dst,
-                                           uint32_t kmer_add, uint32_t dgram_add) {
+                                           uint32_t kmer_add, uint32_t dgram_add, const DenseSchedule* dn) {
     std::vector<uint32_t> ends;
     if (ops.empty()) return ends;
-    if (sc.slot.size() < n_slots) sc.slot.resize(n_slots, LevelScratch::Slot{0, 0, 0, 0});
-    if (++sc.epoch == 0) { for (auto& s : sc.slot) s.stamp = 0; sc.epoch = 1; }
+    const uint32_t n_dense_slots = dn ? dn->n_dense_slots : 0;
+    const uint64_t block_n = dn && dn->block_slots ? dn->block_slots : 1;
+    if (sc.slot.size() < (size_t)n_slots + n_dense_slots) sc.slot.resize((size_t)n_slots + n_dense_slots, LevelScratch::Slot{0, 0, 0, 0});
+    if (n_dense_slots && sc.block.size() < n_dense_slots / block_n + 1) sc.block.resize(n_dense_slots / block_n + 1, LevelScratch::Block{0, 0, 0, 0, 0});
+    if (++sc.epoch == 0) {
+        for (auto& s : sc.slot) s.stamp = 0;
+        for (auto& b : sc.block) b.stamp = 0;
+        sc.epoch = 1;
+    }
     auto touch = [&](uint32_t s) -> LevelScratch::Slot& {
-        LevelScratch::Slot& x = sc.slot[s];
+        LevelScratch::Slot& x = sc.slot[(s & TXQ_DENSE_SLOT_BIT) ? n_slots + (s & ~TXQ_DENSE_SLOT_BIT) : s];
         if (x.stamp != sc.epoch) x = LevelScratch::Slot{sc.epoch, 0, 0, 0};
         return x;
+    };
+    // hazards between dense ops (whole blocks) and ordinary ops on single slots of a block are kept per block:
+    // dw / dr = last level a dense op wrote / read the block, sw / sr = last level an ordinary op wrote / read a slot of it
+    auto block_of = [&](uint32_t s) -> LevelScratch::Block* {
+        if (!(s & TXQ_DENSE_SLOT_BIT)) return nullptr;
+        LevelScratch::Block& b = sc.block[(s & ~TXQ_DENSE_SLOT_BIT) / block_n];
+        if (b.stamp != sc.epoch) b = LevelScratch::Block{sc.epoch, 0, 0, 0, 0};
+        return &b;
     };
     // level of op = smallest level that respects every hazard against earlier ops (levels from 1)
     sc.level_of.resize(ops.size());
     uint32_t top = 0;
     for (size_t i = 0; i < ops.size(); ++i) {
         const txq_op& o = ops[i];
+        uint32_t lvl = 1;
+        auto after = [&](uint32_t l) { if (l + 1 > lvl) lvl = l + 1; };
+        if (o.kmer == TXQ_DENSE_OP) {
+            if (!dn) throw std::logic_error("dense op without a dense table");
+            const txq_dense_op& d = dn->table[o.dst];
+            if (d.kind == TXQ_DENSE_REDUCE) {
+                LevelScratch::Block& x = *block_of(d.src);
+                LevelScratch::Slot& sd = touch(d.dst);
+                LevelScratch::Block* bd = block_of(d.dst);
+                after(x.dw); after(x.sw);
+                after(sd.wr); after(sd.rd);
+                if (bd) { after(bd->dw); after(bd->dr); }
+                if (sd.acc > lvl) lvl = sd.acc;  // an accumulation: shares its level with others into the same slot
+                if (x.dr < lvl) x.dr = lvl;
+                sd.acc = lvl;
+                if (bd && bd->sw < lvl) bd->sw = lvl;
+            } else {
+                LevelScratch::Block& y = *block_of(d.dst);
+                after(y.dw); after(y.dr); after(y.sw); after(y.sr);
+                if (d.kind == TXQ_DENSE_STEP) {
+                    LevelScratch::Block& x = *block_of(d.src);
+                    after(x.dw); after(x.sw);
+                    if (x.dr < lvl) x.dr = lvl;
+                }
+                y.dw = lvl;
+            }
+            sc.level_of[i] = lvl;
+            if (lvl > top) top = lvl;
+            continue;
+        }
         LevelScratch::Slot& sd = touch(o.dst);
         LevelScratch::Slot& sa = touch(o.a);
         LevelScratch::Slot& sb = touch(o.b);
+        LevelScratch::Block* bd = block_of(o.dst);
+        LevelScratch::Block* ba = block_of(o.a);
+        LevelScratch::Block* bb = block_of(o.b);
         const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
-        uint32_t lvl = 1;
-        auto after = [&](uint32_t l) { if (l + 1 > lvl) lvl = l + 1; };
+        if (bd) { after(bd->dw); after(bd->dr); }
         if (accumulate) {
             LevelScratch::Slot& src = o.dst == o.a ? sb : sa;
+            LevelScratch::Block* bs = o.dst == o.a ? bb : ba;
             after(src.wr); after(src.acc);   // RAW on the source
+            if (bs) after(bs->dw);
             after(sd.wr); after(sd.rd);      // after the last full write and every earlier reader
             if (sd.acc > lvl) lvl = sd.acc;  // may share a level with other accumulations
             if (src.rd < lvl) src.rd = lvl;
+            if (bs && bs->sr < lvl) bs->sr = lvl;
             sd.acc = lvl;
         } else {
             after(sa.wr); after(sa.acc);
             after(sb.wr); after(sb.acc);
+            if (ba) after(ba->dw);
+            if (bb) after(bb->dw);
             // WAR / WAW on dst; an in-place op (dst == a or b) reads its own old value, which is fine
             after(sd.wr); after(sd.acc);
             const uint32_t rd_dst = sd.rd;
             after(rd_dst);
             if (sa.rd < lvl) sa.rd = lvl;
             if (sb.rd < lvl) sb.rd = lvl;
+            if (ba && ba->sr < lvl) ba->sr = lvl;
+            if (bb && bb->sr < lvl) bb->sr = lvl;
             sd.wr = lvl;
         }
+        if (bd && bd->sw < lvl) bd->sw = lvl;
         sc.level_of[i] = lvl;
         if (lvl > top) top = lvl;
     }
@@ -584,9 +907,11 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
     for (uint32_t l : sc.level_of) ++ends[l - 1];
     sc.pos.assign(top, 0);
     for (uint32_t l = 1; l < top; ++l) sc.pos[l] = sc.pos[l - 1] + ends[l - 1];
+    const uint32_t dense_add = dn ? dn->index_add : 0;
     for (size_t i = 0; i < ops.size(); ++i) {
         txq_op o = ops[i];
-        if (o.kmer != TXQ_NO_KMER) o.kmer = (o.kmer & kDgramFlag) ? (o.kmer & ~kDgramFlag) + dgram_add : o.kmer + kmer_add;
+        if (o.kmer == TXQ_DENSE_OP) o.dst += dense_add;
+        else if (o.kmer != TXQ_NO_KMER) o.kmer = (o.kmer & kDgramFlag) ? (o.kmer & ~kDgramFlag) + dgram_add : o.kmer + kmer_add;
         dst[sc.pos[sc.level_of[i] - 1]++] = o;
     }
     for (uint32_t l = 1; l < top; ++l) ends[l] += ends[l - 1];

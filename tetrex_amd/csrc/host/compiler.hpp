@@ -24,6 +24,7 @@
 #include "kgraph.hpp"
 #include "../../../include/txq_program.h"
 
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -51,6 +52,22 @@ struct GapOptions {
 uint64_t dgram_residue_code(int symbol);
 // the d-gram codes one sequence record contributes (DGramIndex::process_sequence)
 void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_gap, std::vector<uint64_t>& out);
+
+// Dense DP steps (include/txq_program.h, version 3): where a state list saturates, the host keeps it as a
+// block of A^(k-1) device slots and emits one op per residue set instead of one per state and residue.
+struct DenseOptions {
+    bool enabled = false;          // the executor runs dense ops (a flat-IBF device session)
+    uint32_t min_states = 128;     // a list with at least this many full-length states becomes a block
+    uint32_t sparse_below = 24;    // a block whose shape holds at most this many entries is enumerated again
+    uint64_t slot_bytes = 0;       // bytes of one mask on the executing device (budgets; 0 = 128)
+    uint64_t max_block_bytes = 256ull << 20;
+    uint32_t max_blocks = 24;      // per query, live at the same time
+    std::atomic<int64_t>* pool = nullptr;  // bytes all queries of a run may still take (null: unlimited)
+};
+using DenseVec = std::vector<txq_dense_op>;
+// slots of one dense block, A^(k-1), for this encoder — 0 when dense blocks cannot be used with it (k too
+// large for a block to fit the limits, or dense steps switched off)
+uint64_t dense_block_slots(const KmerEncoder& enc, const DenseOptions& opt);
 
 // op.kmer of an op that ANDs with a d-gram mask: bit 31 set on the index into the d-gram table
 // (local to one expansion; run_staged rebases both kinds into the stage's single table, d-grams last)
@@ -109,15 +126,22 @@ class KmerTable {
 class QueryExpansion {
   public:
     using Intern = KmerTable&;
-    QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps = {});
+    QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps = {}, DenseOptions dense = {});
+    ~QueryExpansion();
 
     bool done() const { return cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
     // verified_only: stop before the first item that would consume a state the device has not yet
     // reported on (see frontier_slots / prune).
-    void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr, bool verified_only = false);
+    // Dense ops (DenseOptions::enabled) go to `dense`; their op-stream entries index it from its size at the call.
+    void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr, bool verified_only = false,
+                 DenseVec* dense = nullptr);
     uint32_t n_slots() const { return high_water_; }
+    // slots of the dense region (a multiple of the block size A^(k-1)); 0 while the query never went dense
+    uint32_t n_dense_slots() const { return (uint32_t)(n_blocks_ * dense_n_); }
+    uint64_t dense_steps() const { return dense_steps_; }
+    uint64_t dense_block_slots() const { return dense_n_; }  // A^(k-1), 0 when dense blocks are off for this query
     // distinct non-constant slots of waiting states that were not asked about before (a waiting
     // state's mask only ever grows, so one answer per state is enough); marks them as asked
     void frontier_slots(std::vector<uint32_t>& out);
@@ -144,7 +168,10 @@ class QueryExpansion {
     // RESULT.  Where a join's list shows that (almost) none of the arrivals made from it can merge —
     // sparse state sets, typical at k = 6 — the receiver gets no table and just appends (`append_only`):
     // its look-ups, growth and initialisation were a third of the expansion time there.
-    struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; };
+    // a block of the dense region as one list's (part of the) state set; shape[j] = codes that can occur at suffix
+    // position j (0 = oldest): a superset, entries outside the real set are zero masks
+    struct DenseRef { uint32_t block; uint32_t owned; uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; };
+    struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; std::vector<DenseRef> dense; };
     static constexpr uint32_t kMergeSample = 4096;  // lists shorter than this are not worth the question
     bool merging_pays(const StateVec& list);
     static size_t merge_sample_threshold();
@@ -187,6 +214,31 @@ class QueryExpansion {
     std::vector<uint32_t> seen_;  // frontier_slots: slot -> epoch
     uint32_t seen_epoch_ = 0;
 
+    // ---- dense blocks ----
+    DenseOptions dense_;
+    bool dense_ok_ = false;
+    unsigned dense_pos_ = 0;      // k - 1
+    uint32_t dense_a_ = 0;        // alphabet size A
+    uint64_t dense_n_ = 0;        // A^(k-1)
+    uint64_t n_blocks_ = 0, pool_taken_ = 0, dense_steps_ = 0;
+    std::vector<uint32_t> block_refs_, free_blocks_, parked_blocks_;
+    size_t free_block_head_ = 0;
+    DenseVec* dense_out_ = nullptr;
+    uint32_t dense_slot(uint32_t block, uint64_t index) const { return TXQ_DENSE_SLOT_BIT | (uint32_t)(block * dense_n_ + index); }
+    uint64_t dense_index(uint64_t kmer) const;
+    uint64_t shape_entries(const DenseRef& r) const;
+    bool can_take_blocks(size_t n);
+    uint32_t new_block(OpVec& out);
+    void release_block(uint32_t block);
+    void emit_dense(OpVec& out, const txq_dense_op& d);
+    DenseRef* owned_block(NodeStates& ns, OpVec& out);
+    void densify(NodeStates& ns, OpVec& out);
+    void materialise(int32_t item, OpVec& out, bool all);
+    void dense_receivers(int32_t item, std::vector<int32_t>& out) const;
+    std::vector<int32_t> receivers_scratch_;
+    void dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out);
+    bool small_enough(const DenseRef& r) const { return shape_entries(r) <= dense_.sparse_below; }
+
     uint32_t fresh();
     void share(uint32_t s);
     void drop(uint32_t s);
@@ -202,7 +254,9 @@ class QueryExpansion {
 // Scratch vectors are reused across calls (sized to n_slots).
 struct LevelScratch {
     struct Slot { uint32_t stamp, wr, rd, acc; };  // last full write / last read / last accumulation level of a slot, valid when stamp == epoch
+    struct Block { uint32_t stamp, dw, dr, sw, sr; };  // a dense block: last dense write / dense read / ordinary write / ordinary read
     std::vector<Slot> slot;
+    std::vector<Block> block;
     uint32_t epoch = 0;
     std::vector<uint32_t> level_of, pos;
     OpVec sorted;
@@ -210,8 +264,10 @@ struct LevelScratch {
 std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch& scratch);
 // Same, but leaves `ops` alone and writes the reordered ops to `dst` (room for ops.size()), adding
 // `kmer_add` to every k-mer index and `dgram_add` to every (flag-stripped) d-gram index on the way.
+// dense ops of the program (op.dst indexes `table`; `index_add` rebases it into the stage's table)
+struct DenseSchedule { const txq_dense_op* table; uint32_t index_add; uint32_t n_dense_slots; uint64_t block_slots; };
 std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, LevelScratch& scratch, txq_op* dst,
-                                           uint32_t kmer_add, uint32_t dgram_add);
+                                           uint32_t kmer_add, uint32_t dgram_add, const DenseSchedule* dense = nullptr);
 
 // What executes a stage: the GPU session (device_index.cpp) or a test double.
 struct StageExecutor {
@@ -232,11 +288,13 @@ struct StagedOptions {
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;
+    DenseOptions dense;                      // run_staged fills `pool` itself
+    uint64_t dense_pool_bytes = 48ull << 30; // device memory all dense blocks of a run may take
 };
 
 struct StagedStats {
     size_t stages = 0;
-    uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0;
+    uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0, dense_ops = 0;
     double expand_seconds = 0, execute_seconds = 0;  // host expansion vs. StageExecutor::stage
 };
 

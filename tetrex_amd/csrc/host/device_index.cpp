@@ -101,7 +101,11 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     if (messages) messages->assign(regexes.size(), std::string());
     if (regexes.empty()) return masks;
     TxqStageExecutor exec(ix, regexes.size(), aux);
-    const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, options ? *options : StagedOptions{}, status, messages);
+    StagedOptions opt = options ? *options : StagedOptions{};
+    // saturated state lists run as dense DP steps on the device where the index allows it (TETREX_DENSE=0 switches them off)
+    opt.dense.enabled = txq_index_supports_dense(ix) != 0;
+    opt.dense.slot_bytes = info.shard_words * 8;
+    const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
     if (stats) *stats = st;
     exec.finish(masks.data());
     return masks;

@@ -25,6 +25,8 @@ class KmerEncoder {
     Alphabet alphabet() const { return alphabet_; }
     unsigned bits_per_symbol() const { return bits_; }
     uint64_t symbol_mask() const { return (1ULL << bits_) - 1ULL; }
+    // residue codes are 0 .. alphabet_size()-1 (Base 21: the 20 residues + the catch-all code 20; Murphy / Li 10; DNA 4)
+    unsigned alphabet_size() const { return mol_ == Molecule::DNA ? 4u : alphabet_ == Alphabet::Base ? 21u : 10u; }
     uint64_t kmer_mask() const { return kmer_mask_; }
     // mask selecting the (k-1)-symbol suffix of a forward k-mer (collector state key)
     uint64_t suffix_mask() const { return suffix_mask_; }

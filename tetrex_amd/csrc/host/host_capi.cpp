@@ -122,6 +122,13 @@ struct CallbackExecutor final : StageExecutor {
 int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
                    size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps, txh_stage_fn fn,
                    void* user, int* status, uint64_t* stats6) {
+    return txh_run_staged_dense(regex, n, dna, k, reduction, bins, ops_per_query_per_stage, ops_per_stage, gaps, nullptr, fn, user,
+                                status, stats6);
+}
+
+int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
+                         size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps,
+                         const txh_dense_options* dense, txh_stage_fn fn, void* user, int* status, uint64_t* stats6) {
     try {
         KmerEncoder enc = encoder(dna, k, reduction);
         std::vector<std::string> rx(regex, regex + n);
@@ -133,6 +140,14 @@ int txh_run_staged(const char* const* regex, size_t n, int dna, unsigned k, unsi
         if (ops_per_query_per_stage) { opt.ops_per_query_per_stage = ops_per_query_per_stage; opt.stage_target_ops = 0; opt.verified_levels = false; }
         if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
         if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0, gaps->min_gap, gaps->max_gap};
+        if (dense && dense->enabled) {
+            opt.dense.enabled = true;
+            if (dense->min_states) opt.dense.min_states = dense->min_states;
+            if (dense->sparse_below) opt.dense.sparse_below = dense->sparse_below - 1;  // 1 = never enumerate again
+            if (dense->max_blocks) opt.dense.max_blocks = dense->max_blocks;
+            opt.dense.slot_bytes = dense->slot_bytes;
+            if (dense->pool_bytes) opt.dense_pool_bytes = dense->pool_bytes;
+        }
         std::vector<int> st;
         std::vector<std::string> why;
         const StagedStats s = run_staged(enc, bins, rx, exec, opt, &st, &why);

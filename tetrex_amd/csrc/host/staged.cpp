@@ -76,13 +76,20 @@ class StagedRun {
     StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
-          dgram_tables_(n_, KmerTable(false)), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
+          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
         overlap_ = !env_is("TETREX_NO_OVERLAP", '1');
         run_on_budget_ = std::max(opt.ops_per_task, opt.ops_per_query_per_stage);
+        dense_ = opt.dense;
+        if (const char* e = std::getenv("TETREX_DENSE")) dense_.enabled = dense_.enabled && e[0] != '0';  // A/B knob: TETREX_DENSE=0
+        if (const char* e = std::getenv("TETREX_DENSE_MIN")) dense_.min_states = (uint32_t)std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("TETREX_DENSE_SPARSE_BELOW")) dense_.sparse_below = (uint32_t)std::max(0, std::atoi(e));
+        if (opt.gaps.dgram_loaded || dense_block_slots(enc, dense_) == 0) dense_.enabled = false;  // version-2 blobs, as before
+        dense_pool_.store((int64_t)std::min<uint64_t>(opt.dense_pool_bytes, (uint64_t)INT64_MAX));
+        dense_.pool = &dense_pool_;
         if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
     }
 
@@ -140,7 +147,8 @@ class StagedRun {
             try {
                 if (bins_ <= 1) { passthrough_[i] = 1; return; }  // include/query.h:265-272
                 const std::string postfix = preprocess_query(regexes_[i], enc_);
-                q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps);
+                q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps, dense_);
+                if (q_[i]->dense_block_slots()) dense_block_slots_.store(q_[i]->dense_block_slots(), std::memory_order_relaxed);
             } catch (const std::exception& e) {
                 fail(i, e);
             }
@@ -153,6 +161,7 @@ class StagedRun {
         ops_[i].clear();
         tables_[i].clear();
         dgram_tables_[i].clear();
+        dense_ops_[i].clear();
         q_[i].reset();
         status_[i] = -1;
         why_[i] = e.what();
@@ -178,13 +187,14 @@ class StagedRun {
                 const size_t grown = run_on_budget_ << (2 * std::min<uint32_t>(run_on_stages_[i], 2));
                 if (!asks) ++run_on_stages_[i];
                 q_[i]->advance(asks ? feedback_budget : grown, tables_[i], ops_[i], &dgram_tables_[i],
-                               asks && verified_levels_ && q_[i]->mostly_dying());
+                               asks && verified_levels_ && q_[i]->mostly_dying(), dense_.enabled ? &dense_ops_[i] : nullptr);
             } catch (const std::exception& e) {
                 fail(i, e);
                 return;
             }
             total.fetch_add(ops_[i].size(), std::memory_order_relaxed);
             slots_[i] = q_[i]->n_slots();
+            dslots_[i] = q_[i]->n_dense_slots();
             if (q_[i]->done()) {  // free the expansion's tables here, on the worker
                 fin_states_[i] = q_[i]->states();
                 fin_pruned_[i] = q_[i]->pruned();
@@ -235,35 +245,49 @@ class StagedRun {
     // probes the last `stage_dgrams` entries on the auxiliary index) | programs | ops | levels
     Blob assemble() {
         const size_t m = touched_.size();
-        std::vector<uint32_t> base(m), dbase(m), first_op(m);
-        size_t stage_kmers = 0, stage_dgrams = 0, stage_ops = 0;
+        std::vector<uint32_t> base(m), dbase(m), first_op(m), first_dense(m);
+        size_t stage_kmers = 0, stage_dgrams = 0, stage_ops = 0, stage_dense = 0;
         for (size_t j = 0; j < m; ++j) {
             base[j] = (uint32_t)stage_kmers;
             stage_kmers += tables_[touched_[j]].values().size();
             first_op[j] = (uint32_t)stage_ops;
             stage_ops += ops_[touched_[j]].size();
+            first_dense[j] = (uint32_t)stage_dense;
+            stage_dense += dense_ops_[touched_[j]].size();
         }
+        st_.dense_ops += stage_dense;
         for (size_t j = 0; j < m; ++j) {
             dbase[j] = (uint32_t)(stage_kmers + stage_dgrams);
             stage_dgrams += dgram_tables_[touched_[j]].values().size();
         }
         if (stage_kmers + stage_dgrams > 0x7FFFFFF0u) throw std::runtime_error("stage k-mer table overflow");
         if (stage_ops > 0xFFFFFFFFu) throw std::runtime_error("stage has more than 2^32 operations");
-        txq_blob_header_v2 h{};
+        // version 3 (dense table between the programs and the ops) whenever this run may use dense blocks
+        const bool v3 = dense_.enabled;
+        txq_blob_header_v3 h3{};
+        txq_blob_header_v2& h = h3.v2;
         h.magic = TXQ_PROGRAM_MAGIC;
-        h.version = TXQ_PROGRAM_VERSION_LEVELS;
+        h.version = v3 ? TXQ_PROGRAM_VERSION_DENSE : TXQ_PROGRAM_VERSION_LEVELS;
         h.n_programs = (uint32_t)n_;
         h.n_kmers = (uint32_t)(stage_kmers + stage_dgrams);
         h.n_ops = (uint32_t)stage_ops;
         h.n_aux_kmers = stage_dgrams;
-        h.kmers_offset = sizeof(txq_blob_header_v2);
+        h.kmers_offset = v3 ? sizeof(txq_blob_header_v3) : sizeof(txq_blob_header_v2);
         h.programs_offset = h.kmers_offset + (stage_kmers + stage_dgrams) * sizeof(uint64_t);
-        h.ops_offset = h.programs_offset + n_ * sizeof(txq_program_v2);
+        h3.dense_offset = h.programs_offset + n_ * sizeof(txq_program_v2);
+        h3.n_dense = (uint32_t)stage_dense;
+        h3.k = enc_.k();
+        h3.bits = enc_.bits_per_symbol();
+        h3.alphabet = enc_.alphabet_size();
+        h3.canonical = enc_.molecule() == Molecule::DNA ? 1u : 0u;
+        h.ops_offset = h3.dense_offset + (v3 ? stage_dense * sizeof(txq_dense_op) : 0);
         h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
         // a program has at most one level per op, and per op at worst one k-mer: the ceiling of the reservation
         const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 4, opt_.limits.max_ops);
         uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
-                                           sizeof(txq_blob_header_v2) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
+                                           sizeof(txq_blob_header_v3) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
+        txq_dense_op* blob_dense = reinterpret_cast<txq_dense_op*>(blob + h3.dense_offset);
+        const uint64_t block_slots = dense_block_slots_.load(std::memory_order_relaxed);
         uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
         txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
         pool_.run(m, [&](size_t j, int t) {
@@ -272,7 +296,10 @@ class StagedRun {
             if (!km.empty()) std::memcpy(blob_kmers + base[j], km.data(), km.size() * 8);
             const KmerVec& dg = dgram_tables_[i].values();
             if (!dg.empty()) std::memcpy(blob_kmers + dbase[j], dg.data(), dg.size() * 8);
-            levels_[i] = schedule_levels_into(ops_[i], slots_[i], scratch_[t], blob_ops + first_op[j], base[j], dbase[j]);
+            const DenseVec& dn = dense_ops_[i];
+            if (!dn.empty()) std::memcpy(blob_dense + first_dense[j], dn.data(), dn.size() * sizeof(txq_dense_op));
+            const DenseSchedule ds{dn.data(), first_dense[j], dslots_[i], block_slots};
+            levels_[i] = schedule_levels_into(ops_[i], slots_[i], scratch_[t], blob_ops + first_op[j], base[j], dbase[j], v3 ? &ds : nullptr);
         });
         lap("levels");
         txq_program_v2* pr = reinterpret_cast<txq_program_v2*>(blob + h.programs_offset);
@@ -282,21 +309,23 @@ class StagedRun {
         for (size_t i = 0; i < n_; ++i) {
             if (j < m && touched_[j] == i) {
                 const uint32_t nl = (uint32_t)levels_[i].size();
-                pr[i] = txq_program_v2{first_op[j], (uint32_t)ops_[i].size(), slots_[i], at_level, nl, 0};
+                pr[i] = txq_program_v2{first_op[j], (uint32_t)ops_[i].size(), slots_[i], at_level, nl, dslots_[i]};
                 if (nl) std::memcpy(lv + at_level, levels_[i].data(), (size_t)nl * 4);
                 at_level += nl;
                 ++j;
             } else {
-                pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, 0};
+                pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, dslots_[i]};
             }
         }
         h.n_levels = at_level;
         if (at_level & 1) lv[at_level] = 0;
-        std::memcpy(blob, &h, sizeof h);
+        if (v3) std::memcpy(blob, &h3, sizeof h3);
+        else std::memcpy(blob, &h, sizeof h);
         // the blob holds the stage now: the per-query buffers are free for the next one
         for (uint32_t i : touched_) {
+            dense_ops_[i].clear();
             if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
-            else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); }  // finished: storage back to the cache
+            else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); DenseVec().swap(dense_ops_[i]); }  // finished: storage back to the cache
             levels_[i].clear();
         }
         lap("blob");
@@ -385,6 +414,11 @@ class StagedRun {
     // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared
     // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
     std::vector<KmerTable> tables_, dgram_tables_;
+    std::vector<DenseVec> dense_ops_;  // per query: the dense ops of the stage being built (op.dst of a TXQ_DENSE_OP indexes it)
+    std::vector<uint32_t> dslots_;     // per query: slots of its dense region
+    DenseOptions dense_;
+    std::atomic<int64_t> dense_pool_{0};
+    std::atomic<uint64_t> dense_block_slots_{0};
     std::vector<LevelScratch> scratch_;               // per thread
     std::vector<std::vector<uint8_t>> dead_scratch_;  // per thread
     std::vector<std::vector<uint32_t>> levels_, asks_;

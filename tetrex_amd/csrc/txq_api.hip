@@ -30,13 +30,13 @@ int fail_hip(hipError_t e, const char* what) {
 }
 int require_init() {
     if (g_device < 0) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
-    // the HIP device is a per-thread setting: a thread other than the one that called txq_init
-    // (e.g. the host's stage-submission thread) would otherwise talk to device 0
-    static thread_local int t_device = -1;
-    if (t_device != g_device) {
+    // The HIP device is a per-thread setting: a thread other than the one that called txq_init (e.g. the host's
+    // stage-submission thread) would otherwise talk to device 0, and the embedding application may have selected
+    // another device since the last call (torch.cuda.set_device): always ask, never trust a cached answer.
+    int current = -1;
+    if (hipGetDevice(&current) != hipSuccess || current != g_device) {
         hipError_t e = hipSetDevice(g_device);
         if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
-        t_device = g_device;
     }
     return TXQ_OK;
 }
@@ -114,7 +114,8 @@ void Index::release() {
         if (host_pipe.bounce[i]) (void)hipHostFree(host_pipe.bounce[i]);
     }
     host_pipe = HostPipe{};
-    for (void* p : {(void*)session_cache.chunk, (void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
+    for (const ArenaChunk& c : session_cache.chunks) (void)hipFree(c.p);
+    for (void* p : {(void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
     if (d_merged) (void)hipFree(d_merged);
@@ -268,8 +269,15 @@ int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
     return TXQ_OK;
 }
 
+int txq_index_supports_dense(const txq_index* ix) {
+    return ix && !ix->is_hibf && !ix->ibf.empty() && (ix->ibf[0].bin_size >> 32) == 0 && ix->shard_words > 0 ? 1 : 0;
+}
+
 int txq_index_free(txq_index* ix) {
     if (!ix) return TXQ_OK;
+    if (ix->open_sessions > 0)
+        return fail(TXQ_ERR_STATE, "the index still has %d open session(s): end them first (txq_session_end)", ix->open_sessions);
+    if (g_device >= 0) (void)require_init();
     ix->release();
     delete ix;
     return TXQ_OK;
@@ -413,7 +421,9 @@ int txq_session_set_aux_index(txq_session* s, txq_index* aux) {
         if (aux->user_bins != s->ix->user_bins || aux->shard_word0 != s->ix->shard_word0 || aux->shard_words != s->ix->shard_words)
             return fail(TXQ_ERR_ARG, "the auxiliary index must cover the same bins and the same shard as the main index");
     }
+    if (s->aux) --s->aux->open_sessions;
     s->aux = aux;
+    if (aux) ++aux->open_sessions;
     return TXQ_OK;
 }
 
@@ -426,7 +436,8 @@ int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const
 
 int txq_session_end(txq_session* s, uint64_t* final_masks) {
     if (!s) return TXQ_OK;
-    int rc = TXQ_OK;
+    int rc = require_init();  // the calling thread may never have selected the device
+    if (rc != TXQ_OK) { delete static_cast<Session*>(s); return rc; }
     if (final_masks && s->n_programs && s->W) {
         Index& ix = *s->ix;
         const size_t bytes = s->n_programs * (size_t)s->W * 8;

@@ -16,6 +16,14 @@
 //                  it expands them further.  One __ballot per queried slot.
 // Most queries finish in one stage; txq_run_programs is exactly that case.
 // Format of a stage's op list: include/txq_program.h.
+//
+// Dense DP steps (blob version 3): where a query's state set saturates, the host keeps it as a block of
+// A^(k-1) slots in the program's DENSE REGION and sends one op per residue set instead of one per state and
+// residue.  dense_kernel runs such a step as the fused probe-AND-OR of the collector: for every destination
+// suffix it hashes the k-mers of all predecessor states, gathers their h IBF rows, ANDs them with the
+// predecessor's mask and ORs the result into the destination — the per-k-mer masks M[k] never exist in HBM
+// (algorithmic bytes per state visit: h*W*8 of rows + W*8 of source mask, the latter L2-resident).
+// Programs with dense ops always run level by level (a dense op is cut into tiles, one workgroup each).
 #include "txq_internal.hpp"
 #include <algorithm>
 #include <thread>
@@ -38,23 +46,31 @@ __device__ __forceinline__ void slot_store(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// slot -> its W words: ordinary slots live in the program's slot region S, slots with TXQ_DENSE_SLOT_BIT in its dense region D
+__device__ __forceinline__ uint64_t* slot_ptr(uint64_t* S, uint64_t* D, uint32_t s, uint32_t W) {
+    return (s & TXQ_DENSE_SLOT_BIT) ? D + (size_t)(s & ~TXQ_DENSE_SLOT_BIT) * W : S + (size_t)s * W;
+}
+
 template <int G>
-__device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, const uint64_t* __restrict__ M, uint32_t W, uint32_t sub,
+__device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, uint64_t* D, const uint64_t* __restrict__ M, uint32_t W, uint32_t sub,
                                         bool concurrent) {
     const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
+    uint64_t* pd = slot_ptr(S, D, o.dst, W);
     if (concurrent && accumulate) {  // slot[dst] |= slot[src]; other ops of the level may hit dst too
-        const uint32_t src = o.dst == o.a ? o.b : o.a;
+        const uint64_t* ps = slot_ptr(S, D, o.dst == o.a ? o.b : o.a, W);
         for (uint32_t w = sub; w < W; w += G) {
-            const uint64_t x = slot_load(S + (size_t)src * W + w);
-            if (x) __hip_atomic_fetch_or(S + (size_t)o.dst * W + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint64_t x = slot_load(ps + w);
+            if (x) __hip_atomic_fetch_or(pd + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         return;
     }
+    const uint64_t* pa = slot_ptr(S, D, o.a, W);
+    const uint64_t* pb = slot_ptr(S, D, o.b, W);
     for (uint32_t w = sub; w < W; w += G) {
-        uint64_t x = slot_load(S + (size_t)o.a * W + w);
+        uint64_t x = slot_load(pa + w);
         if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
-        x |= slot_load(S + (size_t)o.b * W + w);
-        slot_store(S + (size_t)o.dst * W + w, x);
+        x |= slot_load(pb + w);
+        slot_store(pd + w, x);
     }
 }
 
@@ -71,10 +87,11 @@ __global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict
         const DevProgram pr = progs[p];
         if (pr.n_ops == 0) continue;
         uint64_t* S = slot_base[p];  // [slots][W]
+        uint64_t* D = slot_base[n_programs + p];
         const txq_op* op = ops + pr.first_op;
         if (pr.n_levels == 0) {
             if (group == 0)
-                for (uint32_t i = 0; i < pr.n_ops; ++i) run_op<G>(op[i], S, M, W, sub, false);
+                for (uint32_t i = 0; i < pr.n_ops; ++i) run_op<G>(op[i], S, D, M, W, sub, false);
             __syncthreads();
             continue;
         }
@@ -82,7 +99,7 @@ __global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict
         uint32_t begin = 0;
         for (uint32_t l = 0; l < pr.n_levels; ++l) {
             const uint32_t end = lv[l];
-            for (uint32_t i = begin + group; i < end; i += n_groups) run_op<G>(op[i], S, M, W, sub, true);
+            for (uint32_t i = begin + group; i < end; i += n_groups) run_op<G>(op[i], S, D, M, W, sub, true);
             __syncthreads();
             begin = end;
         }
@@ -99,25 +116,178 @@ static inline uint32_t unit_ops(uint32_t W) { return W >= kUnitWords ? 1u : kUni
 
 template <int G>
 __global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
-                                                         uint64_t* const* __restrict__ slot_base, const uint64_t* __restrict__ M,
-                                                         uint32_t W) {
+                                                         uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                         const uint64_t* __restrict__ M, uint32_t W) {
     const ExecUnit u = units[blockIdx.x];
     const uint32_t sub = threadIdx.x % G, group = threadIdx.x / G, n_groups = blockDim.x / G;
     uint64_t* S = slot_base[u.program];
+    uint64_t* D = slot_base[n_programs + u.program];
     for (uint32_t i = u.begin + group; i < u.end; i += n_groups) {
         const txq_op o = ops[i];
+        uint64_t* pd = slot_ptr(S, D, o.dst, W);
         if (o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b)) {
-            const uint32_t src = o.dst == o.a ? o.b : o.a;
+            const uint64_t* ps = slot_ptr(S, D, o.dst == o.a ? o.b : o.a, W);
             for (uint32_t w = sub; w < W; w += G) {
-                const uint64_t x = S[(size_t)src * W + w];
-                if (x) __hip_atomic_fetch_or(S + (size_t)o.dst * W + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint64_t x = ps[w];
+                if (x) __hip_atomic_fetch_or(pd + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         } else {
+            const uint64_t* pa = slot_ptr(S, D, o.a, W);
+            const uint64_t* pb = slot_ptr(S, D, o.b, W);
             for (uint32_t w = sub; w < W; w += G) {
-                uint64_t x = S[(size_t)o.a * W + w];
+                uint64_t x = pa[w];
                 if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
-                x |= S[(size_t)o.b * W + w];
-                S[(size_t)o.dst * W + w] = x;
+                x |= pb[w];
+                pd[w] = x;
+            }
+        }
+    }
+}
+
+// ---- dense DP steps ---------------------------------------------------------------------------
+// One workgroup per tile: `count` work entries of one dense op, starting at `first`.
+//   ZERO    entries = slots of the block
+//   REDUCE  entries = suffixes inside shape[0] x .. x shape[k-2]
+//   STEP    entries = destination suffixes (x1 .. x_{k-2}, r) inside shape[1] x .. x shape[k-2] x R; each is
+//           handled by G lanes (a lane owns 16 bytes of the mask: WIDE, or one word) which loop over the
+//           predecessors a in shape[0], two at a time: 2 * (H row gathers + 1 source mask) loads in flight
+struct DenseTile { uint32_t program, op, first, count; };
+struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; };
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool WIDE> struct Lane;
+template <> struct Lane<true> {
+    using T = u32x4;
+    static constexpr uint32_t kWords = 2;
+    static __device__ __forceinline__ T load(const uint64_t* p) { return *reinterpret_cast<const T*>(p); }
+    static __device__ __forceinline__ void store(uint64_t* p, T v) { *reinterpret_cast<T*>(p) = v; }
+    static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
+    static __device__ __forceinline__ bool any(T v) { return (v.x | v.y | v.z | v.w) != 0u; }
+};
+template <> struct Lane<false> {
+    using T = uint64_t;
+    static constexpr uint32_t kWords = 1;
+    static __device__ __forceinline__ T load(const uint64_t* p) { return *p; }
+    static __device__ __forceinline__ void store(uint64_t* p, T v) { *p = v; }
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ bool any(T v) { return v != 0; }
+};
+
+__device__ __forceinline__ uint64_t canonical_dna(uint64_t fwd, uint32_t k) {
+    uint64_t rc = 0, f = fwd;
+    for (uint32_t i = 0; i < k; ++i) { rc = (rc << 2) | ((f & 3u) ^ 2u); f >>= 2; }
+    return fwd <= rc ? fwd : rc;
+}
+
+// (src[a-th predecessor] & row_0 & .. & row_{H-1}) for lane chunk `c` of the k-mer `value`
+template <int H, bool WIDE>
+__device__ __forceinline__ void issue_loads(const IbfDev& f, const uint64_t* src_slot, uint64_t value, uint32_t c,
+                                            typename Lane<WIDE>::T (&x)[H + 1]) {
+    using L = Lane<WIDE>;
+    x[H] = L::load(src_slot + (size_t)c * L::kWords);
+#pragma unroll
+    for (int i = 0; i < H; ++i) {
+        const uint64_t row = hash_row(value, kSeeds[i], f.hash_shift, f.bin_size);
+        x[i] = L::load(f.words + row * f.stride + (size_t)c * L::kWords);
+    }
+}
+
+template <int H, bool WIDE>
+__global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
+                                                    uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
+                                                    uint32_t G, DenseParams P) {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // [j < pos]: codes of shape[j]; [pos]: codes of r_mask
+    __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    const DenseTile t = tiles[blockIdx.x];
+    const txq_dense_op d = dops[t.op];
+    uint64_t* S = slot_base[t.program];
+    uint64_t* D = slot_base[n_programs + t.program];
+    if (d.kind == TXQ_DENSE_ZERO) {
+        uint64_t* blk = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+        const size_t end = ((size_t)t.first + t.count) * W;
+        for (size_t i = (size_t)t.first * W + threadIdx.x; i < end; i += blockDim.x) blk[i] = 0;
+        return;
+    }
+    if (threadIdx.x <= P.pos) {
+        const uint32_t j = threadIdx.x;
+        const uint32_t mask = j < P.pos ? d.shape[j] : d.r_mask;
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < 32; ++c)
+            if ((mask >> c) & 1u) codes[j][n++] = (uint8_t)c;
+        cnt[j] = n;
+    }
+    __syncthreads();
+    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
+    const uint32_t end = t.first + t.count;
+    if (d.kind == TXQ_DENSE_REDUCE) {
+        uint64_t* dst = slot_ptr(S, D, d.dst, W);
+        uint32_t wl = 1;
+        while (wl < W && wl < blockDim.x) wl <<= 1;
+        const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, groups = blockDim.x / wl;
+        for (uint32_t w = sub; w < W; w += wl) {
+            uint64_t acc = 0;
+            for (uint32_t e = t.first + grp; e < end; e += groups) {
+                uint32_t r = e, idx = 0;
+                for (uint32_t j = P.pos; j-- > 0;) {
+                    idx += (uint32_t)codes[j][r % cnt[j]] * P.pow_a[P.pos - 1 - j];
+                    r /= cnt[j];
+                }
+                acc |= src[(size_t)idx * W + w];
+            }
+            if (acc) __hip_atomic_fetch_or(dst + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // STEP
+    uint64_t* dstb = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+    const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, groups = blockDim.x / G;
+    const uint32_t chunks = (W + L::kWords - 1) / L::kWords;
+    const uint32_t n_r = cnt[P.pos], n_a = cnt[0];
+    const uint32_t a_stride = P.pow_a[P.pos - 1];
+    for (uint32_t e = t.first + grp; e < end; e += groups) {
+        uint32_t q = e / n_r;
+        const uint32_t r = codes[P.pos][e % n_r];
+        uint32_t mid = 0;
+        uint64_t mid_val = 0;
+        for (uint32_t j = P.pos; j-- > 1;) {
+            const uint32_t c = codes[j][q % cnt[j]];
+            q /= cnt[j];
+            mid += c * P.pow_a[P.pos - 1 - j];
+            mid_val |= (uint64_t)c << (P.bits * (P.pos - 1 - j));
+        }
+        const uint64_t low = (mid_val << P.bits) | r;  // the k-mer without its oldest residue
+        uint64_t* dst = dstb + ((size_t)mid * P.A + r) * W;
+        for (uint32_t c = sub; c < chunks; c += G) {
+            T acc = L::zero();
+            uint32_t i = 0;
+            for (; i + 1 < n_a; i += 2) {
+                const uint32_t a0 = codes[0][i], a1 = codes[0][i + 1];
+                uint64_t v0 = ((uint64_t)a0 << (P.bits * P.pos)) | low, v1 = ((uint64_t)a1 << (P.bits * P.pos)) | low;
+                if (P.canonical) { v0 = canonical_dna(v0, P.k); v1 = canonical_dna(v1, P.k); }
+                T x0[H + 1], x1[H + 1];
+                issue_loads<H, WIDE>(f, src + ((size_t)a0 * a_stride + mid) * W, v0, c, x0);
+                issue_loads<H, WIDE>(f, src + ((size_t)a1 * a_stride + mid) * W, v1, c, x1);
+                T y0 = x0[H], y1 = x1[H];
+#pragma unroll
+                for (int h = 0; h < H; ++h) { y0 &= x0[h]; y1 &= x1[h]; }
+                acc |= y0 | y1;
+            }
+            if (i < n_a) {
+                const uint32_t a0 = codes[0][i];
+                uint64_t v0 = ((uint64_t)a0 << (P.bits * P.pos)) | low;
+                if (P.canonical) v0 = canonical_dna(v0, P.k);
+                T x0[H + 1];
+                issue_loads<H, WIDE>(f, src + ((size_t)a0 * a_stride + mid) * W, v0, c, x0);
+                T y0 = x0[H];
+#pragma unroll
+                for (int h = 0; h < H; ++h) y0 &= x0[h];
+                acc |= y0;
+            }
+            if (L::any(acc)) {
+                uint64_t* p = dst + (size_t)c * L::kWords;
+                L::store(p, L::load(p) | acc);
             }
         }
     }
@@ -171,13 +341,16 @@ __global__ __launch_bounds__(256) void gather_result_kernel(uint64_t* const* __r
     } while (0)
 
 // Host-side validation: nothing malformed may reach the GPU (a stray slot or k-mer index would
-// be an out-of-bounds access there).  Accepts version 1 (op order) and version 2 (levels) blobs and
-// normalises the program table.
+// be an out-of-bounds access there).  Accepts version 1 (op order), 2 (levels) and 3 (levels + dense
+// ops) blobs and normalises the program table.
 struct BlobView {
-    uint32_t n_kmers = 0, n_ops = 0, n_levels = 0;
-    uint64_t kmers_offset = 0, ops_offset = 0, levels_offset = 0, n_aux_kmers = 0;
+    uint32_t n_kmers = 0, n_ops = 0, n_levels = 0, n_dense = 0;
+    uint64_t kmers_offset = 0, ops_offset = 0, levels_offset = 0, n_aux_kmers = 0, dense_offset = 0;
+    DenseParams dense{};
+    uint32_t block_slots = 0;  // A^(k-1) when the blob is version 3
     std::vector<DevProgram> programs;
-    std::vector<uint32_t> n_slots;
+    std::vector<uint32_t> n_slots, n_dense_slots;
+    std::vector<uint8_t> has_dense;  // the program has dense ops in this stage
 };
 
 static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, BlobView* out) {
@@ -185,10 +358,13 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     if ((uintptr_t)blob % 8) return fail(TXQ_ERR_PROGRAM, "blob must be 8-byte aligned");
     const txq_blob_header* h1 = (const txq_blob_header*)blob;
     if (h1->magic != TXQ_PROGRAM_MAGIC) return fail(TXQ_ERR_PROGRAM, "bad blob magic");
-    const bool v2 = h1->version == TXQ_PROGRAM_VERSION_LEVELS;
+    const bool v3 = h1->version == TXQ_PROGRAM_VERSION_DENSE;
+    const bool v2 = v3 || h1->version == TXQ_PROGRAM_VERSION_LEVELS;
     if (!v2 && h1->version != TXQ_PROGRAM_VERSION) return fail(TXQ_ERR_PROGRAM, "unsupported blob version %u", h1->version);
-    if (v2 && bytes < sizeof(txq_blob_header_v2)) return fail(TXQ_ERR_PROGRAM, "blob shorter than its header");
+    if (bytes < (v3 ? sizeof(txq_blob_header_v3) : v2 ? sizeof(txq_blob_header_v2) : sizeof(txq_blob_header)))
+        return fail(TXQ_ERR_PROGRAM, "blob shorter than its header");
     const txq_blob_header_v2* h2 = (const txq_blob_header_v2*)blob;
+    const txq_blob_header_v3* h3 = (const txq_blob_header_v3*)blob;
     BlobView v;
     uint64_t programs_offset;
     if (v2) {
@@ -211,9 +387,31 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
         !in_range(programs_offset, n_programs, v2 ? sizeof(txq_program_v2) : sizeof(txq_program)) ||
         (v2 && !in_range(v.levels_offset, v.n_levels, 4)))
         return fail(TXQ_ERR_PROGRAM, "blob table outside the blob");
+    if (v3) {
+        v.n_dense = h3->n_dense;
+        v.dense_offset = h3->dense_offset;
+        if (v.dense_offset % 8 || !in_range(v.dense_offset, v.n_dense, sizeof(txq_dense_op))) return fail(TXQ_ERR_PROGRAM, "dense table outside the blob");
+        DenseParams& P = v.dense;
+        P.k = h3->k; P.bits = h3->bits; P.A = h3->alphabet; P.canonical = h3->canonical ? 1u : 0u;
+        if (P.k < 2 || P.k - 1 > TXQ_DENSE_MAX_POSITIONS || P.bits < 1 || P.bits > 8 || (uint64_t)P.bits * P.k > 64 || P.A < 1 || P.A > 32 ||
+            P.A > (1u << P.bits) || (P.canonical && P.bits != 2))
+            return fail(TXQ_ERR_PROGRAM, "dense parameters out of range (k %u, %u bits, alphabet %u)", P.k, P.bits, P.A);
+        P.pos = P.k - 1;
+        uint64_t n = 1;
+        P.pow_a[0] = 1;
+        for (uint32_t j = 1; j <= P.pos; ++j) {
+            n *= P.A;
+            if (n > (1u << 22)) return fail(TXQ_ERR_PROGRAM, "dense block of %u^%u slots is too large", P.A, P.pos);
+            P.pow_a[j] = (uint32_t)n;
+        }
+        v.block_slots = (uint32_t)n;
+    }
     v.programs.resize(n_programs);
     v.n_slots.resize(n_programs);
+    v.n_dense_slots.assign(n_programs, 0);
+    v.has_dense.assign(n_programs, 0);
     const txq_op* ops = (const txq_op*)(blob + v.ops_offset);
+    const txq_dense_op* dops = v3 ? (const txq_dense_op*)(blob + v.dense_offset) : nullptr;
     const uint32_t* levels = v2 ? (const uint32_t*)(blob + v.levels_offset) : nullptr;
     for (uint32_t p = 0; p < n_programs; ++p) {
         DevProgram d{};
@@ -221,13 +419,18 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             const txq_program_v2& s = ((const txq_program_v2*)(blob + programs_offset))[p];
             d = DevProgram{s.first_op, s.n_ops, s.first_level, s.n_levels};
             v.n_slots[p] = s.n_slots;
+            if (v3) {
+                v.n_dense_slots[p] = s.reserved;
+                if (s.reserved % v.block_slots || s.reserved >= TXQ_DENSE_SLOT_BIT)
+                    return fail(TXQ_ERR_PROGRAM, "program %u: dense slots not a multiple of the block size", p);
+            }
         } else {
             const txq_program& s = ((const txq_program*)(blob + programs_offset))[p];
             d = DevProgram{s.first_op, s.n_ops, 0, 0};
             v.n_slots[p] = s.n_slots;
         }
         const uint32_t n_slots = v.n_slots[p];
-        if (n_slots < TXQ_SLOT_FIRST_FREE) return fail(TXQ_ERR_PROGRAM, "program %u: n_slots < 3", p);
+        if (n_slots < TXQ_SLOT_FIRST_FREE || n_slots >= TXQ_DENSE_SLOT_BIT) return fail(TXQ_ERR_PROGRAM, "program %u: n_slots out of range", p);
         if (d.first_op > v.n_ops || d.n_ops > v.n_ops - d.first_op) return fail(TXQ_ERR_PROGRAM, "program %u: ops out of range", p);
         if (d.n_levels) {
             if (d.first_level > v.n_levels || d.n_levels > v.n_levels - d.first_level) return fail(TXQ_ERR_PROGRAM, "program %u: levels out of range", p);
@@ -241,16 +444,37 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
         }
         v.programs[p] = d;
     }
-    // every op of every program: operands inside the program's slot region, k-mer inside the table.
-    // Large stages (hundreds of MB of ops) are checked by several threads, each taking whole programs.
+    // every op of every program: operands inside the program's slot regions, k-mer inside the table, dense ops on
+    // whole blocks.  Large stages (hundreds of MB of ops) are checked by several threads, each taking whole programs.
     struct Bad { uint32_t program = 0xFFFFFFFFu, op = 0; int kind = 0; };
     auto check_program = [&](uint32_t p, Bad& bad) {
         const DevProgram& d = v.programs[p];
-        const uint32_t n_slots = v.n_slots[p];
+        const uint32_t n_slots = v.n_slots[p], n_dense_slots = v.n_dense_slots[p];
         const txq_op* o = ops + d.first_op;
+        auto slot_ok = [&](uint32_t s) { return (s & TXQ_DENSE_SLOT_BIT) ? (s & ~TXQ_DENSE_SLOT_BIT) < n_dense_slots : s < n_slots; };
+        auto block_ok = [&](uint32_t s) {
+            const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT;
+            return (s & TXQ_DENSE_SLOT_BIT) && i % v.block_slots == 0 && i < n_dense_slots;  // n_dense_slots is a multiple of the block size
+        };
         for (uint32_t i = 0; i < d.n_ops; ++i) {
             int kind = 0;
-            if (o[i].dst >= n_slots || o[i].a >= n_slots || o[i].b >= n_slots) kind = 1;
+            if (o[i].kmer == TXQ_DENSE_OP) {
+                if (!v3 || o[i].dst >= v.n_dense || d.n_levels == 0) kind = 4;
+                else {
+                    const txq_dense_op& x = dops[o[i].dst];
+                    const uint32_t code_mask = v.dense.A >= 32 ? 0xFFFFFFFFu : ((1u << v.dense.A) - 1u);
+                    bool ok = x.kind <= TXQ_DENSE_REDUCE;
+                    if (ok && x.kind != TXQ_DENSE_REDUCE) ok = block_ok(x.dst);
+                    if (ok && x.kind != TXQ_DENSE_ZERO) {
+                        ok = block_ok(x.src);
+                        for (uint32_t j = 0; ok && j < v.dense.pos; ++j) ok = (x.shape[j] & ~code_mask) == 0;
+                    }
+                    if (ok && x.kind == TXQ_DENSE_STEP) ok = x.src != x.dst && (x.r_mask & ~code_mask) == 0;
+                    if (ok && x.kind == TXQ_DENSE_REDUCE) ok = slot_ok(x.dst) && x.dst != TXQ_SLOT_ZERO && x.dst != TXQ_SLOT_ONES;
+                    if (!ok) kind = 4;
+                    v.has_dense[p] = 1;
+                }
+            } else if (!slot_ok(o[i].dst) || !slot_ok(o[i].a) || !slot_ok(o[i].b)) kind = 1;
             else if (o[i].dst == TXQ_SLOT_ZERO || o[i].dst == TXQ_SLOT_ONES) kind = 2;
             else if (o[i].kmer != TXQ_NO_KMER && o[i].kmer >= v.n_kmers) kind = 3;
             if (kind) { if (p < bad.program) bad = Bad{p, i, kind}; return; }
@@ -272,7 +496,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
         for (const Bad& b : found) if (b.program < bad.program) bad = b;
     }
     if (bad.program != 0xFFFFFFFFu) {
-        static const char* const what[] = {"", "slot out of range", "writes a constant slot", "k-mer index out of range"};
+        static const char* const what[] = {"", "slot out of range", "writes a constant slot", "k-mer index out of range", "malformed dense op"};
         return fail(TXQ_ERR_PROGRAM, "program %u op %u: %s", bad.program, bad.op, what[bad.kind]);
     }
     *out = std::move(v);
@@ -285,67 +509,76 @@ static double now_s() {
 
 Session::~Session() {
     if (std::getenv("TXQ_TRACE"))
-        fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded; validate %.3f s, upload %.3f s, device+sync %.3f s\n",
-                n_programs, n_stages, bytes_uploaded / 1e6, t_validate, t_upload, t_device);
-    if (owns_cache && ix) {  // hand the buffers back for the next session (keep only the first chunk)
+        fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s\n",
+                n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device);
+    if (aux) --aux->open_sessions;
+    if (ix) --ix->open_sessions;
+    if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
-        for (size_t i = 1; i < chunks.size(); ++i) (void)hipFree(chunks[i]);
-        c.chunk = chunks.empty() ? nullptr : chunks[0];
-        c.chunk_cap = chunks.empty() ? 0 : first_chunk_cap;
+        size_t kept = 0;
+        for (const Index::ArenaChunk& k : chunks) {
+            if (kept + k.cap * 8 <= Index::kArenaKeepBytes) { c.chunks.push_back(k); kept += k.cap * 8; }
+            else (void)hipFree(k.p);
+        }
         c.d_base = d_base; c.cap_base = cap_base;
         c.d_blob = d_blob; c.cap_blob = cap_blob;
         c.d_aux = d_aux; c.cap_aux = cap_aux;
         c.in_use = false;
         return;
     }
-    for (uint64_t* c : chunks) (void)hipFree(c);
+    for (const Index::ArenaChunk& k : chunks) (void)hipFree(k.p);
     for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
 }
 
-// bump allocation of `words` 64-bit words of slot storage
+// bump allocation of `words` 64-bit words of slot storage (an even number wherever W is even: 16-byte lanes)
 static int arena_alloc(Session& s, size_t words, uint64_t** out) {
-    if (s.chunks.empty() || s.chunk_used + words > s.chunk_cap) {
-        size_t cap = s.chunks.empty() ? (size_t)1 << 20 : (size_t)8 << 20;  // 8 MiB first, then 64 MiB chunks
+    while (s.cur < s.chunks.size() && s.chunk_used + words > s.chunks[s.cur].cap) { ++s.cur; s.chunk_used = 0; }  // adopted chunks
+    if (s.cur >= s.chunks.size()) {
+        // 8 MiB first, then as much again as the session already holds (at least 64 MiB): few, large chunks
+        size_t cap = s.chunks.empty() ? (size_t)1 << 20 : std::max((size_t)8 << 20, s.arena_words);
         if (words > cap) cap = words;
         uint64_t* c = nullptr;
         TXQ_HIP(hipMalloc((void**)&c, cap * 8));
-        if (s.chunks.empty()) s.first_chunk_cap = cap;
-        s.chunks.push_back(c);
-        s.chunk_cap = cap;
+        s.chunks.push_back(Index::ArenaChunk{c, cap});
+        s.arena_words += cap;
+        s.cur = s.chunks.size() - 1;
         s.chunk_used = 0;
     }
-    *out = s.chunks.back() + s.chunk_used;
+    *out = s.chunks[s.cur].p + s.chunk_used;
     s.chunk_used += words;
     return TXQ_OK;
 }
 
 int session_begin(Index& ix, size_t n_programs, Session** out) {
-    if (n_programs >> 31) return fail(TXQ_ERR_ARG, "too many programs");
+    if (n_programs >> 30) return fail(TXQ_ERR_ARG, "too many programs");
     Session* s = new (std::nothrow) Session();
     if (!s) return fail(TXQ_ERR_NOMEM, "out of host memory");
     s->ix = &ix;
+    ++ix.open_sessions;
     s->n_programs = n_programs;
     s->W = (uint32_t)ix.shard_words;
-    s->base.assign(n_programs, nullptr);
+    s->base.assign(2 * n_programs, nullptr);
     s->cap.assign(n_programs, 0);
+    s->dcap.assign(n_programs, 0);
     Index::SessionCache& c = ix.session_cache;
     if (!c.in_use) {  // adopt the previous session's buffers
         c.in_use = true;
         s->owns_cache = true;
-        if (c.chunk) { s->chunks.push_back(c.chunk); s->chunk_cap = s->first_chunk_cap = c.chunk_cap; s->chunk_used = 0; }
+        s->chunks.swap(c.chunks);
+        for (const Index::ArenaChunk& k : s->chunks) s->arena_words += k.cap;
         s->d_base = c.d_base; s->cap_base = c.cap_base;
         s->d_blob = c.d_blob; s->cap_blob = c.cap_blob;
         s->d_aux = c.d_aux; s->cap_aux = c.cap_aux;
         c = Index::SessionCache{};
         c.in_use = true;
     }
-    if (n_programs > s->cap_base) {
+    if (2 * n_programs > s->cap_base) {
         if (s->d_base) (void)hipFree(s->d_base);
         s->d_base = nullptr;
         s->cap_base = 0;
-        hipError_t e = hipMalloc((void**)&s->d_base, n_programs * sizeof(uint64_t*));
+        hipError_t e = hipMalloc((void**)&s->d_base, 2 * n_programs * sizeof(uint64_t*));
         if (e != hipSuccess) { delete s; return fail_hip(e, "hipMalloc(session)"); }
-        s->cap_base = n_programs;
+        s->cap_base = 2 * n_programs;
     }
     *out = s;
     return TXQ_OK;
@@ -356,48 +589,111 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
     bool moved = false;
     for (size_t p = 0; p < s.n_programs; ++p) {
         const uint32_t need = bv.n_slots[p];
-        if (need <= s.cap[p]) continue;
-        uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
-        if (cap < need) cap = need;
-        uint64_t* region = nullptr;
-        if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
-        if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
-        else fresh->push_back((uint32_t)p);
-        s.base[p] = region;
-        s.cap[p] = cap;
-        moved = true;
+        if (need > s.cap[p]) {
+            uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
+            if (cap < need) cap = need;
+            uint64_t* region = nullptr;
+            if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
+            if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
+            else fresh->push_back((uint32_t)p);
+            s.base[p] = region;
+            s.cap[p] = cap;
+            moved = true;
+        }
+        const uint32_t dneed = bv.n_dense_slots[p];
+        if (dneed > s.dcap[p]) {  // whole blocks; doubling keeps the copies (and the abandoned regions) within 2x
+            uint32_t cap = s.dcap[p] ? s.dcap[p] * 2 : dneed;
+            if (cap < dneed) cap = dneed;
+            uint64_t* region = nullptr;
+            if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
+            if (s.dcap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
+            s.base[s.n_programs + p] = region;
+            s.dcap[p] = cap;
+            moved = true;
+        }
     }
-    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
+    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
     return TXQ_OK;
 }
 
-// Big level-scheduled programs leave the one-workgroup-per-program kernel: their ops are cut into
-// units per dependency level (units of level l, all programs, are contiguous in `units`) and every
-// level becomes one launch over the whole GPU.  Returns the number of programs left to exec_kernel.
-static size_t plan_units(BlobView& bv, const uint32_t* levels_host, uint32_t W, std::vector<ExecUnit>* units, std::vector<size_t>* level_units) {
+// Big level-scheduled programs, and every program with dense ops, leave the one-workgroup-per-program kernel:
+// their ops are cut into units per dependency level (units of level l, all programs, are contiguous in `units`),
+// their dense ops into tiles, and every level becomes one launch of each kind over the whole GPU.
+// Returns the number of programs left to exec_kernel.
+struct LevelPlan { size_t units = 0, tiles = 0; };
+static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, std::vector<ExecUnit>* units,
+                         std::vector<DenseTile>* tiles, std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
+    const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
+    const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
+    const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
     std::vector<std::vector<ExecUnit>> per_level;
+    std::vector<std::vector<DenseTile>> tiles_level;
+    // entries per tile: every lane group of the workgroup gets two destination suffixes of a step
+    const uint32_t step_tile = 2 * (256 / (G_dense ? G_dense : 1));
     size_t n_small = 0;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
         DevProgram& d = bv.programs[p];
+        const bool dense = bv.has_dense[p] != 0;
         // small = less work than a unit launch is worth: 2048 ops of a 1024-bin index, 32 ops at 65536 bins
-        if (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u) { n_small += d.n_ops != 0; continue; }
-        if (per_level.size() < d.n_levels) per_level.resize(d.n_levels);
+        if (!dense && (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u)) { n_small += d.n_ops != 0; continue; }
+        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); tiles_level.resize(d.n_levels); }
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
-            for (uint32_t at = begin; at < end; at += per_unit)
-                per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (end - at < per_unit ? end : at + per_unit)});
+            auto cut = [&](uint32_t from, uint32_t to) {  // a run of ordinary ops -> units
+                for (uint32_t at = from; at < to; at += per_unit)
+                    per_level[l].push_back(ExecUnit{(uint32_t)p, d.first_op + at, d.first_op + (to - at < per_unit ? to : at + per_unit)});
+            };
+            if (!dense) cut(begin, end);
+            else {
+                uint32_t run = begin;
+                for (uint32_t i = begin; i < end; ++i) {
+                    const txq_op& o = ops[d.first_op + i];
+                    if (o.kmer != TXQ_DENSE_OP) continue;
+                    cut(run, i);
+                    run = i + 1;
+                    const txq_dense_op& x = dops[o.dst];
+                    uint64_t entries = 1, per_tile = step_tile;
+                    if (x.kind == TXQ_DENSE_ZERO) { entries = bv.block_slots; per_tile = std::max<uint64_t>(1, 8192 / W); }
+                    else {
+                        for (uint32_t j = x.kind == TXQ_DENSE_STEP ? 1 : 0; j < bv.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
+                        if (x.kind == TXQ_DENSE_STEP) entries *= (uint64_t)__builtin_popcount(x.r_mask) * (__builtin_popcount(x.shape[0]) ? 1 : 0);
+                        else per_tile = 1024;
+                    }
+                    for (uint64_t at = 0; at < entries; at += per_tile)
+                        tiles_level[l].push_back(DenseTile{(uint32_t)p, o.dst, (uint32_t)at, (uint32_t)std::min<uint64_t>(per_tile, entries - at)});
+                }
+                cut(run, end);
+            }
             begin = end;
         }
         d.n_ops = 0;  // the per-program kernel skips it
     }
-    level_units->resize(per_level.size());
+    plan->resize(per_level.size());
     for (size_t l = 0; l < per_level.size(); ++l) {
-        (*level_units)[l] = per_level[l].size();
+        (*plan)[l].units = per_level[l].size();
+        (*plan)[l].tiles = tiles_level[l].size();
         units->insert(units->end(), per_level[l].begin(), per_level[l].end());
+        tiles->insert(tiles->end(), tiles_level[l].begin(), tiles_level[l].end());
     }
     return n_small;
+}
+
+template <bool WIDE>
+static hipError_t launch_dense(const IbfDev& f, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
+                               uint32_t n_programs, uint32_t W, uint32_t G, const DenseParams& P, hipStream_t st) {
+#define TXQ_DENSE(H) dense_kernel<H, WIDE><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, P)
+    switch (f.hash_funs) {
+        case 1: TXQ_DENSE(1); break;
+        case 2: TXQ_DENSE(2); break;
+        case 3: TXQ_DENSE(3); break;
+        case 4: TXQ_DENSE(4); break;
+        case 5: TXQ_DENSE(5); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TXQ_DENSE
+    return hipGetLastError();
 }
 
 int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
@@ -421,20 +717,28 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         for (size_t i = 0; i < n_q; ++i) alive[i] = 0;
         return TXQ_OK;
     }
+    bool any_dense = false;
+    for (uint8_t d : bv.has_dense) any_dense |= d != 0;
+    if (any_dense && (ix.is_hibf || (ix.ibf[0].bin_size >> 32)))
+        return fail(TXQ_ERR_PROGRAM, "dense ops need a flat IBF with fewer than 2^32 rows");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     if (int rc = grow_slot_regions(s, bv, &fresh, st)) return rc;
 
-    const uint32_t* levels_host = h->n_levels ? (const uint32_t*)(blob + h->levels_offset) : nullptr;
+    // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
+    const bool wide = W % 2 == 0 && !ix.is_hibf && ix.ibf[0].stride % 2 == 0;
+    uint32_t g_dense = 1;
+    while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     std::vector<ExecUnit> units;
-    std::vector<size_t> level_units;
-    const size_t n_small = plan_units(bv, levels_host, W, &units, &level_units);
+    std::vector<DenseTile> tiles;
+    std::vector<LevelPlan> plan;
+    const size_t n_small = plan_units(bv, blob, W, g_dense, &units, &tiles, &plan);
 
-    // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units
+    // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units | tiles
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
     if (int rc = ensure((void**)&s.d_blob, &s.cap_blob, blob_pad)) return rc;
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
     const size_t small_bytes = prog_bytes + fresh.size() * 4 + n_q * 8 + ((n_q + 7) & ~(size_t)7) + 64;
-    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit);
+    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit) + 16 + tiles.size() * sizeof(DenseTile);
     if (int rc = ensure((void**)&s.d_aux, &s.cap_aux, aux_bytes)) return rc;
     const size_t nk = h->n_kmers;
     if (int rc = ensure((void**)&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
@@ -446,7 +750,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     uint32_t* d_qs = d_qp + n_q;
     uint8_t* d_alive = (uint8_t*)(d_qs + n_q);
     ExecUnit* d_units = (ExecUnit*)(s.d_aux + small_bytes - 32);
+    DenseTile* d_tiles = (DenseTile*)(((uintptr_t)(d_units + units.size()) + 15) & ~(uintptr_t)15);
     if (!units.empty()) TXQ_HIP(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(ExecUnit), hipMemcpyHostToDevice, st));
+    if (!tiles.empty()) TXQ_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, st));
     if (!fresh.empty()) TXQ_HIP(hipMemcpyAsync(d_fresh, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice, st));
     if (n_q) {
         TXQ_HIP(hipMemcpyAsync(d_qp, q_prog, n_q * 4, hipMemcpyHostToDevice, st));
@@ -486,9 +792,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const int g_units = g < 256 ? g : 256;
         const txq_op* d_ops = (const txq_op*)(s.d_blob + h->ops_offset);
         const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(s.d_blob + h->levels_offset) : nullptr;
+        const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(s.d_blob + h->dense_offset) : nullptr;
+        const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, (uint32_t)s.n_programs, ix.scratch_masks, W)
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, ix.scratch_masks, W)
             switch (g) {
                 case 1: TXQ_EXEC(1); break;
                 case 2: TXQ_EXEC(2); break;
@@ -504,24 +812,32 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             }
 #undef TXQ_EXEC
         }
-        size_t first = 0;
-        for (size_t l = 0; l < level_units.size(); ++l) {
-            const size_t cnt = level_units[l];
-            if (cnt == 0) continue;
-#define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, ix.scratch_masks, W)
-            switch (g_units) {
-                case 1: TXQ_UNITS(1); break;
-                case 2: TXQ_UNITS(2); break;
-                case 4: TXQ_UNITS(4); break;
-                case 8: TXQ_UNITS(8); break;
-                case 16: TXQ_UNITS(16); break;
-                case 32: TXQ_UNITS(32); break;
-                case 64: TXQ_UNITS(64); break;
-                case 128: TXQ_UNITS(128); break;
-                default: TXQ_UNITS(256); break;
-            }
+        size_t first = 0, first_tile = 0;
+        for (size_t l = 0; l < plan.size(); ++l) {
+            const size_t cnt = plan[l].units;
+            if (cnt) {
+#define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W)
+                switch (g_units) {
+                    case 1: TXQ_UNITS(1); break;
+                    case 2: TXQ_UNITS(2); break;
+                    case 4: TXQ_UNITS(4); break;
+                    case 8: TXQ_UNITS(8); break;
+                    case 16: TXQ_UNITS(16); break;
+                    case 32: TXQ_UNITS(32); break;
+                    case 64: TXQ_UNITS(64); break;
+                    case 128: TXQ_UNITS(128); break;
+                    default: TXQ_UNITS(256); break;
+                }
 #undef TXQ_UNITS
-            first += cnt;
+                first += cnt;
+            }
+            if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: two launches, no order implied
+                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, bv.dense, st)
+                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, bv.dense, st);
+                if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
+                first_tile += plan[l].tiles;
+                s.n_dense_tiles += plan[l].tiles;
+            }
         }
     }
     hipError_t e = hipGetLastError();

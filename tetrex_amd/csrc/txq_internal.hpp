@@ -40,13 +40,16 @@ struct Index {
 
     // Device buffers of the last session, kept for the next one: a single query must not pay
     // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.
+    struct ArenaChunk { uint64_t* p; size_t cap; };  // cap in 64-bit words
     struct SessionCache {
-        uint64_t* chunk = nullptr; size_t chunk_cap = 0;  // first slot-arena chunk (words)
+        std::vector<ArenaChunk> chunks;                    // slot-arena chunks, at most kArenaKeepBytes in all
         uint64_t** d_base = nullptr; size_t cap_base = 0;  // entries
         unsigned char* d_blob = nullptr; size_t cap_blob = 0;
         unsigned char* d_aux = nullptr; size_t cap_aux = 0;
         bool in_use = false;
     } session_cache;
+    static constexpr size_t kArenaKeepBytes = (size_t)16 << 30;
+    int open_sessions = 0;  // txq_index_free refuses while a session still points at this index
 
     // txq_probe (host buffers): two streams with their device and pinned bounce buffers
     struct HostPipe {
@@ -69,17 +72,18 @@ struct Session {
     Index* aux = nullptr;  // optional d-gram index (flat IBF, same bins and shard as ix)
     size_t n_programs = 0;
     uint32_t W = 0;
-    std::vector<uint64_t*> chunks;  // arena chunks
-    size_t chunk_used = 0, chunk_cap = 0, first_chunk_cap = 0;
-    std::vector<uint64_t*> base;    // per program: its slot region [cap][W]
+    std::vector<Index::ArenaChunk> chunks;  // arena chunks; bump allocation in chunks[cur]
+    size_t cur = 0, chunk_used = 0, arena_words = 0;
+    std::vector<uint64_t*> base;    // [2 * n_programs]: per program its slot region [cap][W], then its dense region [dcap][W]
     std::vector<uint32_t> cap;      // per program: slots allocated
-    uint64_t** d_base = nullptr; size_t cap_base = 0;
+    std::vector<uint32_t> dcap;     // per program: dense slots allocated (include/txq_program.h, version 3)
+    uint64_t** d_base = nullptr; size_t cap_base = 0;  // device copy of `base`
     bool owns_cache = false;  // buffers came from / go back to ix->session_cache
     unsigned char* d_blob = nullptr; size_t cap_blob = 0;
     unsigned char* d_aux = nullptr; size_t cap_aux = 0;
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
-    size_t n_stages = 0, bytes_uploaded = 0;
+    size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0;
     ~Session();
 };
 

@@ -116,13 +116,25 @@ def dgram_values(seq, min_gap, max_gap):
     return out[:n].copy()
 
 
-def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0, gaps=None):
+class DenseOptions(C.Structure):
+    _fields_ = [("enabled", C.c_int), ("min_states", C.c_uint32), ("sparse_below", C.c_uint32), ("max_blocks", C.c_uint32),
+                ("slot_bytes", C.c_uint64), ("pool_bytes", C.c_uint64)]
+
+
+def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0, gaps=None, dense=None):
     """Drive the C++ staged expansion with a Python executor.
 
-    stage(blob: bytes, query_program: list, query_slot: list) -> iterable of bool (alive)."""
+    stage(blob: bytes, query_program: list, query_slot: list) -> iterable of bool (alive).
+    dense: None, or dict(min_states=, sparse_below=, max_blocks=, slot_bytes=, pool_bytes=) to switch dense DP
+    steps on (the executor then gets version-3 blobs)."""
     L = lib()
-    L.txh_run_staged.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
-                                 C.c_size_t, C.POINTER(GapOptions), STAGE_FN, C.c_void_p, C.POINTER(C.c_int), u64p]
+    L.txh_run_staged_dense.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
+                                       C.c_size_t, C.POINTER(GapOptions), C.POINTER(DenseOptions), STAGE_FN, C.c_void_p,
+                                       C.POINTER(C.c_int), u64p]
+    d = None
+    if dense is not None:
+        d = DenseOptions(1, dense.get("min_states", 0), dense.get("sparse_below", 0), dense.get("max_blocks", 0),
+                         dense.get("slot_bytes", 0), dense.get("pool_bytes", 0))
     g = None
     if gaps is not None:  # dict(augment=, dgram_loaded=, min_gap=, max_gap=)
         g = GapOptions(int(gaps.get("augment", 0)), int(gaps.get("dgram_loaded", 0)), gaps.get("min_gap", 0), gaps.get("max_gap", 0))
@@ -142,8 +154,9 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
             err.append(e)
             return -1
 
-    rc = L.txh_run_staged(arr, n, int(dna), k, reduction, bins, ops_per_query_per_stage, ops_per_stage,
-                          C.byref(g) if g is not None else None, STAGE_FN(cb), None, status, stats)
+    rc = L.txh_run_staged_dense(arr, n, int(dna), k, reduction, bins, ops_per_query_per_stage, ops_per_stage,
+                                C.byref(g) if g is not None else None, C.byref(d) if d is not None else None, STAGE_FN(cb), None,
+                                status, stats)
     if err:
         raise err[0]
     if rc < 0:
@@ -170,10 +183,11 @@ def record_values_array(seq, k, dna=True, reduction=0, wraparound=False):
 
 
 def parse_blob(blob):
-    """Decode a txq_program.h blob (version 1 or 2): (kmers uint64[], [(n_slots, ops array [n,4] =
-    kmer,dst,a,b)]).  Version-2 ops are in level order, which is also a valid sequential order."""
+    """Decode a txq_program.h blob (version 1, 2 or 3): (kmers uint64[], [(n_slots, ops array [n,4] =
+    kmer,dst,a,b)]).  Version-2/3 ops are in level order, which is also a valid sequential order.
+    The dense table of a version-3 blob: blob_dense()."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
-    assert magic == 0x50515854 and ver in (1, 2)
+    assert magic == 0x50515854 and ver in (1, 2, 3)
     if ver == 1:
         _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off = struct.unpack_from("<6I3Q", blob, 0)
         stride = 4
@@ -193,13 +207,29 @@ def parse_blob(blob):
 def blob_aux_kmers(blob):
     """Number of trailing k-mer table entries that belong to the auxiliary (d-gram) index."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
-    return struct.unpack_from("<6I5Q", blob, 0)[-1] if ver == 2 else 0
+    return struct.unpack_from("<6I5Q", blob, 0)[-1] if ver >= 2 else 0
+
+
+DENSE_OP = 0xFFFFFFFE
+DENSE_SLOT_BIT = 0x40000000
+
+
+def blob_dense(blob):
+    """Dense part of a version-3 blob: (params dict(k, bits, alphabet, canonical), table uint32[n, 16] =
+    kind, dst, src, r_mask, shape[11], reserved, per-program dense slot counts); None for older versions."""
+    magic, ver = struct.unpack_from("<2I", blob, 0)
+    if ver != 3:
+        return None
+    _, _, n_prog, _, _, _, _, p_off, _, _, _, d_off, n_dense, k, bits, alphabet, canonical, _ = struct.unpack_from("<6I5QQ6I", blob, 0)
+    table = np.frombuffer(blob, dtype="<u4", count=n_dense * 16, offset=d_off).reshape(n_dense, 16)
+    progs = np.frombuffer(blob, dtype="<u4", count=n_prog * 6, offset=p_off).reshape(n_prog, 6)
+    return dict(k=k, bits=bits, alphabet=alphabet, canonical=canonical), table, [int(r[5]) for r in progs]
 
 
 def blob_levels(blob):
-    """Level tables of a version-2 blob: list of per-program end-index lists."""
+    """Level tables of a version-2/3 blob: list of per-program end-index lists."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
-    if ver != 2:
+    if ver < 2:
         return None
     _, _, n_prog, n_kmers, n_ops, n_lv, k_off, p_off, o_off, l_off, _ = struct.unpack_from("<6I5Q", blob, 0)
     progs = np.frombuffer(blob, dtype="<u4", count=n_prog * 6, offset=p_off).reshape(n_prog, 6)
