@@ -163,6 +163,10 @@ template <> struct Lane<true> {
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *reinterpret_cast<T*>(p) = v; }
     static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
     static __device__ __forceinline__ bool any(T v) { return (v.x | v.y | v.z | v.w) != 0u; }
+    static __device__ __forceinline__ T shfl_xor(T v, uint32_t o) {
+        return T{(uint32_t)__shfl_xor((int)v.x, (int)o), (uint32_t)__shfl_xor((int)v.y, (int)o), (uint32_t)__shfl_xor((int)v.z, (int)o),
+                 (uint32_t)__shfl_xor((int)v.w, (int)o)};
+    }
 };
 template <> struct Lane<false> {
     using T = uint64_t;
@@ -171,6 +175,9 @@ template <> struct Lane<false> {
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *p = v; }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool any(T v) { return v != 0; }
+    static __device__ __forceinline__ T shfl_xor(T v, uint32_t o) {
+        return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, (int)o);
+    }
 };
 
 __device__ __forceinline__ uint64_t canonical_dna(uint64_t fwd, uint32_t k) {
@@ -195,7 +202,7 @@ __device__ __forceinline__ void issue_loads(const IbfDev& f, const uint64_t* src
 template <int H, bool WIDE>
 __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
                                                     uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
-                                                    uint32_t G, DenseParams P) {
+                                                    uint32_t G, uint32_t SL, DenseParams P) {
     using L = Lane<WIDE>;
     using T = typename L::T;
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // [j < pos]: codes of shape[j]; [pos]: codes of r_mask
@@ -240,15 +247,22 @@ __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* _
         }
         return;
     }
-    // STEP
+    // STEP.  A destination suffix gets SL lane groups of G lanes: group `slice` takes every SL-th predecessor (three
+    // at a time: 3 * (H row gathers + 1 source mask) loads in flight per lane), the slices are ORed with xor-shuffles.
+    // One suffix per lane-group set and pass; a tile is short so that a level with few programs is not one long chain.
     uint64_t* dstb = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
-    const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, groups = blockDim.x / G;
+    const uint32_t lanes = G * SL;  // per suffix, a power of two <= 64
+    const uint32_t sub = threadIdx.x % G, slice = (threadIdx.x / G) % SL, grp = threadIdx.x / lanes, groups = blockDim.x / lanes;
     const uint32_t chunks = (W + L::kWords - 1) / L::kWords;
     const uint32_t n_r = cnt[P.pos], n_a = cnt[0];
     const uint32_t a_stride = P.pow_a[P.pos - 1];
-    for (uint32_t e = t.first + grp; e < end; e += groups) {
-        uint32_t q = e / n_r;
-        const uint32_t r = codes[P.pos][e % n_r];
+    const uint32_t a_shift = P.bits * P.pos;
+    const uint32_t rounds = (t.count + groups - 1) / groups;  // every lane takes part in the shuffles of every round
+    for (uint32_t it = 0; it < rounds; ++it) {
+        const uint32_t e = t.first + it * groups + grp;
+        const bool live = e < end;
+        uint32_t q = live ? e / n_r : 0;
+        const uint32_t r = codes[P.pos][live ? e % n_r : 0];
         uint32_t mid = 0;
         uint64_t mid_val = 0;
         for (uint32_t j = P.pos; j-- > 1;) {
@@ -259,33 +273,40 @@ __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* _
         }
         const uint64_t low = (mid_val << P.bits) | r;  // the k-mer without its oldest residue
         uint64_t* dst = dstb + ((size_t)mid * P.A + r) * W;
-        for (uint32_t c = sub; c < chunks; c += G) {
+        const uint64_t* srcm = src + (size_t)mid * W;
+        for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
+            const uint32_t c = c0 + sub;
+            const bool mine = live && c < chunks;
             T acc = L::zero();
-            uint32_t i = 0;
-            for (; i + 1 < n_a; i += 2) {
-                const uint32_t a0 = codes[0][i], a1 = codes[0][i + 1];
-                uint64_t v0 = ((uint64_t)a0 << (P.bits * P.pos)) | low, v1 = ((uint64_t)a1 << (P.bits * P.pos)) | low;
-                if (P.canonical) { v0 = canonical_dna(v0, P.k); v1 = canonical_dna(v1, P.k); }
-                T x0[H + 1], x1[H + 1];
-                issue_loads<H, WIDE>(f, src + ((size_t)a0 * a_stride + mid) * W, v0, c, x0);
-                issue_loads<H, WIDE>(f, src + ((size_t)a1 * a_stride + mid) * W, v1, c, x1);
-                T y0 = x0[H], y1 = x1[H];
+            if (mine) {
+                uint32_t i = slice;
+                for (; i + 2 * SL < n_a; i += 3 * SL) {
+                    const uint32_t a0 = codes[0][i], a1 = codes[0][i + SL], a2 = codes[0][i + 2 * SL];
+                    uint64_t v0 = ((uint64_t)a0 << a_shift) | low, v1 = ((uint64_t)a1 << a_shift) | low, v2 = ((uint64_t)a2 << a_shift) | low;
+                    if (P.canonical) { v0 = canonical_dna(v0, P.k); v1 = canonical_dna(v1, P.k); v2 = canonical_dna(v2, P.k); }
+                    T x0[H + 1], x1[H + 1], x2[H + 1];
+                    issue_loads<H, WIDE>(f, srcm + (size_t)a0 * a_stride * W, v0, c, x0);
+                    issue_loads<H, WIDE>(f, srcm + (size_t)a1 * a_stride * W, v1, c, x1);
+                    issue_loads<H, WIDE>(f, srcm + (size_t)a2 * a_stride * W, v2, c, x2);
+                    T y0 = x0[H], y1 = x1[H], y2 = x2[H];
 #pragma unroll
-                for (int h = 0; h < H; ++h) { y0 &= x0[h]; y1 &= x1[h]; }
-                acc |= y0 | y1;
-            }
-            if (i < n_a) {
-                const uint32_t a0 = codes[0][i];
-                uint64_t v0 = ((uint64_t)a0 << (P.bits * P.pos)) | low;
-                if (P.canonical) v0 = canonical_dna(v0, P.k);
-                T x0[H + 1];
-                issue_loads<H, WIDE>(f, src + ((size_t)a0 * a_stride + mid) * W, v0, c, x0);
-                T y0 = x0[H];
+                    for (int h = 0; h < H; ++h) { y0 &= x0[h]; y1 &= x1[h]; y2 &= x2[h]; }
+                    acc |= y0 | y1 | y2;
+                }
+                for (; i < n_a; i += SL) {
+                    const uint32_t a0 = codes[0][i];
+                    uint64_t v0 = ((uint64_t)a0 << a_shift) | low;
+                    if (P.canonical) v0 = canonical_dna(v0, P.k);
+                    T x0[H + 1];
+                    issue_loads<H, WIDE>(f, srcm + (size_t)a0 * a_stride * W, v0, c, x0);
+                    T y0 = x0[H];
 #pragma unroll
-                for (int h = 0; h < H; ++h) y0 &= x0[h];
-                acc |= y0;
+                    for (int h = 0; h < H; ++h) y0 &= x0[h];
+                    acc |= y0;
+                }
             }
-            if (L::any(acc)) {
+            for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
+            if (mine && slice == 0 && L::any(acc)) {
                 uint64_t* p = dst + (size_t)c * L::kWords;
                 L::store(p, L::load(p) | acc);
             }
@@ -629,8 +650,9 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
     const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
     std::vector<std::vector<ExecUnit>> per_level;
     std::vector<std::vector<DenseTile>> tiles_level;
-    // entries per tile: every lane group of the workgroup gets two destination suffixes of a step
-    const uint32_t step_tile = 2 * (256 / (G_dense ? G_dense : 1));
+    // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
+    static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
+    const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
     size_t n_small = 0;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
         DevProgram& d = bv.programs[p];
@@ -682,8 +704,8 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
 
 template <bool WIDE>
 static hipError_t launch_dense(const IbfDev& f, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
-                               uint32_t n_programs, uint32_t W, uint32_t G, const DenseParams& P, hipStream_t st) {
-#define TXQ_DENSE(H) dense_kernel<H, WIDE><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, P)
+                               uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, hipStream_t st) {
+#define TXQ_DENSE(H) dense_kernel<H, WIDE><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P)
     switch (f.hash_funs) {
         case 1: TXQ_DENSE(1); break;
         case 2: TXQ_DENSE(2); break;
@@ -728,10 +750,15 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const bool wide = W % 2 == 0 && !ix.is_hibf && ix.ibf[0].stride % 2 == 0;
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
+    // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
+    // 1 / 2 / 4 / 8 slices took 34 / 30 / 34 / 44+ ms end to end: more slices shorten a tile's load chain but multiply the tiles)
+    static const uint32_t want_slices = std::getenv("TXQ_DENSE_SLICES") ? (uint32_t)std::atoi(std::getenv("TXQ_DENSE_SLICES")) : 2u;
+    uint32_t sl_dense = 1;
+    while (sl_dense * 2 <= want_slices && g_dense * sl_dense * 2 <= 64) sl_dense <<= 1;
     std::vector<ExecUnit> units;
     std::vector<DenseTile> tiles;
     std::vector<LevelPlan> plan;
-    const size_t n_small = plan_units(bv, blob, W, g_dense, &units, &tiles, &plan);
+    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, &units, &tiles, &plan);
 
     // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units | tiles
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
@@ -832,8 +859,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 first += cnt;
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: two launches, no order implied
-                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, bv.dense, st)
-                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, bv.dense, st);
+                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, st)
+                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, st);
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
                 s.n_dense_tiles += plan[l].tiles;
