@@ -324,3 +324,43 @@ def test_shards_without_mask_words_and_empty_batches(capi, oracle):
     ix = capi.Index.upload_ibf(5, 101, 3, w)
     assert ix.probe(np.zeros(0, dtype=np.uint64)).shape == (0, 1) and ix.query_masks([], True, 3)[0].shape == (0, 1)
     ix.free()
+
+
+@pytest.mark.parametrize("shape", [dict(user_bins=128 * 70, children=70, h=2), dict(user_bins=256 * 33, children=33, h=3),
+                                   dict(user_bins=512 * 9, children=9, h=1), dict(user_bins=65536, children=256, h=2)],
+                         ids=["70x128", "33x256", "9x512", "256x256"])
+def test_hibf_child_stationary_kernel_on_regular_two_level_trees(capi, oracle, shape, monkeypatch):
+    """Regular two-level trees (the layout `tetrex index` writes) take the child-stationary descent
+    (txq_hibf.hip: hibf_root_kernel + hibf_children_kernel): row widths of 2, 4 and 8 words per child, child
+    counts that do not fill the last wave step, 1-3 hash functions, column shards, ragged batch sizes, alive
+    bits — against the oracle's membership_for restatement, and against the k-mer-stationary kernel
+    (TXQ_HIBF_STATIONARY=0) on the same device buffers."""
+    from helpers import regular_hibf
+    ub, ch, h = shape["user_bins"], shape["children"], shape["h"]
+    rng = np.random.default_rng(ub)
+    per = 12 if ub > 20000 else 30
+    ox, descs, values = regular_hibf(oracle, ub, ch, per, lambda b: rng.integers(0, 1 << 20, size=per, dtype=np.uint64), h=h)
+    present = np.concatenate([values[b][:1] for b in range(0, ub, 37)])
+    kmers = np.concatenate([present, splitmix64(8, 1531) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    assert want.any()
+    for R, r in ((1, 0), (4, 2)) if ch % 4 == 0 else ((1, 0),):
+        ix = capi.Index.upload_hibf(ub, descs, shard_rank=r, n_shards=R)
+        lo, nw = int(ix.info.shard_word0), ix.shard_words
+        dk = capi.DeviceBuffer.from_numpy(kmers)
+        results = []
+        for stationary in ("1", "0"):
+            monkeypatch.setenv("TXQ_HIBF_STATIONARY", stationary)
+            dm = capi.DeviceBuffer(kmers.size * nw * 8)
+            da = capi.DeviceBuffer(((kmers.size + 63) // 64) * 8)
+            ix.probe_device(dk.ptr, kmers.size, dm.ptr, da.ptr)
+            capi.synchronize()
+            got = dm.to_numpy(np.uint64, (kmers.size, nw))
+            assert np.array_equal(got, want[:, lo:lo + nw]), (shape, R, stationary)
+            alive = np.unpackbits(da.to_numpy(np.uint8, (((kmers.size + 63) // 64) * 8,)), bitorder="little")[:kmers.size]
+            assert np.array_equal(alive.astype(bool), got.any(axis=1)), (shape, R, stationary)
+            results.append(got)
+        assert np.array_equal(results[0], results[1])
+        for n in (1, 63, 257):  # ragged batches through the host-buffer entry point
+            assert np.array_equal(ix.probe(kmers[:n]), want[:n, lo:lo + nw])
+        ix.free()

@@ -118,6 +118,11 @@ void Index::release() {
     for (void* p : {(void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
+    if (d_children) (void)hipFree(d_children);
+    if (scratch_cm) (void)hipFree(scratch_cm);
+    if (scratch_crows) (void)hipFree(scratch_crows);
+    scratch_crows = nullptr; cap_crows = 0;
+    d_children = nullptr; scratch_cm = nullptr; cap_cm = 0; n_children = 0;
     if (d_merged) (void)hipFree(d_merged);
     if (d_descend) (void)hipFree(d_descend);
     if (d_nodes) (void)hipFree(d_nodes);

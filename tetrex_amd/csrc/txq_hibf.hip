@@ -409,6 +409,153 @@ __global__ __launch_bounds__(256) void hibf_small_kernel(HibfView t, const uint6
     }
 }
 
+
+// ---- child-stationary descent of regular two-level trees ------------------------------------------------
+// The k-mer-stationary kernels above make every IBF row a cold cache-line fill: a k-mer of the 65536-bin tree reads
+// ~270 random 32-byte rows out of a 31 MB tree that an XCD's 4 MB L2 mostly misses (round 1: 14 of 21 ms per 4 M
+// k-mers).  Here the CHILDREN stay put instead.  The shard's children are cut into groups whose matrices fit an
+// XCD's L2 (~2 MB: 32 children of the 65536-bin tree); workgroup b works on group b % 8 — the dispatcher deals
+// workgroups round-robin over the 8 XCDs, so every XCD keeps probing the same 2 MB (a speed assumption only) —
+// and streams a tile of k-mers past it.  A wave step covers 128 mask words = 64 lanes x 16 B: lane l owns 16
+// bytes of child l / lanes_per_child, gathers that piece of the child's h rows (L2 hits), ANDs, and the wave
+// writes the k-mer's 1-KiB row segment with one coalesced non-temporal store — a child that the root row rules
+// out costs nothing but the zeros.  No LDS row, no atomics: the row segments of different groups are disjoint.
+// Pass 1 (hibf_root_kernel) probes the root once per k-mer and leaves its row (one bit per child) in HBM.
+struct ChildRec {   // 16 bytes, one per child in mask-column order
+    uint64_t words;     // device pointer to the child's rows (stride = row words, a power of two >= 2)
+    uint32_t bin_size;  // rows
+    uint32_t packed;    // hash_shift (bits 0-7) | hash_funs (8-11) | root technical bin (12-31)
+};
+static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
+
+// child_rows != null (all children of one size): also the k-mer's row indexes in a child, child_hf per k-mer — they
+// are the same in every child, so the children kernel reads them instead of hashing again for each of its groups
+__global__ __launch_bounds__(256) void hibf_root_kernel(HibfNode root, const uint64_t* __restrict__ kmers, size_t n,
+                                                        uint64_t* __restrict__ cm, uint32_t row_words, uint32_t* __restrict__ child_rows,
+                                                        uint32_t child_bin_size, uint32_t child_shift, uint32_t child_hf) {
+    const uint64_t* words = (const uint64_t*)root.words;
+    const uint32_t stride = root.stride(), hf = root.hash_funs();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t v = kmers[i];
+        if (child_rows)
+            for (uint32_t j = 0; j < child_hf; ++j) child_rows[i * child_hf + j] = (uint32_t)hash_row_seeded32(v * kSeeds[j], child_shift, child_bin_size);
+        uint32_t r[5];
+#pragma unroll
+        for (uint32_t j = 0; j < 5; ++j) r[j] = j < hf ? (uint32_t)hash_row_seeded32(v * kSeeds[j], root.hash_shift(), root.bin_size) : 0;
+        if (stride == 1) {
+            uint64_t x = ~0ULL;
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j) if (j < hf) x &= gload(words + r[j]);
+            cm[i * row_words] = x;
+            continue;
+        }
+        for (uint32_t w = 0; w < row_words; w += 2) {
+            ulonglong2 x{~0ULL, ~0ULL};
+#pragma unroll
+            for (uint32_t j = 0; j < 5; ++j)
+                if (j < hf) { const ulonglong2 a = gload2(words + (size_t)r[j] * stride + w); x.x &= a.x; x.y &= a.y; }
+            cm[i * row_words + w] = x.x;
+            if (w + 1 < row_words) cm[i * row_words + w + 1] = x.y;
+        }
+    }
+}
+
+typedef uint32_t hu32x4 __attribute__((ext_vector_type(4)));
+
+// 16-byte store of a row segment with a chosen cache policy (gfx950 cache-control bits; MI355X_MICROARCH.md, "stores of each
+// flavour": plain / nt stores keep the line in the XCD's L2, sc1 stores drop it).  The row stream is 8 KB per k-mer against
+// 2 MB of child matrices per XCD that must stay in L2, so the default is a store that does not stay.  flavour is wave-uniform.
+__device__ __forceinline__ void store_row16(hu32x4* p, hu32x4 v, int flavour) {
+    switch (flavour) {
+        case 1: *p = v; break;
+        case 2: asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); break;
+        case 3: asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory"); break;
+        case 4: asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory"); break;
+        default: __builtin_nontemporal_store(v, p); break;
+    }
+}
+
+// U k-mers in flight per wave: U * h 16-byte gathers per lane before the first AND.
+// UNIFORM: all children have the same rows / hash shift / hash count (the synthetic trees, and any index whose bins
+// are equally full): the row indexes are then the same in every lane and the hash runs on the scalar unit — with
+// per-lane hashing the 64-bit multiplies were 40 % of the kernel's time (1 M k-mers x 8 groups x 22 quarter-rate
+// multiplies).  Otherwise only the seed products are scalar.
+template <int U, bool UNIFORM>
+__global__ __launch_bounds__(256) void hibf_children_kernel(const ChildRec* __restrict__ recs, uint32_t n_children, uint32_t lanes_per_child,
+                                                            const uint64_t* __restrict__ kmers, size_t n, const uint64_t* __restrict__ cm,
+                                                            uint32_t cm_words, uint64_t* __restrict__ masks, uint32_t w_out,
+                                                            uint32_t n_steps, uint32_t steps_per_group, uint32_t groups_per_phase,
+                                                            uint32_t n_tiles, uint32_t tile, uint32_t h_max, uint64_t* __restrict__ alive,
+                                                            int store_flavour, const uint32_t* __restrict__ child_rows) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), n_waves = blockDim.x >> 6;
+    const uint32_t gp = blockIdx.x % groups_per_phase, rest = blockIdx.x / groups_per_phase;
+    const uint32_t group = (rest / n_tiles) * groups_per_phase + gp;
+    const size_t first = (size_t)(rest % n_tiles) * tile;
+    const size_t last = first + tile < n ? first + tile : n;
+    const uint32_t children_per_step = 64u / lanes_per_child;
+    for (uint32_t s = 0; s < steps_per_group; ++s) {
+        const uint32_t step = group * steps_per_group + s;  // wave-uniform
+        if (step >= n_steps) break;
+        const uint32_t child = step * children_per_step + lane / lanes_per_child;
+        const bool valid = child < n_children;
+        const ChildRec rec = recs[valid ? child : 0];
+        uint32_t shift = rec.packed & 0xFFu, hf = (rec.packed >> 8) & 0xFu, bin_size = rec.bin_size;
+        const uint32_t tb = rec.packed >> 12;
+        if (UNIFORM) {
+            shift = (uint32_t)__builtin_amdgcn_readfirstlane((int)shift);
+            hf = (uint32_t)__builtin_amdgcn_readfirstlane((int)hf);
+            bin_size = (uint32_t)__builtin_amdgcn_readfirstlane((int)bin_size);
+        }
+        const uint32_t stride = lanes_per_child * 2u;
+        const uint64_t* words = (const uint64_t*)rec.words + (lane % lanes_per_child) * 2u;
+        uint64_t* out = masks + (size_t)step * 128u + lane * 2u;
+        const uint64_t* cmw = cm + (tb >> 6);
+        for (size_t i0 = first + (size_t)wave * U; i0 < last; i0 += (size_t)n_waves * U) {
+            hu32x4 x[U][5];
+            bool hit[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = i0 + u < last ? i0 + u : last - 1;  // a tail step repeats the last k-mer (and stores it again)
+                uint64_t seeded[5] = {0, 0, 0, 0, 0};
+                if (!UNIFORM) {
+                    const uint64_t v = kmers[i];  // wave-uniform: the seed products are scalar
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; ++j) seeded[j] = j < h_max ? v * kSeeds[j] : 0;
+                }
+                hit[u] = valid && ((cmw[i * cm_words] >> (tb & 63u)) & 1u) && !(store_flavour & 16);  // bit 4: timing experiment, no row gathers
+#pragma unroll
+                for (uint32_t j = 0; j < 5; ++j) {
+                    if (j >= h_max) continue;
+                    // a hash function this child does not have repeats its last real row (AND is idempotent)
+                    uint64_t sv = seeded[j];
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; ++q) if (q < j && hf == q + 1) sv = seeded[q];
+                    // UNIFORM: h_max == hf, the rows were hashed once per k-mer by the root pass (a scalar load here)
+                    const uint32_t r = UNIFORM ? child_rows[i * h_max + j] : (uint32_t)hash_row_seeded32(sv, shift, bin_size);
+                    if (hit[u]) x[u][j] = *(const __attribute__((address_space(1))) hu32x4*)(words + (size_t)r * stride);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                hu32x4 acc{0u, 0u, 0u, 0u};
+                if (hit[u]) {
+                    acc = x[u][0];
+#pragma unroll
+                    for (uint32_t j = 1; j < 5; ++j) if (j < h_max) acc &= x[u][j];
+                }
+                const size_t i = i0 + u < last ? i0 + u : last - 1;
+                if (valid && (!(store_flavour & 32) || (acc.x == 0x12345u && acc.y == 0x54321u)))  // bit 5: timing experiment, (almost) no stores
+                    store_row16(reinterpret_cast<hu32x4*>(out + i * w_out), acc, store_flavour & 15);
+                if (alive) {
+                    const bool some = __ballot((acc.x | acc.y | acc.z | acc.w) != 0u) != 0;
+                    if (some && lane == 0) atomicOr((unsigned long long*)(alive + (i >> 6)), 1ULL << (i & 63));
+                }
+            }
+        }
+    }
+}
+
 // the frontier count of a level can exceed the capacity only through a bug; clamp for the reader
 __global__ void hibf_clamp_kernel(uint32_t* count, uint32_t cap) {
     if (threadIdx.x == 0 && blockIdx.x == 0 && *count > cap) *count = cap;
@@ -576,6 +723,43 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
         TXQ_HIP(hipMemcpy(ix.d_nodes, nodes.data(), nodes.size() * sizeof(HibfNode), hipMemcpyHostToDevice));
         ix.device_bytes += nodes.size() * sizeof(HibfNode);
     }
+
+    // Regular two-level tree?  (root: only merged bins; every child: a leaf whose technical bins are an aligned run of
+    // user bins, all children of one power-of-two row width >= 2 words, tiling the mask columns in order; this shard's
+    // column range starts and ends on child boundaries)  -> ChildRec table for the child-stationary descent.
+    if (compact && ix.depth == 2 && n >= 2 && desc.ibf[0].bins < (1u << 20)) {
+        const uint32_t wpr = (uint32_t)desc.ibf[1].bin_words;
+        bool regular = wpr >= 2 && (wpr & (wpr - 1)) == 0 && wpr <= 128;
+        std::vector<uint64_t> by_column(n - 1, UINT64_MAX), root_tb(n, 0);
+        for (uint64_t b = 0; regular && b < desc.ibf[0].bins; ++b) {
+            if (tbu[off[0] + b] != TXQ_MERGED_BIN) { regular = false; break; }
+            root_tb[next[off[0] + b]] = b;
+        }
+        for (uint64_t i = 1; regular && i < n; ++i) {
+            const IbfDev& f = ix.ibf[i];
+            regular = f.ident_word != kNoIdent && desc.ibf[i].bin_words == wpr && f.stride == wpr && f.ident_word % wpr == 0 &&
+                      f.ident_word / wpr < n - 1 && by_column[f.ident_word / wpr] == UINT64_MAX && f.hash_funs <= 5;
+            if (regular) by_column[f.ident_word / wpr] = i;
+        }
+        regular = regular && ix.mask_words == (uint64_t)wpr * (n - 1) && ix.shard_word0 % wpr == 0 && ix.shard_words % wpr == 0 && ix.shard_words > 0;
+        if (regular) {
+            std::vector<ChildRec> recs;
+            uint64_t bytes = 0;
+            for (uint64_t c = ix.shard_word0 / wpr; c < (ix.shard_word0 + ix.shard_words) / wpr; ++c) {
+                const IbfDev& f = ix.ibf[by_column[c]];
+                recs.push_back(ChildRec{(uint64_t)(uintptr_t)f.words, (uint32_t)f.bin_size, f.hash_shift | (f.hash_funs << 8) | ((uint32_t)root_tb[by_column[c]] << 12)});
+                bytes += f.bin_size * (uint64_t)f.stride * 8;
+            }
+            TXQ_HIP(hipMalloc((void**)&ix.d_children, recs.size() * sizeof(ChildRec)));
+            TXQ_HIP(hipMemcpy(ix.d_children, recs.data(), recs.size() * sizeof(ChildRec), hipMemcpyHostToDevice));
+            ix.n_children = (uint32_t)recs.size();
+            ix.children_uniform = true;
+            for (const ChildRec& c : recs) ix.children_uniform = ix.children_uniform && c.bin_size == recs[0].bin_size && (c.packed & 0xFFFu) == (recs[0].packed & 0xFFFu);
+            ix.child_row_words = wpr;
+            ix.children_bytes = bytes;
+            ix.device_bytes += recs.size() * sizeof(ChildRec);
+        }
+    }
     return TXQ_OK;
 }
 
@@ -609,6 +793,73 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
     const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
     *rc = TXQ_OK;
+    // regular two-level trees: the children stay put in L2, the k-mers stream past (TXQ_HIBF_STATIONARY=0: A/B against the kernels below)
+    {
+        const char* off = std::getenv("TXQ_HIBF_STATIONARY");
+        // (narrow masks, <= 16 words, are better off with one lane per k-mer: hibf_small_kernel)
+        if (ix.d_children && ix.n_children && w_out > 16 && !(off && off[0] == '0')) {
+            const uint32_t wpr = ix.child_row_words, lpc = wpr / 2, cps = 64 / lpc;
+            const uint32_t n_steps = (ix.n_children + cps - 1) / cps;
+            // a group = whole wave steps whose children fit ~2 MB (half an XCD's L2); at least 8 groups when there are 8 steps
+            const uint64_t per_step = ix.children_bytes / n_steps + 1;
+            uint32_t spg = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 20) / per_step);
+            if (n_steps >= 8 && (n_steps + spg - 1) / spg < 8) spg = n_steps / 8;
+            if (const char* e = std::getenv("TXQ_HIBF_STEPS_PER_GROUP")) spg = std::max(1, std::atoi(e));
+            const uint32_t n_groups = (n_steps + spg - 1) / spg;
+            const uint32_t gpp = n_groups < 8 ? n_groups : 8;
+            const uint32_t phases = (n_groups + gpp - 1) / gpp;
+            uint32_t tile = 2048;
+            if (const char* e = std::getenv("TXQ_HIBF_TILE")) tile = std::max(64, std::atoi(e));
+            const size_t n_tiles = (n + tile - 1) / tile;
+            if ((size_t)phases * n_tiles * gpp < ((size_t)1 << 31) && n_tiles < ((size_t)1 << 31)) {
+                const IbfDev& root = ix.ibf[0];
+                const uint32_t cm_words = root.stride;
+                if (int e = ensure((void**)&ix.scratch_cm, &ix.cap_cm, n * (size_t)cm_words * 8)) { *rc = e; return true; }
+                HibfNode rn{};
+                rn.words = (uint64_t)(uintptr_t)root.words;
+                rn.bin_size = (uint32_t)root.bin_size;
+                rn.packed = root.stride | (root.hash_shift << 20) | (root.hash_funs << 26);
+                rn.bins = root.bins;
+                size_t rb = (n + 255) / 256;
+                if (rb > 256 * 32) rb = 256 * 32;
+                static const bool force_lanes = std::getenv("TXQ_HIBF_LANE_HASH") != nullptr;  // A/B: per-lane hashing on a uniform tree
+                const bool uniform = ix.children_uniform && !force_lanes;
+                uint32_t* d_child_rows = nullptr;
+                const IbfDev& c0 = ix.ibf[1];  // uniform: every child looks like this one
+                if (uniform) {
+                    if (int e = ensure((void**)&ix.scratch_crows, &ix.cap_crows, n * (size_t)c0.hash_funs * 4)) { *rc = e; return true; }
+                    d_child_rows = ix.scratch_crows;
+                    h_max = c0.hash_funs;
+                }
+                hibf_root_kernel<<<(unsigned)rb, 256, 0, s>>>(rn, d_kmers, n, ix.scratch_cm, cm_words, d_child_rows, (uint32_t)c0.bin_size, c0.hash_shift, c0.hash_funs);
+                if (d_alive) {
+                    hipError_t e = hipMemsetAsync(d_alive, 0, ((n + 63) / 64) * 8, s);
+                    if (e != hipSuccess) { *rc = fail_hip(e, "hipMemsetAsync(alive)"); return true; }
+                }
+                const unsigned grid = (unsigned)((size_t)phases * n_tiles * gpp);
+                static const int unroll = std::getenv("TXQ_HIBF_UNROLL") ? std::atoi(std::getenv("TXQ_HIBF_UNROLL")) : 1;
+                static const int store_flavour = std::getenv("TXQ_HIBF_STORE") ? std::atoi(std::getenv("TXQ_HIBF_STORE")) : 0;
+#define TXQ_CHILDREN(U, UNI) hibf_children_kernel<U, UNI><<<grid, 256, 0, s>>>((const ChildRec*)ix.d_children, ix.n_children, lpc, d_kmers, n, ix.scratch_cm, \
+                                                                                cm_words, d_masks, w_out, n_steps, spg, gpp, (uint32_t)n_tiles, tile, h_max, d_alive, store_flavour, d_child_rows)
+                if (uniform) {
+                    if (unroll == 1) TXQ_CHILDREN(1, true);
+                    else if (unroll == 2) TXQ_CHILDREN(2, true);
+                    else if (unroll == 3) TXQ_CHILDREN(3, true);
+                    else if (unroll == 8) TXQ_CHILDREN(8, true);
+                    else TXQ_CHILDREN(4, true);
+                } else {
+                    if (unroll == 1) TXQ_CHILDREN(1, false);
+                    else if (unroll == 2) TXQ_CHILDREN(2, false);
+                    else if (unroll == 8) TXQ_CHILDREN(8, false);
+                    else TXQ_CHILDREN(4, false);
+                }
+#undef TXQ_CHILDREN
+                hipError_t e = hipGetLastError();
+                if (e != hipSuccess) *rc = fail_hip(e, "hibf child-stationary kernel launch");
+                return true;
+            }
+        }
+    }
     // small trees: one lane per k-mer (TXQ_HIBF_SMALL=0 keeps them on the wave-per-k-mer kernel, for A/B runs)
     const char* small = std::getenv("TXQ_HIBF_SMALL");
     if (ix.max_stride <= 4 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && !(small && small[0] == '0')) {

@@ -24,6 +24,16 @@ struct Index {
     void* d_nodes = nullptr;         // HibfNode[total technical bins + 1] for the fused descent (txq_hibf.hip)
     uint64_t* d_descend = nullptr;   // same layout: merged bins worth descending into for this shard
     uint64_t* d_merged_off = nullptr;
+    // Regular two-level trees (root of merged bins over leaf IBFs that each map an aligned run of user bins, all of
+    // one row width): the child-stationary descent of txq_hibf.hip.  d_children = ChildRec[n_children] in mask-column
+    // order for THIS shard's columns; empty when the tree does not have that shape.
+    void* d_children = nullptr;
+    uint32_t n_children = 0;         // children whose columns this shard owns
+    uint32_t child_row_words = 0;    // mask words per child (power of two >= 2)
+    bool children_uniform = false;   // same rows / hash shift / hash count in every child: scalar hashing
+    uint64_t children_bytes = 0;     // their matrices
+    uint32_t* scratch_crows = nullptr; size_t cap_crows = 0;  // uniform children: per k-mer its row indexes in a child
+    uint64_t* scratch_cm = nullptr; size_t cap_cm = 0;  // root pass output: per k-mer the root row (which children to visit)
     uint32_t depth = 1;              // levels of the tree
     uint64_t hibf_total_tbs = 0;     // technical bins over all IBFs of the tree
     uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
