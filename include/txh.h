@@ -68,6 +68,10 @@ typedef struct {
 int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
                          size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps,
                          const txh_dense_options* dense, txh_stage_fn fn, void* user, int* status, uint64_t* stats6);
+/* Join of column shards (host/compiler.hpp join_shard_masks): shard r holds words [word0[r], word0[r] + words[r]) of
+ * each of the n masks; out receives n x mask_words words.  <0 when the shards do not tile the mask exactly. */
+int txh_join_shard_masks(size_t n, uint64_t mask_words, size_t n_shards, const uint64_t* word0, const uint64_t* words,
+                         const uint64_t* const* shard_masks, uint64_t* out);
 /* the d-gram codes one record contributes (DGramIndex::process_sequence, include/dGramIndex.h:159-211) */
 int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, size_t cap);
 
@@ -81,6 +85,14 @@ int txe_query_masks(void* txq_index_handle, int dna, unsigned k, unsigned reduct
 int txe_query_masks_gapped(void* txq_index_handle, void* aux_index_handle, const txh_gap_options* gaps, int dna, unsigned k,
                            unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,
                            uint64_t* masks, int* status, uint64_t* stats6);
+/* The same on an index that is column-sharded over several GPUs (or several shards on one GPU): handles[r] is shard r
+ * of n_shards as uploaded with txq_index_upload(desc, r, n_shards, ..).  ONE frontier expansion feeds all shards (the
+ * ops are shard-independent), every stage runs on all shards at the same time, a state is pruned when it is dead in
+ * every shard, and the final masks are joined: masks receives n x mask_words words (the FULL mask).  aux_handles (or NULL):
+ * the d-gram index, sharded the same way. */
+int txe_query_masks_sharded(void* const* handles, void* const* aux_handles, size_t n_shards, const txh_gap_options* gaps, int dna,
+                            unsigned k, unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,
+                            uint64_t* masks, int* status, uint64_t* stats6);
 const char* txe_last_error(void);
 /* dense DP ops (include/txq_program.h version 3) the calling thread's last txe_query_masks* run sent to the device */
 uint64_t txe_last_dense_ops(void);

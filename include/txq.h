@@ -88,16 +88,18 @@ typedef struct {
     int      device;       /* HIP device ordinal                                      */
 } txq_index_info;
 
-/* Bind this process to one GPU (one process per GPU; n_devices must be 1 for now).
- * device_ids == NULL selects device 0.  Fails with TXQ_ERR_STATE when no GPU is present:
- * there is no CPU fallback anywhere in this library. */
+/* Bind this process to n_devices GPUs (device_ids == NULL: devices 0 .. n_devices-1).  One process per GPU
+ * (n_devices == 1, the torch.distributed / RCCL deployment) and one process driving all GPUs of a node are both
+ * supported: shard r of an index (txq_index_upload, txq_index_create_ibf) lives on device_ids[r % n_devices], and
+ * every call on an index or session runs on the device that holds it, whichever thread makes it.
+ * Fails with TXQ_ERR_STATE when no GPU is present: there is no CPU fallback anywhere in this library. */
 int txq_init(int n_devices, const int* device_ids);
 int txq_shutdown(void);
 const char* txq_last_error(void);
 int txq_device_count(void); /* >= 0, or a negative txq_status */
 
-/* Copy an index into HBM.  With n_shards > 1 only the mask-word columns of shard
- * `shard_rank` are kept (flat IBF: words [W*r/R, W*(r+1)/R) of every row, re-laid out
+/* Copy an index into HBM (of device_ids[shard_rank % n_devices], see txq_init).  With n_shards > 1 only the
+ * mask-word columns of shard `shard_rank` are kept (flat IBF: words [W*r/R, W*(r+1)/R) of every row, re-laid out
  * contiguously; HIBF: the whole tree is kept and only the user-bin mask columns are sharded). */
 int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out);
 int txq_index_get_info(const txq_index* ix, txq_index_info* info);

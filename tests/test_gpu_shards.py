@@ -1,0 +1,124 @@
+"""The C++ multi-shard product path (host/device_index.cpp ShardedStageExecutor / run_queries_sharded, exported as
+txe_query_masks_sharded; `tetrex query --shards R`): ONE frontier expansion drives all column shards of an index, every
+stage runs on all shards at the same time, pruning takes the OR of the shards' alive bits and the final masks are joined.
+Here all shards share the one GPU of the box (txq_init with one device deals every shard onto it); on a multi-GPU node the
+same code puts shard r on device r.  Full masks must equal the CPU oracle's (reference include/query.h:250-290 run_collection)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from tetrex_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _oracle_index(oracle, bins, m, h, k, dna, per_bin, seed):
+    ox = oracle.Index.ibf(bins, m, h, dna=dna, k=k)
+    rng = np.random.default_rng(seed)
+    bits = (2 if dna else 5) * k
+    for b in range(bins):
+        ox.emplace(rng.integers(0, 1 << min(bits, 62), size=per_bin, dtype=np.uint64), b)
+    return ox
+
+
+@pytest.mark.parametrize("R", [2, 3, 8])
+def test_sharded_queries_equal_the_oracle(capi, oracle, R):
+    ox = _oracle_index(oracle, bins=1000, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=5)
+    sh = ox.shape()
+    qs = PEPTIDE_QUERIES + random_prosite_motifs(40, 11, wildcard=0.1, ranges=0.05)
+    shards = [capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=R) for r in range(R)]
+    full, status, stats = capi.query_masks_sharded(shards, qs, False, 4)
+    assert full.shape == (len(qs), (ox.bins + 63) // 64)
+    one = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    ref, status1, stats1 = one.query_masks(qs, False, 4)
+    assert status == status1 and np.array_equal(full, ref)  # same masks as the unsharded index, query by query
+    checked = 0
+    for q, g, st in zip(qs, full, status):
+        try:
+            want, ost = ox.query(q, with_stats=True)
+        except Exception:
+            assert st != 0
+            continue
+        assert st == 0
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+            checked += 1
+    assert checked > 50 and stats["dense_ops"] > 0
+    for s in shards + [one]:
+        s.free()
+
+
+def test_sharded_feedback_prunes_with_the_or_of_all_shards(capi, oracle):
+    """A sparse index and wildcard motifs: most states die, but a state that is dead in one shard and alive in another
+    must survive.  Tiny stage budgets force many feedback rounds."""
+    ox = _oracle_index(oracle, bins=640, m=60013, h=3, k=4, dna=False, per_bin=400, seed=2)
+    sh = ox.shape()
+    qs = ["LMA.{2,4}E.{2}GLY", "W.{2}[LIVM]D[VFY][LIVM]{3}D.PPGT[GS]D", "LMK.{1,3}A[DE]..GK", "LMAEGLYN"]
+    os.environ["TETREX_DENSE"] = "0"  # enumerated states: the path that asks for feedback
+    try:
+        shards = [capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=5) for r in range(5)]
+        full, status, stats = capi.query_masks_sharded(shards, qs, False, 4, ops_per_query_per_stage=512)
+    finally:
+        del os.environ["TETREX_DENSE"]
+    assert not any(status) and stats["pruned"] > 0 and stats["feedback_queries"] > 0
+    for q, g in zip(qs, full):
+        want, ost = ox.query(q, with_stats=True)
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+    for s in shards:
+        s.free()
+
+
+def test_dna_shards_with_an_empty_shard(capi, oracle):
+    """More shards than mask words: some shards own no column at all and still take part."""
+    ox = _oracle_index(oracle, bins=130, m=4099, h=3, k=5, dna=True, per_bin=300, seed=130)
+    sh = ox.shape()
+    shards = [capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=4) for r in range(4)]
+    assert sorted(s.shard_words for s in shards) == [0, 1, 1, 1]
+    full, status, _ = capi.query_masks_sharded(shards, DNA_QUERIES, True, 5)
+    for q, g, st in zip(DNA_QUERIES, full, status):
+        try:
+            want, ost = ox.query(q, with_stats=True)
+        except Exception:
+            assert st != 0
+            continue
+        if st == 0 and not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+    for s in shards:
+        s.free()
+
+
+def test_cli_query_with_shards(tmp_path, oracle):
+    """`tetrex query --shards 3` narrows to the same bins and prints the same verified matches as the unsharded run."""
+    exe = os.path.join(ROOT, "bin", "tetrex")
+    rng = np.random.default_rng(12)
+    aa = list("ACDEFGHIKLMNPQRSTVWY")
+    files = []
+    for b in range(200):
+        seq = "".join(rng.choice(aa, size=400))
+        if b in (17, 150, 199):
+            seq = seq[:100] + "LMAEGLYN" + seq[108:]
+        p = tmp_path / ("bin%03d.fa" % b)
+        p.write_text(">rec%d\n%s\n" % (b, seq))
+        files.append(str(p))
+    lst = tmp_path / "bins.lst"
+    lst.write_text("\n".join(files) + "\n")
+    subprocess.run([exe, "index", "-k", "4", "-i", str(tmp_path / "idx"), str(lst)], check=True, capture_output=True, timeout=300)
+    outs = []
+    for extra in ([], ["--shards", "3"], ["-D", "0", "--shards", "2"]):
+        r = subprocess.run([exe, "query", "-v", *extra, str(tmp_path / "idx.ibf"), "LMA(E|Q)GLYN"], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        narrowed = [ln for ln in r.stderr.splitlines() if ln.startswith("Narrowed Search")]
+        outs.append((sorted(r.stdout.splitlines()), narrowed))
+    assert outs[0] == outs[1] == outs[2]
+    assert len(outs[0][0]) == 3 and all("LMAEGLYN" in ln for ln in outs[0][0])

@@ -339,6 +339,28 @@ class Index:
         return out
 
 
+def query_masks_sharded(shards, regexes, dna, k, reduction=0, ops_per_query_per_stage=0):
+    """Whole queries on ALL column shards of an index at once (libtetrex_query.so txe_query_masks_sharded): one
+    frontier expansion drives every shard, the final masks are joined.  shards: Index objects, shard r of
+    len(shards).  Returns (full masks [n, mask_words], status list, stats dict)."""
+    Lq = _query_lib()
+    Lq.txe_query_masks_sharded.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_size_t, C.c_void_p, C.c_int, C.c_uint, C.c_uint,
+                                           C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t, u64p, C.POINTER(C.c_int), u64p]
+    n = len(regexes)
+    arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
+    hs = (C.c_void_p * len(shards))(*[s._h for s in shards])
+    masks = np.zeros((n, int(shards[0].info.mask_words)), dtype=np.uint64)
+    status = (C.c_int * n)()
+    stats = (C.c_uint64 * 8)()
+    rc = Lq.txe_query_masks_sharded(hs, None, len(shards), None, int(dna), k, reduction, arr, n, ops_per_query_per_stage,
+                                    masks.ctypes.data_as(u64p), status, stats)
+    if rc < 0:
+        raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
+    keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
+    Lq.txe_last_dense_ops.restype = C.c_uint64
+    return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
+
+
 def _aligned(blob):
     buf = np.frombuffer(blob, dtype=np.uint8)
     al = np.zeros((buf.size + 7) // 8, dtype=np.uint64)

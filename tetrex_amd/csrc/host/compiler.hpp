@@ -303,6 +303,12 @@ struct StagedStats {
 StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
                        const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages);
 
+// Column shards of the masks of n queries -> full-width masks: shard r holds words [word0[r], word0[r] + words[r]) of
+// every mask, row-major [n][words[r]] (what txq_session_end returns for that shard).  The shards must tile
+// [0, mask_words) exactly.  This is the whole "OR-reduce" of the bin-sharded index: the shards are disjoint.
+std::vector<uint64_t> join_shard_masks(size_t n, uint64_t mask_words, const std::vector<uint64_t>& word0, const std::vector<uint64_t>& words,
+                                       const std::vector<const uint64_t*>& shard_masks);
+
 // A batch of queries sharing one k-mer table; serialises to the blob txq_run_programs takes.
 class ProgramBatch {
   public:

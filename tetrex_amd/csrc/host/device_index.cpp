@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <future>
 #include <stdexcept>
 
 namespace tetrex {
@@ -13,44 +14,47 @@ void txq_check(int rc, const char* what) {
     if (rc != TXQ_OK) throw std::runtime_error(std::string(what) + ": " + txq_last_error());
 }
 
-static void ensure_device(int device) {
-    static int bound = -1;
-    if (bound == device) return;
-    txq_check(txq_init(1, &device), "txq_init");
-    bound = device;
+static void ensure_devices(const std::vector<int>& devices) {
+    static std::vector<int> bound;
+    if (bound == devices) return;
+    txq_check(txq_init((int)devices.size(), devices.data()), "txq_init");
+    bound = devices;
 }
+static void ensure_device(int device) { ensure_devices(std::vector<int>{device}); }
 
 static txq_ibf_desc describe(const IbfImage& f) {
     return txq_ibf_desc{f.bins, f.tech_bins, f.bin_size, f.hash_shift, f.bin_words, f.hash_funs, f.words.data()};
 }
 
 DeviceIndex::~DeviceIndex() {
-    if (aux_) txq_index_free(aux_);
-    if (ix_) txq_index_free(ix_);
+    for (txq_index* a : aux_shards_) txq_index_free(a);
+    for (txq_index* s : shards_) txq_index_free(s);
 }
 
 void DeviceIndex::attach_dgram(const DgramImage& dgram) {
     if (!ix_) throw std::runtime_error("index not uploaded");
     if (dgram.ibf.bins != info_.user_bins) throw std::runtime_error("the d-gram index was built over a different number of bins");
-    if (aux_) { txq_index_free(aux_); aux_ = nullptr; }
+    for (txq_index* a : aux_shards_) txq_index_free(a);
+    aux_shards_.clear();
+    aux_ = nullptr;
     txq_ibf_desc d = describe(dgram.ibf);
     txq_index_desc desc{1, &d, nullptr, nullptr, dgram.ibf.bins};
-    txq_check(txq_index_upload(&desc, shard_rank_, n_shards_, &aux_), "txq_index_upload(d-gram)");
+    for (size_t r = 0; r < shards_.size(); ++r) {  // same shard, same device as the main index's shard
+        txq_index* a = nullptr;
+        txq_check(txq_index_upload(&desc, shards_.size() > 1 ? (int)r : shard_rank_, n_shards_, &a), "txq_index_upload(d-gram)");
+        aux_shards_.push_back(a);
+    }
+    aux_ = aux_shards_[0];
     dgram_min_ = dgram.min_gap;
     dgram_max_ = dgram.max_gap;
 }
 
-void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, int n_shards) {
-    ensure_device(device);
-    if (aux_) { txq_index_free(aux_); aux_ = nullptr; }
-    if (ix_) { txq_index_free(ix_); ix_ = nullptr; }
-    shard_rank_ = shard_rank;
-    n_shards_ = n_shards;
-    enc_ = KmerEncoder(image.molecule == "na" ? Molecule::DNA : Molecule::Peptide, image.k, (Alphabet)image.reduction);
+txq_index* DeviceIndex::upload_one(const IndexImage& image, int shard_rank, int n_shards) {
+    txq_index* ix = nullptr;
     if (!image.is_hibf) {
         txq_ibf_desc d = describe(image.ibf);
         txq_index_desc desc{1, &d, nullptr, nullptr, image.ibf.bins};
-        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix_), "txq_index_upload");
+        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix), "txq_index_upload");
     } else {
         const HibfImage& h = image.hibf;
         std::vector<txq_ibf_desc> ds;
@@ -61,8 +65,40 @@ void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, in
             tb.push_back(h.tb_to_user_bin[i].data());
         }
         txq_index_desc desc{ds.size(), ds.data(), nx.data(), tb.data(), h.user_bins};
-        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix_), "txq_index_upload");
+        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix), "txq_index_upload");
     }
+    return ix;
+}
+
+void DeviceIndex::upload(const IndexImage& image, int device, int shard_rank, int n_shards) {
+    ensure_device(device);
+    for (txq_index* a : aux_shards_) txq_index_free(a);
+    for (txq_index* s : shards_) txq_index_free(s);
+    aux_shards_.clear();
+    shards_.clear();
+    aux_ = ix_ = nullptr;
+    shard_rank_ = shard_rank;
+    n_shards_ = n_shards;
+    enc_ = KmerEncoder(image.molecule == "na" ? Molecule::DNA : Molecule::Peptide, image.k, (Alphabet)image.reduction);
+    // the library deals shards over its devices by rank; with one device every rank lands on it
+    ix_ = upload_one(image, shard_rank, n_shards);
+    shards_.push_back(ix_);
+    txq_check(txq_index_get_info(ix_, &info_), "txq_index_get_info");
+}
+
+void DeviceIndex::upload_sharded(const IndexImage& image, const std::vector<int>& devices, int n_shards) {
+    if (devices.empty() || n_shards < 1) throw std::runtime_error("upload_sharded needs at least one device and one shard");
+    ensure_devices(devices);
+    for (txq_index* a : aux_shards_) txq_index_free(a);
+    for (txq_index* s : shards_) txq_index_free(s);
+    aux_shards_.clear();
+    shards_.clear();
+    aux_ = ix_ = nullptr;
+    shard_rank_ = 0;
+    n_shards_ = n_shards;
+    enc_ = KmerEncoder(image.molecule == "na" ? Molecule::DNA : Molecule::Peptide, image.k, (Alphabet)image.reduction);
+    for (int r = 0; r < n_shards; ++r) shards_.push_back(upload_one(image, r, n_shards));
+    ix_ = shards_[0];
     txq_check(txq_index_get_info(ix_, &info_), "txq_index_get_info");
 }
 
@@ -89,6 +125,91 @@ void TxqStageExecutor::finish(uint64_t* masks) {
     txq_session* s = session_;
     session_ = nullptr;
     txq_check(txq_session_end(s, masks), "txq_session_end");
+}
+
+ShardedStageExecutor::ShardedStageExecutor(const std::vector<txq_index*>& shards, size_t n_programs, const std::vector<txq_index*>& aux)
+    : n_programs_(n_programs) {
+    if (shards.empty()) throw std::runtime_error("no shards");
+    if (!aux.empty() && aux.size() != shards.size()) throw std::runtime_error("the d-gram index must be sharded like the main index");
+    try {
+        for (size_t r = 0; r < shards.size(); ++r) {
+            txq_index_info info{};
+            txq_check(txq_index_get_info(shards[r], &info), "txq_index_get_info");
+            info_.push_back(info);
+            txq_session* s = nullptr;
+            txq_check(txq_session_begin(shards[r], n_programs, &s), "txq_session_begin");
+            sessions_.push_back(s);
+            if (!aux.empty()) txq_check(txq_session_set_aux_index(s, aux[r]), "txq_session_set_aux_index");
+        }
+    } catch (...) {
+        for (txq_session* s : sessions_) txq_session_end(s, nullptr);
+        throw;
+    }
+}
+ShardedStageExecutor::~ShardedStageExecutor() {
+    for (txq_session* s : sessions_)
+        if (s) txq_session_end(s, nullptr);
+}
+void ShardedStageExecutor::stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& qp, const std::vector<uint32_t>& qs,
+                                 std::vector<uint8_t>& alive) {
+    const size_t R = sessions_.size(), nq = qp.size();
+    std::vector<std::vector<uint8_t>> answers(R, std::vector<uint8_t>(nq, 0));
+    std::vector<std::string> errors(R);
+    auto run = [&](size_t r) {  // txq_last_error() is per thread: fetch it on the thread that made the call
+        if (txq_session_stage(sessions_[r], blob, blob_bytes, qp.data(), qs.data(), nq, answers[r].data()) != TXQ_OK)
+            errors[r] = std::string("txq_session_stage (shard ") + std::to_string(r) + "): " + txq_last_error();
+    };
+    std::vector<std::future<void>> others;
+    for (size_t r = 1; r < R; ++r) others.push_back(std::async(std::launch::async, run, r));
+    run(0);
+    for (auto& f : others) f.get();
+    for (const std::string& e : errors)
+        if (!e.empty()) throw std::runtime_error(e);
+    alive.assign(nq, 0);
+    for (size_t r = 0; r < R; ++r)
+        for (size_t i = 0; i < nq; ++i) alive[i] |= answers[r][i];
+}
+std::vector<uint64_t> ShardedStageExecutor::finish() {
+    const size_t R = sessions_.size();
+    std::vector<std::vector<uint64_t>> part(R);
+    std::vector<uint64_t> word0(R), words(R);
+    std::vector<const uint64_t*> ptr(R);
+    std::string error;
+    for (size_t r = 0; r < R; ++r) {
+        part[r].resize(n_programs_ * info_[r].shard_words + 1);
+        txq_session* s = sessions_[r];
+        sessions_[r] = nullptr;
+        if (txq_session_end(s, part[r].data()) != TXQ_OK && error.empty()) error = std::string("txq_session_end: ") + txq_last_error();
+        word0[r] = info_[r].shard_word0;
+        words[r] = info_[r].shard_words;
+        ptr[r] = part[r].data();
+    }
+    if (!error.empty()) throw std::runtime_error(error);
+    return join_shard_masks(n_programs_, info_[0].mask_words, word0, words, ptr);
+}
+
+std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards, const KmerEncoder& enc, const std::vector<std::string>& regexes,
+                                          std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
+                                          const StagedOptions* options, const std::vector<txq_index*>& aux) {
+    if (shards.empty()) throw std::runtime_error("no shards");
+    txq_index_info info{};
+    txq_check(txq_index_get_info(shards[0], &info), "txq_index_get_info");
+    if (status) status->assign(regexes.size(), 0);
+    if (messages) messages->assign(regexes.size(), std::string());
+    if (regexes.empty()) return std::vector<uint64_t>();
+    ShardedStageExecutor exec(shards, regexes.size(), aux);
+    StagedOptions opt = options ? *options : StagedOptions{};
+    opt.dense.enabled = true;
+    opt.dense.slot_bytes = 0;
+    for (txq_index* s : shards) {  // dense steps only where every shard can run them; budgets by the widest shard
+        txq_index_info i{};
+        txq_check(txq_index_get_info(s, &i), "txq_index_get_info");
+        if (i.shard_words) opt.dense.enabled = opt.dense.enabled && txq_index_supports_dense(s) != 0;
+        opt.dense.slot_bytes = std::max<uint64_t>(opt.dense.slot_bytes, i.shard_words * 8);
+    }
+    const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
+    if (stats) *stats = st;
+    return exec.finish();
 }
 
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
@@ -120,6 +241,7 @@ std::vector<uint64_t> DeviceIndex::query_masks(const std::vector<std::string>& r
         opt.gaps.min_gap = dgram_min_;
         opt.gaps.max_gap = dgram_max_;
     }
+    if (shards_.size() > 1) return run_queries_sharded(shards_, enc_, regexes, status, messages, stats, &opt, aux_shards_);
     return run_queries(ix_, enc_, regexes, status, messages, stats, &opt, aux_);
 }
 

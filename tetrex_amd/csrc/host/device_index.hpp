@@ -30,10 +30,34 @@ class TxqStageExecutor final : public StageExecutor {
     txq_session* session_ = nullptr;
 };
 
+// StageExecutor over the column shards of one index, each with its own txq session (and, with several GPUs, its own
+// device — include/txq.h txq_init).  ONE frontier expansion feeds all shards: a stage's blob goes to every session at the
+// same time (one host thread per shard), and a waiting state counts as alive when any shard says so (the reference's
+// path_.none() over the whole mask, include/otf_collector.h:383).  This is the seam of run_collection /
+// run_multiple_queries (reference include/query.h:250-290,329-346) for a bin-sharded index.
+class ShardedStageExecutor final : public StageExecutor {
+  public:
+    ShardedStageExecutor(const std::vector<txq_index*>& shards, size_t n_programs, const std::vector<txq_index*>& aux = {});
+    ~ShardedStageExecutor() override;
+    void stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& query_program,
+               const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) override;
+    // ends the sessions and joins the shards' RESULT masks: n_programs x mask_words words
+    std::vector<uint64_t> finish();
+
+  private:
+    std::vector<txq_session*> sessions_;
+    std::vector<txq_index_info> info_;
+    size_t n_programs_ = 0;
+};
+
 // Whole queries on an uploaded index: staged expansion + device execution.
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                   std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
                                   const StagedOptions* options, txq_index* aux = nullptr);
+// ... on all column shards of an index: full-width masks (n x mask_words)
+std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards, const KmerEncoder& enc, const std::vector<std::string>& regexes,
+                                          std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
+                                          const StagedOptions* options, const std::vector<txq_index*>& aux = {});
 
 class DeviceIndex {
   public:
@@ -42,8 +66,14 @@ class DeviceIndex {
     DeviceIndex& operator=(const DeviceIndex&) = delete;
     ~DeviceIndex();
 
-    // txq_init + txq_index_upload of a parsed index file
+    // txq_init + txq_index_upload of a parsed index file: ONE shard (shard_rank of n_shards) on one device
     void upload(const IndexImage& image, int device = 0, int shard_rank = 0, int n_shards = 1);
+    // ... ALL n_shards column shards, dealt round-robin over `devices` (`tetrex query --gpus N`); queries then run on
+    // every shard at once and query_masks returns full-width masks
+    void upload_sharded(const IndexImage& image, const std::vector<int>& devices, int n_shards);
+    size_t n_shards_held() const { return shards_.size(); }
+    // words per mask that query_masks returns (the shard's words for upload(), the full mask for upload_sharded())
+    uint64_t result_words() const { return shards_.size() > 1 ? info_.mask_words : info_.shard_words; }
     const txq_index_info& info() const { return info_; }
     KmerEncoder encoder() const { return enc_; }
     uint64_t bins() const { return info_.user_bins; }
@@ -62,6 +92,9 @@ class DeviceIndex {
     uint64_t dgram_max_gap() const { return dgram_max_; }
 
   private:
+    txq_index* upload_one(const IndexImage& image, int shard_rank, int n_shards);
+    std::vector<txq_index*> shards_;      // upload_sharded: all shards (shards_[0] == ix_); upload: just ix_
+    std::vector<txq_index*> aux_shards_;  // the d-gram index, sharded the same way
     txq_index* ix_ = nullptr;
     txq_index* aux_ = nullptr;
     uint64_t dgram_min_ = 0, dgram_max_ = 0;

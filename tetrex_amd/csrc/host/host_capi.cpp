@@ -164,6 +164,17 @@ int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int txh_join_shard_masks(size_t n, uint64_t mask_words, size_t n_shards, const uint64_t* word0, const uint64_t* words,
+                         const uint64_t* const* shard_masks, uint64_t* out) {
+    try {
+        const std::vector<uint64_t> full = join_shard_masks(n, mask_words, std::vector<uint64_t>(word0, word0 + n_shards),
+                                                            std::vector<uint64_t>(words, words + n_shards),
+                                                            std::vector<const uint64_t*>(shard_masks, shard_masks + n_shards));
+        std::memcpy(out, full.data(), full.size() * 8);
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t max_gap, uint64_t* out, size_t cap) {
     std::vector<uint64_t> v;
     dgram_record_values(std::string_view(seq, len), min_gap, max_gap, v);

@@ -98,7 +98,7 @@ size_t popcount_mask(const uint64_t* m, uint64_t words) {
 int cmd_query(int argc, char** argv) {
     const std::vector<OptSpec> spec = {{'d', "draw", false}, {'v', "verbose", false}, {'f', "file", false}, {'c', "conj", false},
                                        {'a', "augment", false}, {'t', "threads", true}, {'o', "output", true}, {'g', "gibf", true},
-                                       {'D', "device", true}, {'S', "stats", false}};
+                                       {'D', "device", true}, {'S', "stats", false}, {'G', "gpus", true}, {'R', "shards", true}};
     Args a;
     try {
         a = parse(argc, argv, 2, spec);
@@ -125,14 +125,24 @@ int cmd_query(int argc, char** argv) {
         return 0;
     }
     const double t_read = now();
+    // -D d[,d..] / --gpus N (not in the reference): the index's bins are cut into column shards, one per device (--shards R:
+    // that many shards, dealt round-robin over the devices); one frontier expansion drives all shards, masks are joined on the host
     DeviceIndex dev;
-    dev.upload(image, std::atoi(a.get("device", "0").c_str()));
+    std::vector<int> devices;
+    for (const std::string& d : split(a.get("device", "0"), ',')) devices.push_back(std::atoi(d.c_str()));
+    if (a.has("gpus")) {
+        devices.clear();
+        for (int d = 0; d < std::max(1, std::atoi(a.get("gpus", "1").c_str())); ++d) devices.push_back(d);
+    }
+    const int n_shards = a.has("shards") ? std::max(1, std::atoi(a.get("shards", "1").c_str())) : (int)devices.size();
+    if (n_shards > 1 || devices.size() > 1) dev.upload_sharded(image, devices, n_shards);
+    else dev.upload(image, devices[0]);
     if (trace) std::cerr << "[tetrex] index read+parse " << (t_read - t_start) << " s, device init+upload " << (now() - t_read) << " s" << std::endl;
     if (a.has("gibf")) dev.attach_dgram(read_dgram_index_file(a.get("gibf", "")));  // include/query.h:259-264
     StagedOptions sopt;
     sopt.gaps.augment = a.has("augment");
     const KmerEncoder enc = dev.encoder();
-    const uint64_t bins = dev.bins(), W = dev.info().shard_words;
+    const uint64_t bins = dev.bins(), W = dev.result_words();
     const VerifyOptions vopt{threads};
     // -S/--stats (not in the reference): one JSON line on stderr about the candidate-mask stage
     auto print_stats = [&](const StagedStats& st, size_t queries, double seconds) {
@@ -183,20 +193,32 @@ int cmd_query(int argc, char** argv) {
         const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why, &st, &sopt);
         print_stats(st, motifs.size(), now() - t0);
         const double batch = (now() - t0) / std::max<size_t>(1, motifs.size());
+        int failed = 0;
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
-            if (status[i]) std::cerr << "[query not searchable: " << why[i] << "] ";
+            if (status[i]) {  // its mask is incomplete: verifying the bins it happens to hold would silently lose matches
+                std::cerr << "[Error] query not searchable, no result written: " << why[i] << std::endl;
+                ++failed;
+                continue;
+            }
             run_one(motifs[i], masks.data() + i * W, ids[i] + ".tsv", true, now() - batch);
         }
-        return 0;
+        return failed ? 1 : 0;
     }
     if (conj) {
         const std::vector<std::string> queries = split(input, ':');
         if (queries.size() == 1) { std::cerr << "Did you use the correct delimiter (:)?" << std::endl; return 0; }
         const double t1 = now();
         StagedStats st;
-        const std::vector<uint64_t> masks = dev.query_masks(queries, nullptr, nullptr, &st, &sopt);
+        std::vector<int> status;
+        std::vector<std::string> why;
+        const std::vector<uint64_t> masks = dev.query_masks(queries, &status, &why, &st, &sopt);
         print_stats(st, queries.size(), now() - t1);
+        for (size_t q = 0; q < queries.size(); ++q)
+            if (status[q]) {  // ANDing a partial mask would drop true candidate bins without a word
+                std::cerr << "[Error] query not searchable: " << queries[q] << ": " << why[q] << std::endl;
+                return 1;
+            }
         std::vector<uint64_t> all(masks.begin(), masks.begin() + W);
         for (size_t q = 1; q < queries.size(); ++q)
             for (uint64_t w = 0; w < W; ++w) all[w] &= masks[q * W + w];

@@ -55,4 +55,39 @@ int txe_query_masks_gapped(void* handle, void* aux_handle, const txh_gap_options
     }
 }
 
+int txe_query_masks_sharded(void* const* handles, void* const* aux_handles, size_t n_shards, const txh_gap_options* gaps, int dna,
+                            unsigned k, unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,
+                            uint64_t* masks, int* status, uint64_t* stats6) {
+    try {
+        std::vector<txq_index*> shards, aux;
+        for (size_t r = 0; r < n_shards; ++r) shards.push_back(static_cast<txq_index*>(handles[r]));
+        if (aux_handles)
+            for (size_t r = 0; r < n_shards; ++r) aux.push_back(static_cast<txq_index*>(aux_handles[r]));
+        const KmerEncoder enc(dna ? Molecule::DNA : Molecule::Peptide, k, (Alphabet)reduction);
+        std::vector<std::string> rx(regex, regex + n);
+        StagedOptions opt;
+        if (ops_per_query_per_stage) opt.ops_per_query_per_stage = ops_per_query_per_stage;
+        if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0 && !aux.empty(), gaps->min_gap, gaps->max_gap};
+        std::vector<int> st;
+        std::vector<std::string> why;
+        StagedStats s;
+        const std::vector<uint64_t> out = run_queries_sharded(shards, enc, rx, &st, &why, &s, &opt, aux);
+        std::copy(out.begin(), out.end(), masks);
+        g_dense_ops = s.dense_ops;
+        int failures = 0;
+        for (size_t i = 0; i < n; ++i) {
+            if (status) status[i] = st[i];
+            if (st[i]) { ++failures; g_qerr = "query " + std::to_string(i) + ": " + why[i]; }
+        }
+        if (stats6) {
+            stats6[0] = s.stages; stats6[1] = s.ops; stats6[2] = s.kmers; stats6[3] = s.states; stats6[4] = s.pruned; stats6[5] = s.feedback_queries;
+            stats6[6] = (uint64_t)(s.expand_seconds * 1e6); stats6[7] = (uint64_t)(s.execute_seconds * 1e6);
+        }
+        return failures;
+    } catch (const std::exception& e) {
+        g_qerr = e.what();
+        return -1;
+    }
+}
+
 }  // extern "C"

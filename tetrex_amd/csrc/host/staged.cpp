@@ -437,6 +437,26 @@ class StagedRun {
 
 }  // namespace
 
+std::vector<uint64_t> join_shard_masks(size_t n, uint64_t mask_words, const std::vector<uint64_t>& word0, const std::vector<uint64_t>& words,
+                                       const std::vector<const uint64_t*>& shard_masks) {
+    if (word0.size() != words.size() || word0.size() != shard_masks.size()) throw std::runtime_error("shard tables of different lengths");
+    std::vector<uint8_t> covered(mask_words, 0);
+    for (size_t r = 0; r < word0.size(); ++r) {
+        if (word0[r] > mask_words || words[r] > mask_words - word0[r]) throw std::runtime_error("shard outside the mask");
+        for (uint64_t w = 0; w < words[r]; ++w) {
+            if (covered[word0[r] + w]) throw std::runtime_error("shards overlap");
+            covered[word0[r] + w] = 1;
+        }
+    }
+    for (uint8_t c : covered)
+        if (!c) throw std::runtime_error("shards do not cover the mask");
+    std::vector<uint64_t> full(n * mask_words);
+    for (size_t r = 0; r < word0.size(); ++r)
+        for (size_t i = 0; i < n && words[r]; ++i)
+            std::memcpy(full.data() + i * mask_words + word0[r], shard_masks[r] + i * words[r], words[r] * 8);
+    return full;
+}
+
 StagedStats run_staged(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec,
                        const StagedOptions& opt, std::vector<int>* status, std::vector<std::string>* messages) {
     return StagedRun(enc, bins, regexes, exec, opt).run(status, messages);

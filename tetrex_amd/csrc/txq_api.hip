@@ -14,7 +14,7 @@
 namespace txq {
 
 static thread_local std::string g_err;
-static int g_device = -1;
+static std::vector<int> g_devices;  // txq_init: shard r of an index lives on g_devices[r % size]
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -28,17 +28,25 @@ int fail(int code, const char* fmt, ...) {
 int fail_hip(hipError_t e, const char* what) {
     return fail(e == hipErrorOutOfMemory ? TXQ_ERR_NOMEM : TXQ_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
 }
-int require_init() {
-    if (g_device < 0) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
-    // The HIP device is a per-thread setting: a thread other than the one that called txq_init (e.g. the host's
-    // stage-submission thread) would otherwise talk to device 0, and the embedding application may have selected
-    // another device since the last call (torch.cuda.set_device): always ask, never trust a cached answer.
+// The HIP device is a per-thread setting: a thread other than the one that called txq_init (e.g. the host's
+// stage-submission threads, one per shard) would otherwise talk to device 0, and the embedding application may
+// have selected another device since the last call (torch.cuda.set_device): always ask, never trust a cached answer.
+static int bind_device(int device) {
     int current = -1;
-    if (hipGetDevice(&current) != hipSuccess || current != g_device) {
-        hipError_t e = hipSetDevice(g_device);
+    if (hipGetDevice(&current) != hipSuccess || current != device) {
+        hipError_t e = hipSetDevice(device);
         if (e != hipSuccess) return fail_hip(e, "hipSetDevice");
     }
     return TXQ_OK;
+}
+int require_init() {
+    if (g_devices.empty()) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
+    return bind_device(g_devices[0]);
+}
+// calls that work on an index run on the device that holds it
+static int bind_index(const Index* ix) {
+    if (g_devices.empty()) return fail(TXQ_ERR_STATE, "txq_init has not been called (or found no GPU); this library has no CPU fallback");
+    return bind_device(ix ? ix->device : g_devices[0]);
 }
 
 #define TXQ_HIP(call)                                        \
@@ -167,27 +175,31 @@ int txq_device_count(void) {
 }
 
 int txq_init(int n_devices, const int* device_ids) {
-    if (n_devices != 1) return fail(TXQ_ERR_ARG, "one process drives one GPU: n_devices must be 1 (got %d)", n_devices);
+    if (n_devices < 1 || n_devices > 64) return fail(TXQ_ERR_ARG, "n_devices must be 1..64 (got %d)", n_devices);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
-        g_device = -1;
+        g_devices.clear();
         return fail(TXQ_ERR_STATE, "no HIP device visible (%s); this library has no CPU fallback",
                     e == hipSuccess ? "device count 0" : hipGetErrorString(e));
     }
-    int dev = device_ids ? device_ids[0] : 0;
-    if (dev < 0 || dev >= n) return fail(TXQ_ERR_ARG, "device %d out of range (have %d)", dev, n);
-    TXQ_HIP(hipSetDevice(dev));
-    hipDeviceProp_t prop;
-    TXQ_HIP(hipGetDeviceProperties(&prop, dev));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-        return fail(TXQ_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
-    g_device = dev;
+    std::vector<int> devices;
+    for (int i = 0; i < n_devices; ++i) {
+        const int dev = device_ids ? device_ids[i] : i;
+        if (dev < 0 || dev >= n) return fail(TXQ_ERR_ARG, "device %d out of range (have %d)", dev, n);
+        hipDeviceProp_t prop;
+        TXQ_HIP(hipGetDeviceProperties(&prop, dev));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(TXQ_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+        devices.push_back(dev);
+    }
+    TXQ_HIP(hipSetDevice(devices[0]));
+    g_devices = devices;
     return TXQ_OK;
 }
 
 int txq_shutdown(void) {
-    g_device = -1;
+    g_devices.clear();
     return TXQ_OK;
 }
 
@@ -204,7 +216,8 @@ int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, t
 
     txq_index* ix = new (std::nothrow) txq_index();
     if (!ix) return fail(TXQ_ERR_NOMEM, "out of host memory");
-    ix->device = g_device;
+    ix->device = g_devices[(size_t)shard_rank % g_devices.size()];  // shards go round-robin over the devices of txq_init
+    if (int rc = bind_device(ix->device)) { delete ix; return rc; }
     ix->is_hibf = hibf;
     ix->user_bins = desc->user_bins;
     ix->mask_words = (desc->user_bins + 63) / 64;
@@ -244,7 +257,8 @@ int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, i
     if (int rc = validate_ibf(d, false)) return rc;
     txq_index* ix = new (std::nothrow) txq_index();
     if (!ix) return fail(TXQ_ERR_NOMEM, "out of host memory");
-    ix->device = g_device;
+    ix->device = g_devices[(size_t)shard_rank % g_devices.size()];
+    if (int rc = bind_device(ix->device)) { delete ix; return rc; }
     ix->user_bins = bins;
     ix->mask_words = d.bin_words;
     uint64_t lo, hi;
@@ -282,14 +296,15 @@ int txq_index_free(txq_index* ix) {
     if (!ix) return TXQ_OK;
     if (ix->open_sessions > 0)
         return fail(TXQ_ERR_STATE, "the index still has %d open session(s): end them first (txq_session_end)", ix->open_sessions);
-    if (g_device >= 0) (void)require_init();
+    if (!g_devices.empty()) (void)bind_device(ix->device);
     ix->release();
     delete ix;
     return TXQ_OK;
 }
 
 int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_words) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || !words) return fail(TXQ_ERR_ARG, "null argument");
     if (ix->is_hibf) return fail(TXQ_ERR_ARG, "download_words is for flat IBFs");
     const IbfDev& f = ix->ibf[0];
@@ -301,7 +316,8 @@ int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_word
 }
 
 int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, void* stream) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || (n && (!d_kmers || !d_masks))) return fail(TXQ_ERR_ARG, "null argument");
     if (n >> 32) return fail(TXQ_ERR_ARG, "at most 2^32-1 k-mers per call");
     hipStream_t s = (hipStream_t)stream;
@@ -315,7 +331,8 @@ int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t*
 // (device -> pinned bounce buffer -> caller's memory, or straight into the caller's memory when
 // that is pinned, e.g. from txq_host_alloc), chunk c+1 is probed.
 int txq_probe(txq_index* ix, const uint64_t* kmers, size_t n, uint64_t* masks) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || (n && (!kmers || !masks))) return fail(TXQ_ERR_ARG, "null argument");
     const size_t W = ix->shard_words;
     if (W == 0 || n == 0) return TXQ_OK;
@@ -385,7 +402,8 @@ int txq_host_free(void* ptr) {
 }
 
 int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* d_bins_of, size_t n, void* stream) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || (n && (!d_values || !d_bins_of))) return fail(TXQ_ERR_ARG, "null argument");
     if (ix->is_hibf) return fail(TXQ_ERR_ARG, "emplace is for flat IBFs");
     hipError_t e = launch_emplace(ix->ibf[0], d_values, d_bins_of, n, (hipStream_t)stream);
@@ -394,13 +412,15 @@ int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* 
 }
 
 int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final_masks, void* stream) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || !blob || (n_programs && !d_final_masks)) return fail(TXQ_ERR_ARG, "null argument");
     return run_programs(*ix, blob, blob_bytes, n_programs, d_final_masks, (hipStream_t)stream);
 }
 
 int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* final_masks) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || !blob || (n_programs && !final_masks)) return fail(TXQ_ERR_ARG, "null argument");
     const size_t bytes = n_programs * ix->shard_words * 8;
     if (bytes == 0) return TXQ_OK;
@@ -411,7 +431,8 @@ int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t 
 }
 
 int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out) {
-    if (int rc = require_init()) return rc;
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
     if (!ix || !out) return fail(TXQ_ERR_ARG, "null argument");
     Session* s = nullptr;
     if (int rc = session_begin(*ix, n_programs, &s)) return rc;
@@ -423,8 +444,9 @@ int txq_session_set_aux_index(txq_session* s, txq_index* aux) {
     if (!s) return fail(TXQ_ERR_ARG, "null argument");
     if (aux) {
         if (aux->is_hibf) return fail(TXQ_ERR_ARG, "the auxiliary index must be a flat IBF");
-        if (aux->user_bins != s->ix->user_bins || aux->shard_word0 != s->ix->shard_word0 || aux->shard_words != s->ix->shard_words)
-            return fail(TXQ_ERR_ARG, "the auxiliary index must cover the same bins and the same shard as the main index");
+        if (aux->user_bins != s->ix->user_bins || aux->shard_word0 != s->ix->shard_word0 || aux->shard_words != s->ix->shard_words ||
+            aux->device != s->ix->device)
+            return fail(TXQ_ERR_ARG, "the auxiliary index must cover the same bins and the same shard (on the same device) as the main index");
     }
     if (s->aux) --s->aux->open_sessions;
     s->aux = aux;
@@ -434,14 +456,15 @@ int txq_session_set_aux_index(txq_session* s, txq_index* aux) {
 
 int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const uint32_t* query_program,
                       const uint32_t* query_slot, size_t n_queries, uint8_t* alive) {
-    if (int rc = require_init()) return rc;
-    if (!s || !blob || (n_queries && (!query_program || !query_slot || !alive))) return fail(TXQ_ERR_ARG, "null argument");
+    if (!s) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(s->ix)) return rc;
+    if ( !blob || (n_queries && (!query_program || !query_slot || !alive))) return fail(TXQ_ERR_ARG, "null argument");
     return session_stage(*s, blob, blob_bytes, query_program, query_slot, n_queries, alive, nullptr);
 }
 
 int txq_session_end(txq_session* s, uint64_t* final_masks) {
     if (!s) return TXQ_OK;
-    int rc = require_init();  // the calling thread may never have selected the device
+    int rc = bind_index(s->ix);  // the calling thread may never have selected the device
     if (rc != TXQ_OK) { delete static_cast<Session*>(s); return rc; }
     if (final_masks && s->n_programs && s->W) {
         Index& ix = *s->ix;

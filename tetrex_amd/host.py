@@ -165,6 +165,22 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
     return list(status), dict(zip(keys, (int(x) for x in stats)))
 
 
+def join_shard_masks(mask_words, shard_word0, shard_masks):
+    """host/compiler.hpp join_shard_masks: shard r = array [n, words_r] holding words [shard_word0[r], +words_r) of every mask."""
+    L = lib()
+    L.txh_join_shard_masks.argtypes = [C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, C.POINTER(u64p), u64p]
+    R = len(shard_masks)
+    parts = [np.ascontiguousarray(m, dtype=np.uint64) for m in shard_masks]
+    n = parts[0].shape[0] if R else 0
+    w0 = np.array(shard_word0, dtype=np.uint64)
+    ws = np.array([p.shape[1] for p in parts], dtype=np.uint64)
+    ptrs = (u64p * R)(*[p.ctypes.data_as(u64p) for p in parts])
+    out = np.zeros((n, mask_words), dtype=np.uint64)
+    if L.txh_join_shard_masks(n, mask_words, R, w0.ctypes.data_as(u64p), ws.ctypes.data_as(u64p), ptrs, out.ctypes.data_as(u64p)) != 0:
+        raise _err()
+    return out
+
+
 def record_values(seq, k, dna=True, reduction=0, wraparound=False):
     s = seq.encode() if isinstance(seq, str) else seq
     cap = len(s) + 2
