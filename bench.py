@@ -8,10 +8,16 @@ Workload (config.workload = "S-IBF-1024", BASELINE configs[1] shape, SURVEY.md Â
   1024 bins per GPU, h = 3, m = compute_bitcount(200000, 0.05f) = 1,247,045 rows (159.6 MB),
   filled by inserting 200,000 uniform 20-bit values (k = 4 x 5 bits/residue) per bin with the
   real hash; probe batch = 2^24 uniform 20-bit k-mers (splitmix64, fixed seeds).
-Multi-GPU (--gpus N, launched by torch.distributed.run): the index has 1024*N bins and is
-sharded by bin-word columns, 1024 bins per rank (BASELINE configs[3] layout); every rank probes
-the same batch against its own column shard; no collective on the probe path (bins are
-independent), so scaling is "weak".  A probe is one k-mer tested against one 1024-bin shard.
+Multi-GPU (--gpus N, launched by torch.distributed.run), two modes:
+  --scaling weak (default): the index has 1024*N bins and is sharded by bin-word columns, 1024 bins per rank
+      (BASELINE configs[3] layout at N = 8); every rank probes the same batch against its own column shard; no
+      collective on the probe path (bins are independent).  value = N * k-mers / time in SHARD-probes/s (one k-mer
+      against one 1024-bin shard); at N = 1 a shard-probe is a probe of the whole index (SURVEY.md Â§8d).
+  --scaling strong: the FIXED 8192-bin x 62.5 M-row index (S-IBF-8192, 64 GB) cut into N column shards; value =
+      k-mers / time = probes of the whole index per second; bytes_per_probe is the per-GPU share (4104 B at N = 1,
+      520 B at N = 8).
+The default line also carries `roofline_hbm`: the same probe kernel on an 8 GB matrix (the 8192-bin config's
+per-GPU shard), which does not fit the 256 MB Infinity Cache that the 160 MB S-IBF-1024 matrix lives in.
 
 Output: ONE JSON line on rank 0 (contract in the task description), including
   roofline     â€” algorithmic bytes of the probe kernel / its HIP-event duration vs 8 TB/s HBM,
@@ -81,23 +87,93 @@ def build_index(capi, torch, bins_total, bins_local, m, h, rank, world, per_bin,
     return ix
 
 
-def pmc_traffic(args, n, W, h, m):
+def pmc_traffic(tag, n, W, h):
     """HBM bytes per probe-kernel launch from the committed rocprofv3 PMC passes
-    (profiles/r*_pmc_traffic_*.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction).
-    PMC counters cannot be collected from inside this process, so the figure is only reported for
-    the exact workload those passes ran; otherwise null."""
-    if not (args.rows == 0 and n == (1 << 24) and W == 16 and h == 3 and args.per_bin == 200000):
-        return None
+    (profiles/r*_pmc_traffic_<tag>.json: 2 x FETCH_SIZE + WRITE_SIZE, KiB -> bytes, gfx950 correction).
+    PMC counters cannot be collected from inside this process: the figure comes from SEPARATE passes of this
+    very command (tools/pmc_traffic.sh), is only reported for the exact workload those passes ran, and is
+    labelled with the file it was read from.  Returns (bytes or None, source or None)."""
+    if not (n == (1 << 24) and W == 16 and h == 3):
+        return None, None
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_S-IBF-1024.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_%s.json" % tag)))
     if not files:
-        return None
+        return None, None
     with open(files[-1]) as f:
         kernels = json.load(f)["kernels"]
     for name, k in kernels.items():
         if name.startswith("void txq::probe_kernel<8, 3") and "hbm_traffic_bytes_per_launch_corrected" in k:
-            return k["hbm_traffic_bytes_per_launch_corrected"]
-    return None
+            return k["hbm_traffic_bytes_per_launch_corrected"], "profiles/" + os.path.basename(files[-1]) + " (separate rocprofv3 --pmc passes, not measured in this run)"
+    return None, None
+
+
+def timed_probe_steps(torch, dist, ix, d_kmers, n, d_masks, stream, steps, warmup, world, coll_device):
+    """W untimed + K timed launches of the probe path, barrier + synchronize on both sides, max over ranks.
+    Returns (elapsed seconds, mean kernel seconds by HIP events on the launch stream)."""
+    def step():
+        ix.probe_device(d_kmers.data_ptr(), n, d_masks.data_ptr(), None, stream.cuda_stream)
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record(stream)
+        step()
+        b.record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, float(np.mean([a.elapsed_time(b) for a, b in evs])) / 1e3
+
+
+def hbm_leg(capi, torch, args, h):
+    """The out-of-cache leg of the default line: the SAME probe kernel on the 8192-bin config's per-GPU shard â€” 1024
+    bins x 62.5 M rows = 8 GB, 30x the Infinity Cache â€” with uniform 40-bit k-mers, so every row gather goes to HBM.
+    Rank-local, after the timed region; does not touch `value`."""
+    rows, bits, per_bin = 62500000, 40, 20000
+    ix = build_index(capi, torch, 1024, 1024, rows, h, 0, 1, per_bin, bits)
+    W = ix.shard_words
+    n = args.kmers
+    kmers = splitmix64(12, n) >> np.uint64(64 - bits)
+    d_kmers = torch.from_numpy(kmers.view(np.int64)).cuda()
+    d_masks = torch.empty((n, W), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream()
+    steps = max(5, min(args.steps, 20))
+    elapsed, kernel_s = timed_probe_steps(torch, None, ix, d_kmers, n, d_masks, stream, steps, 2, 1, "cuda")
+    # parity: a slice of the timed output against single probes of the same device matrix (no oracle copy of 8 GB)
+    present = build_probe_check(ix, d_masks, kmers, torch)
+    bytes_per_probe = h * W * 8 + W * 8 + 8
+    achieved = bytes_per_probe * n / kernel_s / 1e9
+    traffic, source = pmc_traffic("S-IBF-1024-rows62500000", n, W, h)
+    out = {"bound": "hbm", "kernel": "txq::probe_kernel<8,3,2,false>", "workload": "S-IBF-1024-rows62500000 (8 GB, the 8192-bin index's per-GPU shard)",
+           "matrix_bytes": int(ix.info.device_bytes), "kmer_bits": bits, "kmers_per_step": n, "steps": steps,
+           "probes_per_s": n * steps / elapsed, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+           "bytes_per_probe": bytes_per_probe, "avg_kernel_ms": kernel_s * 1e3, "traffic": traffic, "self_check_rows": present}
+    if source:
+        out["traffic_source"] = source
+    ix.free()
+    return out
+
+
+def build_probe_check(ix, d_masks, kmers, torch):
+    """Size-independent property on the big matrix: the batch kernel's masks equal those of the same k-mers probed
+    one small batch at a time through the host-buffer entry point (different launch geometry, same matrix)."""
+    sample = np.concatenate([kmers[:257], kmers[-129:]])
+    want = ix.probe(sample)
+    got = torch.cat([d_masks[:257], d_masks[-129:]]).cpu().numpy().view(np.uint64)
+    if not np.array_equal(got, want):
+        raise SystemExit("bench: batch probe and single probes disagree on the out-of-cache matrix")
+    return int(sample.size)
 
 
 def cpu_baseline(ix, m, h, bins_local, kmers, sample, threads):
@@ -207,6 +283,8 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
         **({"cpu_baseline": cpu} if cpu else {}),
         "metric": "end-to-end queries/sec (regex -> candidate-bin mask, verification excluded)",
         "batch_queries_per_s": len(motifs) / total,
+        **({"collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                           "op": "all_gather of the final masks (%d x %d words per rank)" % (len(motifs), int(ix.shard_words))}} if world > 1 else {}),
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
                   "k": k, **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
         "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
@@ -316,6 +394,10 @@ def main():
     ap.add_argument("--hibf-per-bin", type=int, default=300)
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
     ap.add_argument("--kmer-bits", type=int, default=20)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: 1024 bins per GPU (index of 1024*N bins), value in shard-probes/s; strong: the fixed 8192-bin x 62.5 M-row "
+                         "index cut into N column shards, value in whole-index probes/s")
+    ap.add_argument("--no-hbm-leg", action="store_true", help="skip the out-of-cache roofline_hbm leg (8 GB matrix)")
     ap.add_argument("--rehearse-single-device", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host "
                          "tensors (RCCL refuses two ranks on one device); numbers from such a run are not bench results")
@@ -347,8 +429,23 @@ def main():
 
     capi.init(local_rank)
     h = args.hash
-    bins_local = args.bins_per_gpu
-    bins_total = bins_local * world
+    strong = args.scaling == "strong"
+    if strong:  # S-IBF-8192 (SURVEY.md Â§8d): fixed index, N column shards
+        bins_total = 8192
+        if bins_total % (64 * world):
+            raise SystemExit("--scaling strong needs a GPU count that divides 128 mask words")
+        bins_local = bins_total // world
+        if args.rows == 0:
+            args.rows = 62500000
+        if args.kmer_bits == 20:
+            args.kmer_bits = 40
+        if args.per_bin == 200000:
+            args.per_bin = 20000
+        if args.kmers == (1 << 24) and world < 8:
+            args.kmers = 1 << 22 if world == 1 else 1 << 23  # the mask batch is kmers x (1024 / N) bytes
+    else:
+        bins_local = args.bins_per_gpu
+        bins_total = bins_local * world
     m = args.rows if args.rows > 0 else compute_bitcount(args.per_bin, 0.05)
     value_bits = args.kmer_bits
 
@@ -363,62 +460,43 @@ def main():
     d_kmers = torch.from_numpy(kmers_host.view(np.int64)).cuda()
     d_masks = torch.empty((n, W), dtype=torch.int64, device="cuda")
     stream = torch.cuda.current_stream()
+    elapsed, avg_kernel_s = timed_probe_steps(torch, dist, ix, d_kmers, n, d_masks, stream, args.steps, args.warmup, world, args.coll_device)
 
-    def step():
-        ix.probe_device(d_kmers.data_ptr(), n, d_masks.data_ptr(), None, stream.cuda_stream)
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for a, b in evs:
-        a.record(stream)
-        step()
-        b.record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=args.coll_device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    kernel_ms = [a.elapsed_time(b) for a, b in evs]
-    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
-
-    bytes_per_probe = h * W * 8 + W * 8 + 8  # SURVEY.md Â§8(d): rows + mask write + k-mer read
+    bytes_per_probe = h * W * 8 + W * 8 + 8  # SURVEY.md Â§8(d): rows + mask write + k-mer read (per GPU: its share of the index)
     achieved = bytes_per_probe * n / avg_kernel_s / 1e9
-    value = world * n * args.steps / elapsed
+    # strong: a probe is one k-mer against the WHOLE index, answered by all ranks together; weak: one k-mer against one shard
+    value = n * args.steps / elapsed if strong else world * n * args.steps / elapsed
+    cache_resident = int(ix.info.device_bytes) < (200 << 20)
+    traffic, traffic_source = pmc_traffic("S-IBF-1024", n, W, h) if (not strong and args.rows == 0 and args.per_bin == 200000) else (None, None)
 
     out = {
         "metric": "k-mer IBF probes/sec",
         "value": value,
-        "unit": "probes/s",
+        "unit": "probes/s" if (strong or world == 1) else "shard-probes/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "u64",
         "data": "synthetic" if not args.rehearse_single_device else "synthetic (REHEARSAL: all ranks on one device, gloo collectives; not a bench result)",
         "config": {
-            "workload": workload_name(bins_local, m, args),
+            "workload": "S-IBF-8192" if strong else workload_name(bins_local, m, args),
             "bins_per_gpu": bins_local, "bins_total": bins_total, "hash_funs": h, "bin_size_rows": m,
             "kmers_per_step": n, "kmer_bits": value_bits, "values_per_bin": args.per_bin,
             "matrix_bytes_per_gpu": int(ix.info.device_bytes), "mask_words": W,
             "parallelism": "bin-column shards x%d, no collective on the probe path" % world,
-            "probe_unit": "one k-mer against one %d-bin shard" % bins_local,
+            "probe_unit": ("one k-mer against all %d bins (answered by %d shard(s) together)" % (bins_total, world)) if (strong or world == 1)
+                          else "one k-mer against one %d-bin shard (a whole-index probe is %d of them)" % (bins_local, world),
+            "whole_index_probes_per_s": n * args.steps / elapsed,
             "index_build_s": round(t_build, 2),
         },
         "roofline": {
             "bound": "hbm",
+            "resident": ("infinity-cache: the %.0f MB matrix fits the 256 MB MALL, so this is a cache gather rate â€” see roofline_hbm for the "
+                         "out-of-cache figure" % (int(ix.info.device_bytes) / 1e6)) if cache_resident else "hbm (matrix far larger than the 256 MB Infinity Cache)",
             "kernel": "txq::probe_kernel<8,3,2,false>" if (W == 16 and h == 3) else "txq::probe_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
@@ -426,11 +504,15 @@ def main():
             "frac": achieved / HBM_PEAK_GBS,
             "bytes_per_probe": bytes_per_probe,
             "avg_kernel_ms": avg_kernel_s * 1e3,
-            "traffic": pmc_traffic(args, n, W, h, m),
+            "traffic": traffic,
+            **({"traffic_source": traffic_source} if traffic_source else {}),
         },
     }
+    if world > 1:
+        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                             "note": "no collective on the probe path; the end-to-end leg all-gathers the final masks"}
 
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu and not strong and m < (1 << 24):
         sample = min(args.cpu_sample, n)
         cpu_masks, cpu_rate, cpu_dt = cpu_baseline(ix, m, h, bins_local, kmers_host, sample, threads=1)
         # the timed GPU output doubles as a parity check on the CPU sample
@@ -449,12 +531,19 @@ def main():
                                              "sample": "same sample, %d threads, %.1f s" % (ncores, mt_dt)}
         out["parity_checked_probes"] = int(sample)
 
-    if not args.no_queries:
+    if not args.no_queries and not strong:
         args.m_rows = m
         out["end_to_end"] = end_to_end_queries(ix, torch, dist, world, rank, args)
 
     ix.free()
-    if not args.no_hibf:
+    if not args.no_hbm_leg and not strong and cache_resident:
+        try:
+            leg = hbm_leg(capi, torch, args, h)
+            if rank == 0:
+                out["roofline_hbm"] = leg
+        except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
+            out["roofline_hbm"] = {"error": repr(e)}
+    if not args.no_hibf and not strong:
         try:
             out["hibf"] = hibf_descent(capi, torch, args, rank, world)
             # the Swissprot-HIBF shape (BASELINE configs[2]): 1024 user bins, 16 children of 64 bins

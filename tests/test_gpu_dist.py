@@ -92,10 +92,35 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
                 "dtype", "data", "config", "roofline"):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["scaling"] == "weak" and out["config"]["bins_total"] == 2048
+    # weak mode counts probes of ONE 1024-bin shard; the whole-index rate is spelled out beside it
+    assert out["unit"] == "shard-probes/s" and abs(out["value"] - 2 * out["config"]["whole_index_probes_per_s"]) < 1e-6 * out["value"]
+    assert out["collective"]["ranks"] == 2 and out["collective"]["backend"] == "gloo"
     assert "error" not in out["end_to_end"], out["end_to_end"]
-    assert out["end_to_end"]["batch"]["failed"] == 0
+    assert out["end_to_end"]["batch"]["failed"] == 0 and out["end_to_end"]["collective"]["ranks"] == 2
+    assert out["end_to_end"]["batch"]["gather_seconds"] > 0
     assert "error" not in out["hibf"], out["hibf"]
     assert out["hibf"]["column_shards"] == 2 and out["hibf"]["mask_bytes_per_kmer"] == 4096
+
+
+def test_bench_strong_scaling_rehearsal():
+    """--scaling strong: the fixed 8192-bin index cut into N column shards (here N = 2 on one GPU, with fewer rows than
+    the real 62.5 M so that the rehearsal builds in seconds): value counts probes of the WHOLE index, bytes_per_probe is
+    the per-GPU share."""
+    import json
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--scaling", "strong", "--rows", "2000003", "--per-bin", "500", "--kmers", str(1 << 18), "--rehearse-single-device"]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "strong" and out["unit"] == "probes/s" and out["n_gpus"] == 2
+    cfg = out["config"]
+    assert cfg["bins_total"] == 8192 and cfg["bins_per_gpu"] == 4096 and cfg["mask_words"] == 64 and cfg["workload"] == "S-IBF-8192"
+    assert out["roofline"]["bytes_per_probe"] == 3 * 64 * 8 + 64 * 8 + 8
+    assert abs(out["value"] - cfg["whole_index_probes_per_s"]) < 1e-6 * out["value"]
+    assert "end_to_end" not in out and "hibf" not in out
 
 
 def test_bench_single_gpu_contract_line_with_all_legs():
@@ -114,6 +139,10 @@ def test_bench_single_gpu_contract_line_with_all_legs():
     assert out["higher_is_better"] is True and out["dtype"] == "u64" and out["config"]["workload"].startswith("S-IBF-1024")
     roof = out["roofline"]
     assert roof["bound"] == "hbm" and roof["peak"] == 8000.0 and roof["frac"] > 0 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
+    assert roof["resident"].startswith("infinity-cache") and ("traffic_source" in roof) == (roof["traffic"] is not None)
+    hbm = out["roofline_hbm"]  # the out-of-cache leg: same kernel, 8 GB matrix
+    assert "error" not in hbm and hbm["matrix_bytes"] >= 8_000_000_000 and hbm["bytes_per_probe"] == 520 and 0 < hbm["frac"] < 1
+    assert hbm["self_check_rows"] > 0 and abs(hbm["frac"] - hbm["achieved"] / hbm["peak"]) < 1e-9
     cpu = out["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and out["parity_checked_probes"] == 1 << 18
     e2e = out["end_to_end"]
