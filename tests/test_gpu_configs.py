@@ -23,23 +23,50 @@ def _popcount(m):
 
 
 def test_config3_1024_bin_hibf_with_a_batch_of_1k_motifs(capi, oracle):
-    """configs[2]: 1024-bin HIBF (k=4 peptides), 1k PROSITE-style motifs in one streamed batch."""
+    """configs[2]: 1024-bin HIBF (k=4 peptides), 1k PROSITE-style motifs in one streamed batch.  Every bin holds the
+    4-mers of its own random sequence and every motif is a window of some bin's sequence with residue classes, wildcards
+    and x(m,n) gaps worked in (the bench batch's mix), so a motif has a home bin it must be found in and most masks are
+    neither empty nor full — a descent that returned zeros, or ones, would fail here."""
+    from tetrex_amd import host
     rng = np.random.default_rng(3)
-    ox, descs, values = regular_hibf(oracle, 1024, 64, 1500, lambda b: rng.integers(0, 1 << 20, size=1500, dtype=np.uint64), h=3)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    seqs = [aa[rng.integers(0, 20, size=1503)].tobytes() for _ in range(1024)]
+    ox, descs, values = regular_hibf(oracle, 1024, 64, 1500, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=3)
     ix = capi.Index.upload_hibf(1024, descs)
     assert ix.info.n_ibf == 65 and ix.info.is_hibf
-    motifs = random_prosite_motifs(1000, 12, wildcard=0.03, classes=0.3, ranges=0.0, min_len=5, max_len=9)
+    motifs, home = [], []
+    for _ in range(1000):
+        b = int(rng.integers(0, 1024))
+        n = int(rng.integers(6, 13))
+        at = int(rng.integers(0, 1503 - n))
+        w = [chr(c) for c in seqs[b][at:at + n]]
+        for p in range(1, n - 1):  # both ends stay literal so that trimming does not eat the motif
+            r = rng.random()
+            if r < 0.10:
+                w[p] = "."
+            elif r < 0.40:
+                others = rng.choice([c for c in "ACDEFGHIKLMNPQRSTVWY" if c != w[p]], size=int(rng.integers(1, 5)), replace=False)
+                w[p] = "[" + "".join(sorted(set([w[p]]) | set(others))) + "]"
+            elif r < 0.45:
+                lo = int(rng.integers(0, 2))
+                w[p] = ".{%d,%d}" % (lo, lo + int(rng.integers(1, 3)))  # the one residue that was here fits the gap
+        motifs.append("".join(w))
+        home.append(b)
     got, status, stats = ix.query_masks(motifs, False, 4)
     assert not any(status)
-    checked = informative = 0
+    checked = informative = skipped = 0
     for i, rx in enumerate(motifs):
+        assert (int(got[i, home[i] >> 6]) >> (home[i] & 63)) & 1, rx  # no false negatives: the home bin is a candidate
         want, ost = ox.query(rx, with_stats=True)
         if ost["quirk_merges"]:
+            skipped += 1
             continue
         assert np.array_equal(got[i], want), rx
         checked += 1
         informative += 0 < _popcount(want) < 1024
-    assert checked > 950 and informative > 20
+    assert skipped < 100, skipped          # the reference's result is well defined for > 90 % of the batch
+    assert checked > 900 and informative > 850, (checked, informative)
+    assert sum("." in m for m in motifs) > 300
     ix.free()
 
 
