@@ -66,9 +66,14 @@ def test_translate_and_kgraph_agree_with_the_oracle(host, oracle, rx):
         assert got["labels"] == want["labels"] and got["succ"] == [tuple(s) for s in want["succ"]]
 
 
-def _check_masks(host, oracle, ox, rx, dna, k, budget):
+DENSE = [dict(), dict(min_states=2, sparse_below=3), dict(min_states=1, sparse_below=1)]  # the product's defaults, and nearly / really everything dense
+
+
+def _check_masks(host, oracle, ox, rx, dna, k, budget, dense=0):
+    """Dense DP steps are on, as in the product on a flat IBF: a generated regex such as ((.*)*)* saturates every list of
+    its (large) k-graph, which enumerated state by state is millions of ops — nothing a Python test double can run."""
     sim = SessionSimulator(ox, 1)
-    status, _ = host.run_staged([rx], dna, k, 0, ox.bins, sim.stage, budget)
+    status, _ = host.run_staged([rx], dna, k, 0, ox.bins, sim.stage, budget, dense=DENSE[dense])
     try:
         want, st_ = ox.query(rx, with_stats=True)
     except oracle.OracleError:
@@ -80,12 +85,12 @@ def _check_masks(host, oracle, ox, rx, dna, k, budget):
 
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(rx=regex_strategy(AA, max_leaves=6), budget=st.sampled_from([0, 1, 5]))
-def test_peptide_masks_equal_the_oracle(host, oracle, indexes, rx, budget):
-    _check_masks(host, oracle, indexes["pep"], rx, False, 4, budget)
+@given(rx=regex_strategy(AA, max_leaves=6), budget=st.sampled_from([0, 1, 5]), dense=st.sampled_from([0, 0, 1, 2]))
+def test_peptide_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense):
+    _check_masks(host, oracle, indexes["pep"], rx, False, 4, budget, dense)
 
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(rx=regex_strategy("ACGT", max_leaves=8), budget=st.sampled_from([0, 2]))
-def test_dna_masks_equal_the_oracle(host, oracle, indexes, rx, budget):
-    _check_masks(host, oracle, indexes["dna"], rx, True, 3, budget)
+@given(rx=regex_strategy("ACGT", max_leaves=8), budget=st.sampled_from([0, 2]), dense=st.sampled_from([0, 1, 2]))
+def test_dna_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense):
+    _check_masks(host, oracle, indexes["dna"], rx, True, 3, budget, dense)

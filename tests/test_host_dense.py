@@ -117,3 +117,15 @@ def test_dense_cuts_the_host_work_of_a_saturated_motif(host, oracle):
     _, dense, sim = _run(host, ox, qs, False, 4, dict())
     assert plain["ops"] > 200000 and dense["ops"] < plain["ops"] / 50
     assert int(sim.result(0)[0]) == 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("dense", [dict(), dict(min_states=1, sparse_below=1)], ids=["defaults", "everything"])
+def test_nested_stars_that_enumerated_state_by_state_would_exceed_any_op_budget(host, oracle, dense):
+    """((.*)*)* and friends (the first was found by the fuzz test): every list of a large k-graph is saturated — millions
+    of states for the oracle.  As dense blocks the queries need a few thousand ops; the product used to give up on them
+    at 8 M ops.  The starred ones make the reference merge states of different length (quirk merges: its result is
+    implementation-defined there), so parity is asserted on the '+' forms and completion on all."""
+    ox = _index(oracle, bins=96, m=2053, h=3, k=4, dna=False, per_bin=700, seed=11)
+    qs = ["LMK(.+)+HKD", "LMK(.+)+(.+)+HKD", "LMK((.+)+)+KDE", "LMK(.+)+D(.+)+HK", "((.*)*)*", "LMK((.*)*)*KDE", "(.+)+LMK(.*)*"]
+    checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+    assert checked >= 4 and stats["ops"] < 5_000_000

@@ -240,6 +240,7 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
     if (ns.items.capacity() == 0) adopt_storage(ns);
+    if (waiting_ >= limits_.max_live_states) throw std::runtime_error("query holds too many states at the same time");
     if (single_source_[to] || ns.append_only) {  // nothing to merge with, or merging does not pay: no table look-up
         s.asked = 0;
         ns.items.push_back(s);
@@ -597,6 +598,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     if (single_source_[fan_[i]]) input_of_[fan_[i]] = item;
                 readers_[item - n_nodes_ - 1] = readers;
                 waiting_ += (uint64_t)ns.items.size() * readers;
+                if (waiting_ > limits_.max_live_states) throw std::runtime_error("query holds too many states at the same time");
                 table_[item].items.swap(ns.items);  // stays until the last reader is done
                 open_joins_.push_back(item);
             }

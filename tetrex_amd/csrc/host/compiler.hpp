@@ -34,9 +34,15 @@
 
 namespace tetrex {
 
+// What one query may cost.  Staged execution streams a query's ops to the device stage by stage (slots are recycled),
+// so only what the host holds AT ONE TIME needs a bound: the states waiting in the tables (24 bytes each).  A query
+// beyond it fails with a message; the reference would (slowly) answer, so the bound is generous.  One-shot
+// compilation (ProgramBatch: the whole program in one blob) bounds the totals instead.
 struct CompileLimits {
-    size_t max_ops = 8u << 20;     // per query
-    size_t max_states = 8u << 20;  // per query
+    size_t max_ops = SIZE_MAX;                   // cumulative, per query
+    size_t max_states = SIZE_MAX;                // cumulative, per query
+    size_t max_live_states = (size_t)96 << 20;   // waiting at the same time, per query (~2.3 GB)
+    static CompileLimits one_shot() { return CompileLimits{(size_t)8 << 20, (size_t)8 << 20, (size_t)8 << 20}; }
 };
 
 // -a / -g of `tetrex query` (reference include/arg_parse.h:64,68): bypass catastrophic sub-graphs
@@ -312,7 +318,7 @@ std::vector<uint64_t> join_shard_masks(size_t n, uint64_t mask_words, const std:
 // A batch of queries sharing one k-mer table; serialises to the blob txq_run_programs takes.
 class ProgramBatch {
   public:
-    explicit ProgramBatch(const KmerEncoder& enc, CompileLimits limits = {}) : enc_(enc), limits_(limits) {}
+    explicit ProgramBatch(const KmerEncoder& enc, CompileLimits limits = CompileLimits::one_shot()) : enc_(enc), limits_(limits) {}
 
     // Compile one k-graph; throws std::runtime_error when a limit is exceeded.
     size_t add(const KGraph& g);

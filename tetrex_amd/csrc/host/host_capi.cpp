@@ -139,6 +139,8 @@ int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k
         // an explicit per-query budget is taken literally (no adaptive growth, no waiting for verified states)
         if (ops_per_query_per_stage) { opt.ops_per_query_per_stage = ops_per_query_per_stage; opt.stage_target_ops = 0; opt.verified_levels = false; }
         if (ops_per_stage) opt.ops_per_stage = ops_per_stage;
+        // this entry point drives test doubles that run ops in an interpreter: keep a runaway query finite
+        opt.limits.max_ops = (size_t)64 << 20;
         if (gaps) opt.gaps = GapOptions{gaps->augment != 0, gaps->dgram_loaded != 0, gaps->min_gap, gaps->max_gap};
         if (dense && dense->enabled) {
             opt.dense.enabled = true;

@@ -283,7 +283,7 @@ class StagedRun {
         h.ops_offset = h3.dense_offset + (v3 ? stage_dense * sizeof(txq_dense_op) : 0);
         h.levels_offset = h.ops_offset + stage_ops * sizeof(txq_op);
         // a program has at most one level per op, and per op at worst one k-mer: the ceiling of the reservation
-        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 4, opt_.limits.max_ops);
+        const size_t most_ops = opt_.ops_per_stage + (size_t)threads_ * std::min<size_t>(run_on_budget_ << 4, std::min<size_t>(opt_.limits.max_ops, (size_t)64 << 20));
         uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
                                            sizeof(txq_blob_header_v3) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
         txq_dense_op* blob_dense = reinterpret_cast<txq_dense_op*>(blob + h3.dense_offset);
