@@ -149,3 +149,27 @@ def test_more_than_two_to_the_32_rows(capi, oracle):
     assert all((int(got[i, 0]) >> int(bins_of[i])) & 1 for i in range(vals.size))  # no false negatives
     assert int(np.count_nonzero(got[vals.size:])) == 0  # 12000 bits in 2^32 rows: a random probe finds nothing
     ix.free()
+
+
+def test_queries_beyond_eight_million_ops_keep_streaming(capi, monkeypatch):
+    """Round 1 gave up on a query after 8 M mask operations (CompileLimits), where the reference would — slowly — answer.
+    Now only the states held at one time are bounded and the ops stream to the device stage by stage.  Known-answer
+    index: every bit of bins 0..63 set, bins 64..127 empty, so no state ever dies in word 0 and the candidate mask of
+    any searchable motif is exactly word 0 = all ones, word 1 = 0.  Murphy alphabet, k = 6: a run of eight wildcards
+    keeps 10^5 suffix states alive and costs 2 M ops per position when the states are enumerated (TETREX_DENSE=0)."""
+    bins, m, k = 128, 257, 6
+    words = np.zeros((m, 2), dtype=np.uint64)
+    words[:, 0] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    ix = capi.Index.upload_ibf(bins, m, 3, words.reshape(-1))
+    motifs = ["LMKDEF........HKLMNP", "LMAEGLYN"]  # (the reduced-alphabet builder has no X{m,n} over a union: eight dots)
+    for dense in ("1", "0"):
+        monkeypatch.setenv("TETREX_DENSE", dense)
+        got, status, stats = ix.query_masks(motifs, False, k, reduction=1)
+        assert status == [0, 0], (dense, status)
+        for g in got:
+            assert int(g[0]) == 0xFFFFFFFFFFFFFFFF and int(g[1]) == 0
+        if dense == "0":
+            assert stats["ops"] > (8 << 20) and stats["stages"] > 1 and stats["dense_ops"] == 0
+        else:
+            assert stats["dense_ops"] > 0 and stats["ops"] < (1 << 20)
+    ix.free()

@@ -109,7 +109,7 @@ uint64_t dense_block_slots(const KmerEncoder& enc, const DenseOptions& opt) {
         n *= enc.alphabet_size();
         if (n > (1u << 22) || n * slot_bytes > opt.max_block_bytes) return 0;
     }
-    return n * opt.max_blocks < TXQ_DENSE_SLOT_BIT ? n : 0;
+    return n * 2 < TXQ_DENSE_SLOT_BIT ? n : 0;  // room for at least two blocks
 }
 
 QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps, DenseOptions dense)
@@ -121,6 +121,8 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     if (const uint64_t n = gaps_.dgram_loaded ? 0 : tetrex::dense_block_slots(enc_, dense_)) {
         dense_ok_ = true;
         dense_n_ = n;
+        const uint64_t room = (TXQ_DENSE_SLOT_BIT - 1) / n;  // blocks that fit the dense slot numbers
+        if (dense_.max_blocks > room) dense_.max_blocks = (uint32_t)room;
     }
     if (gaps_.augment) g_.augment();
     const int32_t n = n_nodes_ = g_.size();
@@ -398,14 +400,26 @@ QueryExpansion::DenseRef* QueryExpansion::owned_block(NodeStates& ns, OpVec& out
 void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
     if (!dense_ok_ || ns.items.size() < dense_.min_states) return;
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    const uint64_t sym = enc_.symbol_mask();
     size_t full = 0;
-    for (const State& s : ns.items) full += !s.gapped && s.shift >= k - 1;
+    uint32_t shape[TXQ_DENSE_MAX_POSITIONS] = {};
+    for (const State& s : ns.items) {
+        if (s.gapped || s.shift < k - 1) continue;
+        ++full;
+        for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
+    }
     if (full < dense_.min_states) return;
+    // A step visits every suffix of the shape (the product of the per-position code sets), alive or not, at roughly
+    // 0.1 ns per predecessor on the device, where an enumerated state costs the host ~150 ns per residue: the block
+    // pays while the shape is at most ~64 times the states it holds.  At k = 4 that is any list worth the question
+    // (21^3 suffixes); at k = 6 (21^5) only lists of tens of thousands of states.
+    uint64_t product = 1;
+    for (unsigned j = 0; j < dense_pos_; ++j) product *= (uint64_t)__builtin_popcount(shape[j]);
+    if (product > (uint64_t)dense_.max_shape_per_state * full) return;
     bool has_own = false;
     for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
     if (!has_own && !can_take_blocks(1)) return;
     DenseRef* own = owned_block(ns, out);
-    const uint64_t sym = enc_.symbol_mask();
     size_t kept = 0;
     for (size_t i = 0; i < ns.items.size(); ++i) {
         const State s = ns.items[i];
@@ -413,8 +427,8 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
         const uint32_t e = dense_slot(own->block, dense_index(s.kmer));
         emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
         drop(s.slot);
-        for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
     }
+    for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= shape[j];
     ns.items.resize(kept);
 }
 

@@ -65,9 +65,10 @@ struct DenseOptions {
     bool enabled = false;          // the executor runs dense ops (a flat-IBF device session)
     uint32_t min_states = 128;     // a list with at least this many full-length states becomes a block
     uint32_t sparse_below = 24;    // a block whose shape holds at most this many entries is enumerated again
+    uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state
     uint64_t slot_bytes = 0;       // bytes of one mask on the executing device (budgets; 0 = 128)
-    uint64_t max_block_bytes = 256ull << 20;
-    uint32_t max_blocks = 24;      // per query, live at the same time
+    uint64_t max_block_bytes = 1ull << 30;
+    uint32_t max_blocks = 256;     // per query, live at the same time (fewer where 256 blocks exceed the dense slot space); `pool` is the real bound
     std::atomic<int64_t>* pool = nullptr;  // bytes all queries of a run may still take (null: unlimited)
 };
 using DenseVec = std::vector<txq_dense_op>;
