@@ -9,8 +9,9 @@ HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.hpp) include/txq.h include/txq_program.h
 
 HOST_DIR  := $(CSRC)/host
-HOST_SRCS := $(HOST_DIR)/encoder.cpp $(HOST_DIR)/regex_front.cpp $(HOST_DIR)/kgraph.cpp $(HOST_DIR)/compiler.cpp $(HOST_DIR)/staged.cpp $(HOST_DIR)/index_file.cpp $(HOST_DIR)/host_capi.cpp
+HOST_SRCS := $(HOST_DIR)/encoder.cpp $(HOST_DIR)/regex_front.cpp $(HOST_DIR)/kgraph.cpp $(HOST_DIR)/compiler.cpp $(HOST_DIR)/staged.cpp $(HOST_DIR)/index_file.cpp $(HOST_DIR)/matcher.cpp $(HOST_DIR)/host_capi.cpp
 CLI_SRCS  := $(HOST_DIR)/main.cpp $(HOST_DIR)/device_index.cpp $(HOST_DIR)/verify.cpp $(HOST_DIR)/fasta.cpp
+# (the verification matcher, matcher.cpp, is part of the host library so that tests can reach it through txh_regex_find_all)
 HOST_HDRS := $(wildcard $(HOST_DIR)/*.hpp) include/txh.h include/txq_program.h
 HOSTFLAGS := -O2 -g -std=c++20 -fPIC -Wall -Wextra -pthread
 

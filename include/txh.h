@@ -97,6 +97,12 @@ const char* txe_last_error(void);
 /* dense DP ops (include/txq_program.h version 3) the calling thread's last txe_query_masks* run sent to the device */
 uint64_t txe_last_dense_ops(void);
 
+/* The verification matcher (host/matcher.hpp; stands where the reference has RE2, include/query.h:103,148): successive
+ * non-overlapping matches of `pattern` in text[0..len), the RE2::FindAndConsume loop of src/query.cpp:206-216.
+ * posix != 0: leftmost-longest (RE2::POSIX, peptides); 0: leftmost-first (RE2 default, DNA).  out receives (start, length)
+ * pairs; returns the number of matches (may exceed cap / 2 pairs; nothing written past cap), <0 on a syntax error. */
+int64_t txh_regex_find_all(const char* pattern, int posix, const char* text, size_t len, uint64_t* out, size_t cap);
+
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap);

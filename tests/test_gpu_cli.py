@@ -138,3 +138,27 @@ def test_stats_flag_prints_one_json_line(toy):
     st = json.loads(lines[0])
     assert st["queries"] == 1 and st["bins"] == 5 and st["stages"] >= 1 and st["ops"] > 0 and st["kmer_probes"] > 0
     assert st["mask_seconds"] >= st["execute_seconds"] >= 0
+
+
+def test_megabyte_records_with_quantifier_motifs(tmp_path):
+    """with a backtracking matcher a chromosome-length record and a `+` / {m,n} motif overflowed the stack or took
+    exponential time in the verification stage.  Two bins of one 1.5 MB DNA record each; motifs with + * {m,n}; both strands."""
+    rng = np.random.default_rng(21)
+    files = []
+    for b in range(2):
+        seq = "".join(rng.choice(list("ACGT"), size=1_500_000))
+        if b == 1:
+            seq = seq[:700000] + "GATTACCCCCCCCCCCCCCCCCCCCA" + seq[700026:]
+        p = tmp_path / ("chr%d.fa" % b)
+        p.write_text(">chr%d\n%s\n" % (b, seq))
+        files.append(str(p))
+    rc, so, se = run("index", "-n", "-i", "-k", "8", str(tmp_path / "big"), *files)
+    assert rc == 0, se
+    rc, so, se = run("query", "-v", str(tmp_path / "big.ibf"), "GATTAC{10,}A")
+    assert rc == 0, se
+    fwd = [r for r in rows(so) if "REVERSE" not in r[3]]
+    assert [(os.path.basename(r[0]), r[2], r[3]) for r in fwd] == [("chr1.fa", "GATTACCCCCCCCCCCCCCCCCCCCA", "700000,700026")]
+    rc, so, se = run("query", str(tmp_path / "big.ibf"), "ACGT(AC)+GTTT(G|T)+AAC")
+    assert rc == 0, se
+    for r in rows(so):
+        assert r[2].startswith("ACGTAC") and r[2].endswith("AAC")

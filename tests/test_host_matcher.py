@@ -1,0 +1,86 @@
+"""The verification matcher (host/matcher.hpp; the reference uses RE2: include/query.h:103,148, src/query.cpp:194-237):
+leftmost-first for DNA, leftmost-longest for peptides, successive non-overlapping matches, linear time without recursion."""
+import os
+import re
+import subprocess
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def host():
+    from tetrex_amd import host as H
+    H.lib()
+    return H
+
+
+def _consume_loop(finditer_like, text):
+    """The FindAndConsume loop of src/query.cpp:206-216 on top of a 'first match at or after pos' function."""
+    out, pos = [], 0
+    while pos <= len(text):
+        m = finditer_like(text, pos)
+        if m is None:
+            break
+        s, e = m
+        out.append((s, e - s))
+        pos = e if e > s else s + 1
+    return out
+
+
+def test_leftmost_first_equals_pythons_re_on_the_readme_and_prosite_motifs(host):
+    rng = np.random.default_rng(1)
+    dna = "".join(rng.choice(list("ACGT"), size=5000))
+    pep = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=20000))
+    cases = [("A(C+|G+)T", dna), ("AC+G", dna), ("(AC)*GT", dna), ("A[^C]GT", dna), ("AC{1,3}G", dna), ("A.T", dna), ("^ACG|GT$", dna),
+             ("N[^P][ST][^P]", pep), ("K[RK]{2,3}DE", pep), ("[ST].[RK]", pep), ("C.{2,4}C.{3}[LIVMFYWC]", pep), ("L(MA)+EG|W.{2}[LIVM]", pep)]
+    for rx, text in cases:
+        pat = re.compile("(" + rx + ")")
+        want = _consume_loop(lambda t, pos: (lambda m: m.span() if m else None)(pat.search(t, pos)), text)
+        # Python's `^` with a start offset still means position 0, like a search in the remaining input would NOT — the
+        # reference consumes the input, so `^` can only ever match at the very beginning: same thing for these cases
+        assert host.regex_find_all("(" + rx + ")", text, posix=False) == want, rx
+
+
+def test_leftmost_longest_differs_from_leftmost_first_where_it_should(host):
+    # POSIX: the longest match from the leftmost start; RE2 default / Perl: the first alternative that matches
+    assert host.regex_find_all("(LM|LMAE)G?", "XXLMAEGXX", posix=True) == [(2, 5)]
+    assert host.regex_find_all("(LM|LMAE)G?", "XXLMAEGXX", posix=False) == [(2, 2)]
+    assert host.regex_find_all("(A|AC|ACG)(GT|T)?", "ACGT", posix=True) == [(0, 4)]
+    assert host.regex_find_all("(A|AC|ACG)(GT|T)?", "ACGT", posix=False) == [(0, 1)]
+    # anchors are text anchors
+    assert host.regex_find_all("^M.[^P]{2}K$", "MAGGK", posix=True) == [(0, 5)]
+    assert host.regex_find_all("^M.[^P]{2}K$", "MAGGKX", posix=True) == []
+    with pytest.raises(host.HostError):
+        host.regex_find_all("(AC", "ACGT", posix=True)
+
+
+def test_native_differential_fuzz_against_std_regex(tmp_path):
+    """tests/native/matcher_fuzz.cpp: random patterns of the supported grammar x random texts, leftmost-first against
+    std::regex (ECMAScript), leftmost-longest against a brute-force oracle built from std::regex_match."""
+    exe = str(tmp_path / "matcher_fuzz")
+    subprocess.run(["g++", "-O2", "-std=c++20", "-o", exe, os.path.join(ROOT, "tests", "native", "matcher_fuzz.cpp"),
+                    os.path.join(ROOT, "tetrex_amd", "csrc", "host", "matcher.cpp")], check=True, timeout=600)
+    for seed in ("11", "12"):
+        r = subprocess.run([exe, "fuzz", seed, "500"], capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-3000:]
+
+
+def test_megabyte_records_with_quantifier_motifs_take_linear_time(host):
+    """What a backtracking matcher cannot do: chromosome-length records with * + {m,n} motifs — no stack
+    growth, no exponential blow-up.  4 MB of sequence per motif in well under a second each."""
+    rng = np.random.default_rng(2)
+    dna = "".join(rng.choice(list("ACGT"), size=4_000_000))
+    t0 = time.perf_counter()
+    hits = host.regex_find_all("(A(C+|G+)T)", dna, posix=False)
+    assert len(hits) > 10000 and all(dna[s] == "A" and dna[s + n - 1] == "T" for s, n in hits[:200])
+    assert host.regex_find_all("((AC)*GTTTTTTTTTTTT)", dna, posix=False) == [(m.start(), m.end() - m.start()) for m in re.finditer("(AC)*GTTTTTTTTTTTT", dna)]
+    # the classic exponential case for backtrackers: nested quantifiers over a long run that then fails to match
+    run = "A" * 2_000_000 + "C"
+    assert host.regex_find_all("((A+)+G)", run, posix=True) == []
+    assert host.regex_find_all("((A+)+C)", run, posix=True) == [(0, 2_000_001)]
+    assert host.regex_find_all("((A|AA)+C)", run, posix=False) == [(0, 2_000_001)]
+    assert time.perf_counter() - t0 < 20

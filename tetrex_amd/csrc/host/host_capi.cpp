@@ -4,6 +4,7 @@
 #include "encoder.hpp"
 #include "index_file.hpp"
 #include "kgraph.hpp"
+#include "matcher.hpp"
 #include "regex_front.hpp"
 
 #include <cstring>
@@ -194,6 +195,19 @@ int txh_blob_stats(const txh_blob* b, uint64_t* stats4, size_t n) {
     return 0;
 }
 void txh_blob_free(txh_blob* b) { delete b; }
+
+int64_t txh_regex_find_all(const char* pattern, int posix, const char* text, size_t len, uint64_t* out, size_t cap) {
+    try {
+        const Matcher m(pattern, posix ? Matcher::Semantics::LeftmostLongest : Matcher::Semantics::LeftmostFirst);
+        Matcher::Cache cache;
+        size_t n = 0;
+        m.find_all(std::string_view(text, len), cache, [&](size_t s, size_t l) {
+            if (2 * n + 1 < cap) { out[2 * n] = s; out[2 * n + 1] = l; }
+            ++n;
+        });
+        return (int64_t)n;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
 
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap) {

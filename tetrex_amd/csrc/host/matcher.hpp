@@ -1,0 +1,96 @@
+// Host side: the regular-expression matcher of the verification stage — product code.
+//
+// The reference verifies candidate bins with RE2 (absent here): `RE2::FindAndConsume` in a loop, default RE2 syntax
+// (leftmost-first, Perl-like) for DNA (include/query.h:103) and RE2::POSIX (leftmost-longest) for peptides
+// (include/query.h:148); src/query.cpp:194-237 prints every successive non-overlapping match.  RE2's property that
+// matters operationally is linear time without recursion: a chromosome-length record with a `+` motif must neither
+// overflow the stack nor take exponential time, which a backtracking matcher (std::regex) does.
+//
+// This matcher keeps that property with two automata built from one parse of the pattern:
+//   * match STARTS: the reversed pattern, unanchored, as a lazily built DFA run over the text from its end — every
+//     position where it accepts is a position where a match of the pattern starts (one pass per record; while the
+//     DFA rests in its start state the scan only looks for a byte that leaves it);
+//   * match END for a given start: the forward pattern anchored there — as a DFA run until it dies (the last accept
+//     is the longest match: POSIX), or as a Pike VM with ordered threads (the first-priority match: RE2 default).
+// find_all then walks the starts left to right exactly like the FindAndConsume loop.
+// Grammar: literals, '.', [sets] / [^sets] with ranges, ( ), |, * + ? {m} {m,} {m,n}, ^ $ (text begin / end), \x escapes.
+#pragma once
+#include <array>
+#include <cstdint>
+#include <map>
+#include <string>
+#include <string_view>
+#include <vector>
+
+namespace tetrex {
+
+class Matcher {
+  public:
+    enum class Semantics { LeftmostLongest, LeftmostFirst };
+    Matcher(const std::string& pattern, Semantics semantics);  // throws std::runtime_error on a syntax error
+
+    // Lazily built DFA states; one per thread that matches (the Matcher itself is immutable and shared).
+    class Cache {
+      public:
+        Cache() = default;
+      private:
+        friend class Matcher;
+        struct Dfa {
+            std::map<std::vector<uint32_t>, uint32_t> ids;
+            std::vector<std::vector<uint32_t>> sets;  // per state: its NFA instructions
+            std::vector<uint32_t> next;                // [state * n_classes + class], kUnknown until built
+            std::vector<uint8_t> flags;                // bit 0: accepts here, bit 1: accepts if the scan ends here
+            uint32_t start_begin = 0, start_mid = 0;   // start states at / after the scan's first position
+            bool ready = false;
+        } rev, fwd, fwd_un;  // reversed unanchored (match starts), forward anchored (match end), forward unanchored (contains)
+        std::vector<uint8_t> rest_stays;  // rev: classes on which the resting start state stays put
+        std::vector<size_t> starts;
+        std::vector<uint32_t> stack, clist, nlist;
+        std::vector<uint32_t> mark;
+        uint32_t epoch = 0;
+    };
+
+    // successive non-overlapping matches, each searched in what the previous one left (the FindAndConsume loop of
+    // src/query.cpp:206-216); fn(start, length)
+    template <class Fn>
+    void find_all(std::string_view text, Cache& cache, Fn&& fn) const {
+        match_starts(text, cache);
+        size_t pos = 0;
+        for (size_t i = cache.starts.size(); i-- > 0;) {  // starts are collected right to left
+            const size_t s = cache.starts[i];
+            if (s < pos) continue;
+            const size_t e = match_end(text, s, cache);
+            fn(s, e - s);
+            pos = e > s ? e : s + 1;
+        }
+    }
+    // does the pattern match anywhere in the text?
+    bool contains(std::string_view text, Cache& cache) const;
+
+  private:
+    struct Inst { uint8_t op; uint32_t x, y; };  // Char: x = set index, y unused; Split: x preferred over y; Jmp: x
+    enum : uint8_t { kChar, kSplit, kJmp, kBegin, kEnd, kMatch };
+    static constexpr uint32_t kUnknown = 0xFFFFFFFFu, kDead = 0xFFFFFFFEu;
+    struct Prog {
+        std::vector<Inst> inst;
+        uint32_t start = 0;       // anchored entry
+        uint32_t unanchored = 0;  // entry behind a leading any-byte loop
+    };
+    Semantics semantics_;
+    std::vector<std::array<uint64_t, 4>> sets_;  // byte sets of the pattern
+    std::array<uint8_t, 256> class_of_{};        // byte -> equivalence class
+    std::vector<std::vector<uint8_t>> set_has_class_;  // [set][class]
+    uint32_t n_classes_ = 1;
+    Prog fwd_, rev_;
+
+    void match_starts(std::string_view text, Cache& cache) const;
+    size_t match_end(std::string_view text, size_t start, Cache& cache) const;
+    size_t pike_end(std::string_view text, size_t start, Cache& cache) const;
+    // DFA plumbing
+    void dfa_init(const Prog& p, bool unanchored, Cache::Dfa& d, Cache& c) const;
+    uint32_t dfa_state(const Prog& p, Cache::Dfa& d, std::vector<uint32_t>& seeds, bool at_begin, Cache& c) const;
+    uint32_t dfa_step(const Prog& p, Cache::Dfa& d, uint32_t state, uint32_t cls, Cache& c) const;
+    void closure(const Prog& p, const std::vector<uint32_t>& seeds, bool at_begin, bool at_end, std::vector<uint32_t>& out, Cache& c) const;
+};
+
+}  // namespace tetrex

@@ -1,9 +1,9 @@
 #include "verify.hpp"
 #include "fasta.hpp"
+#include "matcher.hpp"
 #include "regex_front.hpp"
 
 #include <algorithm>
-#include <regex>
 #include <sstream>
 #include <stdexcept>
 
@@ -21,19 +21,6 @@ char complement(char c) {
     }
 }
 
-// successive non-overlapping matches, each searched on the remaining text (RE2::FindAndConsume)
-template <class Fn>
-void find_all(const std::string& text, const std::regex& rx, Fn&& fn) {
-    size_t pos = 0;
-    std::smatch m;
-    while (pos <= text.size()) {
-        if (!std::regex_search(text.begin() + (std::ptrdiff_t)pos, text.end(), m, rx)) break;
-        const size_t start = pos + (size_t)m.position(0), len = (size_t)m.length(0);
-        fn(start, len);
-        pos = start + (len ? len : 1);
-    }
-}
-
 }  // namespace
 
 size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths, const std::string& regex,
@@ -42,8 +29,9 @@ size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::str
     const bool reduced = !dna && enc.alphabet() != Alphabet::Base;
     std::string pattern = regex;
     if (reduced) pattern = reduce_query_alphabet(pattern, enc.reduce_table());
-    pattern = "(" + pattern + ")";
-    const std::regex rx(pattern, dna ? std::regex::ECMAScript : std::regex::extended);
+    pattern = "(" + pattern + ")";  // as the reference hands it to RE2 (include/query.h:103,148)
+    // RE2 default syntax (leftmost-first) for DNA, RE2::POSIX (leftmost-longest) for peptides
+    const Matcher rx(pattern, dna ? Matcher::Semantics::LeftmostFirst : Matcher::Semantics::LeftmostLongest);
     std::vector<std::string> fwd(bins.size()), rev(bins.size());
     std::vector<size_t> found(bins.size(), 0);
     std::string error;
@@ -52,17 +40,18 @@ size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::str
         try {
             const std::string& path = bin_paths.at(bins[i]);
             std::ostringstream f, r;
+            Matcher::Cache cache;  // lazily built automaton states: per thread
             for_each_record(path, [&](const FastaRecord& rec) {
                 std::string seq = rec.seq;
                 if (reduced) for (char& c : seq) c = enc.reduce((unsigned char)c);
-                find_all(seq, rx, [&](size_t s, size_t n) {
+                rx.find_all(seq, cache, [&](size_t s, size_t n) {
                     f << path << "\t>" << rec.name << "\t" << seq.substr(s, n) << "\t" << s << "," << s + n << "\n";
                     ++found[i];
                 });
                 if (dna) {
                     std::string rc(seq.rbegin(), seq.rend());
                     for (char& c : rc) c = complement(c);
-                    find_all(rc, rx, [&](size_t s, size_t n) {
+                    rx.find_all(rc, cache, [&](size_t s, size_t n) {
                         r << path << "\t>" << rec.name << "\t" << rc.substr(s, n) << "\tREVERSE STRAND HIT\n";
                         ++found[i];
                     });
@@ -87,8 +76,8 @@ size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::str
 
 size_t verify_conjunction(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths,
                           const std::vector<std::string>& queries, std::ostream& out, const VerifyOptions& opt) {
-    std::vector<std::regex> rxs;
-    for (const auto& q : queries) rxs.emplace_back("(" + q + ")", std::regex::ECMAScript);
+    std::vector<Matcher> rxs;
+    for (const auto& q : queries) rxs.emplace_back("(" + q + ")", Matcher::Semantics::LeftmostFirst);
     std::vector<std::string> rows(bins.size());
     std::vector<size_t> found(bins.size(), 0);
     std::string error;
@@ -97,9 +86,10 @@ size_t verify_conjunction(const std::vector<uint64_t>& bins, const std::vector<s
         try {
             const std::string& path = bin_paths.at(bins[i]);
             std::ostringstream o;
+            std::vector<Matcher::Cache> caches(rxs.size());
             for_each_record(path, [&](const FastaRecord& rec) {
-                for (const auto& rx : rxs)
-                    if (!std::regex_search(rec.seq, rx)) return;
+                for (size_t q = 0; q < rxs.size(); ++q)
+                    if (!rxs[q].contains(rec.seq, caches[q])) return;
                 o << path << "\t>" << rec.name << "\tN --> ";
                 for (const auto& q : queries) o << q << " --> ";
                 o << "C\n";

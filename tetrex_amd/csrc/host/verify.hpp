@@ -5,8 +5,8 @@
 //   reverse_verify_fasta_hit  src/query.cpp:167-191   "binpath\t>name\tmatch\tREVERSE STRAND HIT"
 //   verify_reduced_fasta_hit  src/query.cpp:240-315   (sequence mapped through the reduction first)
 //   verify_fasta_set          src/query.cpp:318-339   (-c conjunction)
-// The reference matches with RE2 (absent here); this build uses std::regex: POSIX-extended
-// leftmost-longest for peptides (RE2::POSIX), ECMAScript leftmost-first for DNA (RE2 default).
+// The reference matches with RE2 (absent here); this build has its own linear-time matcher (matcher.hpp):
+// leftmost-longest for peptides (RE2::POSIX), leftmost-first for DNA (RE2 default syntax).
 #pragma once
 #include "encoder.hpp"
 

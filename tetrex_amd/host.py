@@ -181,6 +181,20 @@ def join_shard_masks(mask_words, shard_word0, shard_masks):
     return out
 
 
+def regex_find_all(pattern, text, posix):
+    """The verification matcher (host/matcher.hpp): [(start, length), ...] of successive non-overlapping matches."""
+    L = lib()
+    L.txh_regex_find_all.restype = C.c_int64
+    L.txh_regex_find_all.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t, u64p, C.c_size_t]
+    t = text.encode() if isinstance(text, str) else text
+    cap = 2 * (len(t) + 2)
+    out = np.zeros(cap, dtype=np.uint64)
+    n = L.txh_regex_find_all(pattern.encode(), int(posix), t, len(t), out.ctypes.data_as(u64p), cap)
+    if n < 0:
+        raise _err()
+    return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
+
+
 def record_values(seq, k, dna=True, reduction=0, wraparound=False):
     s = seq.encode() if isinstance(seq, str) else seq
     cap = len(s) + 2

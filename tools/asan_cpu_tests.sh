@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 H=tetrex_amd/csrc/host
 mkdir -p /tmp/tetrex_asan
 g++ -O1 -g -std=c++20 -fPIC -fsanitize=address,undefined -fno-omit-frame-pointer -shared -pthread \
-    -o /tmp/tetrex_asan/libtetrex_host.so $H/encoder.cpp $H/regex_front.cpp $H/kgraph.cpp $H/compiler.cpp $H/staged.cpp $H/index_file.cpp $H/host_capi.cpp
+    -o /tmp/tetrex_asan/libtetrex_host.so $H/encoder.cpp $H/regex_front.cpp $H/kgraph.cpp $H/compiler.cpp $H/staged.cpp $H/index_file.cpp $H/matcher.cpp $H/host_capi.cpp
 make -C oracle liboracle_asan.so > /dev/null
 # python does not link libstdc++, so it must be preloaded next to libasan for __cxa_throw interception
 env LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)" ASAN_OPTIONS=detect_leaks=0 \
