@@ -1,6 +1,7 @@
 #include "matcher.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <functional>
 #include <stdexcept>
 
@@ -268,6 +269,11 @@ void Matcher::match_starts(std::string_view text, Cache& c) const {
             for (uint32_t k = 0; k < n_classes_; ++k) by_class[k] = dfa_step(rev_, d, d.start_mid, k, c) == d.start_mid;
             for (unsigned b = 0; b < 256; ++b) c.rest_stays[b] = by_class[class_of_[b]];
         }
+        // a motif that ends in one fixed residue leaves the resting state on that byte only: memrchr finds it
+        c.single_leaver = -1;
+        int leavers = 0;
+        for (unsigned b = 0; b < 256; ++b) if (!c.rest_stays[b]) { ++leavers; c.single_leaver = (int)b; }
+        if (leavers != 1) c.single_leaver = -1;
     }
     c.starts.clear();
     const size_t n = text.size();
@@ -280,9 +286,14 @@ void Matcher::match_starts(std::string_view text, Cache& c) const {
     for (size_t i = 1; i <= n; ++i) {  // i bytes consumed from the end; the text position reached is n - i
         if (state == rest) {  // nothing of the pattern in flight: look for the next byte that starts something
             const unsigned char* p = t + (n - i);  // the byte about to be consumed; the scan runs towards t
-            while (p - t >= 4 && (stays[p[0]] & stays[p[-1]] & stays[p[-2]] & stays[p[-3]])) p -= 4;
-            while (p >= t && stays[*p]) --p;
-            if (p < t) break;  // ran off the beginning while resting (`rest` cannot accept at the end either: its flags are 0)
+            if (c.single_leaver >= 0) {
+                p = static_cast<const unsigned char*>(memrchr(t, c.single_leaver, (size_t)(p - t) + 1));
+                if (!p) break;
+            } else {
+                while (p - t >= 4 && (stays[p[0]] & stays[p[-1]] & stays[p[-2]] & stays[p[-3]])) p -= 4;
+                while (p >= t && stays[*p]) --p;
+                if (p < t) break;  // ran off the beginning while resting (`rest` cannot accept at the end either: its flags are 0)
+            }
             i = n - (size_t)(p - t);
         }
         const uint32_t cls = class_of_[t[n - i]];

@@ -43,7 +43,8 @@ class Matcher {
             uint32_t start_begin = 0, start_mid = 0;   // start states at / after the scan's first position
             bool ready = false;
         } rev, fwd, fwd_un;  // reversed unanchored (match starts), forward anchored (match end), forward unanchored (contains)
-        std::vector<uint8_t> rest_stays;  // rev: classes on which the resting start state stays put
+        std::vector<uint8_t> rest_stays;  // rev: bytes on which the resting start state stays put
+        int single_leaver = -1;           // the one byte that leaves it, if there is exactly one
         std::vector<size_t> starts;
         std::vector<uint32_t> stack, clist, nlist;
         std::vector<uint32_t> mark;
