@@ -110,6 +110,8 @@ int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* s
 /* ---- .ibf index files (include/index_base.h:160-202 layout; see host/index_file.hpp) ---- */
 typedef struct txh_index txh_index;
 int txh_index_parse(const void* bytes, size_t n, txh_index** out);
+/* the same from a file, the way `tetrex query` loads it: the file is mapped and the bit matrices stay in the mapping */
+int txh_index_load(const char* path, txh_index** out);
 /* a flat IBF index image from raw words; paths = '\n'-separated bin paths (one per bin) */
 int txh_index_from_ibf(unsigned k, int dna, unsigned reduction, unsigned hash_count, uint64_t bins, uint64_t bin_size,
                        const uint64_t* words, const char* paths, txh_index** out);

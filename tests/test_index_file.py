@@ -138,3 +138,26 @@ def test_reader_rejects_garbage(host):
             host.IndexFile.parse(good[:cut])
     with pytest.raises(host.HostError):
         host.IndexFile.parse(good + b"\0")
+
+
+def test_mapped_load_equals_parsed_bytes(tmp_path, host):
+    """`tetrex query` maps the index file instead of reading it (read_index_file): same description, same words, and the
+    image can be serialised again — for a flat IBF, an HIBF and the legacy fixture."""
+    import os
+    from conftest import GOLDEN
+    rng = np.random.default_rng(8)
+    words = rng.integers(0, 1 << 63, size=37 * 2, dtype=np.uint64)
+    flat = host.IndexFile.from_ibf(5, False, 1, 3, 100, 37, words, ["bin%d.fa" % i for i in range(100)])
+    p = tmp_path / "flat.ibf"
+    flat.save(p)
+    for path in (str(p), os.path.join(GOLDEN, "ibf_idx.ibf")):
+        a = host.IndexFile.load(path)
+        b = host.IndexFile.parse(open(path, "rb").read())
+        assert a.describe() == b.describe()
+        assert np.array_equal(a.words(), b.words())
+        assert a.serialise() == b.serialise()
+    with pytest.raises(host.HostError):
+        host.IndexFile.load(str(tmp_path / "missing.ibf"))
+    (tmp_path / "empty.ibf").write_bytes(b"")
+    with pytest.raises(host.HostError):
+        host.IndexFile.load(str(tmp_path / "empty.ibf"))

@@ -22,8 +22,10 @@ static void ensure_devices(const std::vector<int>& devices) {
 }
 static void ensure_device(int device) { ensure_devices(std::vector<int>{device}); }
 
+void DeviceIndex::warm_up(const std::vector<int>& devices) { ensure_devices(devices); }
+
 static txq_ibf_desc describe(const IbfImage& f) {
-    return txq_ibf_desc{f.bins, f.tech_bins, f.bin_size, f.hash_shift, f.bin_words, f.hash_funs, f.words.data()};
+    return txq_ibf_desc{f.bins, f.tech_bins, f.bin_size, f.hash_shift, f.bin_words, f.hash_funs, f.word_data()};  // possibly a view into the mapped index file
 }
 
 DeviceIndex::~DeviceIndex() {

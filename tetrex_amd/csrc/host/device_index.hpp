@@ -66,6 +66,8 @@ class DeviceIndex {
     DeviceIndex& operator=(const DeviceIndex&) = delete;
     ~DeviceIndex();
 
+    // txq_init alone (HIP start-up costs ~0.5 s): `tetrex query` runs it on a helper thread while the index file is mapped and parsed
+    static void warm_up(const std::vector<int>& devices);
     // txq_init + txq_index_upload of a parsed index file: ONE shard (shard_rank of n_shards) on one device
     void upload(const IndexImage& image, int device = 0, int shard_rank = 0, int n_shards = 1);
     // ... ALL n_shards column shards, dealt round-robin over `devices` (`tetrex query --gpus N`); queries then run on

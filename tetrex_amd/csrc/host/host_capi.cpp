@@ -228,6 +228,15 @@ int txh_index_parse(const void* bytes, size_t n, txh_index** out) {
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int txh_index_load(const char* path, txh_index** out) {
+    try {
+        auto ix = std::make_unique<txh_index>();
+        ix->image = read_index_file(path);
+        *out = ix.release();
+        return 0;
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int txh_index_from_ibf(unsigned k, int dna, unsigned reduction, unsigned hash_count, uint64_t bins, uint64_t bin_size,
                        const uint64_t* words, const char* paths, txh_index** out) {
     try {
@@ -290,8 +299,8 @@ static const IbfImage* pick(const txh_index* ix, uint64_t id) {
 int64_t txh_index_words(const txh_index* ix, uint64_t ibf_id, uint64_t* out, size_t cap) {
     const IbfImage* f = pick(ix, ibf_id);
     if (!f) return fail("IBF id out of range");
-    if (out && cap >= f->words.size()) std::memcpy(out, f->words.data(), f->words.size() * 8);
-    return (int64_t)f->words.size();
+    if (out && cap >= f->word_count()) std::memcpy(out, f->word_data(), f->word_count() * 8);
+    return (int64_t)f->word_count();
 }
 
 int64_t txh_index_maps(const txh_index* ix, uint64_t ibf_id, uint64_t* next_ibf_id, uint64_t* tb_to_user, size_t cap) {

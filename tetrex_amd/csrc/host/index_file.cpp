@@ -1,4 +1,9 @@
 #include "index_file.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "encoder.hpp"
 
 #include <cstring>
@@ -18,9 +23,10 @@ void IbfImage::shape(uint64_t bin_count, uint64_t rows, uint64_t h) {
 }
 
 bool IbfImage::consistent() const {
+    if (mapped && !words.empty()) return false;
     return bins >= 1 && bin_size >= 1 && bin_words == (bins + 63) / 64 && tech_bins == bin_words * 64 &&
            hash_shift == (uint64_t)__builtin_clzll(bin_size) && hash_funs >= 1 && hash_funs <= 5 &&
-           words.size() == bin_size * bin_words;
+           word_count() == bin_size * bin_words;
 }
 
 namespace {
@@ -29,7 +35,14 @@ struct ParseError : std::runtime_error { using std::runtime_error::runtime_error
 
 class In {
   public:
-    In(const uint8_t* p, size_t n) : p_(p), n_(n) {}
+    In(const uint8_t* p, size_t n, bool zero_copy = false) : zero_copy(zero_copy), p_(p), n_(n) {}
+    const bool zero_copy;  // large arrays stay where they are (the caller keeps the buffer alive)
+    const uint8_t* view(size_t n) {
+        if (left() < n) throw ParseError("unexpected end of file");
+        const uint8_t* v = p_ + at_;
+        at_ += n;
+        return v;
+    }
     size_t at() const { return at_; }
     size_t left() const { return n_ - at_; }
     template <class T> T get() {
@@ -93,6 +106,11 @@ void read_bit_vector(In& in, const Variant& v, IbfImage& f) {
     auto take = [&](uint64_t n_words) {
         if (n_words != stored) throw ParseError("bit-vector word count mismatch");
         if (n_words > in.left() / 8) throw ParseError("bit vector beyond end of file");
+        if (in.zero_copy) {  // the first `exact` words are the matrix; padding words follow
+            f.words.clear();
+            f.mapped = in.view((size_t)n_words * 8);
+            return;
+        }
         std::vector<uint64_t> w((size_t)n_words);
         in.bytes(w.data(), w.size() * 8);
         w.resize((size_t)exact);
@@ -189,8 +207,8 @@ void read_decomposer(In& in, const IndexImage& ix) {
     }
 }
 
-IndexImage parse_current(const uint8_t* p, size_t n, const Variant& v) {
-    In in(p, n);
+IndexImage parse_current(const uint8_t* p, size_t n, const Variant& v, bool zero_copy = false) {
+    In in(p, n, zero_copy);
     IndexImage ix;
     ix.k = in.get<uint8_t>();
     ix.molecule = in.str();
@@ -308,7 +326,7 @@ DgramImage read_dgram_index_file(const std::string& path) {
     return parse_dgram_index(read_whole_file(path));
 }
 
-IndexImage parse_index(const std::vector<uint8_t>& bytes) {
+static IndexImage parse_any(const uint8_t* data, size_t size, bool zero_copy) {
     std::string first_error;
     for (int ibfver = 1; ibfver >= 0; --ibfver)
         for (int bv = 0; bv < 3; ++bv)
@@ -318,20 +336,42 @@ IndexImage parse_index(const std::vector<uint8_t>& bytes) {
                         for (int prev = 1; prev >= 0; --prev) {
                             const Variant v{ibfver != 0, bv, pad != 0, occ, hv != 0, prev != 0};
                             try {
-                                return parse_current(bytes.data(), bytes.size(), v);
+                                return parse_current(data, size, v, zero_copy);
                             } catch (const ParseError& e) {
                                 if (first_error.empty()) first_error = e.what();
                             }
                         }
     try {
-        return parse_legacy(bytes.data(), bytes.size());
+        return parse_legacy(data, size);
     } catch (const ParseError&) {
     }
     throw std::runtime_error("not a TetRex index (no known layout variant fits): " + first_error);
 }
 
+IndexImage parse_index(const std::vector<uint8_t>& bytes) { return parse_any(bytes.data(), bytes.size(), false); }
+
+// The file is mapped, not read: the scalars and tables are parsed out of the mapping, the bit matrices stay in it
+// (IbfImage::mapped) and go from the page cache straight into the upload's copies.
 IndexImage read_index_file(const std::string& path) {
-    return parse_index(read_whole_file(path));
+    struct Mapping {
+        void* p = MAP_FAILED;
+        size_t n = 0;
+        ~Mapping() { if (p != MAP_FAILED) munmap(p, n); }
+    };
+    const int fd = ::open(path.c_str(), O_RDONLY | O_CLOEXEC);
+    if (fd < 0) throw std::runtime_error("Filepath " + path + " not valid");
+    struct stat st{};
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd); throw std::runtime_error("Filepath " + path + " not valid"); }
+    if (st.st_size == 0) { ::close(fd); throw std::runtime_error("not a TetRex index: the file is empty"); }
+    auto m = std::make_shared<Mapping>();
+    m->n = (size_t)st.st_size;
+    m->p = mmap(nullptr, m->n, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m->p == MAP_FAILED) return parse_index(read_whole_file(path));  // e.g. a file system without mmap: read it
+    (void)madvise(m->p, m->n, MADV_WILLNEED);  // start the read-ahead now; the upload touches the pages next
+    IndexImage image = parse_any(static_cast<const uint8_t*>(m->p), m->n, true);
+    image.mapping = m;
+    return image;
 }
 
 void peek_index_params(const std::vector<uint8_t>& bytes, uint8_t& k, std::string& molecule, bool& is_hibf) {
@@ -366,7 +406,7 @@ void write_ibf(Out& o, const IbfImage& f) {
     o.put<uint32_t>(1);
     o.put(f.bins); o.put(f.tech_bins); o.put(f.bin_size); o.put(f.hash_shift); o.put(f.bin_words); o.put(f.hash_funs);
     o.put<uint64_t>(f.tech_bins * f.bin_size);
-    o.raw(f.words.data(), f.words.size() * 8);
+    o.raw(f.word_data(), f.word_count() * 8);
 }
 }  // namespace
 

@@ -302,8 +302,13 @@ class IndexFile:
 
     @classmethod
     def load(cls, path):
-        with open(path, "rb") as f:
-            return cls.parse(f.read())
+        """read_index_file: the file is mapped, its bit matrices are not copied (what `tetrex query` does)."""
+        L = _index_api()
+        L.txh_index_load.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        h = C.c_void_p()
+        if L.txh_index_load(str(path).encode(), C.byref(h)) != 0:
+            raise _err()
+        return cls(h.value)
 
     @classmethod
     def from_ibf(cls, k, dna, reduction, hash_count, bins, bin_size, words, paths):
