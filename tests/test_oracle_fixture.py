@@ -157,3 +157,13 @@ def test_config1_end_to_end_on_cpu(oracle, golden, variant):
     mask, stats = ix.query("A(C+|G+)T", with_stats=True)
     assert [b for b in range(5) if (int(mask[0]) >> b) & 1] == g["candidate_bins"]
     assert stats["probes"] == 6  # 6 forward k-mers, 3 distinct canonical row sets
+
+
+def test_regenerable_golden_files_regenerate_identically():
+    """tests/golden/regenerate.py --check: hash_kat.json, config1_masks.json and config2_kmers.json come out of an independent
+    pure-Python model of SURVEY.md §8(c)'s formulas applied to the reference-held data files, byte for byte as committed."""
+    import subprocess
+    import sys
+    from conftest import GOLDEN
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "regenerate.py"), "--check"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
