@@ -526,11 +526,13 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         }
         bool densify_here = false;
         if (dense_ok_) {
-            // Dense part of this item's input: shapes that have shrunk to a few entries are enumerated again; so is
-            // everything when the blocks its steps would accumulate into cannot be had (budget), or when this call
-            // has nowhere to put dense ops.  A list that is about to be densified needs those blocks as well.
+            // Dense part of this item's input.  First, shapes that have shrunk to a few entries are enumerated again (so is
+            // everything when this call has nowhere to put dense ops).  Then the blocks the item will need are reserved: one
+            // per list its steps accumulate into that has none yet, plus its own if its enumerated states are about to become
+            // a block.  If they cannot be had (budget), the rest of the dense input is enumerated as well.
             const int32_t next = order_[cursor_];
             NodeStates& cur = table_[next];
+            if (!cur.dense.empty()) materialise(next, out, !go_dense);
             const bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
             if (!cur.dense.empty() || may_densify) {
                 dense_receivers(next, receivers_scratch_);
@@ -544,7 +546,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 for (const DenseRef& d : cur.dense) own |= d.owned != 0;
                 const bool ok = go_dense && can_take_blocks(need + (may_densify && !own ? 1 : 0));
                 densify_here = ok && may_densify;
-                if (!cur.dense.empty()) materialise(next, out, !ok);
+                if (!ok && !cur.dense.empty()) materialise(next, out, true);
             }
         }
         const int32_t item = order_[cursor_++];
