@@ -105,8 +105,8 @@ int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, t
 int txq_index_get_info(const txq_index* ix, txq_index_info* info);
 int txq_index_free(txq_index* ix);
 
-/* 1 when sessions on this index execute dense DP steps (include/txq_program.h version 3: flat IBF with
- * fewer than 2^32 rows), 0 otherwise. */
+/* 1 when sessions on this index execute dense DP steps (include/txq_program.h version 3: any HIBF, and flat IBFs
+ * with fewer than 2^32 rows), 0 otherwise. */
 int txq_index_supports_dense(const txq_index* ix);
 
 /* An empty (all-zero) flat IBF living only in HBM, for device-side construction. */

@@ -114,7 +114,8 @@ typedef struct {
  * may read and write them (scattering enumerated states into a block, copying block entries out).
  * A dense op sits in the op stream as  { kmer = TXQ_DENSE_OP, dst = index into the dense table, a = b = 0 }
  * and obeys the level rules with its blocks as operands (a step reads all of src, reads and writes all of dst).
- * Flat-IBF sessions only. */
+ * On a flat IBF a step is one fused kernel; on an HIBF the predecessor k-mers are written out, descended as one
+ * batch and combined (txq_exec.hip). */
 #define TXQ_PROGRAM_VERSION_DENSE 3u
 #define TXQ_DENSE_OP 0xFFFFFFFEu
 #define TXQ_DENSE_SLOT_BIT 0x40000000u

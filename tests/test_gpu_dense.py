@@ -138,3 +138,56 @@ def test_saturated_motifs_cost_few_host_ops(capi, oracle):
             assert np.array_equal(g, m), q
             compared += 1
     assert compared >= 6
+
+
+@pytest.mark.parametrize("tree", ["irregular-3-levels", "16x64", "40x128"])
+def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
+    """Dense steps on an HIBF session: the predecessor k-mers of a step are written out, descended as one batch
+    (whatever descent kernel the tree takes: fused, lane-per-k-mer, child-stationary) and combined
+    (txq_exec.hip dense_hibf_*).  Masks against the oracle's collect() over membership_for, thresholds forced low."""
+    from helpers import random_hibf, regular_hibf
+    rng = np.random.default_rng(17)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    from tetrex_amd import host
+    if tree == "irregular-3-levels":
+        ox, descs, values = random_hibf(oracle, 21, user_bins=300, levels=3, n_values=60)
+        ub = 300
+        seqs = None
+
+        def spell(v):
+            return "".join("ACDEFGHIKLMNPQRSTVWY"[(int(v) >> sh) & 31] for sh in (15, 10, 5, 0))
+        planted = [spell(v) for b in range(0, 300, 23) for v in values[b][:3] if all(((int(v) >> sh) & 31) < 20 for sh in (15, 10, 5, 0))]
+    else:
+        planted = []
+        children, per_child = (16, 64) if tree == "16x64" else (40, 128)
+        ub = children * per_child
+        seqs = [aa[rng.integers(0, 20, size=203)].tobytes() for _ in range(ub)]
+        ox, descs, values = regular_hibf(oracle, ub, children, 200, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=2)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]", "LMA(E|Q)GLYN", "A.CD", "K[RK]DE"]
+    qs += planted[:12] + [p[0] + "." + p[2:] for p in planted[:6]] + [p[:2] + "[" + "".join(sorted(set(p[2] + "AK"))) + "]" + p[3] for p in planted[6:12]]
+    if seqs is not None:  # windows of the bins' own sequences with wildcards: non-trivial masks
+        for b in range(0, ub, max(1, ub // 12)):
+            w = [chr(c) for c in seqs[b][50:60]]
+            w[3] = "."
+            w[5] = "[" + "".join(sorted(set([w[5], "A", "K"]))) + "]"
+            w[7] = ".{0,2}"
+            qs.append("".join(w))
+    ix = capi.Index.upload_hibf(ub, descs)
+    for knobs in (("2", "2"), ("1", "0"), None):
+        if knobs:
+            monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
+            monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
+        else:
+            monkeypatch.delenv("TETREX_DENSE_MIN")
+            monkeypatch.delenv("TETREX_DENSE_SPARSE_BELOW")
+        got, status, stats = ix.query_masks(qs, False, 4)
+        assert stats["dense_ops"] > 0
+        hits = 0
+        for q, g, st in zip(qs, got, status):
+            want, ost = ox.query(q, with_stats=True)
+            assert st == 0, q
+            if not ost["quirk_merges"]:
+                assert np.array_equal(g, want), (q, knobs)
+                hits += int(want.any())
+        assert hits >= 3
+    ix.free()

@@ -139,11 +139,12 @@ void Index::release() {
     if (d_merged_off) (void)hipFree(d_merged_off);
     d_merged = d_merged_off = nullptr;
     for (void* p : {(void*)scratch_kmers, (void*)scratch_masks, (void*)frontier[0], (void*)frontier[1], (void*)d_counts,
-                    (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final})
+                    (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final, (void*)scratch_dense_kmers, (void*)scratch_dense_masks})
         if (p) (void)hipFree(p);
     d_ibf = nullptr; d_next = d_tb_user = nullptr; d_map_off = nullptr;
     scratch_kmers = scratch_masks = nullptr; frontier[0] = frontier[1] = nullptr; d_counts = nullptr;
     scratch_blob = nullptr; scratch_slots = scratch_final = nullptr;
+    scratch_dense_kmers = scratch_dense_masks = nullptr; cap_dense_kmers = cap_dense_masks = 0;
 }
 
 int ensure(void** p, size_t* cap, size_t bytes) {
@@ -289,7 +290,8 @@ int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
 }
 
 int txq_index_supports_dense(const txq_index* ix) {
-    return ix && !ix->is_hibf && !ix->ibf.empty() && (ix->ibf[0].bin_size >> 32) == 0 && ix->shard_words > 0 ? 1 : 0;
+    if (!ix || ix->ibf.empty() || ix->shard_words == 0) return 0;
+    return ix->is_hibf || (ix->ibf[0].bin_size >> 32) == 0 ? 1 : 0;  // HIBF: steps run as k-mer batches through the descent
 }
 
 int txq_index_free(txq_index* ix) {

@@ -314,6 +314,90 @@ __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* _
     }
 }
 
+// ---- dense steps on an HIBF --------------------------------------------------------------------
+// M[k-mer] of an HIBF is a tree descent (txq_hibf.hip), not h row gathers, so a step cannot be fused.  It runs as
+// three launches over a chunk of step tiles: the predecessor k-mers of every destination suffix are written out
+// (pair p of a tile = suffix first + p / n_a, predecessor p % n_a), descended in one hibf_probe batch, and the
+// combine kernel ANDs each mask with its predecessor's slot and ORs the result into the destination suffix.
+// pair_base[tile] = index of the tile's first pair in the chunk's k-mer / mask arrays.
+__device__ __forceinline__ void dense_codes(const txq_dense_op& d, const DenseParams& P, uint8_t (*codes)[32], uint32_t* cnt) {
+    if (threadIdx.x <= P.pos) {
+        const uint32_t j = threadIdx.x;
+        const uint32_t mask = j < P.pos ? d.shape[j] : d.r_mask;
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < 32; ++c)
+            if ((mask >> c) & 1u) codes[j][n++] = (uint8_t)c;
+        cnt[j] = n;
+    }
+    __syncthreads();
+}
+// destination suffix number e of a step -> index of (x1 .. x_{k-2}) in A^(k-2), the rolled-in code r, and the k-mer without its oldest residue
+__device__ __forceinline__ void dense_entry(const DenseParams& P, const uint8_t (*codes)[32], const uint32_t* cnt, uint32_t e, uint32_t* mid,
+                                            uint32_t* r, uint64_t* low) {
+    const uint32_t n_r = cnt[P.pos];
+    uint32_t q = e / n_r;
+    *r = codes[P.pos][e % n_r];
+    uint32_t m = 0;
+    uint64_t mv = 0;
+    for (uint32_t j = P.pos; j-- > 1;) {
+        const uint32_t c = codes[j][q % cnt[j]];
+        q /= cnt[j];
+        m += c * P.pow_a[P.pos - 1 - j];
+        mv |= (uint64_t)c << (P.bits * (P.pos - 1 - j));
+    }
+    *mid = m;
+    *low = (mv << P.bits) | *r;
+}
+
+__global__ __launch_bounds__(256) void dense_hibf_kmers_kernel(const DenseTile* __restrict__ tiles, const uint32_t* __restrict__ pair_base,
+                                                               const txq_dense_op* __restrict__ dops, DenseParams P, uint64_t* __restrict__ kmers) {
+    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
+    __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    const DenseTile t = tiles[blockIdx.x];
+    const txq_dense_op d = dops[t.op];
+    dense_codes(d, P, codes, cnt);
+    const uint32_t n_a = cnt[0];
+    uint64_t* out = kmers + pair_base[blockIdx.x];
+    for (uint32_t p = threadIdx.x; p < t.count * n_a; p += blockDim.x) {
+        uint32_t mid, r;
+        uint64_t low;
+        dense_entry(P, codes, cnt, t.first + p / n_a, &mid, &r, &low);
+        uint64_t v = ((uint64_t)codes[0][p % n_a] << (P.bits * P.pos)) | low;
+        if (P.canonical) v = canonical_dna(v, P.k);
+        out[p] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_hibf_combine_kernel(const DenseTile* __restrict__ tiles, const uint32_t* __restrict__ pair_base,
+                                                                 const txq_dense_op* __restrict__ dops, uint64_t* const* __restrict__ slot_base,
+                                                                 uint32_t n_programs, uint32_t W, DenseParams P, const uint64_t* __restrict__ masks) {
+    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
+    __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    const DenseTile t = tiles[blockIdx.x];
+    const txq_dense_op d = dops[t.op];
+    dense_codes(d, P, codes, cnt);
+    uint64_t* D = slot_base[n_programs + t.program];
+    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
+    uint64_t* dstb = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+    const uint64_t* M = masks + (size_t)pair_base[blockIdx.x] * W;
+    uint32_t wl = 1;  // lanes per suffix: one word each
+    while (wl < W && wl < blockDim.x) wl <<= 1;
+    const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, groups = blockDim.x / wl;
+    const uint32_t n_a = cnt[0], a_stride = P.pow_a[P.pos - 1];
+    for (uint32_t e = grp; e < t.count; e += groups) {
+        uint32_t mid, r;
+        uint64_t low;
+        dense_entry(P, codes, cnt, t.first + e, &mid, &r, &low);
+        uint64_t* dst = dstb + ((size_t)mid * P.A + r) * W;
+        for (uint32_t w = sub; w < W; w += wl) {
+            uint64_t acc = 0;
+            for (uint32_t i = 0; i < n_a; ++i)
+                acc |= src[((size_t)codes[0][i] * a_stride + mid) * W + w] & M[((size_t)e * n_a + i) * W + w];
+            if (acc) dst[w] |= acc;
+        }
+    }
+}
+
 // constants of programs that just received their first slot region
 __global__ __launch_bounds__(256) void init_slots_kernel(uint64_t* const* __restrict__ slot_base, const uint32_t* __restrict__ which,
                                                          uint32_t n, uint32_t W, uint64_t user_bins, uint64_t word0) {
@@ -641,15 +725,18 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
 // their ops are cut into units per dependency level (units of level l, all programs, are contiguous in `units`),
 // their dense ops into tiles, and every level becomes one launch of each kind over the whole GPU.
 // Returns the number of programs left to exec_kernel.
-struct LevelPlan { size_t units = 0, tiles = 0; };
-static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, std::vector<ExecUnit>* units,
-                         std::vector<DenseTile>* tiles, std::vector<LevelPlan>* plan) {
+struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0; };
+// hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
+// HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel
+static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
+                         std::vector<DenseTile>* tiles, std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
+                         std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
     const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
     const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
     const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
     std::vector<std::vector<ExecUnit>> per_level;
-    std::vector<std::vector<DenseTile>> tiles_level;
+    std::vector<std::vector<DenseTile>> tiles_level, hsteps_level;
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
     static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
     const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
@@ -659,7 +746,7 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
         const bool dense = bv.has_dense[p] != 0;
         // small = less work than a unit launch is worth: 2048 ops of a 1024-bin index, 32 ops at 65536 bins
         if (!dense && (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u)) { n_small += d.n_ops != 0; continue; }
-        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); tiles_level.resize(d.n_levels); }
+        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); tiles_level.resize(d.n_levels); hsteps_level.resize(d.n_levels); }
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
@@ -683,8 +770,10 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
                         if (x.kind == TXQ_DENSE_STEP) entries *= (uint64_t)__builtin_popcount(x.r_mask) * (__builtin_popcount(x.shape[0]) ? 1 : 0);
                         else per_tile = 1024;
                     }
+                    const bool hstep = hibf && x.kind == TXQ_DENSE_STEP;
+                    if (hstep) per_tile = 256;  // 256 suffixes x up to 32 predecessors: at most 8192 k-mers per tile
                     for (uint64_t at = 0; at < entries; at += per_tile)
-                        tiles_level[l].push_back(DenseTile{(uint32_t)p, o.dst, (uint32_t)at, (uint32_t)std::min<uint64_t>(per_tile, entries - at)});
+                        (hstep ? hsteps_level : tiles_level)[l].push_back(DenseTile{(uint32_t)p, o.dst, (uint32_t)at, (uint32_t)std::min<uint64_t>(per_tile, entries - at)});
                 }
                 cut(run, end);
             }
@@ -696,8 +785,13 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
     for (size_t l = 0; l < per_level.size(); ++l) {
         (*plan)[l].units = per_level[l].size();
         (*plan)[l].tiles = tiles_level[l].size();
+        (*plan)[l].hsteps = hsteps_level[l].size();
         units->insert(units->end(), per_level[l].begin(), per_level[l].end());
         tiles->insert(tiles->end(), tiles_level[l].begin(), tiles_level[l].end());
+        for (const DenseTile& t : hsteps_level[l]) {
+            hsteps->push_back(t);
+            hstep_na->push_back((uint32_t)__builtin_popcount(dops[t.op].shape[0]));
+        }
     }
     return n_small;
 }
@@ -741,8 +835,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     }
     bool any_dense = false;
     for (uint8_t d : bv.has_dense) any_dense |= d != 0;
-    if (any_dense && (ix.is_hibf || (ix.ibf[0].bin_size >> 32)))
-        return fail(TXQ_ERR_PROGRAM, "dense ops need a flat IBF with fewer than 2^32 rows");
+    if (any_dense && !ix.is_hibf && (ix.ibf[0].bin_size >> 32))
+        return fail(TXQ_ERR_PROGRAM, "dense ops need fewer than 2^32 rows");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     if (int rc = grow_slot_regions(s, bv, &fresh, st)) return rc;
 
@@ -756,16 +850,44 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     uint32_t sl_dense = 1;
     while (sl_dense * 2 <= want_slices && g_dense * sl_dense * 2 <= 64) sl_dense <<= 1;
     std::vector<ExecUnit> units;
-    std::vector<DenseTile> tiles;
+    std::vector<DenseTile> tiles, hsteps;
+    std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
-    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, &units, &tiles, &plan);
+    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf, &units, &tiles, &hsteps, &hstep_na, &plan);
+    // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
+    // never across a level; pair_base[tile] = first pair of the tile within its chunk
+    std::vector<uint32_t> pair_base(hsteps.size(), 0);
+    std::vector<size_t> chunk_first;
+    std::vector<uint32_t> chunk_pairs;
+    size_t most_pairs = 0;
+    {
+        const uint64_t budget = std::max<uint64_t>(((uint64_t)2 << 30) / ((uint64_t)W * 8), 8192);
+        size_t at = 0;
+        for (const LevelPlan& lp : plan) {
+            uint64_t pairs = 0;
+            for (size_t i = 0; i < lp.hsteps; ++i, ++at) {
+                const uint64_t mine = (uint64_t)hsteps[at].count * hstep_na[at];
+                if (i == 0 || pairs + mine > budget) {
+                    if (!chunk_first.empty() && !chunk_pairs.empty()) most_pairs = std::max<size_t>(most_pairs, chunk_pairs.back());
+                    chunk_first.push_back(at);
+                    chunk_pairs.push_back(0);
+                    pairs = 0;
+                }
+                pair_base[at] = (uint32_t)pairs;
+                pairs += mine;
+                chunk_pairs.back() = (uint32_t)pairs;
+            }
+        }
+        for (uint32_t c : chunk_pairs) most_pairs = std::max<size_t>(most_pairs, c);
+        chunk_first.push_back(hsteps.size());
+    }
 
     // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units | tiles
     const size_t blob_pad = (bytes + 7) & ~(size_t)7;
     if (int rc = ensure((void**)&s.d_blob, &s.cap_blob, blob_pad)) return rc;
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
     const size_t small_bytes = prog_bytes + fresh.size() * 4 + n_q * 8 + ((n_q + 7) & ~(size_t)7) + 64;
-    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit) + 16 + tiles.size() * sizeof(DenseTile);
+    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit) + 32 + (tiles.size() + hsteps.size()) * sizeof(DenseTile) + hsteps.size() * 4;
     if (int rc = ensure((void**)&s.d_aux, &s.cap_aux, aux_bytes)) return rc;
     const size_t nk = h->n_kmers;
     if (int rc = ensure((void**)&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
@@ -780,6 +902,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     DenseTile* d_tiles = (DenseTile*)(((uintptr_t)(d_units + units.size()) + 15) & ~(uintptr_t)15);
     if (!units.empty()) TXQ_HIP(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(ExecUnit), hipMemcpyHostToDevice, st));
     if (!tiles.empty()) TXQ_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, st));
+    DenseTile* d_hsteps = d_tiles + tiles.size();
+    uint32_t* d_pair_base = (uint32_t*)(d_hsteps + hsteps.size());
+    if (!hsteps.empty()) {
+        TXQ_HIP(hipMemcpyAsync(d_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile), hipMemcpyHostToDevice, st));
+        TXQ_HIP(hipMemcpyAsync(d_pair_base, pair_base.data(), hsteps.size() * 4, hipMemcpyHostToDevice, st));
+        if (int rc = ensure((void**)&ix.scratch_dense_kmers, &ix.cap_dense_kmers, most_pairs * 8)) return rc;
+        if (int rc = ensure((void**)&ix.scratch_dense_masks, &ix.cap_dense_masks, most_pairs * (size_t)W * 8)) return rc;
+    }
     if (!fresh.empty()) TXQ_HIP(hipMemcpyAsync(d_fresh, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice, st));
     if (n_q) {
         TXQ_HIP(hipMemcpyAsync(d_qp, q_prog, n_q * 4, hipMemcpyHostToDevice, st));
@@ -839,7 +969,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             }
 #undef TXQ_EXEC
         }
-        size_t first = 0, first_tile = 0;
+        size_t first = 0, first_tile = 0, first_hstep = 0, chunk = 0;
         for (size_t l = 0; l < plan.size(); ++l) {
             const size_t cnt = plan[l].units;
             if (cnt) {
@@ -857,6 +987,20 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 }
 #undef TXQ_UNITS
                 first += cnt;
+            }
+            // HIBF: the level's steps, chunk by chunk: k-mers of all (suffix, predecessor) pairs -> tree descent -> combine
+            for (const size_t level_end = first_hstep + plan[l].hsteps; first_hstep < level_end; ++chunk) {
+                const size_t c0 = chunk_first[chunk], c1 = chunk_first[chunk + 1];
+                const uint32_t pairs = chunk_pairs[chunk];
+                if (pairs) {
+                    dense_hibf_kmers_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, bv.dense, ix.scratch_dense_kmers);
+                    TXQ_HIP(hipGetLastError());
+                    if (int rc = hibf_probe(ix, ix.scratch_dense_kmers, pairs, ix.scratch_dense_masks, nullptr, st)) return rc;
+                    dense_hibf_combine_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, s.d_base, np, W, bv.dense, ix.scratch_dense_masks);
+                    TXQ_HIP(hipGetLastError());
+                }
+                first_hstep = c1;
+                s.n_dense_tiles += c1 - c0;
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: two launches, no order implied
                 hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, st)

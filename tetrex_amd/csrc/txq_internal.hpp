@@ -47,6 +47,8 @@ struct Index {
     unsigned char* scratch_blob = nullptr; size_t cap_blob = 0;
     uint64_t* scratch_slots = nullptr; size_t cap_slots = 0;
     uint64_t* scratch_final = nullptr; size_t cap_final = 0;
+    uint64_t* scratch_dense_kmers = nullptr; size_t cap_dense_kmers = 0;  // dense steps on an HIBF: the pairs' k-mers ...
+    uint64_t* scratch_dense_masks = nullptr; size_t cap_dense_masks = 0;  // ... and their descended masks
 
     // Device buffers of the last session, kept for the next one: a single query must not pay
     // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.
