@@ -63,8 +63,9 @@ void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_ga
 // block of A^(k-1) device slots and emits one op per residue set instead of one per state and residue.
 struct DenseOptions {
     bool enabled = false;          // the executor runs dense ops (a flat-IBF device session)
-    uint32_t min_states = 128;     // a list with at least this many full-length states becomes a block
-    uint32_t sparse_below = 24;    // a block whose shape holds at most this many entries is enumerated again
+    // (bench batch, 1000 motifs at k = 4: min_states / sparse_below 128 / 24: 30 ms; 64 / 24: 23 ms; 32 / 16: 18 ms; 24 / 12: 19 ms)
+    uint32_t min_states = 32;      // a list with at least this many full-length states becomes a block
+    uint32_t sparse_below = 16;    // a block whose shape holds at most this many entries is enumerated again
     uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state
     uint64_t slot_bytes = 0;       // bytes of one mask on the executing device (budgets; 0 = 128)
     uint64_t max_block_bytes = 1ull << 30;
@@ -153,7 +154,8 @@ class QueryExpansion {
     // state's mask only ever grows, so one answer per state is enough); marks them as asked
     void frontier_slots(std::vector<uint32_t>& out);
     // feedback is pointless where (almost) nothing dies: stop asking after enough evidence
-    bool wants_feedback() const { return asked_ < 2048 || pruned_ * 50 >= asked_; }
+    // (a query that runs dense steps has shown that its lists saturate instead of dying: it stops asking too)
+    bool wants_feedback() const { return dense_steps_ == 0 && (asked_ < 2048 || pruned_ * 50 >= asked_); }
     // where a quarter or more of the states die, expanding an unconfirmed state is mostly wasted work:
     // such a query only expands what the device has confirmed alive (advance(..., verified_only))
     bool mostly_dying() const { return asked_ >= 64 && pruned_ * 4 >= asked_; }

@@ -199,7 +199,7 @@ __device__ __forceinline__ void issue_loads(const IbfDev& f, const uint64_t* src
     }
 }
 
-template <int H, bool WIDE>
+template <int H, bool WIDE, int UA>
 __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
                                                     uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
                                                     uint32_t G, uint32_t SL, DenseParams P) {
@@ -280,18 +280,22 @@ __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* _
             T acc = L::zero();
             if (mine) {
                 uint32_t i = slice;
-                for (; i + 2 * SL < n_a; i += 3 * SL) {
-                    const uint32_t a0 = codes[0][i], a1 = codes[0][i + SL], a2 = codes[0][i + 2 * SL];
-                    uint64_t v0 = ((uint64_t)a0 << a_shift) | low, v1 = ((uint64_t)a1 << a_shift) | low, v2 = ((uint64_t)a2 << a_shift) | low;
-                    if (P.canonical) { v0 = canonical_dna(v0, P.k); v1 = canonical_dna(v1, P.k); v2 = canonical_dna(v2, P.k); }
-                    T x0[H + 1], x1[H + 1], x2[H + 1];
-                    issue_loads<H, WIDE>(f, srcm + (size_t)a0 * a_stride * W, v0, c, x0);
-                    issue_loads<H, WIDE>(f, srcm + (size_t)a1 * a_stride * W, v1, c, x1);
-                    issue_loads<H, WIDE>(f, srcm + (size_t)a2 * a_stride * W, v2, c, x2);
-                    T y0 = x0[H], y1 = x1[H], y2 = x2[H];
+                for (; i + (UA - 1) * SL < n_a; i += UA * SL) {  // UA predecessors at a time: UA * (H + 1) loads in flight
+                    T x[UA][H + 1];
 #pragma unroll
-                    for (int h = 0; h < H; ++h) { y0 &= x0[h]; y1 &= x1[h]; y2 &= x2[h]; }
-                    acc |= y0 | y1 | y2;
+                    for (int u = 0; u < UA; ++u) {
+                        const uint32_t a = codes[0][i + u * SL];
+                        uint64_t v = ((uint64_t)a << a_shift) | low;
+                        if (P.canonical) v = canonical_dna(v, P.k);
+                        issue_loads<H, WIDE>(f, srcm + (size_t)a * a_stride * W, v, c, x[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        T y = x[u][H];
+#pragma unroll
+                        for (int h = 0; h < H; ++h) y &= x[u][h];
+                        acc |= y;
+                    }
                 }
                 for (; i < n_a; i += SL) {
                     const uint32_t a0 = codes[0][i];
@@ -396,6 +400,16 @@ __global__ __launch_bounds__(256) void dense_hibf_combine_kernel(const DenseTile
             if (acc) dst[w] |= acc;
         }
     }
+}
+
+// grown slot regions keep their contents: all moves of a stage in ONE launch (a hipMemcpyAsync per program cost 20 ms
+// of host time when a thousand programs' dense regions doubled in the same stage); blockIdx.y cuts a move into 16 slices
+struct RegionMove { uint64_t* dst; const uint64_t* src; size_t words; };
+__global__ __launch_bounds__(256) void move_regions_kernel(const RegionMove* __restrict__ moves) {
+    const RegionMove m = moves[blockIdx.x];
+    const size_t per = (m.words + gridDim.y - 1) / gridDim.y;
+    const size_t lo = per * blockIdx.y, hi = lo + per < m.words ? lo + per : m.words;
+    for (size_t i = lo + threadIdx.x; i < hi; i += blockDim.x) m.dst[i] = m.src[i];
 }
 
 // constants of programs that just received their first slot region
@@ -614,10 +628,13 @@ static double now_s() {
 
 Session::~Session() {
     if (std::getenv("TXQ_TRACE"))
-        fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s\n",
-                n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device);
+        fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s; "
+                        "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles)\n",
+                n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, n_levels, n_unit_launches, n_units,
+                n_dense_launches, n_dense_tiles);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
+    if (d_moves) (void)hipFree(d_moves);
     if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
         size_t kept = 0;
@@ -634,6 +651,7 @@ Session::~Session() {
     for (const Index::ArenaChunk& k : chunks) (void)hipFree(k.p);
     for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
 }
+
 
 // bump allocation of `words` 64-bit words of slot storage (an even number wherever W is even: 16-byte lanes)
 static int arena_alloc(Session& s, size_t words, uint64_t** out) {
@@ -692,6 +710,7 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 // (re)size the programs' slot regions to what the stage needs; a grown region keeps its contents
 static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, hipStream_t st) {
     bool moved = false;
+    std::vector<RegionMove> moves;
     for (size_t p = 0; p < s.n_programs; ++p) {
         const uint32_t need = bv.n_slots[p];
         if (need > s.cap[p]) {
@@ -699,7 +718,7 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             if (cap < need) cap = need;
             uint64_t* region = nullptr;
             if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
-            if (s.cap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[p], (size_t)s.cap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
+            if (s.cap[p]) moves.push_back(RegionMove{region, s.base[p], (size_t)s.cap[p] * s.W});
             else fresh->push_back((uint32_t)p);
             s.base[p] = region;
             s.cap[p] = cap;
@@ -711,11 +730,18 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             if (cap < dneed) cap = dneed;
             uint64_t* region = nullptr;
             if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
-            if (s.dcap[p]) TXQ_HIP(hipMemcpyAsync(region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W * 8, hipMemcpyDeviceToDevice, st));
+            if (s.dcap[p]) moves.push_back(RegionMove{region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W});
             s.base[s.n_programs + p] = region;
             s.dcap[p] = cap;
             moved = true;
         }
+    }
+    if (!moves.empty()) {
+        if (int rc = ensure((void**)&s.d_moves, &s.cap_moves, moves.size() * sizeof(RegionMove))) return rc;
+        TXQ_HIP(hipMemcpyAsync(s.d_moves, moves.data(), moves.size() * sizeof(RegionMove), hipMemcpyHostToDevice, st));
+        TXQ_HIP(hipStreamSynchronize(st));  // `moves` is a local
+        move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)s.d_moves);
+        TXQ_HIP(hipGetLastError());
     }
     if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
     return TXQ_OK;
@@ -799,7 +825,14 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
 template <bool WIDE>
 static hipError_t launch_dense(const IbfDev& f, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
                                uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, hipStream_t st) {
-#define TXQ_DENSE(H) dense_kernel<H, WIDE><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P)
+    // predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
+    static const int ua = std::getenv("TXQ_DENSE_UNROLL") ? std::atoi(std::getenv("TXQ_DENSE_UNROLL")) : 3;
+#define TXQ_DENSE(H) \
+    do { \
+        if (ua >= 6) dense_kernel<H, WIDE, 6><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
+        else if (ua <= 2) dense_kernel<H, WIDE, 2><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
+        else dense_kernel<H, WIDE, 3><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
+    } while (0)
     switch (f.hash_funs) {
         case 1: TXQ_DENSE(1); break;
         case 2: TXQ_DENSE(2); break;
@@ -972,7 +1005,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         size_t first = 0, first_tile = 0, first_hstep = 0, chunk = 0;
         for (size_t l = 0; l < plan.size(); ++l) {
             const size_t cnt = plan[l].units;
+            ++s.n_levels;
             if (cnt) {
+                ++s.n_unit_launches;
+                s.n_units += cnt;
 #define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W)
                 switch (g_units) {
                     case 1: TXQ_UNITS(1); break;
@@ -1008,6 +1044,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
                 s.n_dense_tiles += plan[l].tiles;
+                ++s.n_dense_launches;
             }
         }
     }

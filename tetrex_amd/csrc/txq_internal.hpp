@@ -93,9 +93,10 @@ struct Session {
     bool owns_cache = false;  // buffers came from / go back to ix->session_cache
     unsigned char* d_blob = nullptr; size_t cap_blob = 0;
     unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+    unsigned char* d_moves = nullptr; size_t cap_moves = 0;  // list of grown regions to copy (txq_exec.hip move_regions_kernel)
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
-    size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0;
+    size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;
     ~Session();
 };
 

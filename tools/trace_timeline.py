@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Busy / idle breakdown of the GPU during the LAST batch of tools/e2e_profile.py from a rocprofv3 kernel trace (csv):
+launches, busy time per kernel, and the gaps between consecutive kernels (launch-bound time)."""
+import csv, sys, collections
+rows = []
+with open(sys.argv[1]) as f:
+    for r in csv.DictReader(f):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:50]))
+rows.sort()
+# the last batch = after the last gap longer than 20 ms... the script runs 4 repetitions back to back: split on gaps > 3 ms
+cuts = [0] + [i for i in range(1, len(rows)) if rows[i][0] - rows[i - 1][1] > 3_000_000] + [len(rows)]
+seg = rows[cuts[-2]:cuts[-1]]
+span = (seg[-1][1] - seg[0][0]) / 1e3
+busy = collections.Counter(); n = collections.Counter()
+gap_hist = collections.Counter(); gaps = 0.0
+for i, (s, e, name) in enumerate(seg):
+    busy[name] += (e - s) / 1e3; n[name] += 1
+    if i:
+        g = (s - seg[i - 1][1]) / 1e3
+        if g > 0:
+            gaps += g
+            gap_hist[min(int(g // 5) * 5, 100)] += 1
+print("last batch: %d launches over %.1f us; busy %.1f us, idle between kernels %.1f us" % (len(seg), span, sum(busy.values()), gaps))
+for name, t in busy.most_common():
+    print("  %-52s %5d launches %9.1f us" % (name, n[name], t))
+print("  gaps by size (us):", sorted(gap_hist.items()))
