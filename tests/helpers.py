@@ -233,10 +233,62 @@ class SessionSimulator:
                 acc |= D[sb + ai * A ** (pos - 1) + mid] & self.ox.probe(val)
             D[db + mid * A + r] |= acc
 
+    def _check_level_races(self, blob, progs, dense):
+        """The device runs the ops of one dependency level concurrently (txq_program.h, version 2/3 rules): within a level
+        no op may read what another op writes, plain writes are unique, only accumulations (dst |= src, and DENSE_REDUCE)
+        may share a destination — with dense ops counted by their whole blocks (a step reads all of src, reads and writes
+        all of dst).  This simulator executes sequentially, so it checks the rule instead of depending on it."""
+        levels = self.host.blob_levels(blob)
+        if levels is None:
+            return
+        BIT, DOP = self.DENSE_BIT, self.DENSE_OP
+        N = dense[0]["alphabet"] ** (dense[0]["k"] - 1) if dense is not None else 0
+        for p, ((n_slots, ops), ends) in enumerate(zip(progs, levels)):
+            begin = 0
+            for end in ends:
+                writes, accs, reads = {}, set(), {}   # single slots
+                wr_ranges, rd_ranges = [], []         # (lo, hi, op) over dense slot ids
+                for i in range(begin, end):
+                    k, d, a, b = (int(x) for x in ops[i])
+                    if k == DOP:
+                        kind, dst, src = (int(x) for x in dense[1][d][:3])
+                        if kind == 0:
+                            wr_ranges.append((dst, dst + N, i))
+                        elif kind == 1:
+                            wr_ranges.append((dst, dst + N, i))
+                            rd_ranges.append((src, src + N, i))
+                        else:
+                            accs.add(dst)
+                            rd_ranges.append((src, src + N, i))
+                    elif k == NO_KMER and (d == a or d == b):
+                        accs.add(d)
+                        reads.setdefault(b if d == a else a, set()).add(i)
+                    else:
+                        assert d not in writes, "two plain writes to one slot in a level"
+                        writes[d] = i
+                        reads.setdefault(a, set()).add(i)
+                        reads.setdefault(b, set()).add(i)
+                for d, i in writes.items():
+                    assert d not in accs, "slot written and accumulated in one level"
+                    assert reads.get(d, set()) <= {i}, "slot written and read by different ops of one level"
+                for d in accs:
+                    assert not reads.get(d), "accumulated slot read in the same level"
+                inside = lambda s, r: (s & BIT) and r[0] <= s < r[1]
+                for r in wr_ranges:  # a block a dense op writes: nobody else touches it in this level
+                    for s_ in list(writes) + list(accs) + list(reads):
+                        assert not inside(s_, r), "ordinary op touches a block that a dense op of the same level writes"
+                    for q in wr_ranges + rd_ranges:
+                        assert q[2] == r[2] or q[1] <= r[0] or r[1] <= q[0], "two dense ops on one block in a level"
+                for r in rd_ranges:  # a block a dense op reads: nobody writes into it in this level
+                    for s_ in list(writes) + list(accs):
+                        assert not inside(s_, r), "ordinary op writes into a block that a dense op of the same level reads"
+                begin = end
+
     def stage(self, blob, qp, qs):
         kmers, progs = self.host.parse_blob(blob)
         assert len(progs) == len(self.slots)
         dense = self.host.blob_dense(blob)
+        self._check_level_races(blob, progs, dense)
         if dense is not None:
             for p, want in enumerate(dense[2]):
                 have = self.dense[p].shape[0]
