@@ -60,5 +60,18 @@ int main() {
     const StagedStats st2 = run_staged(enc, 1024, motifs, keep, opt, &status, &why);
     std::printf("all alive: stages %zu ops %llu states %llu pruned %llu\n", st2.stages, (unsigned long long)st2.ops, (unsigned long long)st2.states,
                 (unsigned long long)st2.pruned);
-    return st2.stages > 1 && st2.pruned == 0 ? 0 : 1;
+    if (!(st2.stages > 1 && st2.pruned == 0)) return 1;
+    // dense DP steps: the block budget is one atomic pool shared by the expansion threads; a small pool makes some
+    // queries fall back to enumerated states while others hold blocks
+    FakeExecutor dense_exec;
+    dense_exec.kill_every = 0;
+    StagedOptions dopt = opt;
+    dopt.dense.enabled = true;
+    dopt.dense.slot_bytes = 128;
+    dopt.dense_pool_bytes = (uint64_t)40 * 9261 * 128;  // room for 40 blocks among 96 queries
+    const StagedStats st3 = run_staged(enc, 1024, motifs, dense_exec, dopt, &status, &why);
+    failed = 0;
+    for (int s : status) failed += s != 0;
+    std::printf("dense: stages %zu ops %llu dense ops %llu failed %zu\n", st3.stages, (unsigned long long)st3.ops, (unsigned long long)st3.dense_ops, failed);
+    return st3.dense_ops > 0 && failed == 0 && st3.ops < st2.ops ? 0 : 1;
 }
