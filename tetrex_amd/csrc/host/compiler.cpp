@@ -342,20 +342,24 @@ uint64_t QueryExpansion::shape_entries(const DenseRef& r) const {
 
 // makes sure the next `n` new_block() calls succeed (blocks come from the free list or extend the region)
 bool QueryExpansion::can_take_blocks(size_t n) {
-    const size_t available = free_blocks_.size() - free_block_head_;
+    // The most recently released blocks stay out of circulation while new ones can be had: a recycled block must be zeroed
+    // AFTER its last reader, which puts its DENSE_ZERO one level behind the step that read it and the next step one more
+    // level behind that — a chain of steps ping-ponging between two blocks needs two levels per step instead of one.
+    const size_t in_list = free_blocks_.size() - free_block_head_;
+    size_t available = in_list > dense_.cool_down ? in_list - dense_.cool_down : 0;
     if (n <= available) return true;
     const size_t more = n - available;
-    if (n_blocks_ + more > dense_.max_blocks) return false;
+    if (n_blocks_ + more > dense_.max_blocks) return n <= in_list;  // at the cap: the cooling ones will do, if there are enough
     const int64_t bytes = (int64_t)(more * dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128));
     if (dense_.pool) {
         if (dense_.pool->fetch_sub(bytes, std::memory_order_relaxed) - bytes < 0) {
             dense_.pool->fetch_add(bytes, std::memory_order_relaxed);
-            return false;
+            return n <= in_list;  // no memory for new blocks: the cooling ones will do
         }
         pool_taken_ += (uint64_t)bytes;  // the device keeps the region until the session ends: nothing is handed back
     }
-    for (size_t i = 0; i < more; ++i) {
-        free_blocks_.push_back((uint32_t)n_blocks_++);
+    for (size_t i = 0; i < more; ++i) {  // new blocks go to the FRONT: they are taken before the released ones that are still cooling
+        free_blocks_.insert(free_blocks_.begin() + (std::ptrdiff_t)free_block_head_, (uint32_t)n_blocks_++);
         block_refs_.push_back(0);
     }
     return true;
@@ -493,7 +497,7 @@ void QueryExpansion::dense_receivers(int32_t item, std::vector<int32_t>& out) co
     if (item > n_nodes_) {
         for (uint32_t i = fan_first_[item - n_nodes_ - 1]; i < fan_first_[item - n_nodes_]; ++i) {
             const int32_t t = fan_[i];
-            if (g_.label[t] < 256 && single_source_[t]) add(forward_[t]);
+            if (g_.label[t] < 256) add(forward_[t]);
         }
     } else if (g_.label[item] < 256) add(forward_[item]);
 }
@@ -577,13 +581,16 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     if (!single_source_[fan_[i]]) arrive(fan_[i], s, out);
             }
             if (!ns.dense.empty()) {
-                // one step per receiver for all the residue nodes that only this join feeds; a target with other
-                // sources (or a Match / Gap node) takes a reference to the block and deals with it on its turn
+                // One step per receiver for ALL the residue nodes this join feeds — also those with other sources: a block
+                // arriving at a residue node merges with nothing there, it only needs the node's residue and receiver, and the
+                // receiver is processed after the node in any case.  (Handing such nodes a reference instead made every one of
+                // the 20 nodes of a wildcard inside x(m,n) do its own step into the same block, one dependency level each:
+                // 165 levels for the bench batch instead of ~60.)  Match / Gap nodes take a reference and deal with it on their turn.
                 struct Group { int32_t receiver; uint32_t r_mask; };
                 std::vector<Group> groups;
                 for (uint32_t i = lo; i < hi; ++i) {
                     const int32_t t = fan_[i];
-                    if (g_.label[t] < 256 && single_source_[t]) {
+                    if (g_.label[t] < 256) {
                         if (dangling_[t]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
                         if (forward_[t] == KGraph::kNone) continue;
                         const uint32_t bit = 1u << enc_.code((unsigned char)g_.label[t]);

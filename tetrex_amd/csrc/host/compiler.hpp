@@ -66,6 +66,7 @@ struct DenseOptions {
     // (bench batch, 1000 motifs at k = 4: min_states / sparse_below 128 / 24: 30 ms; 64 / 24: 23 ms; 32 / 16: 18 ms; 24 / 12: 19 ms)
     uint32_t min_states = 32;      // a list with at least this many full-length states becomes a block
     uint32_t sparse_below = 16;    // a block whose shape holds at most this many entries is enumerated again
+    uint32_t cool_down = 1;        // released blocks kept out of circulation while new ones can be had (see can_take_blocks)
     uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state
     uint64_t slot_bytes = 0;       // bytes of one mask on the executing device (budgets; 0 = 128)
     uint64_t max_block_bytes = 1ull << 30;

@@ -87,6 +87,7 @@ class StagedRun {
         if (const char* e = std::getenv("TETREX_DENSE")) dense_.enabled = dense_.enabled && e[0] != '0';  // A/B knob: TETREX_DENSE=0
         if (const char* e = std::getenv("TETREX_DENSE_MIN")) dense_.min_states = (uint32_t)std::max(1, std::atoi(e));
         if (const char* e = std::getenv("TETREX_DENSE_SPARSE_BELOW")) dense_.sparse_below = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("TETREX_DENSE_COOL")) dense_.cool_down = (uint32_t)std::max(0, std::atoi(e));
         if (opt.gaps.dgram_loaded || dense_block_slots(enc, dense_) == 0) dense_.enabled = false;  // version-2 blobs, as before
         dense_pool_.store((int64_t)std::min<uint64_t>(opt.dense_pool_bytes, (uint64_t)INT64_MAX));
         dense_.pool = &dense_pool_;

@@ -60,7 +60,7 @@ struct Index {
         unsigned char* d_aux = nullptr; size_t cap_aux = 0;
         bool in_use = false;
     } session_cache;
-    static constexpr size_t kArenaKeepBytes = (size_t)16 << 30;
+    static constexpr size_t kArenaKeepBytes = (size_t)64 << 30;
     int open_sessions = 0;  // txq_index_free refuses while a session still points at this index
 
     // txq_probe (host buffers): two streams with their device and pinned bounce buffers
