@@ -191,3 +191,18 @@ def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
                 hits += int(want.any())
         assert hits >= 3
     ix.free()
+
+
+def test_large_blocks_k5_base_alphabet_and_k6_murphy(capi, oracle, monkeypatch):
+    """Blocks of 21^4 = 194 481 slots (k = 5, Base alphabet) and 10^5 slots (k = 6, Murphy): the dense slot ids reach
+    beyond 2^20, ZERO / REDUCE tiles number in the hundreds, and the regions of a query take tens of MB."""
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    ox = _oracle_index(oracle, bins=130, m=8191, h=3, k=5, dna=False, per_bin=1200, seed=55)
+    qs = ["LMKDE..[KR]G.HK", "WKLMN[LIVM].D[FY]..K", "LMKDA.C.E.GH", "CLMKD.{1,2}C..[LIVMFYWC]K"]
+    checked, dense_ops = _check(capi, ox, qs, False, 5)
+    assert checked == len(qs) and dense_ops > 10
+    ox = _oracle_index(oracle, bins=96, m=8191, h=2, k=6, dna=False, per_bin=1500, seed=56, reduction=1)
+    qs = ["LMKDEF..[KR]G.HKL", "WKLMNP[LIVM].D[FY]..KD"]
+    checked, dense_ops = _check(capi, ox, qs, False, 6, 1)
+    assert checked >= 1 and dense_ops > 4
