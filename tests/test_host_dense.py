@@ -129,3 +129,17 @@ def test_nested_stars_that_enumerated_state_by_state_would_exceed_any_op_budget(
     qs = ["LMK(.+)+HKD", "LMK(.+)+(.+)+HKD", "LMK((.+)+)+KDE", "LMK(.+)+D(.+)+HK", "((.*)*)*", "LMK((.*)*)*KDE", "(.+)+LMK(.*)*"]
     checked, stats, sim = _run(host, ox, qs, False, 4, dense)
     assert checked >= 4 and stats["ops"] < 5_000_000
+
+
+def test_queries_begin_in_waves_when_block_memory_is_short(host, oracle):
+    """A pool of a few blocks for a dozen wildcard motifs: the ones that have not begun wait while those under way finish
+    and hand their blocks back, instead of all starting at once and most falling back to enumerated states.  Same masks,
+    several stages, about the ops of an unlimited pool."""
+    ox = _index(oracle, bins=100, m=2053, h=3, k=4, dna=False, per_bin=700, seed=12)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "CLM.{2,4}C...[LIVMFYWC]", "KRK..[DE].GH", "HKL.{1,2}[ST]..P",
+          "LMK..A..GK", "WKL.[LIVM]..D.[FY]", "LMKA..E.GH.", "CLM..C...[LIVMFYWC]", "KRK.[DE]..GH", "HKL..[ST]..P"]
+    block = 21 ** 3 * 128
+    checked, free, _ = _run(host, ox, qs, False, 4, dict(slot_bytes=128))
+    checked2, tight, sim = _run(host, ox, qs, False, 4, dict(slot_bytes=128, pool_bytes=12 * block))
+    assert checked == checked2 == len(qs)
+    assert tight["stages"] > free["stages"] and tight["ops"] < 3 * free["ops"]

@@ -356,7 +356,7 @@ bool QueryExpansion::can_take_blocks(size_t n) {
             dense_.pool->fetch_add(bytes, std::memory_order_relaxed);
             return n <= in_list;  // no memory for new blocks: the cooling ones will do
         }
-        pool_taken_ += (uint64_t)bytes;  // the device keeps the region until the session ends: nothing is handed back
+        pool_taken_ += (uint64_t)bytes;  // the stage driver hands them back once the device has run the query's last ops
     }
     for (size_t i = 0; i < more; ++i) {  // new blocks go to the FRONT: they are taken before the released ones that are still cooling
         free_blocks_.insert(free_blocks_.begin() + (std::ptrdiff_t)free_block_head_, (uint32_t)n_blocks_++);

@@ -150,6 +150,7 @@ class QueryExpansion {
     // slots of the dense region (a multiple of the block size A^(k-1)); 0 while the query never went dense
     uint32_t n_dense_slots() const { return (uint32_t)(n_blocks_ * dense_n_); }
     uint64_t dense_steps() const { return dense_steps_; }
+    uint64_t pool_taken() const { return pool_taken_; }  // bytes of the run's dense pool this query holds
     uint64_t dense_block_slots() const { return dense_n_; }  // A^(k-1), 0 when dense blocks are off for this query
     // distinct non-constant slots of waiting states that were not asked about before (a waiting
     // state's mask only ever grows, so one answer per state is enough); marks them as asked

@@ -77,7 +77,8 @@ class StagedRun {
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
           dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
-          fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), busy_(threads_, 0.0) {
+          fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
+          busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
@@ -89,7 +90,11 @@ class StagedRun {
         if (const char* e = std::getenv("TETREX_DENSE_SPARSE_BELOW")) dense_.sparse_below = (uint32_t)std::max(0, std::atoi(e));
         if (const char* e = std::getenv("TETREX_DENSE_COOL")) dense_.cool_down = (uint32_t)std::max(0, std::atoi(e));
         if (opt.gaps.dgram_loaded || dense_block_slots(enc, dense_) == 0) dense_.enabled = false;  // version-2 blobs, as before
-        dense_pool_.store((int64_t)std::min<uint64_t>(opt.dense_pool_bytes, (uint64_t)INT64_MAX));
+        uint64_t pool_bytes = opt.dense_pool_bytes;
+        if (const char* e = std::getenv("TETREX_DENSE_POOL_MB")) pool_bytes = (uint64_t)std::max(0LL, std::atoll(e)) << 20;  // device memory for dense blocks
+        dense_pool_.store((int64_t)std::min<uint64_t>(pool_bytes, (uint64_t)INT64_MAX));
+        dense_total_ = dense_pool_.load();
+        admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)INT64_MAX / 4);
         dense_.pool = &dense_pool_;
         if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
     }
@@ -163,7 +168,9 @@ class StagedRun {
         tables_[i].clear();
         dgram_tables_[i].clear();
         dense_ops_[i].clear();
+        if (q_[i]) held_[i] = q_[i]->pool_taken();
         q_[i].reset();
+        flushed_[i] = 1;  // nothing of it is left to run
         status_[i] = -1;
         why_[i] = e.what();
     }
@@ -177,10 +184,25 @@ class StagedRun {
         }
         std::fill(busy_.begin(), busy_.end(), 0.0);
         std::atomic<size_t> total{already};
+        // Dense blocks are device memory: when the run's pool runs low, queries that have not begun wait for a later stage —
+        // those under way finish, hand their blocks back (and the device recycles their regions) — instead of everybody
+        // starting at once and the late ones falling back to enumerated states.  Somebody is always under way.
+        size_t under_way = 0;
+        for (size_t i = 0; i < n_; ++i) under_way += q_[i] && started_[i] && !q_[i]->done();
+        std::atomic<size_t> begun{under_way};
         pool_.run(set.size(), [&](size_t at, int t) {
             const size_t i = set[at];
             const double t0 = trace_ ? now_seconds() : 0.0;
             if (total.load(std::memory_order_relaxed) >= opt_.ops_per_stage) return;  // waits for a later stage
+            if (dense_.enabled && !started_[i]) {
+                // admission by an estimate of four blocks per query (what a chain of steps through x(m,n) gaps holds at a time)
+                if (admitted_.fetch_add(admit_bytes_, std::memory_order_relaxed) + admit_bytes_ > dense_total_ && begun.load(std::memory_order_relaxed) > 0) {
+                    admitted_.fetch_sub(admit_bytes_, std::memory_order_relaxed);
+                    return;
+                }
+                started_[i] = 1;
+                begun.fetch_add(1, std::memory_order_relaxed);
+            }
             try {
                 // a query that gains nothing from feedback only pauses to keep the stage's tasks even
                 const bool asks = q_[i]->wants_feedback();
@@ -199,6 +221,7 @@ class StagedRun {
             if (q_[i]->done()) {  // free the expansion's tables here, on the worker
                 fin_states_[i] = q_[i]->states();
                 fin_pruned_[i] = q_[i]->pruned();
+                held_[i] = q_[i]->pool_taken();
                 q_[i].reset();
             }
             if (trace_) busy_[t] += now_seconds() - t0;
@@ -213,6 +236,16 @@ class StagedRun {
 
     // advance: fills touched_ (queries with something for this stage) and returns the stage's op count
     size_t advance_stage(bool first) {
+        // Queries whose last ops the device has been given in an earlier stage are through with their dense blocks: the
+        // bytes go back to the pool and to the admission budget now, and this stage's program table reports them with zero
+        // dense slots, so the device recycles their regions before it sizes those of the queries admitted next.
+        if (dense_.enabled)
+            for (size_t i = 0; i < n_; ++i)
+                if (!q_[i] && started_[i] && flushed_[i] && !released_[i]) {
+                    released_[i] = 1;
+                    dense_pool_.fetch_add((int64_t)held_[i], std::memory_order_relaxed);
+                    admitted_.fetch_sub(admit_bytes_, std::memory_order_relaxed);
+                }
         touched_.clear();
         std::vector<uint32_t> act;
         size_t unfinished = 0;
@@ -315,6 +348,7 @@ class StagedRun {
                 at_level += nl;
                 ++j;
             } else {
+                if (released_[i]) dslots_[i] = 0;  // its dense region goes to the queries admitted now (see advance_stage)
                 pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, dslots_[i]};
             }
         }
@@ -324,6 +358,7 @@ class StagedRun {
         else std::memcpy(blob, &h, sizeof h);
         // the blob holds the stage now: the per-query buffers are free for the next one
         for (uint32_t i : touched_) {
+            if (!q_[i]) flushed_[i] = 1;  // finished, and its last ops are in this blob
             dense_ops_[i].clear();
             if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
             else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); DenseVec().swap(dense_ops_[i]); }  // finished: storage back to the cache
@@ -427,6 +462,11 @@ class StagedRun {
     std::vector<uint32_t> touched_;                   // queries with ops or k-mers in the stage being built, ascending
     std::vector<uint8_t> ahead_;                      // advanced while the previous stage executed
     std::vector<uint32_t> run_on_stages_;             // per query: stages it has run without asking for feedback
+    std::vector<uint8_t> started_;                    // per query: its expansion has begun (dense-memory admission)
+    std::vector<uint8_t> flushed_, released_;         // finished and its last ops handed to the device / its blocks handed back
+    std::vector<uint64_t> held_;                      // bytes of the dense pool a finished query still holds
+    int64_t dense_total_ = 0, admit_bytes_ = 0;       // the pool's size; what a query is assumed to need when it is admitted
+    std::atomic<int64_t> admitted_{0};
     size_t carried_ = 0;                              // ops those produced
     std::vector<double> busy_;
     BlobStore blob_store_;

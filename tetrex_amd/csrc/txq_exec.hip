@@ -711,6 +711,17 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, hipStream_t st) {
     bool moved = false;
     std::vector<RegionMove> moves;
+    std::vector<std::pair<uint32_t, uint64_t*>> outgrown;
+    // a program that reports no dense slots any more is finished with its blocks: its region serves another program
+    // (the kernels of this stage run after everything the old owner launched: same stream)
+    if (bv.block_slots)
+        for (size_t p = 0; p < s.n_programs; ++p)
+            if (bv.n_dense_slots[p] == 0 && s.dcap[p]) {
+                s.free_dense.emplace(s.dcap[p], s.base[s.n_programs + p]);
+                s.base[s.n_programs + p] = nullptr;
+                s.dcap[p] = 0;
+                moved = true;
+            }
     for (size_t p = 0; p < s.n_programs; ++p) {
         const uint32_t need = bv.n_slots[p];
         if (need > s.cap[p]) {
@@ -729,8 +740,16 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             uint32_t cap = s.dcap[p] ? s.dcap[p] * 2 : dneed;
             if (cap < dneed) cap = dneed;
             uint64_t* region = nullptr;
-            if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
-            if (s.dcap[p]) moves.push_back(RegionMove{region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W});
+            auto recycled = s.free_dense.lower_bound(dneed);  // the smallest released region that is large enough, within reason
+            if (recycled != s.free_dense.end() && recycled->first <= 4 * (uint64_t)cap) {
+                cap = recycled->first;
+                region = recycled->second;
+                s.free_dense.erase(recycled);
+            } else if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
+            if (s.dcap[p]) {
+                moves.push_back(RegionMove{region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W});
+                outgrown.emplace_back(s.dcap[p], s.base[s.n_programs + p]);  // reusable from the NEXT stage on: this stage's moves still read it
+            }
             s.base[s.n_programs + p] = region;
             s.dcap[p] = cap;
             moved = true;
@@ -743,6 +762,7 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
         move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)s.d_moves);
         TXQ_HIP(hipGetLastError());
     }
+    for (const auto& r : outgrown) s.free_dense.emplace(r.first, r.second);
     if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
     return TXQ_OK;
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include "txq_kernels.hpp"
 #include "../../include/txq.h"
+#include <map>
 #include <vector>
 
 namespace txq {
@@ -89,6 +90,7 @@ struct Session {
     std::vector<uint64_t*> base;    // [2 * n_programs]: per program its slot region [cap][W], then its dense region [dcap][W]
     std::vector<uint32_t> cap;      // per program: slots allocated
     std::vector<uint32_t> dcap;     // per program: dense slots allocated (include/txq_program.h, version 3)
+    std::multimap<uint32_t, uint64_t*> free_dense;  // dense regions given back by finished programs / outgrown: capacity in slots -> region
     uint64_t** d_base = nullptr; size_t cap_base = 0;  // device copy of `base`
     bool owns_cache = false;  // buffers came from / go back to ix->session_cache
     unsigned char* d_blob = nullptr; size_t cap_blob = 0;
