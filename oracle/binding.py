@@ -189,10 +189,30 @@ class Index:
         keys = ("probes", "states", "quirk_merges", "dgram_probes", "gap_nodes")
         return mask, dict(zip(keys, (int(x) for x in stats)))
 
-    def query(self, regex, with_stats=False):
+    def expected_mask(self, regex, augment=False):
+        """The mask a correct implementation must return: the reference's (restated) result where that is well defined
+        (no quirk merges), otherwise the result under well-defined merges.  Returns (mask, quirk_merges)."""
+        if augment:
+            mask, st = self.query_aug(regex, augment=True)
+        else:
+            mask, st = self.query(regex, with_stats=True)
+        if st["quirk_merges"]:
+            mask = self.query(regex, well_defined=True, augment=augment)
+        return mask, st["quirk_merges"]
+
+    def query(self, regex, with_stats=False, well_defined=False, augment=False):
+        """well_defined=True: states are keyed by what they are, so the merges that make the reference's result
+        implementation-defined (quirk_merges) do not happen — NOT the reference's rule, but the only defined answer for
+        those queries; identical to the default wherever quirk_merges == 0."""
         mask = np.zeros(self.words_per_mask, dtype=np.uint64)
         stats = np.zeros(3, dtype=np.uint64)
-        if lib().txo_query(self._h, regex.encode(), mask.ctypes.data_as(u64p), stats.ctypes.data_as(u64p)) != 0:
+        L = lib()
+        if well_defined:
+            L.txo_query_well_defined.argtypes = [C.c_void_p, C.c_char_p, C.c_int, u64p, u64p]
+            rc = L.txo_query_well_defined(self._h, regex.encode(), int(augment), mask.ctypes.data_as(u64p), stats.ctypes.data_as(u64p))
+        else:
+            rc = L.txo_query(self._h, regex.encode(), mask.ctypes.data_as(u64p), stats.ctypes.data_as(u64p))
+        if rc != 0:
             raise _err()
         if with_stats:
             return mask, dict(probes=int(stats[0]), states=int(stats[1]), quirk_merges=int(stats[2]))

@@ -251,4 +251,15 @@ int txo_query(txo_index* ix, const char* regex, uint64_t* mask, uint64_t* stats3
     } catch (const std::exception& e) { return fail(e); }
 }
 
+// The same with states keyed by what they are (Collector::well_defined) — NOT the reference's merge rule; see txo_collector.hpp.
+// For the queries where the reference's own result is implementation-defined (quirk_merges > 0).
+int txo_query_well_defined(txo_index* ix, const char* regex, int augment, uint64_t* mask, uint64_t* stats3) {
+    try {
+        QueryResult q = run_query(ix->view, regex, augment != 0, nullptr, true);
+        std::memcpy(mask, q.mask.data(), q.mask.size() * 8);
+        if (stats3) { stats3[0] = q.stats.probes; stats3[1] = q.stats.states; stats3[2] = q.stats.quirk_merges; }
+        return 0;
+    } catch (const std::exception& e) { return fail(e); }
+}
+
 }  // extern "C"

@@ -17,6 +17,8 @@
 #include "txo_regex.hpp"
 #include "txo_kgraph.hpp"
 #include <functional>
+#include <array>
+#include <map>
 #include <unordered_map>
 
 namespace txo {
@@ -75,7 +77,7 @@ struct CollectStats {
 
 struct Collector {
     struct Item { int node; uint8_t shift; uint64_t kmer; Mask path; bool gapped = false; int res1 = 0, res2 = 0; };
-    struct Bucket { std::vector<Item> items; std::unordered_map<uint64_t, size_t> at; size_t head = 0; };
+    struct Bucket { std::vector<Item> items; std::unordered_map<uint64_t, size_t> at; std::map<std::array<uint64_t, 3>, size_t> at_strict; size_t head = 0; };
 
     Graph g;  // own copy: augment() adds Gap / guard nodes
     const IndexView& ix;
@@ -86,6 +88,14 @@ struct Collector {
     uint64_t submask = 0;
     std::unordered_map<uint64_t, Mask> cache;  // kmer_cache_, keyed by FORWARD k-mer
     CollectStats stats;
+    // NOT the reference's behaviour.  The reference merges two states whenever the bits of their (k-1)-symbol suffix are
+    // equal, also when one of them has seen fewer than k-1 symbols (leading residues that encode to 0) or is collecting a
+    // d-gram, and keeps whichever arrived first — an implementation-defined result (robin_hood iteration order; SURVEY.md
+    // §7 "state-merge quirk"), counted in stats.quirk_merges.  well_defined = true keys states by what they ARE (suffix +
+    // how many symbols they have seen; for d-gram states the partial code + residues seen), so such states never merge:
+    // the semantics the product implements.  Tests use it to check the product on exactly those queries where the
+    // reference itself has no defined answer; everywhere else (quirk_merges == 0) both modes give the same masks.
+    bool well_defined = false;
 
     Collector(const Graph& graph, const IndexView& index) : g(graph), ix(index) {
         for (unsigned c = ix.enc.k - 1; c > 0; --c) submask = (submask << ix.enc.lshift) | ix.enc.rmask;
@@ -184,6 +194,19 @@ struct Collector {
     void push(Item&& it) {
         uint64_t key = it.kmer & submask;
         Bucket& b = table[rank[it.node]];
+        if (well_defined) {
+            const unsigned k = ix.enc.k;
+            const std::array<uint64_t, 3> key3 = it.gapped ? std::array<uint64_t, 3>{it.kmer, 1, it.shift}
+                                                           : std::array<uint64_t, 3>{key, 0, (uint64_t)(it.shift < k - 1 ? it.shift : k - 1)};
+            auto f = b.at_strict.find(key3);
+            if (f == b.at_strict.end()) { b.at_strict.emplace(key3, b.items.size()); b.items.push_back(std::move(it)); }
+            else {
+                Item& dst = b.items[f->second];
+                if (dst.shift < it.shift) dst.shift = it.shift;  // k-1 and k symbols seen behave alike from here on
+                for (size_t w = 0; w < dst.path.size(); ++w) dst.path[w] |= it.path[w];
+            }
+            return;
+        }
         auto f = b.at.find(key);
         if (f == b.at.end()) { b.at.emplace(key, b.items.size()); b.items.push_back(std::move(it)); }
         else {
@@ -265,7 +288,8 @@ struct QueryResult {
 };
 
 // preprocess_query + process_query + the `hit_vector &= ...` of run_collection.
-inline QueryResult run_query(const IndexView& ix, const std::string& regex, bool augment = false, const DGramView* dgram = nullptr) {
+inline QueryResult run_query(const IndexView& ix, const std::string& regex, bool augment = false, const DGramView* dgram = nullptr,
+                             bool well_defined = false) {
     QueryResult q;
     std::string rx = regex;
     if (!ix.enc.dna) {
@@ -284,6 +308,7 @@ inline QueryResult run_query(const IndexView& ix, const std::string& regex, bool
     kb.build(q.postfix);
     q.nodes = kb.g.node_count();
     Collector c(kb.g, ix);
+    c.well_defined = well_defined;
     if (dgram) c.dgram = *dgram;
     if (augment && !kb.cats.empty()) {  // include/query.h:243
         const int before = c.g.node_count();

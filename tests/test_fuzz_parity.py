@@ -75,13 +75,12 @@ def _check_masks(host, oracle, ox, rx, dna, k, budget, dense=0):
     sim = SessionSimulator(ox, 1)
     status, _ = host.run_staged([rx], dna, k, 0, ox.bins, sim.stage, budget, dense=DENSE[dense])
     try:
-        want, st_ = ox.query(rx, with_stats=True)
+        want, quirks = ox.expected_mask(rx)
     except oracle.OracleError:
         assert status[0] != 0
         return
     assert status[0] == 0
-    if st_["quirk_merges"] == 0:
-        assert np.array_equal(sim.result(0), want), rx
+    assert np.array_equal(sim.result(0), want), rx
 
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])

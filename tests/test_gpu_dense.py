@@ -30,8 +30,7 @@ def _wants(ox, queries):
     out = []
     for q in queries:
         try:
-            m, st = ox.query(q, with_stats=True)
-            out.append(None if st["quirk_merges"] else m)
+            out.append(ox.expected_mask(q)[0])
         except Exception:
             out.append(False)  # the reference path cannot search it either
     return out

@@ -30,13 +30,11 @@ def _run(host, ox, queries, dna, k, per_query, per_stage=0):
     checked = 0
     for i, q in enumerate(queries):
         try:
-            want, ost = ox.query(q, with_stats=True)
+            want, quirks = ox.expected_mask(q)  # where the reference merges states of different length: the well-defined result
         except Exception:
             assert status[i] != 0
             continue
         assert status[i] == 0, q
-        if ost["quirk_merges"]:
-            continue
         assert np.array_equal(sim.result(i), want), q
         checked += 1
     return checked, stats, sim
