@@ -155,7 +155,7 @@ int cmd_query(int argc, char** argv) {
         if (!a.has("stats")) return;
         std::cerr << "{\"queries\": " << queries << ", \"mask_seconds\": " << seconds << ", \"stages\": " << st.stages
                   << ", \"ops\": " << st.ops << ", \"kmer_probes\": " << st.kmers << ", \"states\": " << st.states
-                  << ", \"pruned_states\": " << st.pruned << ", \"expand_seconds\": " << st.expand_seconds
+                  << ", \"pruned_states\": " << st.pruned << ", \"dense_ops\": " << st.dense_ops << ", \"expand_seconds\": " << st.expand_seconds
                   << ", \"execute_seconds\": " << st.execute_seconds << ", \"bins\": " << bins << "}" << std::endl;
     };
 
