@@ -4,7 +4,10 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <future>
 #include <stdexcept>
 
@@ -228,9 +231,16 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     // saturated state lists run as dense DP steps on the device where the index allows it (TETREX_DENSE=0 switches them off)
     opt.dense.enabled = txq_index_supports_dense(ix) != 0;
     opt.dense.slot_bytes = info.shard_words * 8;
+    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
     if (stats) *stats = st;
-    exec.finish(masks.data());
+    const auto t1 = std::chrono::steady_clock::now();
+    exec.finish(masks.data());  // waits for the device: a stage without feedback questions returns as soon as it is launched
+    if (trace)
+        std::fprintf(stderr, "[tetrex] run_staged %.2f ms, finish (device drain + result copy) %.2f ms\n",
+                     std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     return masks;
 }
 
