@@ -297,6 +297,8 @@ struct StagedOptions {
     size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it quadruples with every further stage the query
                                              // needs (up to 16x), so a skewed batch is not held to many stages by its heaviest query
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
+    size_t wave_ops = 192u << 10;            // queries BEGIN in waves of about this many ops (growing with the ops already emitted), so that the
+                                             // device runs wave n while the host expands wave n+1; 0: everybody begins in the first stage
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;
     DenseOptions dense;                      // run_staged fills `pool` itself

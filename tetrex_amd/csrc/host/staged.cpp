@@ -77,7 +77,7 @@ class StagedRun {
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
           dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
-          fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
+          fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
           busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         verified_levels_ = opt.verified_levels;
@@ -96,6 +96,8 @@ class StagedRun {
         dense_total_ = dense_pool_.load();
         admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)INT64_MAX / 4);
         dense_.pool = &dense_pool_;
+        wave_ops_ = opt.wave_ops;
+        if (const char* e = std::getenv("TETREX_WAVE_OPS")) wave_ops_ = (size_t)std::max(0LL, std::atoll(e));  // A/B knob; 0 = one wave
         if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
     }
 
@@ -107,7 +109,7 @@ class StagedRun {
         for (bool first = true;; first = false) {
             const size_t stage_ops = advance_stage(first);
             bool pending = false;
-            for (size_t i = 0; i < n_; ++i) pending |= q_[i] && !q_[i]->done();
+            for (size_t i = 0; i < n_; ++i) pending |= unbuilt_[i] || (q_[i] && !q_[i]->done());
             if (!first && stage_ops == 0 && !pending) break;
             const Blob blob = assemble();
             Frontier fr = collect_frontier();
@@ -139,6 +141,7 @@ class StagedRun {
         std::vector<uint32_t> program, slot;   // the questions: is slot `slot[a]` of program `program[a]` alive?
         std::vector<uint8_t> alive;            // the answers
         std::vector<uint32_t> run_on;          // unfinished queries that did not ask
+        std::vector<uint32_t> waiting;         // queries that have not begun (a later wave)
     };
 
     void lap(const char* what) {
@@ -148,17 +151,18 @@ class StagedRun {
         lap_at_ = now;
     }
 
+    // A query's k-graph and expansion are built when the query begins (advance_set), i.e. wave by wave: only the first
+    // wave's graphs are built before the device has something to do.
     void build_expansions() {
-        pool_.run(n_, [&](size_t i, int) {
-            try {
-                if (bins_ <= 1) { passthrough_[i] = 1; return; }  // include/query.h:265-272
-                const std::string postfix = preprocess_query(regexes_[i], enc_);
-                q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps, dense_);
-                if (q_[i]->dense_block_slots()) dense_block_slots_.store(q_[i]->dense_block_slots(), std::memory_order_relaxed);
-            } catch (const std::exception& e) {
-                fail(i, e);
-            }
-        });
+        for (size_t i = 0; i < n_; ++i) {
+            if (bins_ <= 1) passthrough_[i] = 1;  // include/query.h:265-272
+            else unbuilt_[i] = 1;
+        }
+    }
+    void build_one(size_t i) {  // throws what the front-end throws
+        const std::string postfix = preprocess_query(regexes_[i], enc_);
+        q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps, dense_);
+        if (q_[i]->dense_block_slots()) dense_block_slots_.store(q_[i]->dense_block_slots(), std::memory_order_relaxed);
     }
 
     // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned query is
@@ -179,11 +183,15 @@ class StagedRun {
     size_t advance_set(std::vector<uint32_t>& set, size_t already, size_t feedback_budget) {
         {
             std::vector<uint64_t> w(n_, 0);
-            for (uint32_t i : set) w[i] = q_[i]->weight();
+            for (uint32_t i : set) w[i] = q_[i] ? q_[i]->weight() : (uint64_t)regexes_[i].size() * regexes_[i].size();  // not built yet: by length
             std::stable_sort(set.begin(), set.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });  // a stage ends when its last task ends
         }
         std::fill(busy_.begin(), busy_.end(), 0.0);
         std::atomic<size_t> total{already};
+        // Queries begin in waves: the first stage goes to the device after about wave_ops_ ops, and the later waves are
+        // expanded while it executes (execute()); the waves grow with what has been emitted, so a large batch does not
+        // turn into many small stages.
+        const size_t wave_limit = wave_ops_ ? std::max<size_t>(wave_ops_, (size_t)(st_.ops / 2)) : 0;
         // Dense blocks are device memory: when the run's pool runs low, queries that have not begun wait for a later stage —
         // those under way finish, hand their blocks back (and the device recycles their regions) — instead of everybody
         // starting at once and the late ones falling back to enumerated states.  Somebody is always under way.
@@ -194,14 +202,25 @@ class StagedRun {
             const size_t i = set[at];
             const double t0 = trace_ ? now_seconds() : 0.0;
             if (total.load(std::memory_order_relaxed) >= opt_.ops_per_stage) return;  // waits for a later stage
-            if (dense_.enabled && !started_[i]) {
+            if (!started_[i]) {
+                if (wave_limit && total.load(std::memory_order_relaxed) >= wave_limit && begun.load(std::memory_order_relaxed) > 0) return;
                 // admission by an estimate of four blocks per query (what a chain of steps through x(m,n) gaps holds at a time)
-                if (admitted_.fetch_add(admit_bytes_, std::memory_order_relaxed) + admit_bytes_ > dense_total_ && begun.load(std::memory_order_relaxed) > 0) {
+                if (dense_.enabled && admitted_.fetch_add(admit_bytes_, std::memory_order_relaxed) + admit_bytes_ > dense_total_ &&
+                    begun.load(std::memory_order_relaxed) > 0) {
                     admitted_.fetch_sub(admit_bytes_, std::memory_order_relaxed);
                     return;
                 }
                 started_[i] = 1;
                 begun.fetch_add(1, std::memory_order_relaxed);
+                if (unbuilt_[i]) {
+                    unbuilt_[i] = 0;
+                    try {
+                        build_one(i);
+                    } catch (const std::exception& e) {
+                        fail(i, e);
+                        return;
+                    }
+                }
             }
             try {
                 // a query that gains nothing from feedback only pauses to keep the stage's tasks even
@@ -260,12 +279,13 @@ class StagedRun {
                 unfinished += q_[i] && !q_[i]->done();
                 continue;
             }
-            if (q_[i] && !q_[i]->done()) { act.push_back((uint32_t)i); ++unfinished; }
+            if (unbuilt_[i] || (q_[i] && !q_[i]->done())) { act.push_back((uint32_t)i); ++unfinished; }
         }
         // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
         size_t feedback_budget = unfinished ? opt_.stage_target_ops / unfinished : opt_.ops_per_query_per_stage;
         if (feedback_budget < opt_.ops_per_query_per_stage) feedback_budget = opt_.ops_per_query_per_stage;
         if (feedback_budget > opt_.ops_per_task) feedback_budget = run_on_budget_;
+        feedback_budget_ = feedback_budget;
         const size_t total = carried_ + advance_set(act, carried_, feedback_budget);
         carried_ = 0;
         for (uint32_t i : act)
@@ -372,6 +392,7 @@ class StagedRun {
     Frontier collect_frontier() {
         Frontier fr;
         for (size_t i = 0; i < n_; ++i) {
+            if (unbuilt_[i] || (q_[i] && !q_[i]->done() && !started_[i])) { fr.waiting.push_back((uint32_t)i); continue; }
             if (!q_[i] || q_[i]->done()) continue;
             (q_[i]->wants_feedback() ? fr.queries : fr.run_on).push_back((uint32_t)i);
         }
@@ -392,19 +413,22 @@ class StagedRun {
         return fr;
     }
 
-    // The device runs the stage; meanwhile the queries that do not wait for its answer go on
-    // (`ahead`; their ops are carried into the next stage).
+    // The device runs the stage; meanwhile the queries that do not wait for its answer go on, and the next wave of
+    // queries begins (`ahead`; their ops are carried into the next stage).
     void execute(const Blob& blob, Frontier& fr) {
         const double start = now_seconds();
-        if (overlap_ && !fr.run_on.empty()) {
+        if (overlap_ && (!fr.run_on.empty() || !fr.waiting.empty())) {
             std::future<void> running = std::async(std::launch::async, [&]() { exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive); });
+            std::vector<uint32_t> set = fr.run_on;
+            set.insert(set.end(), fr.waiting.begin(), fr.waiting.end());
             try {
-                carried_ = advance_set(fr.run_on, 0, run_on_budget_);
+                carried_ = advance_set(set, 0, feedback_budget_);
             } catch (...) {
                 running.wait();
                 throw;
             }
-            for (uint32_t i : fr.run_on) ahead_[i] = 1;
+            for (uint32_t i : set)
+                if (started_[i]) ahead_[i] = 1;
             const double ahead_s = now_seconds() - start;
             lap("ahead");
             running.get();
@@ -462,7 +486,8 @@ class StagedRun {
     std::vector<uint32_t> touched_;                   // queries with ops or k-mers in the stage being built, ascending
     std::vector<uint8_t> ahead_;                      // advanced while the previous stage executed
     std::vector<uint32_t> run_on_stages_;             // per query: stages it has run without asking for feedback
-    std::vector<uint8_t> started_;                    // per query: its expansion has begun (dense-memory admission)
+    std::vector<uint8_t> started_;                    // per query: its expansion has begun (waves, dense-memory admission)
+    std::vector<uint8_t> unbuilt_;                    // per query: its k-graph is still to be built (when it begins)
     std::vector<uint8_t> flushed_, released_;         // finished and its last ops handed to the device / its blocks handed back
     std::vector<uint64_t> held_;                      // bytes of the dense pool a finished query still holds
     int64_t dense_total_ = 0, admit_bytes_ = 0;       // the pool's size; what a query is assumed to need when it is admitted
@@ -471,7 +496,8 @@ class StagedRun {
     std::vector<double> busy_;
     BlobStore blob_store_;
     StagedStats st_;
-    size_t run_on_budget_ = 0;
+    size_t run_on_budget_ = 0, feedback_budget_ = 0;  // the latter: what a query that asks gets per stage (advance_stage sets it)
+    size_t wave_ops_ = 0;
     bool trace_ = false, verified_levels_ = true, overlap_ = true;
     double lap_at_ = 0;
 };

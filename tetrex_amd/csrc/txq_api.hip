@@ -123,7 +123,10 @@ void Index::release() {
     }
     host_pipe = HostPipe{};
     for (const ArenaChunk& c : session_cache.chunks) (void)hipFree(c.p);
-    for (void* p : {(void*)session_cache.d_base, (void*)session_cache.d_blob, (void*)session_cache.d_aux})
+    for (StagingSet& t : session_cache.set)
+        if (t.done) (void)hipEventDestroy(t.done);
+    if (session_cache.upload) (void)hipStreamDestroy(session_cache.upload);
+    for (void* p : {(void*)session_cache.set[0].d_blob, (void*)session_cache.set[0].d_aux, (void*)session_cache.set[1].d_blob, (void*)session_cache.set[1].d_aux})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
     if (d_children) (void)hipFree(d_children);
@@ -149,7 +152,10 @@ void Index::release() {
 
 int ensure(void** p, size_t* cap, size_t bytes) {
     if (*cap >= bytes && *p) return TXQ_OK;
-    if (*p) (void)hipFree(*p);
+    if (*p) {  // kernels in flight may still use the buffer (a session's stages are not waited for one by one)
+        (void)hipDeviceSynchronize();
+        (void)hipFree(*p);
+    }
     *p = nullptr; *cap = 0;
     hipError_t e = hipMalloc(p, bytes);
     if (e != hipSuccess) return fail_hip(e, "hipMalloc(scratch)");

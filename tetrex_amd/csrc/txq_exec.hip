@@ -634,7 +634,8 @@ Session::~Session() {
                 n_dense_launches, n_dense_tiles);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
-    if (d_moves) (void)hipFree(d_moves);
+    for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
+        if (t.pending) { (void)hipEventSynchronize(t.done); t.pending = false; }
     if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
         size_t kept = 0;
@@ -642,14 +643,18 @@ Session::~Session() {
             if (kept + k.cap * 8 <= Index::kArenaKeepBytes) { c.chunks.push_back(k); kept += k.cap * 8; }
             else (void)hipFree(k.p);
         }
-        c.d_base = d_base; c.cap_base = cap_base;
-        c.d_blob = d_blob; c.cap_blob = cap_blob;
-        c.d_aux = d_aux; c.cap_aux = cap_aux;
+        c.set[0] = set[0];
+        c.set[1] = set[1];
+        c.upload = upload;
         c.in_use = false;
         return;
     }
     for (const Index::ArenaChunk& k : chunks) (void)hipFree(k.p);
-    for (void* p : {(void*)d_base, (void*)d_blob, (void*)d_aux}) if (p) (void)hipFree(p);
+    for (Index::StagingSet& t : set) {
+        if (t.done) (void)hipEventDestroy(t.done);
+        for (void* p : {(void*)t.d_blob, (void*)t.d_aux}) if (p) (void)hipFree(p);
+    }
+    if (upload) (void)hipStreamDestroy(upload);
 }
 
 
@@ -689,28 +694,29 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
         s->owns_cache = true;
         s->chunks.swap(c.chunks);
         for (const Index::ArenaChunk& k : s->chunks) s->arena_words += k.cap;
-        s->d_base = c.d_base; s->cap_base = c.cap_base;
-        s->d_blob = c.d_blob; s->cap_blob = c.cap_blob;
-        s->d_aux = c.d_aux; s->cap_aux = c.cap_aux;
+        s->set[0] = c.set[0];
+        s->set[1] = c.set[1];
+        s->upload = c.upload;
         c = Index::SessionCache{};
         c.in_use = true;
     }
-    if (2 * n_programs > s->cap_base) {
-        if (s->d_base) (void)hipFree(s->d_base);
-        s->d_base = nullptr;
-        s->cap_base = 0;
-        hipError_t e = hipMalloc((void**)&s->d_base, 2 * n_programs * sizeof(uint64_t*));
-        if (e != hipSuccess) { delete s; return fail_hip(e, "hipMalloc(session)"); }
-        s->cap_base = 2 * n_programs;
+    if (!s->upload) {
+        hipError_t e = hipStreamCreateWithFlags(&s->upload, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete s; return fail_hip(e, "hipStreamCreate(session upload)"); }
     }
+    for (Index::StagingSet& t : s->set)
+        if (!t.done) {
+            hipError_t e = hipEventCreateWithFlags(&t.done, hipEventDisableTiming);
+            if (e != hipSuccess) { delete s; return fail_hip(e, "hipEventCreate(session)"); }
+        }
     *out = s;
     return TXQ_OK;
 }
 
 // (re)size the programs' slot regions to what the stage needs; a grown region keeps its contents
-static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, hipStream_t st) {
-    bool moved = false;
-    std::vector<RegionMove> moves;
+// (host side only: the caller uploads `moves` and the base table with the stage and launches move_regions_kernel)
+static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out) {
+    std::vector<RegionMove>& moves = *moves_out;
     std::vector<std::pair<uint32_t, uint64_t*>> outgrown;
     // a program that reports no dense slots any more is finished with its blocks: its region serves another program
     // (the kernels of this stage run after everything the old owner launched: same stream)
@@ -720,7 +726,6 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
                 s.free_dense.emplace(s.dcap[p], s.base[s.n_programs + p]);
                 s.base[s.n_programs + p] = nullptr;
                 s.dcap[p] = 0;
-                moved = true;
             }
     for (size_t p = 0; p < s.n_programs; ++p) {
         const uint32_t need = bv.n_slots[p];
@@ -733,7 +738,6 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             else fresh->push_back((uint32_t)p);
             s.base[p] = region;
             s.cap[p] = cap;
-            moved = true;
         }
         const uint32_t dneed = bv.n_dense_slots[p];
         if (dneed > s.dcap[p]) {  // whole blocks; doubling keeps the copies (and the abandoned regions) within 2x
@@ -752,18 +756,9 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             }
             s.base[s.n_programs + p] = region;
             s.dcap[p] = cap;
-            moved = true;
         }
     }
-    if (!moves.empty()) {
-        if (int rc = ensure((void**)&s.d_moves, &s.cap_moves, moves.size() * sizeof(RegionMove))) return rc;
-        TXQ_HIP(hipMemcpyAsync(s.d_moves, moves.data(), moves.size() * sizeof(RegionMove), hipMemcpyHostToDevice, st));
-        TXQ_HIP(hipStreamSynchronize(st));  // `moves` is a local
-        move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)s.d_moves);
-        TXQ_HIP(hipGetLastError());
-    }
     for (const auto& r : outgrown) s.free_dense.emplace(r.first, r.second);
-    if (moved) TXQ_HIP(hipMemcpyAsync(s.d_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
     return TXQ_OK;
 }
 
@@ -891,7 +886,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (any_dense && !ix.is_hibf && (ix.ibf[0].bin_size >> 32))
         return fail(TXQ_ERR_PROGRAM, "dense ops need fewer than 2^32 rows");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
-    if (int rc = grow_slot_regions(s, bv, &fresh, st)) return rc;
+    std::vector<RegionMove> moves;
+    if (int rc = grow_slot_regions(s, bv, &fresh, &moves)) return rc;
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
     const bool wide = W % 2 == 0 && !ix.is_hibf && ix.ibf[0].stride % 2 == 0;
@@ -935,51 +931,75 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         chunk_first.push_back(hsteps.size());
     }
 
-    // staging: blob | normalised program table | fresh-program list | feedback queries | alive bytes | units | tiles
-    const size_t blob_pad = (bytes + 7) & ~(size_t)7;
-    if (int rc = ensure((void**)&s.d_blob, &s.cap_blob, blob_pad)) return rc;
+    // Staging set of this stage (the other one may still be read by the previous stage's kernels; this one was last used
+    // two stages ago): blob, and aux = program table | fresh-program list | feedback queries | alive bytes | units | tiles |
+    // HIBF steps | their pair bases | region moves | region bases.  Everything is copied on the upload stream and the host
+    // waits for THOSE copies only (pageable sources, some of them locals) — not for the kernels of the previous stage.
+    Index::StagingSet& S = s.set[(s.n_stages - 1) & 1];
+    if (S.pending) {
+        TXQ_HIP(hipEventSynchronize(S.done));
+        S.pending = false;
+    }
+    size_t aux_bytes = 0;
+    auto place = [&](size_t bytes) { const size_t at = aux_bytes; aux_bytes = (aux_bytes + bytes + 15) & ~(size_t)15; return at; };
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
-    const size_t small_bytes = prog_bytes + fresh.size() * 4 + n_q * 8 + ((n_q + 7) & ~(size_t)7) + 64;
-    const size_t aux_bytes = small_bytes + units.size() * sizeof(ExecUnit) + 32 + (tiles.size() + hsteps.size()) * sizeof(DenseTile) + hsteps.size() * 4;
-    if (int rc = ensure((void**)&s.d_aux, &s.cap_aux, aux_bytes)) return rc;
+    const size_t at_progs = place(prog_bytes), at_fresh = place(fresh.size() * 4), at_qp = place(n_q * 4), at_qs = place(n_q * 4), at_alive = place(n_q);
+    const size_t at_units = place(units.size() * sizeof(ExecUnit)), at_tiles = place(tiles.size() * sizeof(DenseTile));
+    const size_t at_hsteps = place(hsteps.size() * sizeof(DenseTile)), at_pair_base = place(hsteps.size() * 4);
+    const size_t at_moves = place(moves.size() * sizeof(RegionMove)), at_base = place(2 * s.n_programs * sizeof(uint64_t*));
+    const size_t blob_pad = (bytes + 7) & ~(size_t)7;
+    if (int rc = ensure((void**)&S.d_blob, &S.cap_blob, blob_pad)) return rc;
+    if (int rc = ensure((void**)&S.d_aux, &S.cap_aux, aux_bytes + 16)) return rc;
     const size_t nk = h->n_kmers;
-    if (int rc = ensure((void**)&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
-    TXQ_HIP(hipMemcpyAsync(s.d_blob, blob, bytes, hipMemcpyHostToDevice, st));
-    DevProgram* d_progs = (DevProgram*)s.d_aux;
-    TXQ_HIP(hipMemcpyAsync(d_progs, bv.programs.data(), prog_bytes, hipMemcpyHostToDevice, st));
-    uint32_t* d_fresh = (uint32_t*)(s.d_aux + prog_bytes);
-    uint32_t* d_qp = d_fresh + fresh.size();
-    uint32_t* d_qs = d_qp + n_q;
-    uint8_t* d_alive = (uint8_t*)(d_qs + n_q);
-    ExecUnit* d_units = (ExecUnit*)(s.d_aux + small_bytes - 32);
-    DenseTile* d_tiles = (DenseTile*)(((uintptr_t)(d_units + units.size()) + 15) & ~(uintptr_t)15);
-    if (!units.empty()) TXQ_HIP(hipMemcpyAsync(d_units, units.data(), units.size() * sizeof(ExecUnit), hipMemcpyHostToDevice, st));
-    if (!tiles.empty()) TXQ_HIP(hipMemcpyAsync(d_tiles, tiles.data(), tiles.size() * sizeof(DenseTile), hipMemcpyHostToDevice, st));
-    DenseTile* d_hsteps = d_tiles + tiles.size();
-    uint32_t* d_pair_base = (uint32_t*)(d_hsteps + hsteps.size());
+    // scratch the kernels in flight may still use: replacing it drains the device (ensure), so replace it generously
+    auto ensure_scratch = [&](uint64_t** p, size_t* cap, size_t need) -> int {
+        if (*p && *cap >= need) return TXQ_OK;
+        return ensure((void**)p, cap, std::max(need + need / 2, (size_t)64 << 20));
+    };
+    if (int rc = ensure_scratch(&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
+    hipStream_t up = s.upload;
+    auto send = [&](size_t at, const void* src, size_t n) -> hipError_t {
+        return n ? hipMemcpyAsync(S.d_aux + at, src, n, hipMemcpyHostToDevice, up) : hipSuccess;
+    };
+    TXQ_HIP(hipMemcpyAsync(S.d_blob, blob, bytes, hipMemcpyHostToDevice, up));
+    TXQ_HIP(send(at_progs, bv.programs.data(), prog_bytes));
+    TXQ_HIP(send(at_fresh, fresh.data(), fresh.size() * 4));
+    TXQ_HIP(send(at_qp, q_prog, n_q * 4));
+    TXQ_HIP(send(at_qs, q_slot, n_q * 4));
+    TXQ_HIP(send(at_units, units.data(), units.size() * sizeof(ExecUnit)));
+    TXQ_HIP(send(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile)));
+    TXQ_HIP(send(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile)));
+    TXQ_HIP(send(at_pair_base, pair_base.data(), hsteps.size() * 4));
+    TXQ_HIP(send(at_moves, moves.data(), moves.size() * sizeof(RegionMove)));
+    TXQ_HIP(send(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*)));
+    DevProgram* d_progs = (DevProgram*)(S.d_aux + at_progs);
+    uint32_t* d_fresh = (uint32_t*)(S.d_aux + at_fresh);
+    uint32_t* d_qp = (uint32_t*)(S.d_aux + at_qp);
+    uint32_t* d_qs = (uint32_t*)(S.d_aux + at_qs);
+    uint8_t* d_alive = S.d_aux + at_alive;
+    ExecUnit* d_units = (ExecUnit*)(S.d_aux + at_units);
+    DenseTile* d_tiles = (DenseTile*)(S.d_aux + at_tiles);
+    DenseTile* d_hsteps = (DenseTile*)(S.d_aux + at_hsteps);
+    uint32_t* d_pair_base = (uint32_t*)(S.d_aux + at_pair_base);
+    s.d_base = (uint64_t**)(S.d_aux + at_base);
     if (!hsteps.empty()) {
-        TXQ_HIP(hipMemcpyAsync(d_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile), hipMemcpyHostToDevice, st));
-        TXQ_HIP(hipMemcpyAsync(d_pair_base, pair_base.data(), hsteps.size() * 4, hipMemcpyHostToDevice, st));
-        if (int rc = ensure((void**)&ix.scratch_dense_kmers, &ix.cap_dense_kmers, most_pairs * 8)) return rc;
-        if (int rc = ensure((void**)&ix.scratch_dense_masks, &ix.cap_dense_masks, most_pairs * (size_t)W * 8)) return rc;
+        if (int rc = ensure_scratch(&ix.scratch_dense_kmers, &ix.cap_dense_kmers, most_pairs * 8)) return rc;
+        if (int rc = ensure_scratch(&ix.scratch_dense_masks, &ix.cap_dense_masks, most_pairs * (size_t)W * 8)) return rc;
     }
-    if (!fresh.empty()) TXQ_HIP(hipMemcpyAsync(d_fresh, fresh.data(), fresh.size() * 4, hipMemcpyHostToDevice, st));
-    if (n_q) {
-        TXQ_HIP(hipMemcpyAsync(d_qp, q_prog, n_q * 4, hipMemcpyHostToDevice, st));
-        TXQ_HIP(hipMemcpyAsync(d_qs, q_slot, n_q * 4, hipMemcpyHostToDevice, st));
-    }
-    // pageable host buffers: the copies above have left host memory once the stream drains;
-    // `fresh`/`base` are locals, so drain before they go out of scope or are reused
-    TXQ_HIP(hipStreamSynchronize(st));
+    TXQ_HIP(hipStreamSynchronize(up));
     s.t_upload += now_s() - t0;
     t0 = now_s();
 
+    if (!moves.empty()) {  // after everything earlier stages launched on the regions, before anything of this stage
+        move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)(S.d_aux + at_moves));
+        TXQ_HIP(hipGetLastError());
+    }
     if (!fresh.empty()) {
         size_t blocks = (fresh.size() * W + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
     }
-    const uint64_t* d_kmers = (const uint64_t*)(s.d_blob + h->kmers_offset);
+    const uint64_t* d_kmers = (const uint64_t*)(S.d_blob + h->kmers_offset);
     const size_t n_aux = (size_t)h->n_aux_kmers, n_main = nk - n_aux;
     if (n_aux && !s.aux) return fail(TXQ_ERR_STATE, "the blob has auxiliary (d-gram) k-mers but the session has no auxiliary index");
     if (n_main) {
@@ -1000,9 +1020,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         int g = 1;
         while (g < 1024 && (uint32_t)g < W) g <<= 1;
         const int g_units = g < 256 ? g : 256;
-        const txq_op* d_ops = (const txq_op*)(s.d_blob + h->ops_offset);
-        const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(s.d_blob + h->levels_offset) : nullptr;
-        const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(s.d_blob + h->dense_offset) : nullptr;
+        const txq_op* d_ops = (const txq_op*)(S.d_blob + h->ops_offset);
+        const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(S.d_blob + h->levels_offset) : nullptr;
+        const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(S.d_blob + h->dense_offset) : nullptr;
         const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
@@ -1078,7 +1098,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         TXQ_HIP(hipMemcpyAsync(alive, d_alive, n_q, hipMemcpyDeviceToHost, st));
         TXQ_HIP(hipStreamSynchronize(st));
     }
-    if (std::getenv("TXQ_TRACE")) { (void)hipStreamSynchronize(st); }
+    TXQ_HIP(hipEventRecord(S.done, st));
+    S.pending = true;
+    static const bool trace_sync = std::getenv("TXQ_TRACE_SYNC") != nullptr;  // charges the device time to the stage that caused it
+    if (trace_sync) (void)hipStreamSynchronize(st);
     s.t_device += now_s() - t0;
     return TXQ_OK;
 }

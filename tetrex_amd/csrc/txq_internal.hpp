@@ -54,11 +54,19 @@ struct Index {
     // Device buffers of the last session, kept for the next one: a single query must not pay
     // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.
     struct ArenaChunk { uint64_t* p; size_t cap; };  // cap in 64-bit words
-    struct SessionCache {
-        std::vector<ArenaChunk> chunks;                    // slot-arena chunks, at most kArenaKeepBytes in all
-        uint64_t** d_base = nullptr; size_t cap_base = 0;  // entries
+    // What one stage of a session uploads: the blob, and `aux` = program table, lists, units, tiles, region moves and the
+    // table of region bases.  A session alternates between two sets, so stage n+1 is uploaded (on its own stream) while
+    // the kernels of stage n still read theirs; `done` is recorded behind a stage's last kernel.
+    struct StagingSet {
         unsigned char* d_blob = nullptr; size_t cap_blob = 0;
         unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+    };
+    struct SessionCache {
+        std::vector<ArenaChunk> chunks;  // slot-arena chunks, at most kArenaKeepBytes in all
+        StagingSet set[2];
+        hipStream_t upload = nullptr;
         bool in_use = false;
     } session_cache;
     static constexpr size_t kArenaKeepBytes = (size_t)64 << 30;
@@ -91,11 +99,10 @@ struct Session {
     std::vector<uint32_t> cap;      // per program: slots allocated
     std::vector<uint32_t> dcap;     // per program: dense slots allocated (include/txq_program.h, version 3)
     std::multimap<uint32_t, uint64_t*> free_dense;  // dense regions given back by finished programs / outgrown: capacity in slots -> region
-    uint64_t** d_base = nullptr; size_t cap_base = 0;  // device copy of `base`
-    bool owns_cache = false;  // buffers came from / go back to ix->session_cache
-    unsigned char* d_blob = nullptr; size_t cap_blob = 0;
-    unsigned char* d_aux = nullptr; size_t cap_aux = 0;
-    unsigned char* d_moves = nullptr; size_t cap_moves = 0;  // list of grown regions to copy (txq_exec.hip move_regions_kernel)
+    uint64_t** d_base = nullptr;  // device copy of `base` as of the last stage (lives in that stage's staging set)
+    bool owns_cache = false;      // buffers came from / go back to ix->session_cache
+    Index::StagingSet set[2];     // stage n uses set[n & 1]
+    hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
     size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;

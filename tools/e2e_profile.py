@@ -11,7 +11,7 @@ m = bench.compute_bitcount(200000, 0.05)
 ix = bench.build_index(capi, torch, 1024, 1024, m, 3, 0, 1, 200000, 20)
 motifs = random_prosite_motifs(int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 6)
 ix.query_masks(motifs[:10], False, 4)
-for rep in range(4):
+for rep in range(int(os.environ.get("REPS", "6"))):
     t0 = time.perf_counter()
     masks, status, stats = ix.query_masks(motifs, False, 4)
     dt = time.perf_counter() - t0
