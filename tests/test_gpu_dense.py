@@ -113,6 +113,30 @@ def test_dense_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
         assert checked == len(qs) and dense_ops > 30
 
 
+@pytest.mark.parametrize("task_ops", [None, "300"])
+def test_waves_of_queries_on_a_session_that_is_never_waited_for(capi, oracle, monkeypatch, task_ops):
+    """Small waves (TETREX_WAVE_OPS): many stages none of which asks a question, so the host submits stage n+1 (other
+    staging set, upload stream) while the kernels of stage n run; with a small task budget the queries also CONTINUE
+    across those stages (regions grow and move, blocks live from one stage to the next).  Masks equal the oracle's."""
+    monkeypatch.setenv("TETREX_WAVE_OPS", "500")
+    if task_ops:
+        monkeypatch.setenv("TETREX_TASK_OPS", task_ops)
+    ox = _oracle_index(oracle, bins=1000, m=30011, h=3, k=4, dna=False, per_bin=3000, seed=21)
+    qs = random_prosite_motifs(120, 21, wildcard=0.12, ranges=0.08)
+    wants = _wants(ox, qs)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    for rep in range(2):  # the second session adopts the first one's staging sets and stream
+        got, status, stats = ix.query_masks(qs, False, 4, 0, 0)
+        assert stats["stages"] >= 4 and stats["dense_ops"] > 50
+        for q, g, w, st in zip(qs, got, wants, status):
+            if w is False:
+                assert st != 0, q
+            else:
+                assert st == 0 and np.array_equal(g, w), q
+    ix.free()
+
+
 def test_saturated_motifs_cost_few_host_ops(capi, oracle):
     """Defaults: the wildcard-rich motifs of the bench batch.  Masks equal the oracle's and the host emits a small
     fraction of the ops it needs without dense steps."""

@@ -101,3 +101,22 @@ def test_default_policy_on_sparse_and_dense_indexes_at_k5(host, oracle):
     assert checked == len(qs) and stats["pruned"] == 0
     for i in range(len(qs)):
         assert int(sim.result(i)[0]) == 0xFFFFFFFFFFFFFFFF
+
+
+@pytest.mark.parametrize("wave_ops", ["0", "64", "2000"])
+def test_waves_of_queries_give_the_same_masks(host, oracle, monkeypatch, wave_ops):
+    """Queries begin in waves (TETREX_WAVE_OPS; the k-graph of a query is built when it begins), the later waves while
+    the previous stage executes: more stages, the same masks, and a motif that fails to parse fails alone."""
+    ox = _index(oracle, bins=130, m=4099, h=3, k=4, dna=False, per_bin=900, seed=11)
+    qs = random_prosite_motifs(24, 5, wildcard=0.05, ranges=0.03)
+    qs.insert(7, "AC(DE")  # syntax error in the middle of a wave
+    monkeypatch.setenv("TETREX_WAVE_OPS", wave_ops)
+    checked, stats, sim = _run(host, ox, qs, False, 4, 0)
+    assert checked >= len(qs) - 6
+    if wave_ops == "0":
+        test_waves_of_queries_give_the_same_masks.one_wave = stats
+    elif wave_ops == "64":
+        assert stats["stages"] >= 4
+        one = getattr(test_waves_of_queries_give_the_same_masks, "one_wave", None)
+        if one is not None:
+            assert stats["stages"] > one["stages"]

@@ -114,12 +114,11 @@ struct ExecUnit { uint32_t program, begin, end; };
 static constexpr uint32_t kUnitWords = 2048;  // mask words one unit moves per operand: 128 ops of a 1024-bin index, 2 ops at 65536 bins
 static inline uint32_t unit_ops(uint32_t W) { return W >= kUnitWords ? 1u : kUnitWords / W; }
 
-template <int G>
-__global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
-                                                         uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                         const uint64_t* __restrict__ M, uint32_t W) {
-    const ExecUnit u = units[blockIdx.x];
-    const uint32_t sub = threadIdx.x % G, group = threadIdx.x / G, n_groups = blockDim.x / G;
+// g_log2: log2 of the lanes per op (a power of two <= 256)
+__device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restrict__ ops, uint64_t* const* __restrict__ slot_base,
+                                         uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
+    const uint32_t G = 1u << g_log2;
+    const uint32_t sub = threadIdx.x & (G - 1), group = threadIdx.x >> g_log2, n_groups = blockDim.x >> g_log2;
     uint64_t* S = slot_base[u.program];
     uint64_t* D = slot_base[n_programs + u.program];
     for (uint32_t i = u.begin + group; i < u.end; i += n_groups) {
@@ -143,6 +142,16 @@ __global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restr
         }
     }
 }
+
+__global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
+                                                         uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                         const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
+    run_unit(units[blockIdx.x], ops, slot_base, n_programs, M, W, g_log2);
+}
+
+// The units of a level that also has dense tiles ride in the dense launch (its first `n_units` workgroups): the ordinary
+// and the dense ops of one level are independent, and a level costs one kernel boundary instead of two.
+struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M; uint32_t n_units, g_log2; };
 
 // ---- dense DP steps ---------------------------------------------------------------------------
 // One workgroup per tile: `count` work entries of one dense op, starting at `first`.
@@ -202,12 +211,16 @@ __device__ __forceinline__ void issue_loads(const IbfDev& f, const uint64_t* src
 template <int H, bool WIDE, int UA>
 __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
                                                     uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
-                                                    uint32_t G, uint32_t SL, DenseParams P) {
+                                                    uint32_t G, uint32_t SL, DenseParams P, LevelUnits U) {
     using L = Lane<WIDE>;
     using T = typename L::T;
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // [j < pos]: codes of shape[j]; [pos]: codes of r_mask
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
-    const DenseTile t = tiles[blockIdx.x];
+    if (blockIdx.x < U.n_units) {  // the whole workgroup: no barrier has been reached
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
+        return;
+    }
+    const DenseTile t = tiles[blockIdx.x - U.n_units];
     const txq_dense_op d = dops[t.op];
     uint64_t* S = slot_base[t.program];
     uint64_t* D = slot_base[n_programs + t.program];
@@ -839,14 +852,15 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
 
 template <bool WIDE>
 static hipError_t launch_dense(const IbfDev& f, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
-                               uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, hipStream_t st) {
+                               uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, const LevelUnits& U, hipStream_t st) {
+    const size_t grid = n_tiles + U.n_units;
     // predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
     static const int ua = std::getenv("TXQ_DENSE_UNROLL") ? std::atoi(std::getenv("TXQ_DENSE_UNROLL")) : 3;
 #define TXQ_DENSE(H) \
     do { \
-        if (ua >= 6) dense_kernel<H, WIDE, 6><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
-        else if (ua <= 2) dense_kernel<H, WIDE, 2><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
-        else dense_kernel<H, WIDE, 3><<<(unsigned)n_tiles, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P); \
+        if (ua >= 6) dense_kernel<H, WIDE, 6><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        else if (ua <= 2) dense_kernel<H, WIDE, 2><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        else dense_kernel<H, WIDE, 3><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
     } while (0)
     switch (f.hash_funs) {
         case 1: TXQ_DENSE(1); break;
@@ -1020,6 +1034,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         int g = 1;
         while (g < 1024 && (uint32_t)g < W) g <<= 1;
         const int g_units = g < 256 ? g : 256;
+        uint32_t g_units_log2 = 0;
+        while ((1 << g_units_log2) < g_units) ++g_units_log2;
+        static const bool fuse_units = !(std::getenv("TXQ_FUSE_UNITS") && std::getenv("TXQ_FUSE_UNITS")[0] == '0');  // A/B knob
         const txq_op* d_ops = (const txq_op*)(S.d_blob + h->ops_offset);
         const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(S.d_blob + h->levels_offset) : nullptr;
         const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(S.d_blob + h->dense_offset) : nullptr;
@@ -1046,24 +1063,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         for (size_t l = 0; l < plan.size(); ++l) {
             const size_t cnt = plan[l].units;
             ++s.n_levels;
-            if (cnt) {
+            // a flat index runs the level's units inside its dense launch (below); otherwise they are a launch of their own
+            const bool ride = fuse_units && cnt && plan[l].tiles && !ix.is_hibf;
+            if (cnt && !ride) {
                 ++s.n_unit_launches;
-                s.n_units += cnt;
-#define TXQ_UNITS(G) exec_units_kernel<G><<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W)
-                switch (g_units) {
-                    case 1: TXQ_UNITS(1); break;
-                    case 2: TXQ_UNITS(2); break;
-                    case 4: TXQ_UNITS(4); break;
-                    case 8: TXQ_UNITS(8); break;
-                    case 16: TXQ_UNITS(16); break;
-                    case 32: TXQ_UNITS(32); break;
-                    case 64: TXQ_UNITS(64); break;
-                    case 128: TXQ_UNITS(128); break;
-                    default: TXQ_UNITS(256); break;
-                }
-#undef TXQ_UNITS
-                first += cnt;
+                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W, g_units_log2);
             }
+            s.n_units += cnt;
             // HIBF: the level's steps, chunk by chunk: k-mers of all (suffix, predecessor) pairs -> tree descent -> combine
             for (const size_t level_end = first_hstep + plan[l].hsteps; first_hstep < level_end; ++chunk) {
                 const size_t c0 = chunk_first[chunk], c1 = chunk_first[chunk + 1];
@@ -1078,14 +1084,16 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 first_hstep = c1;
                 s.n_dense_tiles += c1 - c0;
             }
-            if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: two launches, no order implied
-                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, st)
-                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, st);
+            if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
+                const LevelUnits lu{d_units + first, d_ops, ix.scratch_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
+                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
                 s.n_dense_tiles += plan[l].tiles;
                 ++s.n_dense_launches;
             }
+            first += cnt;
         }
     }
     hipError_t e = hipGetLastError();
