@@ -327,10 +327,11 @@ class SessionSimulator:
         return self._get(p, 2)
 
 
-def regular_hibf(O, user_bins, children, per_bin, value_fn, h=2, fpr=0.05, dna=False, k=4, reduction=0):
+def regular_hibf(O, user_bins, children, per_bin, value_fn, h=2, fpr=0.05, dna=False, k=4, reduction=0, mixed=False):
     """A regular two-level HIBF (root: `children` merged technical bins; child c: one technical bin
     per user bin of its contiguous range), the layout `tetrex index` writes.  value_fn(user_bin) ->
-    uint64 array of that bin's values.  Returns (oracle index, upload descriptors)."""
+    uint64 array of that bin's values.  mixed: the children differ in their hash counts (h, h + 1) and row counts,
+    and the root has h + 1 hash functions.  Returns (oracle index, upload descriptors)."""
     per_child = -(-user_bins // children)
     ranges = [(c * per_child, min(user_bins, (c + 1) * per_child)) for c in range(children) if c * per_child < user_bins]
     values = [value_fn(b) for b in range(user_bins)]
@@ -339,18 +340,23 @@ def regular_hibf(O, user_bins, children, per_bin, value_fn, h=2, fpr=0.05, dna=F
     m_root = max(1, O.compute_bitcount(max(len(v) for v in root_vals), fpr))
     nxt = np.arange(1, len(ranges) + 1, dtype=np.uint64)
     tbu = np.full(len(ranges), MERGED, dtype=np.uint64)
-    descs = [dict(bins=len(ranges), bin_size=m_root, hash_funs=h, next_ibf_id=nxt, tb_to_user=tbu, words=None)]
-    ox.add_ibf(len(ranges), m_root, h, nxt, tbu)
+    h_root = h + 1 if mixed else h
+    descs = [dict(bins=len(ranges), bin_size=m_root, hash_funs=h_root, next_ibf_id=nxt, tb_to_user=tbu, words=None)]
+    ox.add_ibf(len(ranges), m_root, h_root, nxt, tbu)
     for tb, v in enumerate(root_vals):
         ox.hibf_emplace(0, v, tb)
     for c, (lo, hi) in enumerate(ranges):
         m = max(1, O.compute_bitcount(max(len(values[b]) for b in range(lo, hi)), fpr))
+        hc = h
+        if mixed:
+            m += 7 * (c % 3)
+            hc = h + c % 2
         nx = np.zeros(hi - lo, dtype=np.uint64)
         tb = np.arange(lo, hi, dtype=np.uint64)
-        i = ox.add_ibf(hi - lo, m, h, nx, tb)
+        i = ox.add_ibf(hi - lo, m, hc, nx, tb)
         for t, b in enumerate(range(lo, hi)):
             ox.hibf_emplace(i, values[b], t)
-        descs.append(dict(bins=hi - lo, bin_size=m, hash_funs=h, next_ibf_id=nx, tb_to_user=tb, words=None))
+        descs.append(dict(bins=hi - lo, bin_size=m, hash_funs=hc, next_ibf_id=nx, tb_to_user=tb, words=None))
     for i, d in enumerate(descs):
         d["words"] = ox.hibf_words(i)
     return ox, descs, values

@@ -163,11 +163,15 @@ def test_saturated_motifs_cost_few_host_ops(capi, oracle):
     assert compared >= 6
 
 
-@pytest.mark.parametrize("tree", ["irregular-3-levels", "16x64", "40x128"])
+@pytest.mark.parametrize("tree", ["irregular-3-levels", "16x64", "40x128", "16x64-generic", "40x128-generic", "12x64-mixed", "24x128-mixed",
+                                  "40x128-2shards", "6x256", "16x64-general", "40x128-general", "80x64", "70x128-2shards", "16x64-bylane", "6x256-bylane", "16x64-2shards", "3x64"])
 def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
-    """Dense steps on an HIBF session: the predecessor k-mers of a step are written out, descended as one batch
-    (whatever descent kernel the tree takes: fused, lane-per-k-mer, child-stationary) and combined
-    (txq_exec.hip dense_hibf_*).  Masks against the oracle's collect() over membership_for, thresholds forced low."""
+    """Dense steps on an HIBF session.  Regular two-level trees (the layout `tetrex index` writes) run a step fused like
+    a flat IBF: root bit and child rows gathered per lane (txq_exec.hip TreeRows / TreeRowsByLane for roots of at most 64
+    merged bins / InterleavedRows for small trees of uniform children; one-word and wider children, children of
+    different row and hash counts, column shards).  Other trees — and regular ones with TXQ_DENSE_TREE=0 — write the
+    predecessor k-mers of a step out, descend them as one batch (whatever descent kernel the tree takes) and combine
+    (dense_hibf_*).  Masks against the oracle's collect() over membership_for, thresholds forced low."""
     from helpers import random_hibf, regular_hibf
     rng = np.random.default_rng(17)
     aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
@@ -182,10 +186,19 @@ def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
         planted = [spell(v) for b in range(0, 300, 23) for v in values[b][:3] if all(((int(v) >> sh) & 31) < 20 for sh in (15, 10, 5, 0))]
     else:
         planted = []
-        children, per_child = (16, 64) if tree == "16x64" else (40, 128)
+        shape, _, variant = tree.partition("-")
+        children, per_child = (int(x) for x in shape.split("x"))
         ub = children * per_child
+        if variant == "mixed":
+            ub -= 5  # the last child is not full
+        if variant == "generic":
+            monkeypatch.setenv("TXQ_DENSE_TREE", "0")
+        if variant == "bylane":  # small uniform trees have their children interleaved; this is what they would run otherwise
+            monkeypatch.setenv("TXQ_DENSE_TREE", "2")
+        if variant == "general":  # the variant for large trees (every lane gathers the root words of its own child), forced on a small one
+            monkeypatch.setenv("TXQ_DENSE_TREE", "1")
         seqs = [aa[rng.integers(0, 20, size=203)].tobytes() for _ in range(ub)]
-        ox, descs, values = regular_hibf(oracle, ub, children, 200, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=2)
+        ox, descs, values = regular_hibf(oracle, ub, children, 200, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=2, mixed=variant == "mixed")
     qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]", "LMA(E|Q)GLYN", "A.CD", "K[RK]DE"]
     qs += planted[:12] + [p[0] + "." + p[2:] for p in planted[:6]] + [p[:2] + "[" + "".join(sorted(set(p[2] + "AK"))) + "]" + p[3] for p in planted[6:12]]
     if seqs is not None:  # windows of the bins' own sequences with wildcards: non-trivial masks
@@ -195,25 +208,28 @@ def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
             w[5] = "[" + "".join(sorted(set([w[5], "A", "K"]))) + "]"
             w[7] = ".{0,2}"
             qs.append("".join(w))
-    ix = capi.Index.upload_hibf(ub, descs)
-    for knobs in (("2", "2"), ("1", "0"), None):
-        if knobs:
-            monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
-            monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
-        else:
-            monkeypatch.delenv("TETREX_DENSE_MIN")
-            monkeypatch.delenv("TETREX_DENSE_SPARSE_BELOW")
-        got, status, stats = ix.query_masks(qs, False, 4)
-        assert stats["dense_ops"] > 0
-        hits = 0
-        for q, g, st in zip(qs, got, status):
-            want, ost = ox.query(q, with_stats=True)
-            assert st == 0, q
-            if not ost["quirk_merges"]:
-                assert np.array_equal(g, want), (q, knobs)
-                hits += int(want.any())
-        assert hits >= 3
-    ix.free()
+    n_shards = 2 if tree.endswith("2shards") else 1
+    wants = [ox.query(q, with_stats=True) for q in qs]
+    for rank in range(n_shards):
+        ix = capi.Index.upload_hibf(ub, descs, shard_rank=rank, n_shards=n_shards)
+        lo, nw = int(ix.info.shard_word0), ix.shard_words
+        for knobs in (("2", "2"), ("1", "0"), None):
+            if knobs:
+                monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
+                monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
+            else:
+                monkeypatch.delenv("TETREX_DENSE_MIN")
+                monkeypatch.delenv("TETREX_DENSE_SPARSE_BELOW")
+            got, status, stats = ix.query_masks(qs, False, 4)
+            assert stats["dense_ops"] > 0
+            hits = 0
+            for q, g, st, (want, ost) in zip(qs, got, status, wants):
+                assert st == 0, q
+                if not ost["quirk_merges"]:
+                    assert np.array_equal(g, want[lo:lo + nw]), (q, knobs, rank)
+                    hits += int(want.any())
+            assert hits >= 3
+        ix.free()
 
 
 def test_large_blocks_k5_base_alphabet_and_k6_murphy(capi, oracle, monkeypatch):

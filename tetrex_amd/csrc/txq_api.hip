@@ -130,6 +130,8 @@ void Index::release() {
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
     if (d_children) (void)hipFree(d_children);
+    if (interleaved.words) (void)hipFree(interleaved.words);
+    interleaved = IbfDev{};
     if (scratch_cm) (void)hipFree(scratch_cm);
     if (scratch_crows) (void)hipFree(scratch_crows);
     scratch_crows = nullptr; cap_crows = 0;

@@ -172,6 +172,10 @@ template <> struct Lane<true> {
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *reinterpret_cast<T*>(p) = v; }
     static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
     static __device__ __forceinline__ bool any(T v) { return (v.x | v.y | v.z | v.w) != 0u; }
+    static __device__ __forceinline__ T keep(T v, bool word0, bool word1) {  // zero the words that are not kept
+        const uint32_t m0 = word0 ? ~0u : 0u, m1 = word1 ? ~0u : 0u;
+        return T{v.x & m0, v.y & m0, v.z & m1, v.w & m1};
+    }
     static __device__ __forceinline__ T shfl_xor(T v, uint32_t o) {
         return T{(uint32_t)__shfl_xor((int)v.x, (int)o), (uint32_t)__shfl_xor((int)v.y, (int)o), (uint32_t)__shfl_xor((int)v.z, (int)o),
                  (uint32_t)__shfl_xor((int)v.w, (int)o)};
@@ -184,6 +188,7 @@ template <> struct Lane<false> {
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *p = v; }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool any(T v) { return v != 0; }
+    static __device__ __forceinline__ T keep(T v, bool word0, bool) { return word0 ? v : 0; }
     static __device__ __forceinline__ T shfl_xor(T v, uint32_t o) {
         return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, (int)o);
     }
@@ -195,21 +200,177 @@ __device__ __forceinline__ uint64_t canonical_dna(uint64_t fwd, uint32_t k) {
     return fwd <= rc ? fwd : rc;
 }
 
-// (src[a-th predecessor] & row_0 & .. & row_{H-1}) for lane chunk `c` of the k-mer `value`
+// Where a step's rows M[k-mer] come from.  A lane owns chunk c (16 bytes: WIDE, or one word) of the mask; per
+// predecessor it issues its loads (`issue`: the predecessor's slot chunk and the rows) and combines them later
+// (`combine`: slot & rows), so that several predecessors' loads are in flight at once.
+//
+// Flat IBF: (src & row_0 & .. & row_{H-1}) — the fused probe-AND of SURVEY.md §7 step 6.
 template <int H, bool WIDE>
-__device__ __forceinline__ void issue_loads(const IbfDev& f, const uint64_t* src_slot, uint64_t value, uint32_t c,
-                                            typename Lane<WIDE>::T (&x)[H + 1]) {
+struct FlatRows {
     using L = Lane<WIDE>;
-    x[H] = L::load(src_slot + (size_t)c * L::kWords);
+    using T = typename L::T;
+    struct Loads { T x[H + 1]; };
+    static constexpr bool kRootByLane = false;
+    IbfDev f;
+    uint32_t c;
+    __device__ __forceinline__ void prepare(uint32_t chunk) { c = chunk; }
+    __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
 #pragma unroll
-    for (int i = 0; i < H; ++i) {
-        const uint64_t row = hash_row(value, kSeeds[i], f.hash_shift, f.bin_size);
-        x[i] = L::load(f.words + row * f.stride + (size_t)c * L::kWords);
+        for (int i = 0; i < H; ++i) {
+            const uint64_t row = hash_row(value, kSeeds[i], f.hash_shift, f.bin_size);
+            l.x[i] = L::load(f.words + row * f.stride + (size_t)c * L::kWords);
+        }
     }
-}
+    __device__ __forceinline__ void issue_late(Loads&) const {}
+    __device__ __forceinline__ T combine(const Loads& l) const {
+        T y = l.x[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) y &= l.x[h];
+        return y;
+    }
+};
 
-template <int H, bool WIDE, int UA>
-__global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
+// Regular two-level HIBF (txq_internal.hpp ChildRec; membership_for(·, 1) of reference include/index_hibf.h:132-147 on
+// that shape): the lane's mask words are technical bins of ONE child, so M[k-mer] there = the child's rows ANDed,
+// if the k-mer is in the child's merged bin of the root (the root's rows ANDed, one bit of one word).  Two rounds of
+// loads: the root words of all predecessors in flight (`issue`; the lanes of a suffix read the same words), then — only
+// in the lanes whose child the root lets through — the child's rows and the predecessor's slot chunk (`issue_late`).
+// With 64-bin children a full-width row would be one cache line PER CHILD and hash function; the root keeps that to
+// the few children a k-mer can be in.  H = the most hash functions of any IBF of the tree; an IBF with fewer skips the others.
+template <int H, bool WIDE>
+struct TreeRows {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    struct Loads { T x[H + 1]; uint64_t r[H]; uint64_t value; const uint64_t* src; bool hit; };
+    static constexpr bool kRootByLane = false;
+    HibfNode root;
+    const ChildRec* children;
+    uint32_t wpr_log2;
+    // the lane's child
+    const uint64_t* cw;
+    uint32_t c, c_rows, c_shift, c_hf, col, r_word, r_bit;
+    __device__ __forceinline__ void prepare(uint32_t chunk) {
+        c = chunk;
+        const uint32_t word = chunk * L::kWords;
+        const ChildRec rec = children[word >> wpr_log2];
+        cw = (const uint64_t*)rec.words;
+        c_rows = rec.bin_size;
+        c_shift = rec.packed & 0xFFu;
+        c_hf = (rec.packed >> 8) & 0xFu;
+        col = word & ((1u << wpr_log2) - 1u);
+        r_word = (rec.packed >> 12) >> 6;
+        r_bit = (rec.packed >> 12) & 63u;
+    }
+    __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        l.value = value;
+        l.src = src_slot;
+        const uint64_t* rw = (const uint64_t*)root.words;
+        const uint32_t r_hf = root.hash_funs(), r_stride = root.stride(), r_shift = root.hash_shift();
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+            l.r[i] = (uint32_t)i < r_hf ? rw[hash_row_seeded(value * kSeeds[i], r_shift, root.bin_size) * r_stride + r_word] : ~0ULL;
+    }
+    __device__ __forceinline__ void issue_late(Loads& l) const {
+        uint64_t rb = l.r[0];
+#pragma unroll
+        for (int h = 1; h < H; ++h) rb &= l.r[h];
+        l.hit = (rb >> r_bit) & 1ULL;
+        if (l.hit) {
+            l.x[H] = L::load(l.src + (size_t)c * L::kWords);
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                if ((uint32_t)i < c_hf) l.x[i] = L::load(cw + ((hash_row_seeded(l.value * kSeeds[i], c_shift, c_rows) << wpr_log2) + col));
+                else l.x[i] = ~L::zero();
+            }
+        }
+    }
+    __device__ __forceinline__ T combine(const Loads& l) const {
+        if (!l.hit) return L::zero();
+        T y = l.x[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) y &= l.x[h];
+        return y;
+    }
+    // (TreeRowsByLane) the root's verdict on a k-mer for ALL children: a root of at most 64 merged bins is one word per row
+    __device__ __forceinline__ uint64_t root_word(uint64_t value) const {
+        const uint64_t* rw = (const uint64_t*)root.words;
+        const uint32_t r_hf = root.hash_funs(), r_stride = root.stride(), r_shift = root.hash_shift();
+        uint64_t x = ~0ULL;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+            if ((uint32_t)i < r_hf) x &= rw[hash_row_seeded(value * kSeeds[i], r_shift, root.bin_size) * r_stride];
+        return x;
+    }
+    __device__ __forceinline__ void issue_child(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            if ((uint32_t)i < c_hf) l.x[i] = L::load(cw + ((hash_row_seeded(value * kSeeds[i], c_shift, c_rows) << wpr_log2) + col));
+            else l.x[i] = ~L::zero();
+        }
+    }
+    __device__ __forceinline__ T combine_child(const Loads& l) const {
+        T y = l.x[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) y &= l.x[h];
+        return y;
+    }
+};
+
+// A small regular tree whose children are uniform has them interleaved (Index::interleaved): one row segment per hash
+// function holds the lane's words of ALL its children — the load pattern of a flat IBF — and the root's word (at most 64
+// merged bins) clears the words of the children the k-mer cannot be in.  One round of loads.
+template <int H, bool WIDE>
+struct InterleavedRows {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    struct Loads { T x[H + 1]; uint64_t r[H]; };
+    static constexpr bool kRootByLane = false;
+    IbfDev f;  // the interleaved children
+    HibfNode root;
+    const ChildRec* children;
+    uint32_t wpr_log2;
+    uint32_t c, bit0, bit1;  // root bins of the children behind the lane's first / second word
+    __device__ __forceinline__ void prepare(uint32_t chunk) {
+        c = chunk;
+        const uint32_t word = chunk * L::kWords;
+        bit0 = children[word >> wpr_log2].packed >> 12;
+        bit1 = WIDE ? children[(word + 1) >> wpr_log2].packed >> 12 : bit0;
+    }
+    __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+        const uint64_t* rw = (const uint64_t*)root.words;
+        const uint32_t r_hf = root.hash_funs(), r_stride = root.stride(), r_shift = root.hash_shift();
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            const uint64_t sv = value * kSeeds[i];
+            if ((uint32_t)i < f.hash_funs) l.x[i] = L::load(f.words + hash_row_seeded(sv, f.hash_shift, f.bin_size) * f.stride + (size_t)c * L::kWords);
+            else l.x[i] = ~L::zero();
+            l.r[i] = (uint32_t)i < r_hf ? rw[hash_row_seeded(sv, r_shift, root.bin_size) * r_stride] : ~0ULL;
+        }
+    }
+    __device__ __forceinline__ void issue_late(Loads&) const {}
+    __device__ __forceinline__ T combine(const Loads& l) const {
+        T y = l.x[H];
+        uint64_t rb = l.r[0];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { y &= l.x[h]; rb &= l.r[h]; }
+        return L::keep(y, (rb >> bit0) & 1ULL, (rb >> bit1) & 1ULL);
+    }
+};
+
+// The same tree when its root has at most 64 merged bins and a suffix's lanes cover the whole mask: the lanes of a
+// suffix first take one PREDECESSOR each and gather its root word (the verdict for all children at once — every root
+// row is fetched by exactly one lane, all predecessors in one round), hand the words round with shuffles, and each lane
+// then visits only the predecessors that the root lets into ITS child.  (dense_kernel, kRootByLane)
+template <int H, bool WIDE>
+struct TreeRowsByLane : TreeRows<H, WIDE> {
+    static constexpr bool kRootByLane = true;
+};
+
+template <int H, bool WIDE, int UA, class ROWS>
+__global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
                                                     uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
                                                     uint32_t G, uint32_t SL, DenseParams P, LevelUnits U) {
     using L = Lane<WIDE>;
@@ -287,39 +448,88 @@ __global__ __launch_bounds__(256) void dense_kernel(IbfDev f, const DenseTile* _
         const uint64_t low = (mid_val << P.bits) | r;  // the k-mer without its oldest residue
         uint64_t* dst = dstb + ((size_t)mid * P.A + r) * W;
         const uint64_t* srcm = src + (size_t)mid * W;
+        if constexpr (ROWS::kRootByLane) {  // chunks <= G (host): one pass over the mask
+            const uint32_t ls = threadIdx.x % lanes, first_lane = (threadIdx.x & 63u) & ~(lanes - 1u);
+            const uint32_t c = sub;
+            const bool mine = live && c < chunks;
+            rows.prepare(c < chunks ? c : 0);
+            uint32_t hits = 0;  // bit j: the root lets predecessor j of this suffix into my child
+            for (uint32_t j0 = 0; j0 < n_a; j0 += lanes) {  // n_a <= 32
+                const uint32_t j = j0 + ls;
+                uint64_t rw = 0;
+                if (live && j < n_a) {
+                    uint64_t v = ((uint64_t)codes[0][j] << a_shift) | low;
+                    if (P.canonical) v = canonical_dna(v, P.k);
+                    rw = rows.root_word(v);
+                }
+                const uint32_t span = n_a - j0 < lanes ? n_a - j0 : lanes;
+                for (uint32_t t = 0; t < span; ++t) {  // uniform over the workgroup: every lane shuffles
+                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)rw, (int)(first_lane + t));
+                    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(rw >> 32), (int)(first_lane + t));
+                    const uint64_t w = ((uint64_t)hi << 32) | lo;
+                    hits |= (uint32_t)((w >> rows.r_bit) & 1ULL) << (j0 + t);
+                }
+            }
+            T acc = L::zero();
+            if (mine) {
+                uint32_t todo = 0;  // my slice's share of the predecessors: slice, slice + SL, ...
+                for (uint32_t j = slice; j < n_a; j += SL) todo |= 1u << j;
+                todo &= hits;
+                while (todo) {
+                    typename ROWS::Loads x[UA];
+                    bool have[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        have[u] = todo != 0;
+                        if (have[u]) {
+                            const uint32_t j = (uint32_t)__builtin_ctz(todo);
+                            todo &= todo - 1;
+                            const uint32_t a = codes[0][j];
+                            uint64_t v = ((uint64_t)a << a_shift) | low;
+                            if (P.canonical) v = canonical_dna(v, P.k);
+                            rows.issue_child(srcm + (size_t)a * a_stride * W, v, x[u]);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u)
+                        if (have[u]) acc |= rows.combine_child(x[u]);
+                }
+            }
+            for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
+            if (mine && slice == 0 && L::any(acc)) {
+                uint64_t* p = dst + (size_t)c * L::kWords;
+                L::store(p, L::load(p) | acc);
+            }
+        } else
         for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
             const uint32_t c = c0 + sub;
             const bool mine = live && c < chunks;
             T acc = L::zero();
             if (mine) {
+                rows.prepare(c);
                 uint32_t i = slice;
                 for (; i + (UA - 1) * SL < n_a; i += UA * SL) {  // UA predecessors at a time: UA * (H + 1) loads in flight
-                    T x[UA][H + 1];
+                    typename ROWS::Loads x[UA];
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
                         const uint32_t a = codes[0][i + u * SL];
                         uint64_t v = ((uint64_t)a << a_shift) | low;
                         if (P.canonical) v = canonical_dna(v, P.k);
-                        issue_loads<H, WIDE>(f, srcm + (size_t)a * a_stride * W, v, c, x[u]);
+                        rows.issue(srcm + (size_t)a * a_stride * W, v, x[u]);
                     }
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        T y = x[u][H];
+                    for (int u = 0; u < UA; ++u) rows.issue_late(x[u]);
 #pragma unroll
-                        for (int h = 0; h < H; ++h) y &= x[u][h];
-                        acc |= y;
-                    }
+                    for (int u = 0; u < UA; ++u) acc |= rows.combine(x[u]);
                 }
                 for (; i < n_a; i += SL) {
                     const uint32_t a0 = codes[0][i];
                     uint64_t v0 = ((uint64_t)a0 << a_shift) | low;
                     if (P.canonical) v0 = canonical_dna(v0, P.k);
-                    T x0[H + 1];
-                    issue_loads<H, WIDE>(f, srcm + (size_t)a0 * a_stride * W, v0, c, x0);
-                    T y0 = x0[H];
-#pragma unroll
-                    for (int h = 0; h < H; ++h) y0 &= x0[h];
-                    acc |= y0;
+                    typename ROWS::Loads x0;
+                    rows.issue(srcm + (size_t)a0 * a_stride * W, v0, x0);
+                    rows.issue_late(x0);
+                    acc |= rows.combine(x0);
                 }
             }
             for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
@@ -642,9 +852,9 @@ static double now_s() {
 Session::~Session() {
     if (std::getenv("TXQ_TRACE"))
         fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s; "
-                        "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles)\n",
+                        "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles), step rows: %s\n",
                 n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, n_levels, n_unit_launches, n_units,
-                n_dense_launches, n_dense_tiles);
+                n_dense_launches, n_dense_tiles, row_source);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
@@ -850,19 +1060,22 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
     return n_small;
 }
 
-template <bool WIDE>
-static hipError_t launch_dense(const IbfDev& f, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
+// rows_of(H) makes the kernel's row source for H hash functions (FlatRows / TreeRows)
+template <bool WIDE, template <int, bool> class ROWS, class MAKE>
+static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
                                uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, const LevelUnits& U, hipStream_t st) {
     const size_t grid = n_tiles + U.n_units;
     // predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
     static const int ua = std::getenv("TXQ_DENSE_UNROLL") ? std::atoi(std::getenv("TXQ_DENSE_UNROLL")) : 3;
 #define TXQ_DENSE(H) \
     do { \
-        if (ua >= 6) dense_kernel<H, WIDE, 6><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
-        else if (ua <= 2) dense_kernel<H, WIDE, 2><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
-        else dense_kernel<H, WIDE, 3><<<(unsigned)grid, 256, 0, st>>>(f, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        ROWS<H, WIDE> rows{}; \
+        rows_of(rows); \
+        if (ua >= 6) dense_kernel<H, WIDE, 6, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        else if (ua <= 2) dense_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        else dense_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
     } while (0)
-    switch (f.hash_funs) {
+    switch (hash_funs) {
         case 1: TXQ_DENSE(1); break;
         case 2: TXQ_DENSE(2); break;
         case 3: TXQ_DENSE(3); break;
@@ -904,7 +1117,16 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (int rc = grow_slot_regions(s, bv, &fresh, &moves)) return rc;
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
-    const bool wide = W % 2 == 0 && !ix.is_hibf && ix.ibf[0].stride % 2 == 0;
+    // (a regular two-level HIBF runs its steps fused, too: TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
+    const bool tree_allowed = !(std::getenv("TXQ_DENSE_TREE") && std::getenv("TXQ_DENSE_TREE")[0] == '0');
+    const bool tree = ix.is_hibf && ix.d_children && ix.n_children && tree_allowed && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
+                      (uint64_t)ix.n_children * ix.child_row_words == W;
+    if (any_dense) s.row_source = tree ? "regular tree, fused" : ix.is_hibf ? "HIBF descent" : "flat IBF, fused";
+    if (any_dense && tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && !std::getenv("TXQ_DENSE_TREE"))
+        s.row_source = "regular tree, interleaved children, fused";
+    const char* tree_knob = std::getenv("TXQ_DENSE_TREE");  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; default: best fit
+    const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && !tree_knob;
+    const bool wide = W % 2 == 0 && (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0);
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
@@ -916,7 +1138,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<DenseTile> tiles, hsteps;
     std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
-    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf, &units, &tiles, &hsteps, &hstep_na, &plan);
+    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tiles, &hsteps, &hstep_na, &plan);
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
     // never across a level; pair_base[tile] = first pair of the tile within its chunk
     std::vector<uint32_t> pair_base(hsteps.size(), 0);
@@ -1036,7 +1258,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const int g_units = g < 256 ? g : 256;
         uint32_t g_units_log2 = 0;
         while ((1 << g_units_log2) < g_units) ++g_units_log2;
-        static const bool fuse_units = !(std::getenv("TXQ_FUSE_UNITS") && std::getenv("TXQ_FUSE_UNITS")[0] == '0');  // A/B knob
+        const bool fuse_units = !(std::getenv("TXQ_FUSE_UNITS") && std::getenv("TXQ_FUSE_UNITS")[0] == '0');  // A/B knob
         const txq_op* d_ops = (const txq_op*)(S.d_blob + h->ops_offset);
         const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(S.d_blob + h->levels_offset) : nullptr;
         const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(S.d_blob + h->dense_offset) : nullptr;
@@ -1064,7 +1286,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             const size_t cnt = plan[l].units;
             ++s.n_levels;
             // a flat index runs the level's units inside its dense launch (below); otherwise they are a launch of their own
-            const bool ride = fuse_units && cnt && plan[l].tiles && !ix.is_hibf;
+            const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree);
             if (cnt && !ride) {
                 ++s.n_unit_launches;
                 exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W, g_units_log2);
@@ -1086,8 +1308,28 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
                 const LevelUnits lu{d_units + first, d_ops, ix.scratch_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
-                hipError_t e = wide ? launch_dense<true>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                    : launch_dense<false>(ix.ibf[0], d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                hipError_t e;
+                if (tree) {
+                    uint32_t wpr_log2 = 0;
+                    while ((1u << wpr_log2) < ix.child_row_words) ++wpr_log2;
+                    auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                    // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
+                    const bool by_lane = ix.root_node.bins <= 64 && (wide ? W / 2 : W) <= g_dense && !(tree_knob && tree_knob[0] == '1');
+                    if (interleaved) {
+                        auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                        e = wide ? launch_dense<true, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                    } else if (by_lane)
+                        e = wide ? launch_dense<true, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                    else
+                        e = wide ? launch_dense<true, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                } else {  // (an irregular HIBF only has ZERO / REDUCE tiles here: its steps are `hsteps`)
+                    auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
+                    e = wide ? launch_dense<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                             : launch_dense<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                }
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
                 s.n_dense_tiles += plan[l].tiles;

@@ -31,21 +31,6 @@ struct HibfView {
     uint32_t root_entry;
 };
 
-struct HibfNode {  // 32 bytes = two 16-byte loads per lane
-    uint64_t words;       // device pointer to the IBF's rows
-    uint32_t bin_size;    // rows (< 2^32: the fused kernel is not used for larger IBFs)
-    uint32_t packed;      // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | has merged bins (29)
-    uint32_t off;         // first entry of the IBF's technical bins in the flattened maps
-    uint32_t moff;        // first word of the IBF in `merged` / `descend`
-    uint32_t ident_word;  // see IbfDev::ident_word
-    uint32_t bins;        // technical bins
-    __host__ __device__ uint32_t stride() const { return packed & 0xFFFFFu; }
-    __host__ __device__ uint32_t hash_shift() const { return (packed >> 20) & 63u; }
-    __host__ __device__ uint32_t hash_funs() const { return (packed >> 26) & 7u; }
-    __host__ __device__ bool has_merged() const { return (packed >> 29) & 1u; }
-    __host__ __device__ uint32_t words_per_row() const { return (bins + 63u) >> 6; }
-};
-static_assert(sizeof(HibfNode) == 32, "two 16-byte pieces per node");
 
 // loads through a pointer that was itself read from memory: tell the compiler it is global memory
 // (otherwise it emits flat loads, which also wait on the LDS counter)
@@ -421,12 +406,17 @@ __global__ __launch_bounds__(256) void hibf_small_kernel(HibfView t, const uint6
 // writes the k-mer's 1-KiB row segment with one coalesced non-temporal store — a child that the root row rules
 // out costs nothing but the zeros.  No LDS row, no atomics: the row segments of different groups are disjoint.
 // Pass 1 (hibf_root_kernel) probes the root once per k-mer and leaves its row (one bit per child) in HBM.
-struct ChildRec {   // 16 bytes, one per child in mask-column order
-    uint64_t words;     // device pointer to the child's rows (stride = row words, a power of two >= 2)
-    uint32_t bin_size;  // rows
-    uint32_t packed;    // hash_shift (bits 0-7) | hash_funs (8-11) | root technical bin (12-31)
-};
-static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
+
+// row r of every child side by side: out[r][c * wpr + w] = child c's word w of row r (Index::interleaved)
+__global__ __launch_bounds__(256) void interleave_children_kernel(const ChildRec* __restrict__ ch, uint32_t n_children, uint32_t wpr, uint64_t rows,
+                                                                  uint64_t* __restrict__ out, uint32_t out_stride) {
+    const uint64_t per_row = (uint64_t)n_children * wpr, total = rows * per_row;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t r = i / per_row;
+        const uint32_t w = (uint32_t)(i % per_row), c = w / wpr;
+        out[r * out_stride + w] = gload((const uint64_t*)ch[c].words + r * wpr + w % wpr);
+    }
+}
 
 // child_rows != null (all children of one size): also the k-mer's row indexes in a child, child_hf per k-mer — they
 // are the same in every child, so the children kernel reads them instead of hashing again for each of its groups
@@ -725,11 +715,11 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     }
 
     // Regular two-level tree?  (root: only merged bins; every child: a leaf whose technical bins are an aligned run of
-    // user bins, all children of one power-of-two row width >= 2 words, tiling the mask columns in order; this shard's
+    // user bins, all children of one power-of-two row width, tiling the mask columns in order; this shard's
     // column range starts and ends on child boundaries)  -> ChildRec table for the child-stationary descent.
     if (compact && ix.depth == 2 && n >= 2 && desc.ibf[0].bins < (1u << 20)) {
         const uint32_t wpr = (uint32_t)desc.ibf[1].bin_words;
-        bool regular = wpr >= 2 && (wpr & (wpr - 1)) == 0 && wpr <= 128;
+        bool regular = wpr >= 1 && (wpr & (wpr - 1)) == 0 && wpr <= 128;
         std::vector<uint64_t> by_column(n - 1, UINT64_MAX), root_tb(n, 0);
         for (uint64_t b = 0; regular && b < desc.ibf[0].bins; ++b) {
             if (tbu[off[0] + b] != TXQ_MERGED_BIN) { regular = false; break; }
@@ -757,6 +747,36 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
             for (const ChildRec& c : recs) ix.children_uniform = ix.children_uniform && c.bin_size == recs[0].bin_size && (c.packed & 0xFFFu) == (recs[0].packed & 0xFFFu);
             ix.child_row_words = wpr;
             ix.children_bytes = bytes;
+            const IbfDev& root = ix.ibf[0];
+            ix.root_node = HibfNode{};
+            ix.root_node.words = (uint64_t)(uintptr_t)root.words;
+            ix.root_node.bin_size = (uint32_t)root.bin_size;
+            ix.root_node.packed = root.stride | (root.hash_shift << 20) | (root.hash_funs << 26);
+            ix.root_node.bins = root.bins;
+            ix.tree_hash_max = 1;
+            for (const IbfDev& f : ix.ibf) ix.tree_hash_max = std::max(ix.tree_hash_max, f.hash_funs);
+            const char* il = std::getenv("TXQ_HIBF_INTERLEAVE");  // A/B knob: 0 = never
+            if (ix.children_uniform && root.bins <= 64 && ix.shard_words <= 32 && !(il && il[0] == '0')) {
+                const IbfDev& c0 = ix.ibf[by_column[ix.shard_word0 / wpr]];
+                IbfDev f{};
+                f.bin_size = c0.bin_size;
+                f.hash_shift = c0.hash_shift;
+                f.hash_funs = c0.hash_funs;
+                f.shard_words = (uint32_t)ix.shard_words;
+                f.stride = f.shard_words <= 1 ? 1u : ((f.shard_words + 1u) & ~1u);
+                f.bins = (uint32_t)ix.shard_words * 64u;
+                f.ident_word = kNoIdent;
+                const size_t nbytes = (size_t)f.bin_size * f.stride * 8;
+                TXQ_HIP(hipMalloc((void**)&f.words, nbytes));
+                ix.interleaved = f;  // released with the index from here on
+                TXQ_HIP(hipMemset(f.words, 0, nbytes));
+                const uint64_t total = f.bin_size * ix.shard_words;
+                const unsigned grid = (unsigned)std::min<uint64_t>((total + 255) / 256, 256 * 64);
+                interleave_children_kernel<<<grid ? grid : 1, 256, 0, nullptr>>>((const ChildRec*)ix.d_children, ix.n_children, wpr, f.bin_size, f.words, f.stride);
+                TXQ_HIP(hipGetLastError());
+                TXQ_HIP(hipDeviceSynchronize());
+                ix.device_bytes += nbytes;
+            }
             ix.device_bytes += recs.size() * sizeof(ChildRec);
         }
     }
@@ -797,7 +817,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     {
         const char* off = std::getenv("TXQ_HIBF_STATIONARY");
         // (narrow masks, <= 16 words, are better off with one lane per k-mer: hibf_small_kernel)
-        if (ix.d_children && ix.n_children && w_out > 16 && !(off && off[0] == '0')) {
+        if (ix.d_children && ix.n_children && ix.child_row_words >= 2 && w_out > 16 && !(off && off[0] == '0')) {
             const uint32_t wpr = ix.child_row_words, lpc = wpr / 2, cps = 64 / lpc;
             const uint32_t n_steps = (ix.n_children + cps - 1) / cps;
             // a group = whole wave steps whose children fit ~2 MB (half an XCD's L2); at least 8 groups when there are 8 steps

@@ -7,6 +7,33 @@
 
 namespace txq {
 
+// Everything about one IBF of an HIBF tree in one 32-byte record (txq_hibf.hip: nodes[e] = the child behind merged
+// technical bin e; the dense steps on a regular tree take the root as a kernel argument).
+struct HibfNode {  // 32 bytes = two 16-byte loads per lane
+    uint64_t words;       // device pointer to the IBF's rows
+    uint32_t bin_size;    // rows (< 2^32: the fused kernel is not used for larger IBFs)
+    uint32_t packed;      // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | has merged bins (29)
+    uint32_t off;         // first entry of the IBF's technical bins in the flattened maps
+    uint32_t moff;        // first word of the IBF in `merged` / `descend`
+    uint32_t ident_word;  // see IbfDev::ident_word
+    uint32_t bins;        // technical bins
+    __host__ __device__ uint32_t stride() const { return packed & 0xFFFFFu; }
+    __host__ __device__ uint32_t hash_shift() const { return (packed >> 20) & 63u; }
+    __host__ __device__ uint32_t hash_funs() const { return (packed >> 26) & 7u; }
+    __host__ __device__ bool has_merged() const { return (packed >> 29) & 1u; }
+    __host__ __device__ uint32_t words_per_row() const { return (bins + 63u) >> 6; }
+};
+static_assert(sizeof(HibfNode) == 32, "two 16-byte pieces per node");
+
+// Regular two-level trees: one record per child in mask-column order (child-stationary descent in txq_hibf.hip, dense
+// steps on the tree in txq_exec.hip).
+struct ChildRec {   // 16 bytes, one per child in mask-column order
+    uint64_t words;     // device pointer to the child's rows (stride = row words, a power of two >= 2)
+    uint32_t bin_size;  // rows
+    uint32_t packed;    // hash_shift (bits 0-7) | hash_funs (8-11) | root technical bin (12-31)
+};
+static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
+
 // One HIBF work item: k-mer `kmer` (index into the batch) must be looked up in IBF `ibf`.
 struct WorkItem { uint32_t kmer; uint32_t ibf; };
 
@@ -26,11 +53,18 @@ struct Index {
     uint64_t* d_descend = nullptr;   // same layout: merged bins worth descending into for this shard
     uint64_t* d_merged_off = nullptr;
     // Regular two-level trees (root of merged bins over leaf IBFs that each map an aligned run of user bins, all of
-    // one row width): the child-stationary descent of txq_hibf.hip.  d_children = ChildRec[n_children] in mask-column
+    // one row width): the child-stationary descent of txq_hibf.hip (rows of >= 2 words) and the fused dense steps of
+    // txq_exec.hip.  d_children = ChildRec[n_children] in mask-column
     // order for THIS shard's columns; empty when the tree does not have that shape.
     void* d_children = nullptr;
     uint32_t n_children = 0;         // children whose columns this shard owns
-    uint32_t child_row_words = 0;    // mask words per child (power of two >= 2)
+    uint32_t child_row_words = 0;    // mask words per child (a power of two)
+    // Small regular trees with uniform children (root of <= 64 merged bins, mask of <= 32 words): the children's matrices
+    // once more, row r of all children side by side ([rows][stride] like a flat IBF over the children's hash parameters),
+    // so that a dense step gathers one row segment per hash function instead of one cache line per child.
+    IbfDev interleaved{};
+    HibfNode root_node{};            // host copy of the root's record
+    uint32_t tree_hash_max = 0;      // most hash functions of any IBF of the regular tree
     bool children_uniform = false;   // same rows / hash shift / hash count in every child: scalar hashing
     uint64_t children_bytes = 0;     // their matrices
     uint32_t* scratch_crows = nullptr; size_t cap_crows = 0;  // uniform children: per k-mer its row indexes in a child
@@ -105,6 +139,7 @@ struct Session {
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
+    const char* row_source = "none";  // where the dense steps of the last stage took M[k-mer] from
     size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;
     ~Session();
 };
