@@ -162,3 +162,43 @@ def test_megabyte_records_with_quantifier_motifs(tmp_path):
     assert rc == 0, se
     for r in rows(so):
         assert r[2].startswith("ACGTAC") and r[2].endswith("AAC")
+
+
+def test_hibf_written_by_tetrex_index_takes_the_fused_tree_steps(tmp_path):
+    """`tetrex index` deals the user bins over word-aligned children of equal rows (host/device_index.cpp), so the device
+    recognises the tree as regular with uniform children and runs wildcard motifs as fused dense steps on the
+    interleaved children.  The verified matches equal those found through a flat IBF of the same bins."""
+    import json
+    from tetrex_amd import host
+    rng = np.random.default_rng(3)
+    aa = list("ACDEFGHIKLMNPQRSTVWY")
+    files = []
+    for b in range(200):
+        seqs = ["".join(rng.choice(aa, size=150)) for _ in range(3)]
+        if b % 37 == 5:
+            seqs[1] = seqs[1][:40] + "LMKWACDEQGHK" + seqs[1][52:]
+        p = tmp_path / ("bin%03d.fa" % b)
+        p.write_text("".join(">s%d_%d\n%s\n" % (b, i, s) for i, s in enumerate(seqs)))
+        files.append(str(p))
+    lst = tmp_path / "bins.lst"
+    lst.write_text("\n".join(files) + "\n")
+    out = {}
+    for name, flag in (("flat", ["-i"]), ("tree", [])):
+        rc, so, se = run("index", "-k", "4", *flag, str(tmp_path / name), str(lst))
+        assert rc == 0 and "across 200 bins." in se, se
+    img = host.IndexFile.load(str(tmp_path / "tree.ibf")).describe()
+    assert img["is_hibf"] and [f["bins"] for f in img["ibfs"]] == [4, 64, 64, 64, 8]
+    assert len({f["bin_size"] for f in img["ibfs"][1:]}) == 1
+    env = dict(os.environ, TXQ_TRACE="1")
+    fused = 0
+    for q in ("LMK.AC.{0,2}EQ[GA]HK", "LMK..CDEQGHK", "LMKW.{2,3}EQGHK", "W.C[DE]{1,2}.GHK"):
+        for name in ("flat", "tree"):
+            r = subprocess.run([TETREX, "query", "-S", "-t", "4", str(tmp_path / (name + ".ibf")), q], capture_output=True, text=True, env=env, timeout=300)
+            assert r.returncode == 0, r.stderr
+            out[name] = sorted((os.path.basename(x[0]), x[1], x[2], x[3]) for x in rows(r.stdout))
+            st = json.loads([ln for ln in r.stderr.splitlines() if ln.startswith("{")][0])
+            if name == "tree" and st["dense_ops"]:
+                assert "interleaved children" in r.stderr, r.stderr
+                fused += 1
+        assert out["flat"] == out["tree"] and len(out["flat"]) >= 5, q
+    assert fused >= 2

@@ -354,8 +354,11 @@ IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOpt
     }
     // HIBF with this project's own two-level layout (the reference delegates the layout to
     // seqan::hibf's sketch-based algorithm, which is index construction, not query): user bins are
-    // dealt in order over t_max = 64*ceil(sqrt(B)/64) merged technical bins of the root, each
+    // dealt in order over at most t_max = 64*ceil(sqrt(B)/64) merged technical bins of the root, each
     // pointing at a child IBF with one technical bin per user bin.  B <= t_max: a single level.
+    // A child holds a multiple of 64 user bins, so its rows are whole words of the result mask, and all children
+    // have the rows of the largest user bin (as the flat IBF sizes its bins): the device keeps such a tree's children
+    // side by side and probes them like one flat IBF (csrc/txq_hibf.hip: regular trees, uniform children).
     img.is_hibf = true;
     HibfImage& h = img.hibf;
     const uint64_t B = bin_files.size();
@@ -369,7 +372,10 @@ IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOpt
         h.tb_to_user_bin.emplace_back();
         for (uint64_t b = 0; b < B; ++b) h.tb_to_user_bin.back().push_back(b);
     } else {
-        const uint64_t per_child = (B + tmax - 1) / tmax, n_child = (B + per_child - 1) / per_child;
+        const uint64_t per_child = 64 * (((B + tmax - 1) / tmax + 63) / 64), n_child = (B + per_child - 1) / per_child;
+        std::vector<const std::vector<uint64_t>*> all_bins;
+        for (auto& v : values) all_bins.push_back(&v);
+        const uint64_t child_rows = std::max<uint64_t>(1, compute_bitcount(largest(all_bins), opt.fpr));
         std::vector<std::vector<uint64_t>> merged(n_child);
         h.ibfs.resize(1 + n_child);
         h.next_ibf_id.resize(1 + n_child);
@@ -383,7 +389,7 @@ IndexImage build_index(const std::vector<std::string>& bin_files, const BuildOpt
                 h.tb_to_user_bin[1 + c].push_back(b);
             }
             h.next_ibf_id[1 + c].assign(hi - lo, 0);
-            h.ibfs[1 + c] = build_flat(per_bin, std::max<uint64_t>(1, compute_bitcount(largest(per_bin), opt.fpr)), opt.hash_count);
+            h.ibfs[1 + c] = build_flat(per_bin, child_rows, opt.hash_count);
             h.next_ibf_id[0].push_back(1 + c);
             h.tb_to_user_bin[0].push_back(UINT64_MAX);
         }
