@@ -147,5 +147,7 @@ def test_bench_single_gpu_contract_line_with_all_legs():
     assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["value"] > 0 and out["parity_checked_probes"] == 1 << 18
     e2e = out["end_to_end"]
     assert "error" not in e2e and e2e["batch"]["failed"] == 0 and e2e["cpu_baseline"]["masks_compared"] > 0
+    hb = e2e["hibf_batch"]  # BASELINE configs[2]: the batch on a 1024-user-bin HIBF, fused steps checked against the generic descent
+    assert "error" not in hb and hb["masks_identical"] is True and hb["failed"] == 0 and hb["queries_per_s"] > 0
     assert "error" not in out["hibf"] and out["hibf"]["checked_present_values"] > 0
     assert "error" not in out["hibf_1024"] and out["hibf_1024"]["user_bins"] == 1024

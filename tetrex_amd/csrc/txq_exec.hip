@@ -852,8 +852,9 @@ static double now_s() {
 Session::~Session() {
     if (std::getenv("TXQ_TRACE"))
         fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s; "
+                        "(regions %.3f, plan %.3f, wait for the staging set %.3f, buffers %.3f) "
                         "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles), step rows: %s\n",
-                n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, n_levels, n_unit_launches, n_units,
+                n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, t_grow, t_plan, t_wait, t_alloc, n_levels, n_unit_launches, n_units,
                 n_dense_launches, n_dense_tiles, row_source);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
@@ -1115,6 +1116,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
     if (int rc = grow_slot_regions(s, bv, &fresh, &moves)) return rc;
+    s.t_grow += now_s() - t0;
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
     // (a regular two-level HIBF runs its steps fused, too: TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
@@ -1138,6 +1140,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<DenseTile> tiles, hsteps;
     std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
+    double t1 = now_s();
     const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tiles, &hsteps, &hstep_na, &plan);
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
     // never across a level; pair_base[tile] = first pair of the tile within its chunk
@@ -1171,11 +1174,15 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // two stages ago): blob, and aux = program table | fresh-program list | feedback queries | alive bytes | units | tiles |
     // HIBF steps | their pair bases | region moves | region bases.  Everything is copied on the upload stream and the host
     // waits for THOSE copies only (pageable sources, some of them locals) — not for the kernels of the previous stage.
+    s.t_plan += now_s() - t1;
+    t1 = now_s();
     Index::StagingSet& S = s.set[(s.n_stages - 1) & 1];
     if (S.pending) {
         TXQ_HIP(hipEventSynchronize(S.done));
         S.pending = false;
     }
+    s.t_wait += now_s() - t1;
+    t1 = now_s();
     size_t aux_bytes = 0;
     auto place = [&](size_t bytes) { const size_t at = aux_bytes; aux_bytes = (aux_bytes + bytes + 15) & ~(size_t)15; return at; };
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
@@ -1193,6 +1200,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         return ensure((void**)p, cap, std::max(need + need / 2, (size_t)64 << 20));
     };
     if (int rc = ensure_scratch(&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
+    s.t_alloc += now_s() - t1;
     hipStream_t up = s.upload;
     auto send = [&](size_t at, const void* src, size_t n) -> hipError_t {
         return n ? hipMemcpyAsync(S.d_aux + at, src, n, hipMemcpyHostToDevice, up) : hipSuccess;

@@ -139,6 +139,7 @@ struct Session {
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
+    double t_grow = 0, t_plan = 0, t_wait = 0, t_alloc = 0;  // parts of t_upload: slot regions, units/tiles, waiting for the staging set, scratch
     const char* row_source = "none";  // where the dense steps of the last stage took M[k-mer] from
     size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;
     ~Session();
