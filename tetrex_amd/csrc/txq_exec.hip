@@ -1190,9 +1190,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const size_t at_units = place(units.size() * sizeof(ExecUnit)), at_tiles = place(tiles.size() * sizeof(DenseTile));
     const size_t at_hsteps = place(hsteps.size() * sizeof(DenseTile)), at_pair_base = place(hsteps.size() * 4);
     const size_t at_moves = place(moves.size() * sizeof(RegionMove)), at_base = place(2 * s.n_programs * sizeof(uint64_t*));
-    const size_t blob_pad = (bytes + 7) & ~(size_t)7;
-    if (int rc = ensure((void**)&S.d_blob, &S.cap_blob, blob_pad)) return rc;
+    // a small stage (a single query: a few hundred bytes of blob, a dozen small tables) travels as ONE copy: the blob
+    // rides behind the tables in `aux`
+    const bool packed = aux_bytes + bytes <= ((size_t)256 << 10);
+    const size_t at_blob = packed ? place(bytes) : 0;
+    if (!packed)
+        if (int rc = ensure((void**)&S.d_blob, &S.cap_blob, (bytes + 7) & ~(size_t)7)) return rc;
     if (int rc = ensure((void**)&S.d_aux, &S.cap_aux, aux_bytes + 16)) return rc;
+    const unsigned char* dblob = packed ? S.d_aux + at_blob : S.d_blob;
     const size_t nk = h->n_kmers;
     // scratch the kernels in flight may still use: replacing it drains the device (ensure), so replace it generously
     auto ensure_scratch = [&](uint64_t** p, size_t* cap, size_t need) -> int {
@@ -1202,20 +1207,38 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (int rc = ensure_scratch(&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
     s.t_alloc += now_s() - t1;
     hipStream_t up = s.upload;
-    auto send = [&](size_t at, const void* src, size_t n) -> hipError_t {
-        return n ? hipMemcpyAsync(S.d_aux + at, src, n, hipMemcpyHostToDevice, up) : hipSuccess;
-    };
-    TXQ_HIP(hipMemcpyAsync(S.d_blob, blob, bytes, hipMemcpyHostToDevice, up));
-    TXQ_HIP(send(at_progs, bv.programs.data(), prog_bytes));
-    TXQ_HIP(send(at_fresh, fresh.data(), fresh.size() * 4));
-    TXQ_HIP(send(at_qp, q_prog, n_q * 4));
-    TXQ_HIP(send(at_qs, q_slot, n_q * 4));
-    TXQ_HIP(send(at_units, units.data(), units.size() * sizeof(ExecUnit)));
-    TXQ_HIP(send(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile)));
-    TXQ_HIP(send(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile)));
-    TXQ_HIP(send(at_pair_base, pair_base.data(), hsteps.size() * 4));
-    TXQ_HIP(send(at_moves, moves.data(), moves.size() * sizeof(RegionMove)));
-    TXQ_HIP(send(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*)));
+    if (packed) {
+        s.host_aux.resize(aux_bytes);
+        unsigned char* hb = s.host_aux.data();
+        auto put = [&](size_t at, const void* src, size_t n) { if (n) std::memcpy(hb + at, src, n); };
+        put(at_progs, bv.programs.data(), prog_bytes);
+        put(at_fresh, fresh.data(), fresh.size() * 4);
+        put(at_qp, q_prog, n_q * 4);
+        put(at_qs, q_slot, n_q * 4);
+        put(at_units, units.data(), units.size() * sizeof(ExecUnit));
+        put(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile));
+        put(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile));
+        put(at_pair_base, pair_base.data(), hsteps.size() * 4);
+        put(at_moves, moves.data(), moves.size() * sizeof(RegionMove));
+        put(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*));
+        put(at_blob, blob, bytes);
+        TXQ_HIP(hipMemcpyAsync(S.d_aux, hb, aux_bytes, hipMemcpyHostToDevice, up));
+    } else {
+        auto send = [&](size_t at, const void* src, size_t n) -> hipError_t {
+            return n ? hipMemcpyAsync(S.d_aux + at, src, n, hipMemcpyHostToDevice, up) : hipSuccess;
+        };
+        TXQ_HIP(hipMemcpyAsync(S.d_blob, blob, bytes, hipMemcpyHostToDevice, up));
+        TXQ_HIP(send(at_progs, bv.programs.data(), prog_bytes));
+        TXQ_HIP(send(at_fresh, fresh.data(), fresh.size() * 4));
+        TXQ_HIP(send(at_qp, q_prog, n_q * 4));
+        TXQ_HIP(send(at_qs, q_slot, n_q * 4));
+        TXQ_HIP(send(at_units, units.data(), units.size() * sizeof(ExecUnit)));
+        TXQ_HIP(send(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile)));
+        TXQ_HIP(send(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile)));
+        TXQ_HIP(send(at_pair_base, pair_base.data(), hsteps.size() * 4));
+        TXQ_HIP(send(at_moves, moves.data(), moves.size() * sizeof(RegionMove)));
+        TXQ_HIP(send(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*)));
+    }
     DevProgram* d_progs = (DevProgram*)(S.d_aux + at_progs);
     uint32_t* d_fresh = (uint32_t*)(S.d_aux + at_fresh);
     uint32_t* d_qp = (uint32_t*)(S.d_aux + at_qp);
@@ -1243,7 +1266,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (blocks > 2048) blocks = 2048;
         init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
     }
-    const uint64_t* d_kmers = (const uint64_t*)(S.d_blob + h->kmers_offset);
+    const uint64_t* d_kmers = (const uint64_t*)(dblob + h->kmers_offset);
     const size_t n_aux = (size_t)h->n_aux_kmers, n_main = nk - n_aux;
     if (n_aux && !s.aux) return fail(TXQ_ERR_STATE, "the blob has auxiliary (d-gram) k-mers but the session has no auxiliary index");
     if (n_main) {
@@ -1267,9 +1290,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         uint32_t g_units_log2 = 0;
         while ((1 << g_units_log2) < g_units) ++g_units_log2;
         const bool fuse_units = !(std::getenv("TXQ_FUSE_UNITS") && std::getenv("TXQ_FUSE_UNITS")[0] == '0');  // A/B knob
-        const txq_op* d_ops = (const txq_op*)(S.d_blob + h->ops_offset);
-        const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(S.d_blob + h->levels_offset) : nullptr;
-        const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(S.d_blob + h->dense_offset) : nullptr;
+        const txq_op* d_ops = (const txq_op*)(dblob + h->ops_offset);
+        const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(dblob + h->levels_offset) : nullptr;
+        const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(dblob + h->dense_offset) : nullptr;
         const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;

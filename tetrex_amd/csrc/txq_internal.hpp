@@ -137,6 +137,7 @@ struct Session {
     bool owns_cache = false;      // buffers came from / go back to ix->session_cache
     Index::StagingSet set[2];     // stage n uses set[n & 1]
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
+    std::vector<unsigned char> host_aux;  // a small stage is packed here and sent as one copy
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
     double t_grow = 0, t_plan = 0, t_wait = 0, t_alloc = 0;  // parts of t_upload: slot regions, units/tiles, waiting for the staging set, scratch
