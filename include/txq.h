@@ -109,6 +109,11 @@ int txq_index_free(txq_index* ix);
  * with fewer than 2^32 rows), 0 otherwise. */
 int txq_index_supports_dense(const txq_index* ix);
 
+/* One 64-bit value a host layer may keep with the index (0 after upload); libtetrex_query stores what its staged
+ * expansion has learned about the index there. */
+int txq_index_set_tag(txq_index* ix, uint64_t tag);
+int txq_index_get_tag(const txq_index* ix, uint64_t* tag);
+
 /* An empty (all-zero) flat IBF living only in HBM, for device-side construction. */
 int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, int shard_rank, int n_shards,
                          txq_index** out);
@@ -140,8 +145,10 @@ int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, 
  * each piece (a blob with the NEW ops of every program; slot contents persist in HBM between
  * stages).  After a stage the library answers n_queries feedback questions "has slot
  * query_slot[i] of program query_program[i] any bit set?" (bitvector::none() of
- * include/otf_collector.h:383) into alive[i] (1/0), so the host can prune dead states before
- * expanding them.  Every stage's blob must hold exactly n_programs programs (possibly with no
+ * include/otf_collector.h:383) into alive[i]: 0 = none, otherwise 1 + floor(log2(number of bits set in this
+ * shard's columns)) — alive or not is all the collector needs; how FULL the surviving masks are tells the host whether
+ * state lists saturate on this index (dense DP steps pay) or thin out (pruning pays), so the host can prune dead
+ * states before expanding them.  Every stage's blob must hold exactly n_programs programs (possibly with no
  * ops) and their current n_slots.  txq_session_end copies the RESULT slot of every program to
  * final_masks (n_programs x shard_words, host) and destroys the session; a NULL final_masks
  * just destroys it. */

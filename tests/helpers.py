@@ -320,7 +320,7 @@ class SessionSimulator:
         for p, s in zip(qp, qs):
             v = self._get(p, s)
             assert v is not None
-            out.append(bool(v.any()))
+            out.append(int(np.unpackbits(v.view(np.uint8)).sum()).bit_length())  # 0, or 1 + floor(log2(bits set)) like the device
         return out
 
     def result(self, p):

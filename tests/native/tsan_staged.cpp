@@ -67,6 +67,7 @@ int main() {
     dense_exec.kill_every = 0;
     StagedOptions dopt = opt;
     dopt.dense.enabled = true;
+    dopt.dense_evidence = DenseOptions::kDense;  // the executor above answers a plain 1 (alive): nothing to learn fills from
     dopt.dense.slot_bytes = 128;
     dopt.dense_pool_bytes = (uint64_t)40 * 9261 * 128;  // room for 40 blocks among 96 queries
     const StagedStats st3 = run_staged(enc, 1024, motifs, dense_exec, dopt, &status, &why);

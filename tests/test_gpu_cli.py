@@ -189,7 +189,7 @@ def test_hibf_written_by_tetrex_index_takes_the_fused_tree_steps(tmp_path):
     img = host.IndexFile.load(str(tmp_path / "tree.ibf")).describe()
     assert img["is_hibf"] and [f["bins"] for f in img["ibfs"]] == [4, 64, 64, 64, 8]
     assert len({f["bin_size"] for f in img["ibfs"][1:]}) == 1
-    env = dict(os.environ, TXQ_TRACE="1")
+    env = dict(os.environ, TXQ_TRACE="1", TETREX_DENSE_EVIDENCE="dense")  # (600 residues per bin: left alone, the expansion learns that states thin out)
     fused = 0
     for q in ("LMK.AC.{0,2}EQ[GA]HK", "LMK..CDEQGHK", "LMKW.{2,3}EQGHK", "W.C[DE]{1,2}.GHK"):
         for name in ("flat", "tree"):

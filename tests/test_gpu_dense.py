@@ -10,6 +10,13 @@ from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _lists_saturate(monkeypatch):
+    """These tests are about the dense machinery, on small (sparse) indexes: tell the expansion that lists saturate instead
+    of letting it find out that they do not (tests of that protocol set TETREX_DENSE_EVIDENCE themselves)."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+
+
 @pytest.fixture(scope="module")
 def capi():
     from tetrex_amd import capi as c
@@ -270,3 +277,40 @@ def test_dense_regions_are_recycled_when_block_memory_is_short(capi, oracle, mon
             assert np.array_equal(g, m), q
             compared += 1
     assert compared >= 12
+
+
+@pytest.mark.parametrize("kind", ["saturated", "sparse"])
+def test_a_fresh_index_is_asked_how_states_fare_on_it(capi, oracle, monkeypatch, kind):
+    """TETREX_DENSE_EVIDENCE unset, index tag 0 (a fresh index in the product): the first wildcard query pauses before its first block and reads the
+    fill of the probed states' masks from the device's answers (1 + floor(log2(bits))).  Saturated index: dense steps, tag 1;
+    sparse index: enumerated and pruned, tag 2; the next batch starts from the tag (no pause).  Masks equal the oracle's."""
+    monkeypatch.delenv("TETREX_DENSE_EVIDENCE")
+    bins, k = 1000, 3
+    if kind == "saturated":
+        ox = oracle.Index.ibf(bins, 4099, 2, dna=False, k=k)
+        every = np.arange(1 << 15, dtype=np.uint64)
+        for b in range(bins):
+            if b % 5:
+                ox.emplace(every, b)
+    else:
+        ox = _oracle_index(oracle, bins=bins, m=4099, h=2, k=k, dna=False, per_bin=300, seed=31)
+    qs = ["LMKA..CDE.GH", "WKLA.{1,3}CDEF", "ACDEF...GHIKL", "LMKACDE", "LMK[AC]..[DE]F.HK"]
+    wants = _wants(ox, qs)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    assert ix.tag == 0
+    stages = []
+    for rep in range(2):
+        got, status, stats = ix.query_masks(qs, False, k, 0, 0)
+        for q, g, w, st in zip(qs, got, wants, status):
+            assert st == 0 and np.array_equal(g, w), (q, rep)
+        assert (stats["dense_ops"] > 0) == (kind == "saturated")
+        assert ix.tag & 3 == (1 if kind == "saturated" else 2)
+        stages.append(stats["stages"])
+    assert stages[1] <= stages[0]
+    ix.tag = 3 - (ix.tag & 3)  # told the opposite, the expansion believes it: same masks, the other way of getting them
+    got, status, stats = ix.query_masks(qs, False, k, 0, 0)
+    for q, g, w, st in zip(qs, got, wants, status):
+        assert st == 0 and np.array_equal(g, w), q
+    assert (stats["dense_ops"] > 0) == (kind == "sparse")
+    ix.free()

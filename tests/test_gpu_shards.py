@@ -32,7 +32,8 @@ def _oracle_index(oracle, bins, m, h, k, dna, per_bin, seed):
 
 
 @pytest.mark.parametrize("R", [2, 3, 8])
-def test_sharded_queries_equal_the_oracle(capi, oracle, R):
+def test_sharded_queries_equal_the_oracle(capi, oracle, R, monkeypatch):
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")  # a sparse index: the expansion would find out and enumerate; this test wants blocks on shards
     ox = _oracle_index(oracle, bins=1000, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=5)
     sh = ox.shape()
     qs = PEPTIDE_QUERIES + random_prosite_motifs(40, 11, wildcard=0.1, ranges=0.05)

@@ -10,6 +10,13 @@ from helpers import SessionSimulator
 from motifs import PEPTIDE_QUERIES, DNA_QUERIES, random_prosite_motifs
 
 
+@pytest.fixture(autouse=True)
+def _lists_saturate(monkeypatch):
+    """These tests are about the dense machinery, on small (sparse) indexes: tell the expansion that lists saturate instead
+    of letting it find out that they do not (tests of that protocol set TETREX_DENSE_EVIDENCE themselves)."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+
+
 @pytest.fixture(scope="module")
 def host():
     from tetrex_amd import host as H
@@ -141,3 +148,28 @@ def test_queries_begin_in_waves_when_block_memory_is_short(host, oracle):
     checked2, tight, sim = _run(host, ox, qs, False, 4, dict(slot_bytes=128, pool_bytes=12 * block))
     assert checked == checked2 == len(qs)
     assert tight["stages"] > free["stages"] and tight["ops"] < 3 * free["ops"]
+
+
+@pytest.mark.parametrize("kind", ["saturated", "sparse"])
+def test_the_expansion_asks_before_its_first_block(host, oracle, monkeypatch, kind):
+    """Nothing known about the index (TETREX_DENSE_EVIDENCE=ask, the product's default for a fresh index): a query pauses
+    before the first list that could become a block and reads the fill of its probed states' masks from the answers
+    (1 + floor(log2(bits)), as txq_session_stage gives them).  Saturated index (every k-mer in most bins): blocks from then
+    on; sparse index: no block at all, states are enumerated and pruned.  The masks are the oracle's either way."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "ask")
+    bins, k = 256, 3
+    if kind == "saturated":
+        ox = oracle.Index.ibf(bins, 4099, 2, dna=False, k=k)
+        every = np.arange(1 << 15, dtype=np.uint64)  # all 3-mers over 5-bit codes
+        for b in range(bins):
+            if b % 5:
+                ox.emplace(every, b)
+    else:
+        ox = _index(oracle, bins=bins, m=4099, h=2, k=k, dna=False, per_bin=300, seed=31)
+    qs = ["LMKA..CDE.GH", "WKLA.{1,3}CDEF", "ACDEF...GHIKL", "LMKACDE"]
+    checked, stats, sim = _run(host, ox, qs, False, k, dict(min_states=8, sparse_below=4))
+    assert checked == len(qs)
+    if kind == "saturated":
+        assert sim.dense_steps > 0 and stats["stages"] >= 2
+    else:
+        assert sim.dense_steps == 0

@@ -537,7 +537,18 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             const int32_t next = order_[cursor_];
             NodeStates& cur = table_[next];
             if (!cur.dense.empty()) materialise(next, out, !go_dense);
-            const bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
+            bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
+            if (may_densify && dense_.evidence) {
+                const int ev = dense_.evidence->load(std::memory_order_relaxed);
+                if (ev != DenseOptions::kUnknown) wants_evidence_ = false;
+                if (ev == DenseOptions::kUnknown && !evidence_asked_) {
+                    // the first list of this query that could become a block, and nobody knows yet how states fare on this
+                    // index: stop here for this stage and ask (the waiting states are this stage's questions)
+                    evidence_asked_ = wants_evidence_ = true;
+                    break;
+                }
+                may_densify = ev != DenseOptions::kSparse;  // still unknown after asking: as if they saturate
+            }
             if (!cur.dense.empty() || may_densify) {
                 dense_receivers(next, receivers_scratch_);
                 size_t need = 0;
@@ -792,6 +803,21 @@ void QueryExpansion::frontier_slots(std::vector<uint32_t>& out) {
     for (int32_t j : open_joins_) ask(table_[j].items);  // lists that wait for their readers
 }
 
+void QueryExpansion::observe(const std::vector<uint8_t>& klass, uint64_t* bits, uint64_t* states) {
+    wants_evidence_ = false;
+    const unsigned k = enc_.k();
+    auto look = [&](const StateVec& items) {
+        for (const State& s : items) {
+            if (s.slot >= klass.size() || klass[s.slot] == 0xFF || s.gapped || s.shift < k) continue;  // not asked / never probed
+            const uint8_t b = klass[s.slot];
+            // b = 1 + floor(log2(bits)): the middle of [2^(b-1), 2^b)
+            *bits += b == 0 ? 0 : b == 1 ? 1 : (3ULL << (b - 2));
+            ++*states;
+        }
+    };
+    for (size_t c = cursor_; c < order_.size(); ++c) look(table_[order_[c]].items);
+    for (int32_t j : open_joins_) look(table_[j].items);
+}
 void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     auto is_dead = [&](const State& s) { return s.slot < dead.size() && dead[s.slot]; };

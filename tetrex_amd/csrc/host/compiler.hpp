@@ -72,6 +72,11 @@ struct DenseOptions {
     uint64_t max_block_bytes = 1ull << 30;
     uint32_t max_blocks = 256;     // per query, live at the same time (fewer where 256 blocks exceed the dense slot space); `pool` is the real bound
     std::atomic<int64_t>* pool = nullptr;  // bytes all queries of a run may still take (null: unlimited)
+    // What the run knows about the index (shared by its queries; null = kDense): do the masks of probed states stay full
+    // (lists saturate: blocks pay) or thin out (states die within a few residues: enumerating and pruning pays)?  While
+    // it is unknown, a query pauses once at its first list that could become a block and asks (QueryExpansion::observe).
+    enum Evidence : int { kUnknown = 0, kDense = 1, kSparse = 2 };
+    std::atomic<int>* evidence = nullptr;
 };
 using DenseVec = std::vector<txq_dense_op>;
 // slots of one dense block, A^(k-1), for this encoder — 0 when dense blocks cannot be used with it (k too
@@ -157,7 +162,10 @@ class QueryExpansion {
     void frontier_slots(std::vector<uint32_t>& out);
     // feedback is pointless where (almost) nothing dies: stop asking after enough evidence
     // (a query that runs dense steps has shown that its lists saturate instead of dying: it stops asking too)
-    bool wants_feedback() const { return dense_steps_ == 0 && (asked_ < 2048 || pruned_ * 50 >= asked_); }
+    bool wants_feedback() const { return wants_evidence_ || (dense_steps_ == 0 && (asked_ < 2048 || pruned_ * 50 >= asked_)); }
+    // Feedback of the stage, by slot: 0xFF = not asked, 0 = dead, b = 1 + floor(log2(bits set)) (txq_session_stage).  Adds the
+    // bits of the asked states that have been probed at least once to *bits and their number to *states.
+    void observe(const std::vector<uint8_t>& klass_by_slot, uint64_t* bits, uint64_t* states);
     // where a quarter or more of the states die, expanding an unconfirmed state is mostly wasted work:
     // such a query only expands what the device has confirmed alive (advance(..., verified_only))
     bool mostly_dying() const { return asked_ >= 64 && pruned_ * 4 >= asked_; }
@@ -228,6 +236,7 @@ class QueryExpansion {
     // ---- dense blocks ----
     DenseOptions dense_;
     bool dense_ok_ = false;
+    bool wants_evidence_ = false, evidence_asked_ = false;  // paused before the first list that could become a block
     unsigned dense_pos_ = 0;      // k - 1
     uint32_t dense_a_ = 0;        // alphabet size A
     uint64_t dense_n_ = 0;        // A^(k-1)
@@ -284,7 +293,8 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
 struct StageExecutor {
     virtual ~StageExecutor() = default;
     // Runs the NEW ops of every program (blob in txq_program.h format, all programs present,
-    // 8-byte aligned) and answers alive[i] = slot query_slot[i] of program query_program[i] has a bit set.
+    // 8-byte aligned) and answers alive[i] = 0 when slot query_slot[i] of program query_program[i] has no bit set,
+    // otherwise 1 + floor(log2(bits set)) (a plain 1 is fine for an executor that does not count: "alive, nearly empty").
     virtual void stage(const uint8_t* blob, size_t blob_bytes, const std::vector<uint32_t>& query_program,
                        const std::vector<uint32_t>& query_slot, std::vector<uint8_t>& alive) = 0;
 };
@@ -303,12 +313,17 @@ struct StagedOptions {
     CompileLimits limits;
     DenseOptions dense;                      // run_staged fills `pool` itself
     uint64_t dense_pool_bytes = 48ull << 30; // device memory all dense blocks of a run may take
+    int dense_evidence = DenseOptions::kUnknown;  // what earlier runs learned about this index (StagedStats::dense_evidence); kUnknown: ask
+    uint64_t feedback_bins = 0;              // bins the executor's answers count bits over (a column shard); 0 = all bins
+    double dense_min_fill = 0.25;            // masks of probed states at least this full on average: lists saturate, blocks pay
 };
 
 struct StagedStats {
     size_t stages = 0;
     uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0, dense_ops = 0;
     double expand_seconds = 0, execute_seconds = 0;  // host expansion vs. StageExecutor::stage
+    int dense_evidence = DenseOptions::kUnknown;     // what this run knew / learned about the index (for the next run on it)
+    double observed_fill = -1;                       // mean fraction of bits set in the masks it looked at (-1: it did not look)
 };
 
 // Drives a batch of queries through staged execution.  status[i] != 0: query i could not be

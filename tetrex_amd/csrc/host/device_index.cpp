@@ -170,9 +170,16 @@ void ShardedStageExecutor::stage(const uint8_t* blob, size_t blob_bytes, const s
     for (auto& f : others) f.get();
     for (const std::string& e : errors)
         if (!e.empty()) throw std::runtime_error(e);
+    // an answer is 0 (no bit) or 1 + floor(log2(bits set in the shard's columns)): the shards' counts add up
     alive.assign(nq, 0);
-    for (size_t r = 0; r < R; ++r)
-        for (size_t i = 0; i < nq; ++i) alive[i] |= answers[r][i];
+    for (size_t i = 0; i < nq; ++i) {
+        uint64_t bits = 0;
+        for (size_t r = 0; r < R; ++r) {
+            const uint8_t b = answers[r][i];
+            bits += b == 0 ? 0 : b == 1 ? 1 : (3ULL << (b - 2));  // the middle of [2^(b-1), 2^b)
+        }
+        alive[i] = bits ? (uint8_t)(64 - __builtin_clzll(bits)) : 0;
+    }
 }
 std::vector<uint64_t> ShardedStageExecutor::finish() {
     const size_t R = sessions_.size();
@@ -212,7 +219,11 @@ std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards,
         if (i.shard_words) opt.dense.enabled = opt.dense.enabled && txq_index_supports_dense(s) != 0;
         opt.dense.slot_bytes = std::max<uint64_t>(opt.dense.slot_bytes, i.shard_words * 8);
     }
+    uint64_t tag = 0;
+    (void)txq_index_get_tag(shards[0], &tag);
+    if (opt.dense_evidence == DenseOptions::kUnknown) opt.dense_evidence = (int)(tag & 3);  // what earlier runs learned about the index
     const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
+    if (st.dense_evidence != DenseOptions::kUnknown) (void)txq_index_set_tag(shards[0], (tag & ~(uint64_t)3) | (uint64_t)st.dense_evidence);
     if (stats) *stats = st;
     return exec.finish();
 }
@@ -231,9 +242,14 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     // saturated state lists run as dense DP steps on the device where the index allows it (TETREX_DENSE=0 switches them off)
     opt.dense.enabled = txq_index_supports_dense(ix) != 0;
     opt.dense.slot_bytes = info.shard_words * 8;
+    opt.feedback_bins = std::min<uint64_t>(info.user_bins, info.shard_words * 64);
+    uint64_t tag = 0;
+    (void)txq_index_get_tag(ix, &tag);
+    if (opt.dense_evidence == DenseOptions::kUnknown) opt.dense_evidence = (int)(tag & 3);  // what earlier runs learned about the index
     const bool trace = std::getenv("TETREX_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
+    if (st.dense_evidence != DenseOptions::kUnknown) (void)txq_index_set_tag(ix, (tag & ~(uint64_t)3) | (uint64_t)st.dense_evidence);
     if (stats) *stats = st;
     const auto t1 = std::chrono::steady_clock::now();
     exec.finish(masks.data());  // waits for the device: a stage without feedback questions returns as soon as it is launched

@@ -96,6 +96,10 @@ class StagedRun {
         dense_total_ = dense_pool_.load();
         admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)INT64_MAX / 4);
         dense_.pool = &dense_pool_;
+        evidence_.store(opt.dense_evidence);
+        if (const char* e = std::getenv("TETREX_DENSE_EVIDENCE"))  // A/B knob and tests: dense / sparse / ask
+            evidence_.store(e[0] == 'd' ? DenseOptions::kDense : e[0] == 's' ? DenseOptions::kSparse : DenseOptions::kUnknown);
+        dense_.evidence = &evidence_;
         wave_ops_ = opt.wave_ops;
         if (const char* e = std::getenv("TETREX_WAVE_OPS")) wave_ops_ = (size_t)std::max(0LL, std::atoll(e));  // A/B knob; 0 = one wave
         if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
@@ -130,6 +134,7 @@ class StagedRun {
         }
         if (status) *status = status_;
         if (messages) *messages = why_;
+        st_.dense_evidence = evidence_.load();
         return st_;
     }
 
@@ -377,13 +382,14 @@ class StagedRun {
         if (v3) std::memcpy(blob, &h3, sizeof h3);
         else std::memcpy(blob, &h, sizeof h);
         // the blob holds the stage now: the per-query buffers are free for the next one
-        for (uint32_t i : touched_) {
+        pool_.run(touched_.size(), [&](size_t j, int) {
+            const uint32_t i = touched_[j];
             if (!q_[i]) flushed_[i] = 1;  // finished, and its last ops are in this blob
             dense_ops_[i].clear();
             if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
             else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); DenseVec().swap(dense_ops_[i]); }  // finished: storage back to the cache
             levels_[i].clear();
-        }
+        });
         lap("blob");
         return Blob{blob, h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7), stage_kmers + stage_dgrams};
     }
@@ -442,17 +448,36 @@ class StagedRun {
     }
 
     void prune(const Frontier& fr) {
+        // while nobody knows how states fare on this index, the answers are also read as mask fills (see DenseOptions::evidence)
+        const bool look = dense_.enabled && evidence_.load(std::memory_order_relaxed) == DenseOptions::kUnknown;
+        std::atomic<uint64_t> seen_bits{0}, seen_states{0};
         pool_.run(fr.queries.size(), [&](size_t j, int t) {
+            const uint32_t p = fr.queries[j];
+            if (look && q_[p]) {
+                std::vector<uint8_t>& klass = dead_scratch_[t];
+                klass.assign(q_[p]->n_slots(), 0xFF);
+                for (size_t a = fr.first[j]; a < fr.first[j + 1]; ++a) klass[fr.slot[a]] = fr.alive[a];
+                uint64_t b = 0, n = 0;
+                q_[p]->observe(klass, &b, &n);
+                seen_bits.fetch_add(b, std::memory_order_relaxed);
+                seen_states.fetch_add(n, std::memory_order_relaxed);
+            }
             bool any = false;
             for (size_t a = fr.first[j]; a < fr.first[j + 1] && !any; ++a) any = !fr.alive[a];
             if (!any) return;
-            const uint32_t p = fr.queries[j];
             std::vector<uint8_t>& dead = dead_scratch_[t];
             dead.assign(q_[p]->n_slots(), 0);
             for (size_t a = fr.first[j]; a < fr.first[j + 1]; ++a)
                 if (!fr.alive[a]) dead[fr.slot[a]] = 1;
             q_[p]->prune(dead);
         });
+        if (look && seen_states.load() >= 16) {  // a handful of states is no basis: the next stage looks again
+            const double fill = std::min(1.0, (double)seen_bits.load() / ((double)seen_states.load() * (double)std::max<uint64_t>(opt_.feedback_bins ? opt_.feedback_bins : bins_, 1)));
+            st_.observed_fill = fill;
+            evidence_.store(fill >= opt_.dense_min_fill ? DenseOptions::kDense : DenseOptions::kSparse);
+            if (trace_) std::fprintf(stderr, "[tetrex] masks of %llu probed states are %.1f %% full: %s\n", (unsigned long long)seen_states.load(), fill * 100,
+                                     fill >= opt_.dense_min_fill ? "lists saturate, dense steps" : "states thin out, enumerate and prune");
+        }
         lap("prune");
     }
 
@@ -478,6 +503,7 @@ class StagedRun {
     std::vector<uint32_t> dslots_;     // per query: slots of its dense region
     DenseOptions dense_;
     std::atomic<int64_t> dense_pool_{0};
+    std::atomic<int> evidence_{DenseOptions::kUnknown};  // see DenseOptions::evidence
     std::atomic<uint64_t> dense_block_slots_{0};
     std::vector<LevelScratch> scratch_;               // per thread
     std::vector<std::vector<uint8_t>> dead_scratch_;  // per thread

@@ -312,6 +312,17 @@ int txq_index_free(txq_index* ix) {
     return TXQ_OK;
 }
 
+int txq_index_set_tag(txq_index* ix, uint64_t tag) {
+    if (!ix) return fail(TXQ_ERR_ARG, "null argument");
+    ix->user_tag = tag;
+    return TXQ_OK;
+}
+int txq_index_get_tag(const txq_index* ix, uint64_t* tag) {
+    if (!ix || !tag) return fail(TXQ_ERR_ARG, "null argument");
+    *tag = ix->user_tag;
+    return TXQ_OK;
+}
+
 int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_words) {
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(ix)) return rc;

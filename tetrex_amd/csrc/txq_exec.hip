@@ -161,6 +161,7 @@ struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M;
 //           handled by G lanes (a lane owns 16 bytes of the mask: WIDE, or one word) which loop over the
 //           predecessors a in shape[0], two at a time: 2 * (H row gathers + 1 source mask) loads in flight
 struct DenseTile { uint32_t program, op, first, count; };
+static constexpr uint32_t kRootWordsLds = 4096;  // 32 KB of root verdicts per workgroup (TreeRowsByLane)
 struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; };
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -292,14 +293,14 @@ struct TreeRows {
         for (int h = 0; h < H; ++h) y &= l.x[h];
         return y;
     }
-    // (TreeRowsByLane) the root's verdict on a k-mer for ALL children: a root of at most 64 merged bins is one word per row
-    __device__ __forceinline__ uint64_t root_word(uint64_t value) const {
+    // (TreeRowsByLane) one word of the root's verdict on a k-mer: bit b = the k-mer may be in the child behind merged bin 64 * word + b
+    __device__ __forceinline__ uint64_t root_word(uint64_t value, uint32_t word) const {
         const uint64_t* rw = (const uint64_t*)root.words;
         const uint32_t r_hf = root.hash_funs(), r_stride = root.stride(), r_shift = root.hash_shift();
         uint64_t x = ~0ULL;
 #pragma unroll
         for (int i = 0; i < H; ++i)
-            if ((uint32_t)i < r_hf) x &= rw[hash_row_seeded(value * kSeeds[i], r_shift, root.bin_size) * r_stride];
+            if ((uint32_t)i < r_hf) x &= rw[hash_row_seeded(value * kSeeds[i], r_shift, root.bin_size) * r_stride + word];
         return x;
     }
     __device__ __forceinline__ void issue_child(const uint64_t* src_slot, uint64_t value, Loads& l) const {
@@ -360,10 +361,10 @@ struct InterleavedRows {
     }
 };
 
-// The same tree when its root has at most 64 merged bins and a suffix's lanes cover the whole mask: the lanes of a
-// suffix first take one PREDECESSOR each and gather its root word (the verdict for all children at once — every root
-// row is fetched by exactly one lane, all predecessors in one round), hand the words round with shuffles, and each lane
-// then visits only the predecessors that the root lets into ITS child.  (dense_kernel, kRootByLane)
+// The same tree with the root's verdicts shared: the lanes of a suffix first share out the (predecessor, root word) pairs —
+// every root row is fetched once per suffix, all predecessors in one round, instead of once per lane chunk — and leave
+// the ANDed words in LDS; each lane then visits only the predecessors that the root lets into ITS child.  What the
+// 65536-bin tree needs: its mask is 512 lane chunks wide, its root row 4 words.  (dense_kernel, kRootByLane)
 template <int H, bool WIDE>
 struct TreeRowsByLane : TreeRows<H, WIDE> {
     static constexpr bool kRootByLane = true;
@@ -377,6 +378,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     using T = typename L::T;
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // [j < pos]: codes of shape[j]; [pos]: codes of r_mask
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    __shared__ uint64_t root_words[ROWS::kRootByLane ? kRootWordsLds : 1];  // [suffix of the pass][predecessor < 32][root word]
     if (blockIdx.x < U.n_units) {  // the whole workgroup: no barrier has been reached
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
@@ -448,57 +450,57 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
         const uint64_t low = (mid_val << P.bits) | r;  // the k-mer without its oldest residue
         uint64_t* dst = dstb + ((size_t)mid * P.A + r) * W;
         const uint64_t* srcm = src + (size_t)mid * W;
-        if constexpr (ROWS::kRootByLane) {  // chunks <= G (host): one pass over the mask
-            const uint32_t ls = threadIdx.x % lanes, first_lane = (threadIdx.x & 63u) & ~(lanes - 1u);
-            const uint32_t c = sub;
-            const bool mine = live && c < chunks;
-            rows.prepare(c < chunks ? c : 0);
-            uint32_t hits = 0;  // bit j: the root lets predecessor j of this suffix into my child
-            for (uint32_t j0 = 0; j0 < n_a; j0 += lanes) {  // n_a <= 32
-                const uint32_t j = j0 + ls;
-                uint64_t rw = 0;
-                if (live && j < n_a) {
+        if constexpr (ROWS::kRootByLane) {
+            // Round 1: the root's verdict on every predecessor's k-mer, once per suffix — the lanes of the suffix share out the
+            // (predecessor, root word) pairs and leave the ANDed words in LDS.  Round 2: per mask chunk, only the
+            // predecessors the root lets into the lane's child are visited.
+            const uint32_t ls = threadIdx.x % lanes, rs = rows.root.stride();
+            uint64_t* mine_root = root_words + (size_t)grp * 32u * rs;
+            __syncthreads();  // the previous pass has read its words
+            if (live)
+                for (uint32_t idx = ls; idx < n_a * rs; idx += lanes) {
+                    const uint32_t j = idx / rs, w = idx - j * rs;
                     uint64_t v = ((uint64_t)codes[0][j] << a_shift) | low;
                     if (P.canonical) v = canonical_dna(v, P.k);
-                    rw = rows.root_word(v);
+                    mine_root[idx] = rows.root_word(v, w);
                 }
-                const uint32_t span = n_a - j0 < lanes ? n_a - j0 : lanes;
-                for (uint32_t t = 0; t < span; ++t) {  // uniform over the workgroup: every lane shuffles
-                    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)rw, (int)(first_lane + t));
-                    const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(rw >> 32), (int)(first_lane + t));
-                    const uint64_t w = ((uint64_t)hi << 32) | lo;
-                    hits |= (uint32_t)((w >> rows.r_bit) & 1ULL) << (j0 + t);
-                }
-            }
-            T acc = L::zero();
-            if (mine) {
-                uint32_t todo = 0;  // my slice's share of the predecessors: slice, slice + SL, ...
-                for (uint32_t j = slice; j < n_a; j += SL) todo |= 1u << j;
-                todo &= hits;
-                while (todo) {
-                    typename ROWS::Loads x[UA];
-                    bool have[UA];
+            __syncthreads();
+            uint32_t my_share = 0;  // my slice's share of the predecessors: slice, slice + SL, ...
+            for (uint32_t j = slice; j < n_a; j += SL) my_share |= 1u << j;
+            for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
+                const uint32_t c = c0 + sub;
+                const bool mine = live && c < chunks;
+                T acc = L::zero();
+                if (mine) {
+                    rows.prepare(c);
+                    uint32_t todo = 0;  // bit j: the root lets predecessor j of this suffix into my child
+                    for (uint32_t j = 0; j < n_a; ++j) todo |= (uint32_t)((mine_root[j * rs + rows.r_word] >> rows.r_bit) & 1ULL) << j;
+                    todo &= my_share;
+                    while (todo) {
+                        typename ROWS::Loads x[UA];
+                        bool have[UA];
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) {
-                        have[u] = todo != 0;
-                        if (have[u]) {
-                            const uint32_t j = (uint32_t)__builtin_ctz(todo);
-                            todo &= todo - 1;
-                            const uint32_t a = codes[0][j];
-                            uint64_t v = ((uint64_t)a << a_shift) | low;
-                            if (P.canonical) v = canonical_dna(v, P.k);
-                            rows.issue_child(srcm + (size_t)a * a_stride * W, v, x[u]);
+                        for (int u = 0; u < UA; ++u) {
+                            have[u] = todo != 0;
+                            if (have[u]) {
+                                const uint32_t j = (uint32_t)__builtin_ctz(todo);
+                                todo &= todo - 1;
+                                const uint32_t a = codes[0][j];
+                                uint64_t v = ((uint64_t)a << a_shift) | low;
+                                if (P.canonical) v = canonical_dna(v, P.k);
+                                rows.issue_child(srcm + (size_t)a * a_stride * W, v, x[u]);
+                            }
                         }
-                    }
 #pragma unroll
-                    for (int u = 0; u < UA; ++u)
-                        if (have[u]) acc |= rows.combine_child(x[u]);
+                        for (int u = 0; u < UA; ++u)
+                            if (have[u]) acc |= rows.combine_child(x[u]);
+                    }
                 }
-            }
-            for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
-            if (mine && slice == 0 && L::any(acc)) {
-                uint64_t* p = dst + (size_t)c * L::kWords;
-                L::store(p, L::load(p) | acc);
+                for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
+                if (mine && slice == 0 && L::any(acc)) {
+                    uint64_t* p = dst + (size_t)c * L::kWords;
+                    L::store(p, L::load(p) | acc);
+                }
             }
         } else
         for (uint32_t c0 = 0; c0 < chunks; c0 += G) {
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(256) void init_slots_kernel(uint64_t* const* __rest
     }
 }
 
-// alive[i] = any bit set in slot q_slot[i] of program q_prog[i]; one wave per query
+// alive[i] = 0 when slot q_slot[i] of program q_prog[i] has no bit set, else 1 + floor(log2(bits set)); one wave per query
 __global__ __launch_bounds__(256) void slot_alive_kernel(uint64_t* const* __restrict__ slot_base, const uint32_t* __restrict__ q_prog,
                                                          const uint32_t* __restrict__ q_slot, uint32_t n, uint32_t W,
                                                          uint8_t* __restrict__ alive) {
@@ -660,10 +662,10 @@ __global__ __launch_bounds__(256) void slot_alive_kernel(uint64_t* const* __rest
     const size_t n_waves = (size_t)gridDim.x * (blockDim.x >> 6);
     for (size_t i = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < n; i += n_waves) {
         const uint64_t* s = slot_base[q_prog[i]] + (size_t)q_slot[i] * W;
-        uint64_t any = 0;
-        for (uint32_t w = lane; w < W; w += 64) any |= s[w];
-        const bool live = __ballot(any != 0) != 0;
-        if (lane == 0) alive[i] = live ? 1 : 0;
+        uint32_t bits = 0;
+        for (uint32_t w = lane; w < W; w += 64) bits += (uint32_t)__popcll(s[w]);
+        for (uint32_t o = 32; o; o >>= 1) bits += (uint32_t)__shfl_xor((int)bits, (int)o);
+        if (lane == 0) alive[i] = bits ? (uint8_t)(32 - __clz((int)bits)) : 0;
     }
 }
 
@@ -1345,7 +1347,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     while ((1u << wpr_log2) < ix.child_row_words) ++wpr_log2;
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
-                    const bool by_lane = ix.root_node.bins <= 64 && (wide ? W / 2 : W) <= g_dense && !(tree_knob && tree_knob[0] == '1');
+                    const bool by_lane = (256u / (g_dense * sl_dense)) * 32u * ix.root_node.stride() <= kRootWordsLds && !(tree_knob && tree_knob[0] == '1');
                     if (interleaved) {
                         auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                         e = wide ? launch_dense<true, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)

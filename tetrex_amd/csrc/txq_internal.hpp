@@ -104,6 +104,7 @@ struct Index {
         bool in_use = false;
     } session_cache;
     static constexpr size_t kArenaKeepBytes = (size_t)64 << 30;
+    uint64_t user_tag = 0;  // txq_index_set_tag
     int open_sessions = 0;  // txq_index_free refuses while a session still points at this index
 
     // txq_probe (host buffers): two streams with their device and pinned bounce buffers

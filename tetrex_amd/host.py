@@ -124,7 +124,8 @@ class DenseOptions(C.Structure):
 def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0, gaps=None, dense=None):
     """Drive the C++ staged expansion with a Python executor.
 
-    stage(blob: bytes, query_program: list, query_slot: list) -> iterable of bool (alive).
+    stage(blob: bytes, query_program: list, query_slot: list) -> iterable of answers: False/0 = the slot has no bit set,
+    True/1 = alive, or 1 + floor(log2(bits set)) as txq_session_stage answers (what the expansion reads mask fills from).
     dense: None, or dict(min_states=, sparse_below=, max_blocks=, slot_bytes=, pool_bytes=) to switch dense DP
     steps on (the executor then gets version-3 blobs)."""
     L = lib()
@@ -148,7 +149,7 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
         try:
             res = stage(C.string_at(blob, size), [qp[i] for i in range(nq)], [qs[i] for i in range(nq)])
             for i, a in enumerate(res):
-                alive[i] = 1 if a else 0
+                alive[i] = min(255, int(a))
             return 0
         except Exception as e:  # noqa: BLE001 - reported through the return code
             err.append(e)
