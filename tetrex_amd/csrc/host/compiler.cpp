@@ -399,6 +399,21 @@ QueryExpansion::DenseRef* QueryExpansion::owned_block(NodeStates& ns, OpVec& out
     return &ns.dense.back();
 }
 
+// How many suffixes of its shape a list may have per state it holds and still become a block (0: never).  A step visits
+// every suffix of the shape, alive or not, at (h + 1 ~ 4 loads) x the mask's bytes over ~4 TB/s per predecessor on the
+// device — 0.13 ns for 1024 bins, 8 ns for 65536; an enumerated state costs that as well, plus ~12 ns of the batch's
+// host time per residue.  So narrow masks pay for a block while the shape is up to 64 times the list (at k = 4 that is
+// any list worth the question; at k = 6, 21^5 suffixes, only lists of tens of thousands of states), 8 KiB masks only
+// when the list fills half of its shape.  Where the run has learned that states thin out on this index (most entries
+// of a shape are dead a few residues on, and every later step keeps visiting them) the bar is four times higher.
+uint64_t QueryExpansion::shape_limit() const {
+    const double t_dev = (double)(dense_.slot_bytes ? dense_.slot_bytes : 128) / 1000.0;
+    double per_state = (dense_.host_ns_per_op + t_dev) / t_dev;
+    if (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse) per_state /= 4;
+    if (per_state < 1) return 0;
+    return std::min<uint64_t>((uint64_t)per_state, dense_.max_shape_per_state);
+}
+
 // a list with many full-length states becomes (part of) a block: one scatter op per state now instead of
 // one op per state and residue at every later step
 void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
@@ -413,13 +428,11 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
         for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
     }
     if (full < dense_.min_states) return;
-    // A step visits every suffix of the shape (the product of the per-position code sets), alive or not, at roughly
-    // 0.1 ns per predecessor on the device, where an enumerated state costs the host ~150 ns per residue: the block
-    // pays while the shape is at most ~64 times the states it holds.  At k = 4 that is any list worth the question
-    // (21^3 suffixes); at k = 6 (21^5) only lists of tens of thousands of states.
+    // the shape (the product of the per-position code sets) against the states it holds: shape_limit()
     uint64_t product = 1;
     for (unsigned j = 0; j < dense_pos_; ++j) product *= (uint64_t)__builtin_popcount(shape[j]);
-    if (product > (uint64_t)dense_.max_shape_per_state * full) return;
+    const uint64_t limit = shape_limit();
+    if (limit == 0 || product > limit * full) return;
     bool has_own = false;
     for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
     if (!has_own && !can_take_blocks(1)) return;
@@ -547,7 +560,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     evidence_asked_ = wants_evidence_ = true;
                     break;
                 }
-                may_densify = ev != DenseOptions::kSparse;  // still unknown after asking: as if they saturate
+                // (still unknown after asking: as if they saturate; what the run has learned sets the bar in densify())
             }
             if (!cur.dense.empty() || may_densify) {
                 dense_receivers(next, receivers_scratch_);

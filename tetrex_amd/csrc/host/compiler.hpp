@@ -67,7 +67,8 @@ struct DenseOptions {
     uint32_t min_states = 32;      // a list with at least this many full-length states becomes a block
     uint32_t sparse_below = 16;    // a block whose shape holds at most this many entries is enumerated again
     uint32_t cool_down = 1;        // released blocks kept out of circulation while new ones can be had (see can_take_blocks)
-    uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state
+    uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state (fewer for wide masks: QueryExpansion::shape_limit)
+    double host_ns_per_op = 12.0;       // what an enumerated state and residue costs the batch (wall time, all expansion threads)
     uint64_t slot_bytes = 0;       // bytes of one mask on the executing device (budgets; 0 = 128)
     uint64_t max_block_bytes = 1ull << 30;
     uint32_t max_blocks = 256;     // per query, live at the same time (fewer where 256 blocks exceed the dense slot space); `pool` is the real bound
@@ -253,6 +254,7 @@ class QueryExpansion {
     void emit_dense(OpVec& out, const txq_dense_op& d);
     DenseRef* owned_block(NodeStates& ns, OpVec& out);
     void densify(NodeStates& ns, OpVec& out);
+    uint64_t shape_limit() const;
     void materialise(int32_t item, OpVec& out, bool all);
     void dense_receivers(int32_t item, std::vector<int32_t>& out) const;
     std::vector<int32_t> receivers_scratch_;
