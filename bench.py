@@ -246,7 +246,7 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
             t0 = time.perf_counter()
             ix.query_masks([single], False, k)
             lat.append(time.perf_counter() - t0)
-        ix.query_masks(plain[:10], False, k)
+        ix.query_masks(random_prosite_motifs(args.motifs, 9, wildcard=0.0, classes=0.3, ranges=0.0), False, k)  # warm, as below
         tp = time.perf_counter()
         _, plain_status, plain_stats = ix.query_masks(plain, False, k)
         plain_s = time.perf_counter() - tp
