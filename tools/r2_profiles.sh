@@ -13,7 +13,9 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 python tools/trace_timeline.py $O/prof_e2e/e2e_kernel_trace.csv > $O/e2e_timeline.txt
 rm -f $O/*/*_kernel_trace.csv $O/*/*.db
 TXQ_TRACE=1 timeout -k 10 300 python tools/e2e_profile.py 10000 > $O/e2e_10k.txt 2>&1
+timeout -k 10 300 python tests/perf_config5_queries.py > $O/config5.json 2> /dev/null
+timeout -k 10 100 python tools/single_query_latency.py > $O/single_query_latency.txt 2> /dev/null
 g++ -O2 -std=c++20 -o /tmp/mf tests/native/matcher_fuzz.cpp tetrex_amd/csrc/host/matcher.cpp && /tmp/mf speed 400 > $O/matcher_speed.txt
 timeout -k 10 200 python tests/perf_hibf.py 1048576 300 1 65536 256 > $O/hibf_65536.json 2>/dev/null
 timeout -k 10 200 python tests/perf_hibf.py 1048576 300 8 65536 256 > $O/hibf_65536_shard0of8.json 2>/dev/null
-tail -c 600 $O/bench_default.json; echo; cat $O/e2e_timeline.txt; grep "^rep" $O/e2e_1k.txt | tail -2; grep -E "^rep|session: 10000" $O/e2e_10k.txt | tail -3 | cut -c1-400; cat $O/matcher_speed.txt; head -8 $O/prof_c3/c3_kernel_stats.csv | cut -c1-200; cat $O/hibf_65536_shard0of8.json | cut -c1-300
+tail -c 600 $O/bench_default.json; echo; cat $O/e2e_timeline.txt; grep "^rep" $O/e2e_1k.txt | tail -2; grep -E "^rep|session: 10000" $O/e2e_10k.txt | tail -3 | cut -c1-400; cat $O/matcher_speed.txt; head -8 $O/prof_c3/c3_kernel_stats.csv | cut -c1-200; cat $O/hibf_65536_shard0of8.json | cut -c1-300; cut -c1-700 $O/config5.json; cat $O/single_query_latency.txt
