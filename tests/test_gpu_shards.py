@@ -122,3 +122,26 @@ def test_cli_query_with_shards(tmp_path, oracle):
         outs.append((sorted(r.stdout.splitlines()), narrowed))
     assert outs[0] == outs[1] == outs[2]
     assert len(outs[0][0]) == 3 and all("LMAEGLYN" in ln for ln in outs[0][0])
+
+
+def test_shards_of_a_fresh_index_are_asked_together(capi, oracle, monkeypatch):
+    """Nothing known about the index: the expansion reads mask fills from the feedback answers, which the sharded executor
+    adds up over the shards (1 + floor(log2(bits)) per shard -> of the sum).  Saturated index in 3 shards: blocks, the
+    verdict lands in the first shard's tag, masks equal the oracle's."""
+    monkeypatch.delenv("TETREX_DENSE_EVIDENCE", raising=False)
+    bins, k = 640, 3
+    ox = oracle.Index.ibf(bins, 4099, 2, dna=False, k=k)
+    every = np.arange(1 << 15, dtype=np.uint64)
+    for b in range(bins):
+        if b % 3:
+            ox.emplace(every, b)
+    sh = ox.shape()
+    qs = ["LMKA..CDE.GH", "WKLA.{1,3}CDEF", "ACDEF...GHIKL", "LMKACDE", "LMK[AC]..[DE]F.HK"]
+    shards = [capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=3) for r in range(3)]
+    full, status, stats = capi.query_masks_sharded(shards, qs, False, k)
+    for q, g, st in zip(qs, full, status):
+        want, _ = ox.expected_mask(q)
+        assert st == 0 and np.array_equal(g, want), q
+    assert stats["dense_ops"] > 0 and shards[0].tag & 3 == 1
+    for s in shards:
+        s.free()
