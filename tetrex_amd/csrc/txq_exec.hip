@@ -161,8 +161,21 @@ struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M;
 //           handled by G lanes (a lane owns 16 bytes of the mask: WIDE, or one word) which loop over the
 //           predecessors a in shape[0], two at a time: 2 * (H row gathers + 1 source mask) loads in flight
 struct DenseTile { uint32_t program, op, first, count; };
+// The host does not spell the tiles of a stage out (the bench batch: 210 000 of them for 6 800 dense ops): it sends one
+// group per dense op — its tiles are [first_tile, first_tile + ceil(entries / per_tile)) of the stage's tile array, the
+// groups of one level back to back — and make_tiles_kernel writes them (one workgroup per group).
+struct TileGroup { uint32_t program, op, entries, per_tile; uint64_t first_tile; };
 static constexpr uint32_t kRootWordsLds = 4096;  // 32 KB of root verdicts per workgroup (TreeRowsByLane)
 struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; };
+
+__global__ __launch_bounds__(256) void make_tiles_kernel(const TileGroup* __restrict__ groups, DenseTile* __restrict__ tiles) {
+    const TileGroup g = groups[blockIdx.x];
+    const uint32_t n = (g.entries + g.per_tile - 1) / g.per_tile;
+    for (uint32_t j = threadIdx.x; j < n; j += blockDim.x) {
+        const uint32_t first = j * g.per_tile, left = g.entries - first;
+        tiles[g.first_tile + j] = DenseTile{g.program, g.op, first, left < g.per_tile ? left : g.per_tile};
+    }
+}
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <bool WIDE> struct Lane;
@@ -996,14 +1009,15 @@ struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0; };
 // hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
 // HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel
 static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
-                         std::vector<DenseTile>* tiles, std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
+                         std::vector<TileGroup>* groups, size_t* n_tiles, std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
                          std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
     const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
     const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
     const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
     std::vector<std::vector<ExecUnit>> per_level;
-    std::vector<std::vector<DenseTile>> tiles_level, hsteps_level;
+    std::vector<std::vector<TileGroup>> groups_level;
+    std::vector<std::vector<DenseTile>> hsteps_level;
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
     static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
     const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
@@ -1013,7 +1027,7 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
         const bool dense = bv.has_dense[p] != 0;
         // small = less work than a unit launch is worth: 2048 ops of a 1024-bin index, 32 ops at 65536 bins
         if (!dense && (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u)) { n_small += d.n_ops != 0; continue; }
-        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); tiles_level.resize(d.n_levels); hsteps_level.resize(d.n_levels); }
+        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); groups_level.resize(d.n_levels); hsteps_level.resize(d.n_levels); }
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
@@ -1039,8 +1053,12 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
                     }
                     const bool hstep = hibf && x.kind == TXQ_DENSE_STEP;
                     if (hstep) per_tile = 256;  // 256 suffixes x up to 32 predecessors: at most 8192 k-mers per tile
+                    if (!hstep) {
+                        if (entries) groups_level[l].push_back(TileGroup{(uint32_t)p, o.dst, (uint32_t)entries, (uint32_t)per_tile, 0});
+                        continue;
+                    }
                     for (uint64_t at = 0; at < entries; at += per_tile)
-                        (hstep ? hsteps_level : tiles_level)[l].push_back(DenseTile{(uint32_t)p, o.dst, (uint32_t)at, (uint32_t)std::min<uint64_t>(per_tile, entries - at)});
+                        hsteps_level[l].push_back(DenseTile{(uint32_t)p, o.dst, (uint32_t)at, (uint32_t)std::min<uint64_t>(per_tile, entries - at)});
                 }
                 cut(run, end);
             }
@@ -1051,10 +1069,16 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
     plan->resize(per_level.size());
     for (size_t l = 0; l < per_level.size(); ++l) {
         (*plan)[l].units = per_level[l].size();
-        (*plan)[l].tiles = tiles_level[l].size();
+        size_t level_tiles = 0;
+        for (TileGroup& g : groups_level[l]) {
+            g.first_tile = *n_tiles + level_tiles;
+            level_tiles += (g.entries + g.per_tile - 1) / g.per_tile;
+        }
+        (*plan)[l].tiles = level_tiles;
+        *n_tiles += level_tiles;
+        groups->insert(groups->end(), groups_level[l].begin(), groups_level[l].end());
         (*plan)[l].hsteps = hsteps_level[l].size();
         units->insert(units->end(), per_level[l].begin(), per_level[l].end());
-        tiles->insert(tiles->end(), tiles_level[l].begin(), tiles_level[l].end());
         for (const DenseTile& t : hsteps_level[l]) {
             hsteps->push_back(t);
             hstep_na->push_back((uint32_t)__builtin_popcount(dops[t.op].shape[0]));
@@ -1139,11 +1163,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     uint32_t sl_dense = 1;
     while (sl_dense * 2 <= want_slices && g_dense * sl_dense * 2 <= 64) sl_dense <<= 1;
     std::vector<ExecUnit> units;
-    std::vector<DenseTile> tiles, hsteps;
+    std::vector<TileGroup> tile_groups;
+    size_t n_tiles = 0;
+    std::vector<DenseTile> hsteps;
     std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
     double t1 = now_s();
-    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tiles, &hsteps, &hstep_na, &plan);
+    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &hsteps, &hstep_na, &plan);
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
     // never across a level; pair_base[tile] = first pair of the tile within its chunk
     std::vector<uint32_t> pair_base(hsteps.size(), 0);
@@ -1189,7 +1215,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     auto place = [&](size_t bytes) { const size_t at = aux_bytes; aux_bytes = (aux_bytes + bytes + 15) & ~(size_t)15; return at; };
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
     const size_t at_progs = place(prog_bytes), at_fresh = place(fresh.size() * 4), at_qp = place(n_q * 4), at_qs = place(n_q * 4), at_alive = place(n_q);
-    const size_t at_units = place(units.size() * sizeof(ExecUnit)), at_tiles = place(tiles.size() * sizeof(DenseTile));
+    const size_t at_units = place(units.size() * sizeof(ExecUnit)), at_tiles = place(n_tiles * sizeof(DenseTile)), at_groups = place(tile_groups.size() * sizeof(TileGroup));
     const size_t at_hsteps = place(hsteps.size() * sizeof(DenseTile)), at_pair_base = place(hsteps.size() * 4);
     const size_t at_moves = place(moves.size() * sizeof(RegionMove)), at_base = place(2 * s.n_programs * sizeof(uint64_t*));
     // a small stage (a single query: a few hundred bytes of blob, a dozen small tables) travels as ONE copy: the blob
@@ -1218,7 +1244,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         put(at_qp, q_prog, n_q * 4);
         put(at_qs, q_slot, n_q * 4);
         put(at_units, units.data(), units.size() * sizeof(ExecUnit));
-        put(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile));
+        put(at_groups, tile_groups.data(), tile_groups.size() * sizeof(TileGroup));
         put(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile));
         put(at_pair_base, pair_base.data(), hsteps.size() * 4);
         put(at_moves, moves.data(), moves.size() * sizeof(RegionMove));
@@ -1235,7 +1261,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         TXQ_HIP(send(at_qp, q_prog, n_q * 4));
         TXQ_HIP(send(at_qs, q_slot, n_q * 4));
         TXQ_HIP(send(at_units, units.data(), units.size() * sizeof(ExecUnit)));
-        TXQ_HIP(send(at_tiles, tiles.data(), tiles.size() * sizeof(DenseTile)));
+        TXQ_HIP(send(at_groups, tile_groups.data(), tile_groups.size() * sizeof(TileGroup)));
         TXQ_HIP(send(at_hsteps, hsteps.data(), hsteps.size() * sizeof(DenseTile)));
         TXQ_HIP(send(at_pair_base, pair_base.data(), hsteps.size() * 4));
         TXQ_HIP(send(at_moves, moves.data(), moves.size() * sizeof(RegionMove)));
@@ -1259,6 +1285,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     s.t_upload += now_s() - t0;
     t0 = now_s();
 
+    if (!tile_groups.empty()) {
+        make_tiles_kernel<<<(unsigned)tile_groups.size(), 256, 0, st>>>((const TileGroup*)(S.d_aux + at_groups), d_tiles);
+        TXQ_HIP(hipGetLastError());
+    }
     if (!moves.empty()) {  // after everything earlier stages launched on the regions, before anything of this stage
         move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)(S.d_aux + at_moves));
         TXQ_HIP(hipGetLastError());
