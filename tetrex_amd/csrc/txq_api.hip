@@ -126,7 +126,9 @@ void Index::release() {
     for (StagingSet& t : session_cache.set)
         if (t.done) (void)hipEventDestroy(t.done);
     if (session_cache.upload) (void)hipStreamDestroy(session_cache.upload);
-    for (void* p : {(void*)session_cache.set[0].d_blob, (void*)session_cache.set[0].d_aux, (void*)session_cache.set[1].d_blob, (void*)session_cache.set[1].d_aux})
+    if (session_cache.side) (void)hipStreamDestroy(session_cache.side);
+    for (void* p : {(void*)session_cache.set[0].d_blob, (void*)session_cache.set[0].d_aux, (void*)session_cache.set[1].d_blob, (void*)session_cache.set[1].d_aux,
+                    (void*)session_cache.set[0].d_masks, (void*)session_cache.set[1].d_masks})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
     if (d_children) (void)hipFree(d_children);

@@ -687,7 +687,8 @@ __global__ __launch_bounds__(256) void gather_result_kernel(uint64_t* const* __r
     const size_t total = (size_t)n_programs * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t p = i / W, w = i % W;
-        final_masks[i] = slot_base[p][(size_t)TXQ_SLOT_RESULT * W + w];
+        const uint64_t* region = slot_base[p];
+        final_masks[i] = region ? region[(size_t)TXQ_SLOT_RESULT * W + w] : 0;
     }
 }
 
@@ -871,6 +872,7 @@ Session::~Session() {
                         "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles), step rows: %s\n",
                 n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, t_grow, t_plan, t_wait, t_alloc, n_levels, n_unit_launches, n_units,
                 n_dense_launches, n_dense_tiles, row_source);
+    if (std::getenv("TXQ_TRACE") && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
@@ -885,15 +887,17 @@ Session::~Session() {
         c.set[0] = set[0];
         c.set[1] = set[1];
         c.upload = upload;
+        c.side = side;
         c.in_use = false;
         return;
     }
     for (const Index::ArenaChunk& k : chunks) (void)hipFree(k.p);
     for (Index::StagingSet& t : set) {
         if (t.done) (void)hipEventDestroy(t.done);
-        for (void* p : {(void*)t.d_blob, (void*)t.d_aux}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)t.d_blob, (void*)t.d_aux, (void*)t.d_masks}) if (p) (void)hipFree(p);
     }
     if (upload) (void)hipStreamDestroy(upload);
+    if (side) (void)hipStreamDestroy(side);
 }
 
 
@@ -936,13 +940,16 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
         s->set[0] = c.set[0];
         s->set[1] = c.set[1];
         s->upload = c.upload;
+        s->side = c.side;
         c = Index::SessionCache{};
         c.in_use = true;
     }
-    if (!s->upload) {
-        hipError_t e = hipStreamCreateWithFlags(&s->upload, hipStreamNonBlocking);
-        if (e != hipSuccess) { delete s; return fail_hip(e, "hipStreamCreate(session upload)"); }
-    }
+    s->last_stage.assign(n_programs, 0);
+    for (hipStream_t* st : {&s->upload, &s->side})
+        if (!*st) {
+            hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+            if (e != hipSuccess) { delete s; return fail_hip(e, "hipStreamCreate(session)"); }
+        }
     for (Index::StagingSet& t : s->set)
         if (!t.done) {
             hipError_t e = hipEventCreateWithFlags(&t.done, hipEventDisableTiming);
@@ -956,18 +963,23 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 // (host side only: the caller uploads `moves` and the base table with the stage and launches move_regions_kernel)
 static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out) {
     std::vector<RegionMove>& moves = *moves_out;
-    std::vector<std::pair<uint32_t, uint64_t*>> outgrown;
-    // a program that reports no dense slots any more is finished with its blocks: its region serves another program
-    // (the kernels of this stage run after everything the old owner launched: same stream)
+    // Regions given back two stages ago serve other programs now: whatever used them has finished (a stage waits for the
+    // stage before the previous one, whose staging set it takes over), so a recycled region ties its new owner to nobody.
+    for (const auto& r : s.given_back[1]) s.free_dense.emplace(r.first, r.second);
+    s.given_back[1].swap(s.given_back[0]);
+    s.given_back[0].clear();
+    // a program that reports no dense slots any more is finished with its blocks
     if (bv.block_slots)
         for (size_t p = 0; p < s.n_programs; ++p)
             if (bv.n_dense_slots[p] == 0 && s.dcap[p]) {
-                s.free_dense.emplace(s.dcap[p], s.base[s.n_programs + p]);
+                s.given_back[0].emplace_back(s.dcap[p], s.base[s.n_programs + p]);
                 s.base[s.n_programs + p] = nullptr;
                 s.dcap[p] = 0;
             }
     for (size_t p = 0; p < s.n_programs; ++p) {
-        const uint32_t need = bv.n_slots[p];
+        // a program gets its region with its first ops (a query of a later wave would otherwise get eight slots now and
+        // outgrow them — a move, tied to this stage's init kernel — the moment it begins)
+        const uint32_t need = s.cap[p] || bv.programs[p].n_ops ? bv.n_slots[p] : 0;
         if (need > s.cap[p]) {
             uint32_t cap = s.cap[p] ? s.cap[p] * 2 : 8;
             if (cap < need) cap = need;
@@ -991,13 +1003,12 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             } else if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
             if (s.dcap[p]) {
                 moves.push_back(RegionMove{region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W});
-                outgrown.emplace_back(s.dcap[p], s.base[s.n_programs + p]);  // reusable from the NEXT stage on: this stage's moves still read it
+                s.given_back[0].emplace_back(s.dcap[p], s.base[s.n_programs + p]);  // this stage's move kernel still reads it
             }
             s.base[s.n_programs + p] = region;
             s.dcap[p] = cap;
         }
     }
-    for (const auto& r : outgrown) s.free_dense.emplace(r.first, r.second);
     return TXQ_OK;
 }
 
@@ -1115,7 +1126,7 @@ static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile
 }
 
 int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
-                  uint8_t* alive, hipStream_t st) {
+                  uint8_t* alive, hipStream_t caller_stream) {
     Index& ix = *s.ix;
     const unsigned char* blob = (const unsigned char*)blob_v;
     BlobView bv;
@@ -1139,10 +1150,21 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     for (uint8_t d : bv.has_dense) any_dense |= d != 0;
     if (any_dense && !ix.is_hibf && (ix.ibf[0].bin_size >> 32))
         return fail(TXQ_ERR_PROGRAM, "dense ops need fewer than 2^32 rows");
+    // Does this stage continue anything the previous stage — possibly still running — works on?  Programs with ops in both,
+    // feedback questions, grown regions (moves), an HIBF or a d-gram index (their probes share scratch of the index) tie it
+    // to the previous stage's stream; a stage of other programs only (the next wave of queries) runs beside it.
+    bool continues = n_q != 0 || ix.is_hibf || s.aux != nullptr;
+    for (size_t p = 0; p < s.n_programs; ++p)
+        if (bv.programs[p].n_ops) {
+            continues = continues || s.last_stage[p] + 1 == s.n_stages;
+            s.last_stage[p] = (uint32_t)s.n_stages;
+        }
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
     if (int rc = grow_slot_regions(s, bv, &fresh, &moves)) return rc;
     s.t_grow += now_s() - t0;
+    for (size_t i = 0; i < n_q; ++i)
+        if (!s.base[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: program %u has not run an op yet", i, q_prog[i]);
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
     // (a regular two-level HIBF runs its steps fused, too: TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
@@ -1232,7 +1254,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (*p && *cap >= need) return TXQ_OK;
         return ensure((void**)p, cap, std::max(need + need / 2, (size_t)64 << 20));
     };
-    if (int rc = ensure_scratch(&ix.scratch_masks, &ix.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
+    if (int rc = ensure_scratch(&S.d_masks, &S.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
+    uint64_t* const d_masks = S.d_masks;
     s.t_alloc += now_s() - t1;
     hipStream_t up = s.upload;
     if (packed) {
@@ -1285,6 +1308,16 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     s.t_upload += now_s() - t0;
     t0 = now_s();
 
+    static const bool one_stream = std::getenv("TXQ_ONE_STREAM") != nullptr;  // A/B knob
+    const Index::StagingSet& prev = s.set[s.n_stages & 1];
+    const bool beside = !continues && moves.empty() && prev.pending && s.n_stages > 1 && !one_stream;
+    const int which = beside ? 1 - s.stream_of_last : s.stream_of_last;
+    s.stream_of_last = which;
+    if (beside) ++s.n_beside;
+    if (std::getenv("TXQ_TRACE_STAGES"))
+        fprintf(stderr, "[txq] stage %zu: continues %d (questions %zu), moves %zu, previous pending %d -> stream %d\n", s.n_stages, (int)continues, n_q, moves.size(),
+                (int)prev.pending, which);
+    hipStream_t st = which ? s.side : caller_stream;
     if (!tile_groups.empty()) {
         make_tiles_kernel<<<(unsigned)tile_groups.size(), 256, 0, st>>>((const TileGroup*)(S.d_aux + at_groups), d_tiles);
         TXQ_HIP(hipGetLastError());
@@ -1303,14 +1336,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (n_aux && !s.aux) return fail(TXQ_ERR_STATE, "the blob has auxiliary (d-gram) k-mers but the session has no auxiliary index");
     if (n_main) {
         if (ix.is_hibf) {
-            if (int rc = hibf_probe(ix, d_kmers, n_main, ix.scratch_masks, nullptr, st)) return rc;
+            if (int rc = hibf_probe(ix, d_kmers, n_main, d_masks, nullptr, st)) return rc;
         } else {
-            hipError_t e = launch_probe(ix.ibf[0], d_kmers, n_main, ix.scratch_masks, nullptr, st);
+            hipError_t e = launch_probe(ix.ibf[0], d_kmers, n_main, d_masks, nullptr, st);
             if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
         }
     }
     if (n_aux) {  // d-grams: same bins, same column shard, their own flat IBF
-        hipError_t e = launch_probe(s.aux->ibf[0], d_kmers + n_main, n_aux, ix.scratch_masks + n_main * (size_t)W, nullptr, st);
+        hipError_t e = launch_probe(s.aux->ibf[0], d_kmers + n_main, n_aux, d_masks + n_main * (size_t)W, nullptr, st);
         if (e != hipSuccess) return fail_hip(e, "d-gram probe kernel launch");
     }
     if (h->n_ops) {
@@ -1328,7 +1361,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, ix.scratch_masks, W)
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, d_masks, W)
             switch (g) {
                 case 1: TXQ_EXEC(1); break;
                 case 2: TXQ_EXEC(2); break;
@@ -1352,7 +1385,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree);
             if (cnt && !ride) {
                 ++s.n_unit_launches;
-                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, ix.scratch_masks, W, g_units_log2);
+                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2);
             }
             s.n_units += cnt;
             // HIBF: the level's steps, chunk by chunk: k-mers of all (suffix, predecessor) pairs -> tree descent -> combine
@@ -1370,7 +1403,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 s.n_dense_tiles += c1 - c0;
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
-                const LevelUnits lu{d_units + first, d_ops, ix.scratch_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
+                const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
                 hipError_t e;
                 if (tree) {
                     uint32_t wpr_log2 = 0;
@@ -1422,8 +1455,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
 int session_finish(Session& s, uint64_t* d_final, hipStream_t st) {
     const uint32_t W = s.W;
     if (W == 0 || s.n_programs == 0) return TXQ_OK;
-    for (size_t p = 0; p < s.n_programs; ++p)
-        if (!s.base[p]) return fail(TXQ_ERR_STATE, "program %zu never ran a stage", p);
+    if (s.n_stages == 0) return fail(TXQ_ERR_STATE, "the session never ran a stage");
+    // (a program that never had an op has no region: its RESULT is the initial one, no bin)
+    for (Index::StagingSet& t : s.set)  // stages may have run on two streams: all of them before the results are gathered
+        if (t.pending) {
+            hipError_t e = hipEventSynchronize(t.done);
+            if (e != hipSuccess) return fail_hip(e, "waiting for the last stages");
+            t.pending = false;
+        }
     size_t blocks = (s.n_programs * W + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     gather_result_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, (uint32_t)s.n_programs, W, d_final);

@@ -94,13 +94,14 @@ struct Index {
     struct StagingSet {
         unsigned char* d_blob = nullptr; size_t cap_blob = 0;
         unsigned char* d_aux = nullptr; size_t cap_aux = 0;
+        uint64_t* d_masks = nullptr; size_t cap_masks = 0;  // M[k-mer] of the stage's k-mer table (the probe's output)
         hipEvent_t done = nullptr;
         bool pending = false;
     };
     struct SessionCache {
         std::vector<ArenaChunk> chunks;  // slot-arena chunks, at most kArenaKeepBytes in all
         StagingSet set[2];
-        hipStream_t upload = nullptr;
+        hipStream_t upload = nullptr, side = nullptr;
         bool in_use = false;
     } session_cache;
     static constexpr size_t kArenaKeepBytes = (size_t)64 << 30;
@@ -134,6 +135,11 @@ struct Session {
     std::vector<uint32_t> cap;      // per program: slots allocated
     std::vector<uint32_t> dcap;     // per program: dense slots allocated (include/txq_program.h, version 3)
     std::multimap<uint32_t, uint64_t*> free_dense;  // dense regions given back by finished programs / outgrown: capacity in slots -> region
+    // ... two stages after they were given back: the stage before the current one may still be running, on another stream
+    std::vector<std::pair<uint32_t, uint64_t*>> given_back[2];
+    std::vector<uint32_t> last_stage;  // per program: the last stage (1-based) that had ops for it
+    hipStream_t side = nullptr;        // a stage that continues nothing of the stage in flight runs beside it, on the other stream
+    int stream_of_last = 0;            // 0: the caller's stream, 1: `side`
     uint64_t** d_base = nullptr;  // device copy of `base` as of the last stage (lives in that stage's staging set)
     bool owns_cache = false;      // buffers came from / go back to ix->session_cache
     Index::StagingSet set[2];     // stage n uses set[n & 1]
@@ -143,6 +149,7 @@ struct Session {
     double t_validate = 0, t_upload = 0, t_device = 0;
     double t_grow = 0, t_plan = 0, t_wait = 0, t_alloc = 0;  // parts of t_upload: slot regions, units/tiles, waiting for the staging set, scratch
     const char* row_source = "none";  // where the dense steps of the last stage took M[k-mer] from
+    size_t n_beside = 0;  // stages that ran on the other stream than their predecessor
     size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;
     ~Session();
 };
