@@ -364,3 +364,47 @@ def test_hibf_child_stationary_kernel_on_regular_two_level_trees(capi, oracle, s
         for n in (1, 63, 257):  # ragged batches through the host-buffer entry point
             assert np.array_equal(ix.probe(kmers[:n]), want[:n, lo:lo + nw])
         ix.free()
+
+
+@pytest.mark.parametrize("shape", [dict(user_bins=1024, children=16, h=3), dict(user_bins=6 * 256, children=6, h=2), dict(user_bins=3 * 64 - 9, children=3, h=1),
+                                   dict(user_bins=32 * 64, children=32, h=2), dict(user_bins=5 * 128, children=5, h=4)],
+                         ids=["16x64", "6x256", "3x64-ragged", "32x64", "5x128"])
+def test_small_uniform_trees_are_probed_on_their_interleaved_children(capi, oracle, shape, monkeypatch):
+    """A regular two-level tree with a root of at most 64 merged bins, a mask of at most 32 words and children of equal rows
+    and hash counts (what `tetrex index` writes for up to 2048 bins) keeps its children once more side by side, and a
+    plain k-mer probe gathers them like a flat IBF; the root's word clears the children the k-mer cannot be in
+    (txq_probe.hip TreeRoot).  Masks and alive bits against the oracle's membership_for restatement and against the
+    descent kernels (TXQ_HIBF_INTERLEAVE_PROBE=0) on the same buffers; column shards; ragged batches."""
+    from helpers import regular_hibf
+    ub, ch, h = shape["user_bins"], shape["children"], shape["h"]
+    rng = np.random.default_rng(ub + h)
+    per = 40
+    ox, descs, values = regular_hibf(oracle, ub, ch, per, lambda b: rng.integers(0, 1 << 20, size=per, dtype=np.uint64), h=h)
+    rows = max(d["bin_size"] for d in descs[1:])
+    if len({d["bin_size"] for d in descs[1:]}) > 1:  # (regular_hibf sizes a child by its own largest bin: make them equal, as the product does)
+        pytest.skip("children of different rows")
+    present = np.concatenate([values[b][:2] for b in range(0, ub, 7)])
+    kmers = np.concatenate([present, splitmix64(8, 1531) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    assert want.any()
+    for R, r in ((1, 0), (2, 1)) if ch % 2 == 0 else ((1, 0),):
+        ix = capi.Index.upload_hibf(ub, descs, shard_rank=r, n_shards=R)
+        lo, nw = int(ix.info.shard_word0), ix.shard_words
+        dk = capi.DeviceBuffer.from_numpy(kmers)
+        results = []
+        for interleaved in ("1", "0"):
+            monkeypatch.setenv("TXQ_HIBF_INTERLEAVE_PROBE", interleaved)
+            dm = capi.DeviceBuffer(kmers.size * nw * 8)
+            da = capi.DeviceBuffer(((kmers.size + 63) // 64) * 8)
+            ix.probe_device(dk.ptr, kmers.size, dm.ptr, da.ptr)
+            capi.synchronize()
+            got = dm.to_numpy(np.uint64, (kmers.size, nw))
+            assert np.array_equal(got, want[:, lo:lo + nw]), (shape, R, interleaved)
+            alive = np.unpackbits(da.to_numpy(np.uint8, (((kmers.size + 63) // 64) * 8,)), bitorder="little")[:kmers.size]
+            assert np.array_equal(alive.astype(bool), got.any(axis=1)), (shape, R, interleaved)
+            results.append(got)
+        assert np.array_equal(results[0], results[1])
+        monkeypatch.delenv("TXQ_HIBF_INTERLEAVE_PROBE")
+        for n in (1, 63, 257):
+            assert np.array_equal(ix.probe(kmers[:n]), want[:n, lo:lo + nw])
+        ix.free()

@@ -1151,9 +1151,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (any_dense && !ix.is_hibf && (ix.ibf[0].bin_size >> 32))
         return fail(TXQ_ERR_PROGRAM, "dense ops need fewer than 2^32 rows");
     // Does this stage continue anything the previous stage — possibly still running — works on?  Programs with ops in both,
-    // feedback questions, grown regions (moves), an HIBF or a d-gram index (their probes share scratch of the index) tie it
+    // feedback questions, grown regions (moves), an HIBF that is descended or a d-gram index (scratch of the index) tie it
     // to the previous stage's stream; a stage of other programs only (the next wave of queries) runs beside it.
-    bool continues = n_q != 0 || ix.is_hibf || s.aux != nullptr;
+    bool continues = n_q != 0 || (ix.is_hibf && !ix.probes_interleaved()) || s.aux != nullptr;
     for (size_t p = 0; p < s.n_programs; ++p)
         if (bv.programs[p].n_ops) {
             continues = continues || s.last_stage[p] + 1 == s.n_stages;
@@ -1310,7 +1310,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
 
     static const bool one_stream = std::getenv("TXQ_ONE_STREAM") != nullptr;  // A/B knob
     const Index::StagingSet& prev = s.set[s.n_stages & 1];
-    const bool beside = !continues && moves.empty() && prev.pending && s.n_stages > 1 && !one_stream;
+    const bool beside = !continues && moves.empty() && hsteps.empty() && prev.pending && s.n_stages > 1 && !one_stream;
     const int which = beside ? 1 - s.stream_of_last : s.stream_of_last;
     s.stream_of_last = which;
     if (beside) ++s.n_beside;

@@ -927,6 +927,15 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
 int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     if (n == 0) return TXQ_OK;
+    if (ix.probes_interleaved()) {
+        // a small regular tree of uniform children: its interleaved children are probed like a flat IBF (one row segment per
+        // hash function), the root's word clears the words of the children the k-mer cannot be in (txq_probe.hip TreeRoot)
+        uint32_t wpr_log2 = 0;
+        while ((1u << wpr_log2) < ix.child_row_words) ++wpr_log2;
+        hipError_t e = launch_probe_interleaved(ix.interleaved, ix.root_node, ix.d_children, wpr_log2, d_kmers, n, d_masks, d_alive, s);
+        if (e != hipSuccess) return fail_hip(e, "interleaved probe launch");
+        return TXQ_OK;
+    }
     {
         int rc = TXQ_OK;
         if (hibf_probe_fused(ix, d_kmers, n, d_masks, d_alive, s, &rc)) return rc;

@@ -2,6 +2,7 @@
 #pragma once
 #include "txq_kernels.hpp"
 #include "../../include/txq.h"
+#include <cstdlib>
 #include <map>
 #include <vector>
 
@@ -63,6 +64,12 @@ struct Index {
     // once more, row r of all children side by side ([rows][stride] like a flat IBF over the children's hash parameters),
     // so that a dense step gathers one row segment per hash function instead of one cache line per child.
     IbfDev interleaved{};
+    // plain k-mer probes go to the interleaved children too (TXQ_HIBF_INTERLEAVE_PROBE=0: the tree descent kernels; A/B and tests)
+    bool probes_interleaved() const {
+        const char* off = std::getenv("TXQ_HIBF_INTERLEAVE_PROBE");
+        return is_hibf && interleaved.words && interleaved.stride >= 2 && !(interleaved.stride & 1) && interleaved.shard_words == shard_words &&
+               root_node.bins <= 64 && !(off && off[0] == '0');
+    }
     HibfNode root_node{};            // host copy of the root's record
     uint32_t tree_hash_max = 0;      // most hash functions of any IBF of the regular tree
     bool children_uniform = false;   // same rows / hash shift / hash count in every child: scalar hashing
@@ -161,6 +168,8 @@ int alloc_ibf(const txq_ibf_desc& d, uint64_t w0, uint64_t w1, IbfDev* out, uint
 
 // txq_probe.hip
 hipError_t launch_probe(const IbfDev& f, const uint64_t* kmers, size_t n, uint64_t* masks, uint64_t* alive, hipStream_t s);
+hipError_t launch_probe_interleaved(const IbfDev& interleaved, const HibfNode& root, const void* children, uint32_t wpr_log2, const uint64_t* kmers,
+                                    size_t n, uint64_t* masks, uint64_t* alive, hipStream_t s);
 hipError_t launch_emplace(const IbfDev& f, const uint64_t* values, const uint32_t* bins_of, size_t n, hipStream_t s);
 
 // txq_hibf.hip

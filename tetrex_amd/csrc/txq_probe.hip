@@ -14,7 +14,7 @@
 //     first AND, 8 waves/SIMD); output rows of one step are contiguous (coalesced 1-KiB stores),
 //   * `alive` (mask != 0, the collector's path_.none() test) falls out of one __ballot per step.
 // Algorithmic HBM bytes per probe: h*W*8 (rows) + W*8 (mask) + 8 (k-mer); W = shard_words.
-#include "txq_kernels.hpp"
+#include "txq_internal.hpp"
 #include <cstdlib>
 
 namespace txq {
@@ -33,11 +33,22 @@ __device__ __forceinline__ void store_chunk(const IbfDev& f, uint64_t* masks, si
     else __builtin_nontemporal_store(((uint64_t)acc.y << 32) | acc.x, dst);  // odd tail word
 }
 
+// Where the matrix is the interleaved children of a small regular HIBF (Index::interleaved: row r of every child side by
+// side), the root's rows decide which children's words survive: the hashing lane gathers the root word of its k-mer
+// (at most 64 merged bins) and hands it to the gathering lanes with the row indices.
+struct NoRoot { static constexpr bool kActive = false; };
+struct TreeRoot {
+    static constexpr bool kActive = true;
+    HibfNode root;
+    const ChildRec* children;  // in mask-column order; packed >> 12 = the child's merged bin in the root
+    uint32_t wpr_log2;         // log2(mask words per child)
+};
+
 // LPK lanes per k-mer, H hash functions, U steps in flight.  Requires bin_size < 2^32 and an even
 // stride.  U*H independent 16-byte gathers per lane are issued before the first AND.
-template <int LPK, int H, int U, bool NT>
+template <int LPK, int H, int U, bool NT, class ROOT = NoRoot>
 __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __restrict__ kmers, size_t n,
-                                                    uint64_t* __restrict__ masks, uint64_t* __restrict__ alive) {
+                                                    uint64_t* __restrict__ masks, uint64_t* __restrict__ alive, ROOT R = ROOT{}) {
     constexpr int KPS = 64 / LPK;          // k-mers per step
     constexpr int UU = U < LPK ? U : LPK;  // a tile has LPK steps
     const int lane = threadIdx.x & 63;
@@ -52,6 +63,15 @@ __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __
         uint32_t row[H];
 #pragma unroll
         for (int i = 0; i < H; ++i) row[i] = (uint32_t)hash_row(v, kSeeds[i], f.hash_shift, f.bin_size);
+        uint32_t root_lo = ~0u, root_hi = ~0u;  // the root's verdict on my k-mer: bit b = it may be in the child behind merged bin b
+        if constexpr (ROOT::kActive) {
+            const uint64_t* rw = (const uint64_t*)R.root.words;
+            uint64_t x = ~0ULL;
+            for (uint32_t i = 0; i < R.root.hash_funs(); ++i)
+                x &= rw[hash_row_seeded(v * kSeeds[i], R.root.hash_shift(), R.root.bin_size) * R.root.stride()];
+            root_lo = (uint32_t)x;
+            root_hi = (uint32_t)(x >> 32);
+        }
         bool my_alive = false;
         for (int s = 0; s < LPK; s += UU) {
             uint32_t r[UU][H];
@@ -59,10 +79,21 @@ __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __
             for (int u = 0; u < UU; ++u)
 #pragma unroll
                 for (int i = 0; i < H; ++i) r[u][i] = __shfl(row[i], (s + u) * KPS + grp);
+            uint64_t verdict[UU];
+            if constexpr (ROOT::kActive) {
+#pragma unroll
+                for (int u = 0; u < UU; ++u)
+                    verdict[u] = ((uint64_t)(uint32_t)__shfl((int)root_hi, (s + u) * KPS + grp) << 32) | (uint32_t)__shfl((int)root_lo, (s + u) * KPS + grp);
+            }
             bool nz[UU];
 #pragma unroll
             for (int u = 0; u < UU; ++u) nz[u] = false;
             for (uint32_t c = sub; c < chunks; c += LPK) {
+                uint32_t bin0 = 0, bin1 = 0;  // merged bins of the children behind words 2c and 2c + 1
+                if constexpr (ROOT::kActive) {
+                    bin0 = R.children[(2u * c) >> R.wpr_log2].packed >> 12;
+                    bin1 = 2u * c + 1u < f.shard_words ? R.children[(2u * c + 1u) >> R.wpr_log2].packed >> 12 : bin0;
+                }
                 u32x4 x[UU][H];
 #pragma unroll
                 for (int u = 0; u < UU; ++u)
@@ -76,6 +107,10 @@ __global__ __launch_bounds__(256) void probe_kernel(IbfDev f, const uint64_t* __
                     u32x4 acc = x[u][0];
 #pragma unroll
                     for (int i = 1; i < H; ++i) acc &= x[u][i];
+                    if constexpr (ROOT::kActive) {
+                        const uint32_t m0 = (verdict[u] >> bin0) & 1ULL ? ~0u : 0u, m1 = (verdict[u] >> bin1) & 1ULL ? ~0u : 0u;
+                        acc.x &= m0; acc.y &= m0; acc.z &= m1; acc.w &= m1;
+                    }
                     const size_t kidx = base + (s + u) * KPS + grp;
                     if (kidx < n) store_chunk(f, masks, kidx, c, acc);
                     nz[u] |= nonzero(acc);
@@ -244,6 +279,34 @@ hipError_t launch_probe(const IbfDev& f, const uint64_t* k, size_t n, uint64_t* 
     if (chunks <= 16) return launch_lpk<16>(f, k, n, m, a, s);
     if (chunks <= 32) return launch_lpk<32>(f, k, n, m, a, s);
     return launch_lpk<64>(f, k, n, m, a, s);
+}
+
+// the interleaved children of a small regular HIBF (even stride, rows < 2^32, root of at most 64 merged bins)
+template <int LPK>
+static hipError_t launch_tree_lpk(const IbfDev& f, const TreeRoot& root, const uint64_t* k, size_t n, uint64_t* m, uint64_t* a, hipStream_t s) {
+    const unsigned grid = grid_for((n + 63) / 64, 4);
+    switch (f.hash_funs) {
+        case 1: probe_kernel<LPK, 1, 2, false, TreeRoot><<<grid, 256, 0, s>>>(f, k, n, m, a, root); break;
+        case 2: probe_kernel<LPK, 2, 2, false, TreeRoot><<<grid, 256, 0, s>>>(f, k, n, m, a, root); break;
+        case 3: probe_kernel<LPK, 3, 2, false, TreeRoot><<<grid, 256, 0, s>>>(f, k, n, m, a, root); break;
+        case 4: probe_kernel<LPK, 4, 2, false, TreeRoot><<<grid, 256, 0, s>>>(f, k, n, m, a, root); break;
+        case 5: probe_kernel<LPK, 5, 2, false, TreeRoot><<<grid, 256, 0, s>>>(f, k, n, m, a, root); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+hipError_t launch_probe_interleaved(const IbfDev& f, const HibfNode& root, const void* children, uint32_t wpr_log2, const uint64_t* k, size_t n,
+                                    uint64_t* m, uint64_t* a, hipStream_t s) {
+    if (n == 0 || f.shard_words == 0) return hipSuccess;
+    if ((f.bin_size >> 32) || f.stride < 2 || (f.stride & 1) || root.bins > 64) return hipErrorInvalidValue;
+    const TreeRoot r{root, (const ChildRec*)children, wpr_log2};
+    const uint32_t chunks = f.stride >> 1;
+    if (chunks <= 1) return launch_tree_lpk<1>(f, r, k, n, m, a, s);
+    if (chunks <= 2) return launch_tree_lpk<2>(f, r, k, n, m, a, s);
+    if (chunks <= 4) return launch_tree_lpk<4>(f, r, k, n, m, a, s);
+    if (chunks <= 8) return launch_tree_lpk<8>(f, r, k, n, m, a, s);
+    if (chunks <= 16) return launch_tree_lpk<16>(f, r, k, n, m, a, s);
+    return hipErrorInvalidValue;
 }
 
 hipError_t launch_emplace(const IbfDev& f, const uint64_t* values, const uint32_t* bins_of, size_t n, hipStream_t s) {
