@@ -556,9 +556,15 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 if (ev != DenseOptions::kUnknown) wants_evidence_ = false;
                 if (ev == DenseOptions::kUnknown && !evidence_asked_) {
                     // the first list of this query that could become a block, and nobody knows yet how states fare on this
-                    // index: stop here for this stage and ask (the waiting states are this stage's questions)
-                    evidence_asked_ = wants_evidence_ = true;
-                    break;
+                    // index: stop here for this stage and ask (the waiting states are this stage's questions) — if the list
+                    // has something to tell: states that have been probed at least once (a list right behind leading
+                    // wildcards or residue classes holds none, its masks are still all ones)
+                    size_t probed = 0;
+                    for (const State& s : cur.items) probed += !s.gapped && s.shift >= k;
+                    if (probed >= 16) {
+                        evidence_asked_ = wants_evidence_ = true;
+                        break;
+                    }
                 }
                 // (still unknown after asking: as if they saturate; what the run has learned sets the bar in densify())
             }
