@@ -872,6 +872,9 @@ Session::~Session() {
                         "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles), step rows: %s\n",
                 n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, t_grow, t_plan, t_wait, t_alloc, n_levels, n_unit_launches, n_units,
                 n_dense_launches, n_dense_tiles, row_source);
+    if (std::getenv("TXQ_TRACE") && n_step_pairs)
+        fprintf(stderr, "[txq]   dense work: %llu predecessor visits for %llu destination suffixes, %llu slots zeroed, %llu entries reduced; mask %u words\n",
+                (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
     if (std::getenv("TXQ_TRACE") && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
@@ -1020,7 +1023,7 @@ struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0; };
 // hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
 // HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel
 static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
-                         std::vector<TileGroup>* groups, size_t* n_tiles, std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
+                         std::vector<TileGroup>* groups, size_t* n_tiles, uint64_t (*work)[4], std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
                          std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
     const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
@@ -1062,6 +1065,9 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
                         if (x.kind == TXQ_DENSE_STEP) entries *= (uint64_t)__builtin_popcount(x.r_mask) * (__builtin_popcount(x.shape[0]) ? 1 : 0);
                         else per_tile = 1024;
                     }
+                    if (x.kind == TXQ_DENSE_STEP) { (*work)[0] += entries * (uint64_t)__builtin_popcount(x.shape[0]); (*work)[1] += entries; }
+                    else if (x.kind == TXQ_DENSE_ZERO) (*work)[2] += entries;
+                    else (*work)[3] += entries;
                     const bool hstep = hibf && x.kind == TXQ_DENSE_STEP;
                     if (hstep) per_tile = 256;  // 256 suffixes x up to 32 predecessors: at most 8192 k-mers per tile
                     if (!hstep) {
@@ -1187,11 +1193,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<ExecUnit> units;
     std::vector<TileGroup> tile_groups;
     size_t n_tiles = 0;
+    uint64_t work[4] = {0, 0, 0, 0};
     std::vector<DenseTile> hsteps;
     std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
     double t1 = now_s();
-    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &hsteps, &hstep_na, &plan);
+    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na, &plan);
+    s.n_step_pairs += work[0]; s.n_step_suffixes += work[1]; s.n_zero_slots += work[2]; s.n_reduce_entries += work[3];
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
     // never across a level; pair_base[tile] = first pair of the tile within its chunk
     std::vector<uint32_t> pair_base(hsteps.size(), 0);

@@ -156,6 +156,9 @@ struct Session {
     double t_validate = 0, t_upload = 0, t_device = 0;
     double t_grow = 0, t_plan = 0, t_wait = 0, t_alloc = 0;  // parts of t_upload: slot regions, units/tiles, waiting for the staging set, scratch
     const char* row_source = "none";  // where the dense steps of the last stage took M[k-mer] from
+    // what the dense ops of the session amount to (TXQ_TRACE): predecessor visits and destination suffixes of the steps,
+    // slots zeroed, entries reduced — the algorithmic bytes of dense_kernel follow from these and the mask width
+    uint64_t n_step_pairs = 0, n_step_suffixes = 0, n_zero_slots = 0, n_reduce_entries = 0;
     size_t n_beside = 0;  // stages that ran on the other stream than their predecessor
     size_t n_stages = 0, bytes_uploaded = 0, n_dense_tiles = 0, n_levels = 0, n_unit_launches = 0, n_units = 0, n_dense_launches = 0;
     ~Session();
