@@ -317,3 +317,64 @@ def test_a_fresh_index_is_asked_how_states_fare_on_it(capi, oracle, monkeypatch,
     # where states thin out the bar for a block is four times higher (narrow masks: some lists still clear it)
     assert stats["dense_ops"] <= asked if kind == "saturated" else stats["dense_ops"] >= asked
     ix.free()
+
+
+@pytest.mark.parametrize("index", ["flat", "hibf-16x64"])
+def test_every_way_of_running_a_batch_gives_the_same_masks(capi, oracle, monkeypatch, index):
+    """One batch of 160 PROSITE-style motifs through the combinations of the knobs that choose HOW it runs — enumerated or
+    dense, one wave or many, waves queued or side by side on two streams, unit ops in their own launch or riding in the
+    dense one, tiny per-query budgets (programs that continue across stages), the tree variants of the dense step and of
+    the plain probe — must give, bit for bit, the masks of the plainest way (enumerated, one wave), which the oracle checks."""
+    from helpers import regular_hibf
+    from tetrex_amd import host
+    rng = np.random.default_rng(77)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    qs = random_prosite_motifs(160, 41, wildcard=0.12, ranges=0.06)
+    if index == "flat":
+        ox = _oracle_index(oracle, bins=1000, m=30011, h=3, k=4, dna=False, per_bin=3000, seed=21)
+        sh = ox.shape()
+        ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    else:
+        seqs = [aa[rng.integers(0, 20, size=400)].tobytes() for _ in range(1024)]
+        ox, descs, _ = regular_hibf(oracle, 1024, 16, 400, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=2)
+        ix = capi.Index.upload_hibf(1024, descs)
+    plain = {"TETREX_DENSE": "0", "TETREX_WAVE_OPS": "0"}
+    ways = [plain,
+            {"TETREX_DENSE_EVIDENCE": "dense"},
+            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_WAVE_OPS": "3000"},
+            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_WAVE_OPS": "3000", "TXQ_ONE_STREAM": "1"},
+            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_WAVE_OPS": "800", "TETREX_TASK_OPS": "200", "TXQ_FUSE_UNITS": "0"},
+            {"TETREX_DENSE_EVIDENCE": "sparse", "TETREX_WAVE_OPS": "3000"},
+            {"TETREX_DENSE_EVIDENCE": "ask", "TETREX_WAVE_OPS": "5000"},
+            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_DENSE_MIN": "4", "TETREX_DENSE_SPARSE_BELOW": "2", "TETREX_WAVE_OPS": "2000"}]
+    if index != "flat":
+        ways += [{"TETREX_DENSE_EVIDENCE": "dense", "TXQ_DENSE_TREE": t, "TETREX_WAVE_OPS": "3000"} for t in ("0", "1", "2")]
+        ways += [{"TETREX_DENSE_EVIDENCE": "dense", "TXQ_HIBF_INTERLEAVE_PROBE": "0", "TETREX_WAVE_OPS": "3000"}]
+    knobs = sorted({k for w in ways for k in w})
+    want = None
+    for way in ways:
+        for k in knobs:
+            if k in way:
+                monkeypatch.setenv(k, way[k])
+            else:
+                monkeypatch.delenv(k, raising=False)
+        ix.tag = 0
+        got, status, stats = ix.query_masks(qs, False, 4, 0, 0)
+        if want is None:
+            want, want_status = got, status
+            checked = 0
+            for q, g, st in zip(qs[:40], got, status):  # the plainest way against the oracle
+                try:
+                    w, _ = ox.expected_mask(q)
+                except Exception:
+                    assert st != 0
+                    continue
+                assert st == 0 and np.array_equal(g, w), q
+                checked += 1
+            assert checked >= 30
+        else:
+            assert list(status) == list(want_status), way
+            assert np.array_equal(got, want), way
+            if way.get("TETREX_DENSE_EVIDENCE") == "dense":
+                assert stats["dense_ops"] > 0, way
+    ix.free()
