@@ -33,13 +33,26 @@ def _index(oracle, bins, m, h, k, dna, per_bin, seed, reduction=0):
     return ox
 
 
-def _run(host, ox, queries, dna, k, dense, per_query=0, gaps=None, reduction=0, augment=False):
+def _run(host, ox, queries, dna, k, dense, per_query=0, gaps=None, reduction=0, augment=False, wants=None):
+    """wants: a dict that keeps the oracle's answers between calls on the same index contents (the oracle enumerates every state)."""
     sim = SessionSimulator(ox, len(queries))
     status, stats = host.run_staged(queries, dna, k, reduction, ox.bins, sim.stage, per_query, 0, gaps=gaps, dense=dense)
     checked = 0
     for i, q in enumerate(queries):
         try:
-            want, quirks = ox.expected_mask(q, augment=augment)
+            if wants is not None and q in wants:
+                if wants[q] is None:
+                    raise ValueError(q)
+                want, quirks = wants[q]
+            else:
+                try:
+                    want, quirks = ox.expected_mask(q, augment=augment)
+                except Exception:
+                    if wants is not None:
+                        wants[q] = None
+                    raise
+                if wants is not None:
+                    wants[q] = (want, quirks)
         except Exception:
             assert status[i] != 0
             continue
@@ -124,6 +137,9 @@ def test_dense_cuts_the_host_work_of_a_saturated_motif(host, oracle):
     assert int(sim.result(0)[0]) == 0xFFFFFFFFFFFFFFFF
 
 
+_NESTED_WANTS = {}  # the two runs below use one index (same seed)
+
+
 @pytest.mark.parametrize("dense", [dict(), dict(min_states=1, sparse_below=1)], ids=["defaults", "everything"])
 def test_nested_stars_that_enumerated_state_by_state_would_exceed_any_op_budget(host, oracle, dense):
     """((.*)*)* and friends (the first was found by the fuzz test): every list of a large k-graph is saturated — millions
@@ -132,7 +148,7 @@ def test_nested_stars_that_enumerated_state_by_state_would_exceed_any_op_budget(
     implementation-defined there), so parity is asserted on the '+' forms and completion on all."""
     ox = _index(oracle, bins=96, m=2053, h=3, k=4, dna=False, per_bin=700, seed=11)
     qs = ["LMK(.+)+HKD", "LMK(.+)+(.+)+HKD", "LMK((.+)+)+KDE", "LMK(.+)+D(.+)+HK", "((.*)*)*", "LMK((.*)*)*KDE", "(.+)+LMK(.*)*"]
-    checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+    checked, stats, sim = _run(host, ox, qs, False, 4, dense, wants=_NESTED_WANTS)
     assert checked >= 4 and stats["ops"] < 5_000_000
 
 
