@@ -496,6 +496,12 @@ def main():
     torch.cuda.set_device(local_rank)
     args.coll_device = "cpu" if args.rehearse_single_device else "cuda"
     if world > 1:
+        # the ranks of a node share its CPUs: each rank's expansion threads = its share (at most 16, at least 2)
+        try:
+            cpus = len(os.sched_getaffinity(0))
+        except AttributeError:
+            cpus = os.cpu_count() or 1
+        os.environ.setdefault("TETREX_THREADS", str(max(2, min(16, cpus // world))))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_single_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
