@@ -880,15 +880,15 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
     if (ops.empty()) return ends;
     const uint32_t n_dense_slots = dn ? dn->n_dense_slots : 0;
     const uint64_t block_n = dn && dn->block_slots ? dn->block_slots : 1;
-    if (sc.slot.size() < (size_t)n_slots + n_dense_slots) sc.slot.resize((size_t)n_slots + n_dense_slots, LevelScratch::Slot{0, 0, 0, 0});
-    if (n_dense_slots && sc.block.size() < n_dense_slots / block_n + 1) sc.block.resize(n_dense_slots / block_n + 1, LevelScratch::Block{0, 0, 0, 0, 0});
+    if (sc.slot.size() < (size_t)n_slots) sc.slot.resize((size_t)n_slots, LevelScratch::Slot{0, 0, 0, 0});
+    if (n_dense_slots && sc.block.size() < n_dense_slots / block_n + 1) sc.block.resize(n_dense_slots / block_n + 1, LevelScratch::Block{0, 0, 0, 0, 0, 0});
     if (++sc.epoch == 0) {
         for (auto& s : sc.slot) s.stamp = 0;
         for (auto& b : sc.block) b.stamp = 0;
         sc.epoch = 1;
     }
-    auto touch = [&](uint32_t s) -> LevelScratch::Slot& {
-        LevelScratch::Slot& x = sc.slot[(s & TXQ_DENSE_SLOT_BIT) ? n_slots + (s & ~TXQ_DENSE_SLOT_BIT) : s];
+    auto touch = [&](uint32_t s) -> LevelScratch::Slot& {  // ordinary slots only
+        LevelScratch::Slot& x = sc.slot[s];
         if (x.stamp != sc.epoch) x = LevelScratch::Slot{sc.epoch, 0, 0, 0};
         return x;
     };
@@ -897,7 +897,7 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
     auto block_of = [&](uint32_t s) -> LevelScratch::Block* {
         if (!(s & TXQ_DENSE_SLOT_BIT)) return nullptr;
         LevelScratch::Block& b = sc.block[(s & ~TXQ_DENSE_SLOT_BIT) / block_n];
-        if (b.stamp != sc.epoch) b = LevelScratch::Block{sc.epoch, 0, 0, 0, 0};
+        if (b.stamp != sc.epoch) b = LevelScratch::Block{sc.epoch, 0, 0, 0, 0, 0};
         return &b;
     };
     // level of op = smallest level that respects every hazard against earlier ops (levels from 1)
@@ -935,38 +935,44 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
             if (lvl > top) top = lvl;
             continue;
         }
-        LevelScratch::Slot& sd = touch(o.dst);
-        LevelScratch::Slot& sa = touch(o.a);
-        LevelScratch::Slot& sb = touch(o.b);
-        LevelScratch::Block* bd = block_of(o.dst);
-        LevelScratch::Block* ba = block_of(o.a);
-        LevelScratch::Block* bb = block_of(o.b);
+        // an operand is an ordinary slot (its own record) or a slot of a block (the block's record)
+        struct Ref { LevelScratch::Slot* s; LevelScratch::Block* b; };
+        auto ref = [&](uint32_t slot) -> Ref {
+            if (slot & TXQ_DENSE_SLOT_BIT) return Ref{nullptr, block_of(slot)};
+            return Ref{&touch(slot), nullptr};
+        };
+        auto after_writes_of = [&](const Ref& r) {  // RAW: full writes, accumulations and dense writes
+            if (r.s) { after(r.s->wr); after(r.s->acc); }
+            else { after(r.b->dw); after(r.b->sw); }
+        };
+        auto mark_read = [&](const Ref& r) {
+            if (r.s) { if (r.s->rd < lvl) r.s->rd = lvl; }
+            else if (r.b->sr < lvl) r.b->sr = lvl;
+        };
+        const Ref rd = ref(o.dst), ra = ref(o.a), rb = ref(o.b);
+        LevelScratch::Block* bd = rd.b;
         const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
-        if (bd) { after(bd->dw); after(bd->dr); }
         if (accumulate) {
-            LevelScratch::Slot& src = o.dst == o.a ? sb : sa;
-            LevelScratch::Block* bs = o.dst == o.a ? bb : ba;
-            after(src.wr); after(src.acc);   // RAW on the source
-            if (bs) after(bs->dw);
-            after(sd.wr); after(sd.rd);      // after the last full write and every earlier reader
-            if (sd.acc > lvl) lvl = sd.acc;  // may share a level with other accumulations
-            if (src.rd < lvl) src.rd = lvl;
-            if (bs && bs->sr < lvl) bs->sr = lvl;
-            sd.acc = lvl;
+            const Ref& src = o.dst == o.a ? rb : ra;
+            after_writes_of(src);
+            if (rd.s) {
+                after(rd.s->wr); after(rd.s->rd);        // after the last full write and every earlier reader
+                if (rd.s->acc > lvl) lvl = rd.s->acc;    // may share a level with other accumulations
+            } else {                                     // ... of a block: dense writes / reads, full writes and readers of its slots,
+                after(bd->dw); after(bd->dr); after(bd->fw); after(bd->sr);  // but not the other accumulations into it (sw)
+            }
+            mark_read(src);
+            if (rd.s) rd.s->acc = lvl;
         } else {
-            after(sa.wr); after(sa.acc);
-            after(sb.wr); after(sb.acc);
-            if (ba) after(ba->dw);
-            if (bb) after(bb->dw);
+            after_writes_of(ra);
+            after_writes_of(rb);
             // WAR / WAW on dst; an in-place op (dst == a or b) reads its own old value, which is fine
-            after(sd.wr); after(sd.acc);
-            const uint32_t rd_dst = sd.rd;
-            after(rd_dst);
-            if (sa.rd < lvl) sa.rd = lvl;
-            if (sb.rd < lvl) sb.rd = lvl;
-            if (ba && ba->sr < lvl) ba->sr = lvl;
-            if (bb && bb->sr < lvl) bb->sr = lvl;
-            sd.wr = lvl;
+            if (rd.s) { after(rd.s->wr); after(rd.s->acc); after(rd.s->rd); }
+            else { after(bd->dw); after(bd->dr); after(bd->sw); after(bd->sr); }
+            mark_read(ra);
+            mark_read(rb);
+            if (rd.s) rd.s->wr = lvl;
+            else if (bd->fw < lvl) bd->fw = lvl;
         }
         if (bd && bd->sw < lvl) bd->sw = lvl;
         sc.level_of[i] = lvl;

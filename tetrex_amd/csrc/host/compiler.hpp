@@ -276,7 +276,10 @@ class QueryExpansion {
 // Scratch vectors are reused across calls (sized to n_slots).
 struct LevelScratch {
     struct Slot { uint32_t stamp, wr, rd, acc; };  // last full write / last read / last accumulation level of a slot, valid when stamp == epoch
-    struct Block { uint32_t stamp, dw, dr, sw, sr; };  // a dense block: last dense write / dense read / ordinary write / ordinary read
+    // a dense block: last dense write / dense read / ordinary write (of either kind) / ordinary read / ordinary FULL write of
+    // one of its slots.  The slots of a block have no records of their own: an ordinary op on one of them is ordered
+    // against the block (a block holds thousands of slots, an op on one of them would be a cache miss per record)
+    struct Block { uint32_t stamp, dw, dr, sw, sr, fw; };
     std::vector<Slot> slot;
     std::vector<Block> block;
     uint32_t epoch = 0;
