@@ -13,9 +13,15 @@
 //                  every operation of the collector, so an op is W independent 64-bit lanes.
 //              (3) optional feedback: "is slot s of program p all zero?" (path_.none(),
 //                  include/otf_collector.h:383) for the host to prune dead frontier states before
-//                  it expands them further.  One __ballot per queried slot.
+//                  it expands them further — answered as 0 or 1 + floor(log2(bits set)): how full the
+//                  surviving masks are tells the host whether dense blocks pay on this index.
 // Most queries finish in one stage; txq_run_programs is exactly that case.
 // Format of a stage's op list: include/txq_program.h.
+//
+// Stages are not waited for one by one: a session owns two staging sets (blob, tables, unit and tile-group lists,
+// the probe's output) and uploads on its own stream, so stage n+1 is submitted while the kernels of stage n run —
+// and runs BESIDE them, on the session's second stream, when it continues nothing they work on (the next wave of
+// queries of a batch).  Regions given back by finished programs are reused two stages later.
 //
 // Dense DP steps (blob version 3): where a query's state set saturates, the host keeps it as a block of
 // A^(k-1) slots in the program's DENSE REGION and sends one op per residue set instead of one per state and
@@ -23,7 +29,10 @@
 // suffix it hashes the k-mers of all predecessor states, gathers their h IBF rows, ANDs them with the
 // predecessor's mask and ORs the result into the destination — the per-k-mer masks M[k] never exist in HBM
 // (algorithmic bytes per state visit: h*W*8 of rows + W*8 of source mask, the latter L2-resident).
-// Programs with dense ops always run level by level (a dense op is cut into tiles, one workgroup each).
+// Programs with dense ops always run level by level: a dense op is cut into tiles, one workgroup each (written on
+// the device from one group per op, make_tiles_kernel), and the level's ordinary ops ride in the same launch.
+// Where the rows come from is a policy of the kernel: a flat IBF (FlatRows), a regular two-level HIBF (TreeRows,
+// TreeRowsByLane) or the interleaved children of a small uniform one (InterleavedRows).
 #include "txq_internal.hpp"
 #include <algorithm>
 #include <thread>
