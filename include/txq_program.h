@@ -121,7 +121,8 @@ typedef struct {
 #define TXQ_DENSE_SLOT_BIT 0x40000000u
 #define TXQ_DENSE_MAX_POSITIONS 11u /* k - 1 <= 11 */
 
-enum { TXQ_DENSE_ZERO = 0,   /* dst block := 0                                                        */
+enum { TXQ_DENSE_ZERO = 0,   /* r_mask == 0: dst block := 0; r_mask != 0: only its entries inside shape[0] x .. x
+                                shape[k-2] := 0 (the others are never read before the block is zeroed again)  */
        TXQ_DENSE_STEP = 1,   /* see above                                                             */
        TXQ_DENSE_REDUCE = 2  /* slot dst |= OR of the src entries inside shape[0] x .. x shape[k-2]   */ };
 

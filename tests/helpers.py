@@ -155,12 +155,15 @@ class SessionSimulator:
         self.ones = ones_mask(oracle_index.bins)
         self.slots = [dict() for _ in range(n_programs)]
         self.dense = [np.zeros((0, self.W), dtype=np.uint64) for _ in range(n_programs)]
+        # which dense slots hold defined values: a shaped DENSE_ZERO leaves the rest of its block undefined, and nothing may touch them
+        self.dense_valid = [np.zeros(0, dtype=bool) for _ in range(n_programs)]
         self.stages = 0
         self.dense_steps = 0
         self.dense_kinds = [0, 0, 0]  # ZERO, STEP, REDUCE ops seen
 
     def _get(self, p, s):
         if s & self.DENSE_BIT:
+            assert self.dense_valid[p][s & ~self.DENSE_BIT], "ordinary op reads a dense slot outside the zeroed shape of its block"
             return self.dense[p][s & ~self.DENSE_BIT]
         if s == 0:
             return np.zeros(self.W, dtype=np.uint64)
@@ -170,6 +173,7 @@ class SessionSimulator:
 
     def _set(self, p, s, v):
         if s & self.DENSE_BIT:
+            assert self.dense_valid[p][s & ~self.DENSE_BIT], "ordinary op writes a dense slot outside the zeroed shape of its block"
             self.dense[p][s & ~self.DENSE_BIT] = v
         else:
             self.slots[p][s] = v
@@ -193,10 +197,23 @@ class SessionSimulator:
         N = A ** pos
         D = self.dense[p]
         self.dense_kinds[kind] += 1
-        if kind == 0:  # ZERO
+        if kind == 0:  # ZERO: the whole block, or (r_mask != 0) the entries inside the shape
             b = dst & ~self.DENSE_BIT
             assert b % N == 0 and b + N <= D.shape[0]
-            D[b:b + N] = 0
+            V = self.dense_valid[p]
+            if not r_mask:
+                D[b:b + N] = 0
+                V[b:b + N] = True
+                return
+            shape = [self._codes(int(row[4 + j])) for j in range(pos)]
+            assert all(c < A for cs in shape for c in cs)
+            idx = np.zeros(1, dtype=np.int64)
+            for cs in shape:
+                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
+            D[b:b + N] = np.uint64(0xFFFFFFFFFFFFFFFF)  # nobody may touch the rest: undefined (and poisoned, should a check miss it)
+            D[b + idx] = 0
+            V[b:b + N] = False
+            V[b + idx] = True
             return
         sb = src & ~self.DENSE_BIT
         assert (src & self.DENSE_BIT) and sb % N == 0 and sb + N <= D.shape[0]
@@ -206,6 +223,7 @@ class SessionSimulator:
             idx = np.zeros(1, dtype=np.int64)
             for cs in shape:
                 idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
+            assert self.dense_valid[p][sb + idx].all(), "DENSE_REDUCE reads outside the zeroed shape of its block"
             acc = np.bitwise_or.reduce(D[sb + idx], axis=0) if idx.size else np.zeros(self.W, dtype=np.uint64)
             cur = self._get(p, dst)
             assert cur is not None
@@ -230,7 +248,9 @@ class SessionSimulator:
             for ai in a:
                 fwd = (np.uint64(ai) << np.uint64(bits * (k - 1))) | (midv << np.uint64(bits)) | np.uint64(r)
                 val = self._canonical(fwd, k) if par["canonical"] else fwd
+                assert self.dense_valid[p][sb + ai * A ** (pos - 1) + mid].all(), "DENSE_STEP reads outside the zeroed shape of its source block"
                 acc |= D[sb + ai * A ** (pos - 1) + mid] & self.ox.probe(val)
+            assert self.dense_valid[p][db + mid * A + r].all(), "DENSE_STEP accumulates outside the zeroed shape of its destination block"
             D[db + mid * A + r] |= acc
 
     def _check_level_races(self, blob, progs, dense):
@@ -294,6 +314,7 @@ class SessionSimulator:
                 have = self.dense[p].shape[0]
                 if want > have:
                     self.dense[p] = np.concatenate([self.dense[p], np.zeros((want - have, self.W), dtype=np.uint64)])
+                    self.dense_valid[p] = np.concatenate([self.dense_valid[p], np.zeros(want - have, dtype=bool)])
         n_aux = self.host.blob_aux_kmers(blob)
         n_main = kmers.size - n_aux
         M = self.ox.probe(kmers[:n_main]) if n_main else np.zeros((0, self.W), dtype=np.uint64)

@@ -374,7 +374,21 @@ uint32_t QueryExpansion::new_block(OpVec& out) {
     z.kind = TXQ_DENSE_ZERO;
     z.dst = dense_slot(b, 0);
     emit_dense(out, z);
+    if (zero_at_.size() <= b) { zero_at_.resize(b + 1, 0); zero_epoch_.resize(b + 1, 0); }
+    zero_at_[b] = (uint32_t)(dense_out_->size() - 1);
+    zero_epoch_[b] = dense_epoch_;
     return b;
+}
+
+// The list that owns block r is about to be consumed: its shape is final, and nothing ever reads (or accumulates into)
+// an entry outside it.  If the block's DENSE_ZERO is still in the stage's table, it is told to zero that shape instead
+// of all A^(k-1) slots (31.8 M slots = 4 GB per 1000-motif batch otherwise, a sixth of the dense kernel's bytes).
+void QueryExpansion::shape_zero(const DenseRef& r) {
+    if (!dense_out_ || r.block >= zero_at_.size() || zero_epoch_[r.block] != dense_epoch_ || zero_at_[r.block] >= dense_out_->size()) return;
+    txq_dense_op& z = (*dense_out_)[zero_at_[r.block]];
+    if (z.kind != TXQ_DENSE_ZERO || z.dst != dense_slot(r.block, 0)) return;
+    for (unsigned j = 0; j < dense_pos_; ++j) z.shape[j] = r.shape[j];
+    z.r_mask = 1;  // "the shape is given"
 }
 
 void QueryExpansion::release_block(uint32_t block) {
@@ -384,6 +398,7 @@ void QueryExpansion::release_block(uint32_t block) {
 void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d) {
     if (!dense_out_) throw std::logic_error("dense op without a dense table");
     dense_out_->push_back(d);
+    dense_seen_ = dense_out_->size();
     emit(out, TXQ_DENSE_OP, (uint32_t)(dense_out_->size() - 1), 0, 0);
     if (d.kind == TXQ_DENSE_STEP) ++dense_steps_;
 }
@@ -519,6 +534,10 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
     const unsigned k = enc_.k();
     const size_t start = out.size();
     dense_out_ = dense;
+    if (dense && dense->size() < dense_seen_) {  // the stage driver has shipped the table: earlier ZERO ops are out of reach
+        ++dense_epoch_;
+        dense_seen_ = dense->size();
+    }
     const bool go_dense = dense_ok_ && dense != nullptr;
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
         if (verified_only) {
@@ -549,6 +568,8 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             // a block.  If they cannot be had (budget), the rest of the dense input is enumerated as well.
             const int32_t next = order_[cursor_];
             NodeStates& cur = table_[next];
+            for (const DenseRef& d : cur.dense)
+                if (d.owned) shape_zero(d);
             if (!cur.dense.empty()) materialise(next, out, !go_dense);
             bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
             if (may_densify && dense_.evidence) {
@@ -589,6 +610,8 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         ns.dense.swap(table_[item].dense);
         waiting_ -= ns.items.size();
         if (densify_here) densify(ns, out);
+        for (const DenseRef& d : ns.dense)  // (densify has just added the list's own states to the shape)
+            if (d.owned) shape_zero(d);
         table_[item].append_only = false;
         if (table_[item].by_key.capacity()) {
             table_[item].by_key.clear();

@@ -238,6 +238,10 @@ class QueryExpansion {
     DenseOptions dense_;
     bool dense_ok_ = false;
     bool wants_evidence_ = false, evidence_asked_ = false;  // paused before the first list that could become a block
+    // per block: where its DENSE_ZERO sits in the stage's dense table, while that table is still being filled (see shape_zero)
+    std::vector<uint32_t> zero_at_, zero_epoch_;
+    uint32_t dense_epoch_ = 1;
+    size_t dense_seen_ = 0;
     unsigned dense_pos_ = 0;      // k - 1
     uint32_t dense_a_ = 0;        // alphabet size A
     uint64_t dense_n_ = 0;        // A^(k-1)
@@ -254,6 +258,7 @@ class QueryExpansion {
     void emit_dense(OpVec& out, const txq_dense_op& d);
     DenseRef* owned_block(NodeStates& ns, OpVec& out);
     void densify(NodeStates& ns, OpVec& out);
+    void shape_zero(const DenseRef& r);
     uint64_t shape_limit() const;
     void materialise(int32_t item, OpVec& out, bool all);
     void dense_receivers(int32_t item, std::vector<int32_t>& out) const;

@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     const txq_dense_op d = dops[t.op];
     uint64_t* S = slot_base[t.program];
     uint64_t* D = slot_base[n_programs + t.program];
-    if (d.kind == TXQ_DENSE_ZERO) {
+    if (d.kind == TXQ_DENSE_ZERO && !d.r_mask) {  // the whole block: entries = consecutive slots
         uint64_t* blk = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
         const size_t end = ((size_t)t.first + t.count) * W;
         for (size_t i = (size_t)t.first * W + threadIdx.x; i < end; i += blockDim.x) blk[i] = 0;
@@ -424,8 +424,23 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
         cnt[j] = n;
     }
     __syncthreads();
-    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
     const uint32_t end = t.first + t.count;
+    if (d.kind == TXQ_DENSE_ZERO) {  // the entries inside the shape
+        uint64_t* blk = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+        uint32_t wl = 1;
+        while (wl < W && wl < blockDim.x) wl <<= 1;
+        const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, groups = blockDim.x / wl;
+        for (uint32_t e = t.first + grp; e < end; e += groups) {
+            uint32_t r = e, idx = 0;
+            for (uint32_t j = P.pos; j-- > 0;) {
+                idx += (uint32_t)codes[j][r % cnt[j]] * P.pow_a[P.pos - 1 - j];
+                r /= cnt[j];
+            }
+            for (uint32_t w = sub; w < W; w += wl) blk[(size_t)idx * W + w] = 0;
+        }
+        return;
+    }
+    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
     if (d.kind == TXQ_DENSE_REDUCE) {
         uint64_t* dst = slot_ptr(S, D, d.dst, W);
         uint32_t wl = 1;
@@ -832,10 +847,9 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
                     const uint32_t code_mask = v.dense.A >= 32 ? 0xFFFFFFFFu : ((1u << v.dense.A) - 1u);
                     bool ok = x.kind <= TXQ_DENSE_REDUCE;
                     if (ok && x.kind != TXQ_DENSE_REDUCE) ok = block_ok(x.dst);
-                    if (ok && x.kind != TXQ_DENSE_ZERO) {
-                        ok = block_ok(x.src);
+                    if (ok && x.kind != TXQ_DENSE_ZERO) ok = block_ok(x.src);
+                    if (ok && (x.kind != TXQ_DENSE_ZERO || x.r_mask))
                         for (uint32_t j = 0; ok && j < v.dense.pos; ++j) ok = (x.shape[j] & ~code_mask) == 0;
-                    }
                     if (ok && x.kind == TXQ_DENSE_STEP) ok = x.src != x.dst && (x.r_mask & ~code_mask) == 0;
                     if (ok && x.kind == TXQ_DENSE_REDUCE) ok = slot_ok(x.dst) && x.dst != TXQ_SLOT_ZERO && x.dst != TXQ_SLOT_ONES;
                     if (!ok) kind = 4;
@@ -1068,8 +1082,11 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
                     run = i + 1;
                     const txq_dense_op& x = dops[o.dst];
                     uint64_t entries = 1, per_tile = step_tile;
-                    if (x.kind == TXQ_DENSE_ZERO) { entries = bv.block_slots; per_tile = std::max<uint64_t>(1, 8192 / W); }
-                    else {
+                    if (x.kind == TXQ_DENSE_ZERO) {
+                        per_tile = std::max<uint64_t>(1, 8192 / W);
+                        if (!x.r_mask) entries = bv.block_slots;
+                        else for (uint32_t j = 0; j < bv.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
+                    } else {
                         for (uint32_t j = x.kind == TXQ_DENSE_STEP ? 1 : 0; j < bv.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
                         if (x.kind == TXQ_DENSE_STEP) entries *= (uint64_t)__builtin_popcount(x.r_mask) * (__builtin_popcount(x.shape[0]) ? 1 : 0);
                         else per_tile = 1024;
