@@ -71,10 +71,46 @@ struct BlobStore {
     }
 };
 
+// Expansion threads are kept from run to run (spawning and joining 15 threads is half a millisecond of a 7 ms batch): a
+// run borrows the idle pool of its size, or starts its own when that one is busy (runs on several indexes at once).
+class PoolLease {
+  public:
+    explicit PoolLease(int threads) {
+        {
+            std::lock_guard<std::mutex> lk(mutex());
+            for (Kept& k : kept())
+                if (!k.busy && k.pool->threads() == threads) { k.busy = true; pool_ = k.pool.get(); return; }
+            if (kept().size() < 8) {
+                kept().push_back(Kept{std::make_unique<ThreadPool>(threads), true});
+                pool_ = kept().back().pool.get();
+                return;
+            }
+        }
+        own_ = std::make_unique<ThreadPool>(threads);
+        pool_ = own_.get();
+    }
+    ~PoolLease() {
+        if (own_) return;
+        std::lock_guard<std::mutex> lk(mutex());
+        for (Kept& k : kept())
+            if (k.pool.get() == pool_) k.busy = false;
+    }
+    PoolLease(const PoolLease&) = delete;
+    PoolLease& operator=(const PoolLease&) = delete;
+    ThreadPool& pool() { return *pool_; }
+
+  private:
+    struct Kept { std::unique_ptr<ThreadPool> pool; bool busy; };
+    static std::mutex& mutex() { static std::mutex m; return m; }
+    static std::vector<Kept>& kept() { static std::vector<Kept> v; return v; }
+    ThreadPool* pool_ = nullptr;
+    std::unique_ptr<ThreadPool> own_;
+};
+
 class StagedRun {
   public:
     StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
-        : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), pool_(threads_),
+        : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), lease_(threads_), pool_(lease_.pool()),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
           dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
@@ -488,7 +524,8 @@ class StagedRun {
     const StagedOptions& opt_;
     const size_t n_;
     const int threads_;
-    ThreadPool pool_;  // every query is expanded by one thread at a time; threads own disjoint queries
+    PoolLease lease_;
+    ThreadPool& pool_;  // every query is expanded by one thread at a time; threads own disjoint queries
 
     std::vector<int> status_;
     std::vector<std::string> why_;

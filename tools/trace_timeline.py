@@ -24,3 +24,9 @@ print("last batch: %d launches over %.1f us; busy %.1f us, idle between kernels 
 for name, t in busy.most_common():
     print("  %-52s %5d launches %9.1f us" % (name, n[name], t))
 print("  gaps by size (us):", sorted(gap_hist.items()))
+# where the long gaps are: time since the batch's first launch, what ended before and what began after
+t0 = seg[0][0]
+for i in range(1, len(seg)):
+    g = (seg[i][0] - max(e for _, e, _ in seg[:i])) / 1e3
+    if g >= 100:
+        print("  idle %.0f us at +%.0f us: after %s, before %s" % (g, (seg[i][0] - t0) / 1e3, seg[i - 1][2][:40], seg[i][2][:40]))
