@@ -378,3 +378,39 @@ def test_every_way_of_running_a_batch_gives_the_same_masks(capi, oracle, monkeyp
             if way.get("TETREX_DENSE_EVIDENCE") == "dense":
                 assert stats["dense_ops"] > 0, way
     ix.free()
+
+
+def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
+    """tools/stress_waves.py in small: one batch under random wave sizes, per-query budgets and block pools — stages that
+    run beside each other on two streams, programs that continue across stages, regions that are given back and reused —
+    always the masks of the plainest run (one wave, one stream), which is checked against the oracle."""
+    ox = _oracle_index(oracle, bins=1000, m=30011, h=3, k=4, dna=False, per_bin=3000, seed=33)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    qs = random_prosite_motifs(200, 57, wildcard=0.12, ranges=0.06)
+    monkeypatch.setenv("TETREX_WAVE_OPS", "0")
+    monkeypatch.setenv("TXQ_ONE_STREAM", "1")
+    want, status, _ = ix.query_masks(qs, False, 4, 0, 0)
+    checked = 0
+    for q, g, st in zip(qs[:30], want, status):
+        try:
+            w, _ = ox.expected_mask(q)
+        except Exception:
+            assert st != 0
+            continue
+        assert st == 0 and np.array_equal(g, w), q
+        checked += 1
+    assert checked >= 20
+    monkeypatch.delenv("TXQ_ONE_STREAM")
+    rng = np.random.default_rng(5)
+    for it in range(16):
+        monkeypatch.setenv("TETREX_WAVE_OPS", str(int(rng.integers(200, 20000))))
+        if rng.random() < 0.5:
+            monkeypatch.setenv("TETREX_TASK_OPS", str(int(rng.integers(100, 3000))))
+        else:
+            monkeypatch.delenv("TETREX_TASK_OPS", raising=False)
+        monkeypatch.setenv("TETREX_DENSE_POOL_MB", str(int(rng.choice([100, 1000, 49152]))))
+        got, st, stats = ix.query_masks(qs, False, 4, 0, 0)
+        assert list(st) == list(status) and np.array_equal(got, want), it
+        assert stats["dense_ops"] > 0 and stats["stages"] >= 2
+    ix.free()
