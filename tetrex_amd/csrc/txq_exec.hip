@@ -1342,7 +1342,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     s.t_upload += now_s() - t0;
     t0 = now_s();
 
-    static const bool one_stream = std::getenv("TXQ_ONE_STREAM") != nullptr;  // A/B knob
+    const bool one_stream = std::getenv("TXQ_ONE_STREAM") != nullptr;  // A/B knob (read per stage: tests flip it)
     const Index::StagingSet& prev = s.set[s.n_stages & 1];
     const bool beside = !continues && moves.empty() && hsteps.empty() && prev.pending && s.n_stages > 1 && !one_stream;
     const int which = beside ? 1 - s.stream_of_last : s.stream_of_last;
