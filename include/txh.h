@@ -64,6 +64,8 @@ typedef struct {
     int enabled;
     uint32_t min_states, sparse_below, max_blocks;
     uint64_t slot_bytes, pool_bytes;
+    int tracked; /* 0: the executor keeps no live lists; 1: it does (queries use tracked blocks where the run learns that
+                    states thin out on the index); 2: every query uses tracked blocks */
 } txh_dense_options;
 int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k, unsigned reduction, uint64_t bins,
                          size_t ops_per_query_per_stage, size_t ops_per_stage, const txh_gap_options* gaps,

@@ -105,8 +105,9 @@ int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, t
 int txq_index_get_info(const txq_index* ix, txq_index_info* info);
 int txq_index_free(txq_index* ix);
 
-/* 1 when sessions on this index execute dense DP steps (include/txq_program.h version 3: any HIBF, and flat IBFs
- * with fewer than 2^32 rows), 0 otherwise. */
+/* Do sessions on this index execute dense DP steps (include/txq_program.h version 3)?  0: no (flat IBFs with 2^32 rows
+ * and more).  1: yes (any HIBF: a step runs as a batch of k-mers through the descent).  2: yes, fused into one kernel
+ * (flat IBFs, regular two-level HIBFs) — such sessions also run TRACKED programs (sparse blocks with live lists). */
 int txq_index_supports_dense(const txq_index* ix);
 
 /* One 64-bit value a host layer may keep with the index (0 after upload); libtetrex_query stores what its staged

@@ -124,20 +124,35 @@ typedef struct {
 enum { TXQ_DENSE_ZERO = 0,   /* r_mask == 0: dst block := 0; r_mask != 0: only its entries inside shape[0] x .. x
                                 shape[k-2] := 0 (the others are never read before the block is zeroed again)  */
        TXQ_DENSE_STEP = 1,   /* see above                                                             */
-       TXQ_DENSE_REDUCE = 2  /* slot dst |= OR of the src entries inside shape[0] x .. x shape[k-2]   */ };
+       TXQ_DENSE_REDUCE = 2, /* slot dst |= OR of the src entries inside shape[0] x .. x shape[k-2]   */
+       TXQ_DENSE_FILL = 3    /* every dst entry inside shape[0] x .. x shape[k-2] |= slot src (an ORDINARY slot):
+                                a product-shaped list of states that all carry one mask (the states behind a run
+                                of wildcards that have not been probed yet) becomes a block with one op         */ };
+
+/* Tracked (sparse) blocks.  A program whose txq_program_v2.reserved has TXQ_PROGRAM_TRACKED_BIT set keeps, next to
+ * every block, the list of its entries that hold a bit ("live list").  The meaning of its dense ops is unchanged;
+ * what changes is the work: a STEP is pushed from the live entries of src (rows gathered, ANDed, ORed into the
+ * destination entry, which joins dst's list the first time it receives a bit), a REDUCE reads the live entries only,
+ * a ZERO clears them — cost proportional to the states that are ALIVE, not to the shape.  This is what makes blocks
+ * pay at k >= 6 (21^5 suffixes, of which an index of real sequences keeps a few thousand alive): the collector's
+ * path_.none() pruning (reference include/otf_collector.h:383) happens on the device, entry by entry.
+ * Every dense op of a tracked program carries TXQ_DENSE_TRACKED in `reserved`; entries outside a ZERO's shape are
+ * zero in a tracked block (the device keeps them so), so shape[] of a tracked ZERO is not used. */
+#define TXQ_PROGRAM_TRACKED_BIT 0x80000000u
+#define TXQ_DENSE_TRACKED 1u
 
 typedef struct {
     uint32_t kind;
-    uint32_t dst;     /* ZERO, STEP: first slot of the block (dense slot id); REDUCE: any writable slot   */
-    uint32_t src;     /* STEP, REDUCE: first slot of the block read                                         */
+    uint32_t dst;     /* ZERO, STEP, FILL: first slot of the block (dense slot id); REDUCE: any writable slot */
+    uint32_t src;     /* STEP, REDUCE: first slot of the block read; FILL: the ordinary slot whose mask is spread */
     uint32_t r_mask;  /* STEP: bit c set <=> residue code c is rolled in                                    */
     uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; /* per suffix position (oldest first): codes worth visiting    */
-    uint32_t reserved;
+    uint32_t reserved; /* bit 0: TXQ_DENSE_TRACKED */
 } txq_dense_op; /* 64 bytes */
 
 typedef struct {
     txq_blob_header_v2 v2;   /* version = TXQ_PROGRAM_VERSION_DENSE; txq_program_v2.reserved = the program's
-                                dense slots (a multiple of N)                                              */
+                                dense slots (a multiple of N; bit 31: TXQ_PROGRAM_TRACKED_BIT)                                            */
     uint64_t dense_offset;   /* txq_dense_op[n_dense]                                                       */
     uint32_t n_dense;
     uint32_t k;              /* k-mer length                                                                */

@@ -159,7 +159,9 @@ class SessionSimulator:
         self.dense_valid = [np.zeros(0, dtype=bool) for _ in range(n_programs)]
         self.stages = 0
         self.dense_steps = 0
-        self.dense_kinds = [0, 0, 0]  # ZERO, STEP, REDUCE ops seen
+        self.dense_kinds = [0, 0, 0, 0]  # ZERO, STEP, REDUCE, FILL ops seen
+        self.tracked = [False] * n_programs  # TXQ_PROGRAM_TRACKED_BIT: the program's blocks carry live lists
+        self.tracked_ops = 0
 
     def _get(self, p, s):
         if s & self.DENSE_BIT:
@@ -197,11 +199,14 @@ class SessionSimulator:
         N = A ** pos
         D = self.dense[p]
         self.dense_kinds[kind] += 1
+        # every dense op of a tracked program says so, and only those (include/txq_program.h TXQ_DENSE_TRACKED)
+        assert int(row[15]) == (1 if self.tracked[p] else 0), "dense op and program disagree about tracking"
+        self.tracked_ops += int(row[15])
         if kind == 0:  # ZERO: the whole block, or (r_mask != 0) the entries inside the shape
             b = dst & ~self.DENSE_BIT
             assert b % N == 0 and b + N <= D.shape[0]
             V = self.dense_valid[p]
-            if not r_mask:
+            if not r_mask or self.tracked[p]:  # (a tracked block is kept zero outside its live entries: its ZERO leaves all of it zero)
                 D[b:b + N] = 0
                 V[b:b + N] = True
                 return
@@ -215,10 +220,21 @@ class SessionSimulator:
             V[b:b + N] = False
             V[b + idx] = True
             return
-        sb = src & ~self.DENSE_BIT
-        assert (src & self.DENSE_BIT) and sb % N == 0 and sb + N <= D.shape[0]
         shape = [self._codes(int(row[4 + j])) for j in range(pos)]
         assert all(c < A for cs in shape for c in cs)
+        if kind == 3:  # FILL: every entry inside the shape |= the ordinary slot src
+            b = dst & ~self.DENSE_BIT
+            assert (dst & self.DENSE_BIT) and b % N == 0 and b + N <= D.shape[0] and not (src & self.DENSE_BIT)
+            idx = np.zeros(1, dtype=np.int64)
+            for cs in shape:
+                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
+            v = self._get(p, src)
+            assert v is not None, "DENSE_FILL spreads a slot that was never written"
+            assert self.dense_valid[p][b + idx].all(), "DENSE_FILL writes outside the zeroed shape of its block"
+            D[b + idx] |= v
+            return
+        sb = src & ~self.DENSE_BIT
+        assert (src & self.DENSE_BIT) and sb % N == 0 and sb + N <= D.shape[0]
         if kind == 2:  # REDUCE: slot dst |= OR of the entries inside the shape
             idx = np.zeros(1, dtype=np.int64)
             for cs in shape:
@@ -274,6 +290,9 @@ class SessionSimulator:
                         kind, dst, src = (int(x) for x in dense[1][d][:3])
                         if kind == 0:
                             wr_ranges.append((dst, dst + N, i))
+                        elif kind == 3:
+                            wr_ranges.append((dst, dst + N, i))
+                            reads.setdefault(src, set()).add(i)
                         elif kind == 1:
                             wr_ranges.append((dst, dst + N, i))
                             rd_ranges.append((src, src + N, i))
@@ -311,6 +330,10 @@ class SessionSimulator:
         self._check_level_races(blob, progs, dense)
         if dense is not None:
             for p, want in enumerate(dense[2]):
+                if self.dense[p].shape[0] == 0:
+                    self.tracked[p] = bool(want & 0x80000000)
+                assert (not (want & 0x7FFFFFFF)) or self.tracked[p] == bool(want & 0x80000000), "a program changed its tracking"
+                want &= 0x7FFFFFFF
                 have = self.dense[p].shape[0]
                 if want > have:
                     self.dense[p] = np.concatenate([self.dense[p], np.zeros((want - have, self.W), dtype=np.uint64)])

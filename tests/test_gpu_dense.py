@@ -414,3 +414,93 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
         assert list(st) == list(status) and np.array_equal(got, want), it
         assert stats["dense_ops"] > 0 and stats["stages"] >= 2
     ix.free()
+
+
+# ---- tracked (sparse) blocks: steps pushed from the live lists (csrc/txq_exec.hip sparse_kernel) ----------------------
+
+def test_tracked_blocks_vs_oracle(capi, oracle, monkeypatch):
+    """TETREX_DENSE_TRACKED=1: every query keeps its blocks with live lists; STEP / REDUCE / ZERO / FILL follow the lists
+    (sparse_plan_kernel + sparse_kernel).  Same masks as the oracle and as the run without dense blocks, on a flat index, on
+    column shards, with nearly every list a block."""
+    monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    ox = _oracle_index(oracle, bins=1024, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
+    qs = PEPTIDE_QUERIES + random_prosite_motifs(60, 7, wildcard=0.1, ranges=0.05)
+    wants = _wants(ox, qs)
+    checked, dense_ops = _check(capi, ox, qs, False, 4, shards=(1, 4), wants=wants)
+    assert checked > 300 and dense_ops > 50
+    monkeypatch.setenv("TETREX_DENSE_MIN", "32")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "16")
+    checked, dense_ops = _check(capi, ox, qs, False, 4, wants=wants)
+    assert checked > 60 and dense_ops > 20
+
+
+def test_tracked_blocks_on_odd_and_wide_masks_dna_and_reduced_alphabets(capi, oracle, monkeypatch):
+    monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]", "LMA(E|Q)GLYN"]
+    for bins, per_bin in ((40, 700), (64 * 3 - 5, 700), (64 * 7, 500), (8300, 120)):
+        ox = _oracle_index(oracle, bins=bins, m=2053, h=3, k=4, dna=False, per_bin=per_bin, seed=bins)
+        checked, dense_ops = _check(capi, ox, qs, False, 4, shards=(1, 3) if bins > 200 else (1,))
+        assert checked >= 5 and dense_ops > 20, bins
+    for bins, m, k, per_bin, h in ((70, 257, 3, 8, 3), (300, 4099, 5, 300, 2), (128, 8191, 7, 900, 4)):
+        ox = _oracle_index(oracle, bins=bins, m=m, h=h, k=k, dna=True, per_bin=per_bin, seed=bins)
+        dq = DNA_QUERIES + ["ACG..T.GA", "A.{2,4}CGT.A", "AC[GT]..[AC]CGT"]
+        checked, dense_ops = _check(capi, ox, dq, True, k)
+        assert checked > 8 and dense_ops > 10
+    for red in (1, 2):
+        ox = _oracle_index(oracle, bins=256, m=8191, h=2, k=5, dna=False, per_bin=1500, seed=red, reduction=red)
+        rq = ["LMA(E|Q)GLYN", "LMAEGLYNK", "W[LIVM]D.FYLK", "LMAE(GL|YN)K.DE", "KRDEG..NLMA"]
+        checked, dense_ops = _check(capi, ox, rq, False, 5, red)
+        assert checked >= 3 and dense_ops > 5
+
+
+def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
+    """Tiny stage budgets with tracked blocks: a block's list is written in one stage and read in the next; finished
+    programs hand their blocks to later ones (cleared before they are used again)."""
+    monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+    monkeypatch.setenv("TETREX_DENSE_MIN", "3")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    monkeypatch.setenv("TETREX_WAVE_OPS", "300")
+    ox = _oracle_index(oracle, bins=512, m=2053, h=3, k=4, dna=False, per_bin=800, seed=5)
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "CLM.{2,4}C...[LIVMFYWC]", "LMK.{0,2}C.{0,2}D.{0,2}EK"] * 6
+    for per_query in (3, 40, 0):
+        checked, dense_ops = _check(capi, ox, qs, False, 4, per_query=per_query)
+        assert checked == len(qs) and dense_ops > 30
+
+
+def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
+    """The reference's default k (include/arg_parse.h:12) on the Base alphabet: 21^5 suffixes per block, of which a sparse
+    index keeps a few alive.  With the run told that states thin out (what it learns by asking) wildcard motifs become
+    tracked blocks — a handful of ops instead of one per state and residue — and give the oracle's masks, identical to the
+    run without dense blocks."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "sparse")
+    k = 6
+    ox = oracle.Index.ibf(1024, 20011, 3, dna=False, k=k)
+    rng = np.random.default_rng(66)
+    from tetrex_amd import host as H
+    seqs = []
+    for b in range(1024):  # bins of random residues with a few motif instances planted, so that paths survive
+        s = "".join("ACDEFGHIKLMNPQRSTVWY"[i] for i in rng.integers(0, 20, size=700))
+        if b % 97 == 0:
+            s = s[:100] + "LMKACDEGHW" + s[110:300] + "CAAKCLLLMAAAAAAAAH" + s[318:]
+        seqs.append(s)
+        ox.emplace(H.record_values_array(s, k, dna=False), b)
+    # (motifs whose states the CPU oracle can enumerate in a moment: a literal k-mer or two in front of the wildcards)
+    qs = ["LMK..DEGH", "LMKA..E.H", "KCLL.{2,4}A..[AH]", "L[MK]K.C.[DE]G", "KAC.{1,3}GHW", "LMK.{2,4}GH", "LMKAC.{0,3}W", "CAAK..L.MA.A.....H",
+          "KCLL.{1,3}A.{2,4}A.H"]
+    wants = _wants(ox, qs)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    got, status, stats = ix.query_masks(qs, False, k, 0, 0)
+    assert stats["dense_ops"] > 10 and stats["ops"] < 200000
+    monkeypatch.setenv("TETREX_DENSE", "0")
+    plain, status0, stats0 = ix.query_masks(qs, False, k, 0, 0)
+    for q, g, p0, w, st in zip(qs, got, plain, wants, status):
+        assert st == 0 and w is not False, q
+        assert np.array_equal(g, p0), q
+        assert np.array_equal(g, w), q
+    assert any(int(np.bitwise_or.reduce(g)) for g in got)
+    ix.free()

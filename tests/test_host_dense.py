@@ -189,3 +189,40 @@ def test_the_expansion_asks_before_its_first_block(host, oracle, monkeypatch, ki
         assert sim.dense_steps > 0 and stats["stages"] >= 2
     else:
         assert sim.dense_steps == 0
+
+
+@pytest.mark.parametrize("dense", [dict(min_states=1, sparse_below=1, tracked=2), dict(min_states=8, sparse_below=4, tracked=2), dict(tracked=2)],
+                         ids=["everything", "8/3", "defaults"])
+def test_tracked_blocks_keep_the_meaning_of_the_dense_ops(host, oracle, dense):
+    """Tracked (sparse) blocks (include/txq_program.h): the program says that its blocks carry live lists and every one of its
+    dense ops repeats it; a list becomes a block whatever its shape.  The ops mean what they meant, so the simulator — which
+    evaluates them from their definition — must arrive at the oracle's masks."""
+    ox = _index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
+    qs = [q for q in PEPTIDE_QUERIES if "{2,4}C" not in q] + random_prosite_motifs(25, 3, wildcard=0.1, ranges=0.05)
+    checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+    assert checked >= len(qs) - 8
+    assert sim.dense_steps > 100 and sim.tracked_ops > 100 and any(sim.tracked)
+
+
+def test_a_run_of_unprobed_wildcard_states_is_one_fill(host, oracle):
+    """`LM...` at k = 6: the 21^3 states behind the wildcards have not been probed when they reach full length — they all
+    carry ONES and fill their shape exactly, so the list becomes a block with one DENSE_FILL instead of 9261 scatter ops."""
+    ox = _index(oracle, bins=64, m=2053, h=2, k=6, dna=False, per_bin=400, seed=21)
+    qs = ["LM...KDE", "WK....[DE]H", "LMK.{2,3}A..E"]
+    for dense in (dict(min_states=32, sparse_below=4, tracked=2), dict(min_states=32, sparse_below=4)):
+        checked, stats, sim = _run(host, ox, qs, False, 6, dense)
+        assert checked == len(qs)
+        assert sim.dense_kinds[3] >= 3 and stats["ops"] < 40000
+
+
+def test_sparse_evidence_turns_queries_to_tracked_blocks(host, oracle, monkeypatch):
+    """TETREX_DENSE_EVIDENCE=sparse (what a run learns on an index where states thin out) and an executor that keeps live
+    lists: lists become tracked blocks regardless of their shape; the same run on an executor without lists enumerates."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "sparse")
+    ox = _index(oracle, bins=128, m=4099, h=2, k=5, dna=False, per_bin=600, seed=22)
+    qs = ["LMK..A[DE]..GK", "WKL.[LIVM]D..[FY]", "CLM.{2,4}C...[LIVMFYWC]"]
+    checked, with_lists, sim = _run(host, ox, qs, False, 5, dict(tracked=1))
+    assert checked == len(qs) and any(sim.tracked) and sim.dense_steps > 5
+    checked, without, sim2 = _run(host, ox, qs, False, 5, dict())
+    assert checked == len(qs) and not any(sim2.tracked)
+    assert with_lists["ops"] <= without["ops"]

@@ -367,6 +367,7 @@ bool QueryExpansion::can_take_blocks(size_t n) {
 
 uint32_t QueryExpansion::new_block(OpVec& out) {
     if (free_block_head_ >= free_blocks_.size()) throw std::logic_error("dense block taken without a reservation");
+    decide_tracking();
     const uint32_t b = free_blocks_[free_block_head_++];
     if (free_block_head_ == free_blocks_.size()) { free_blocks_.clear(); free_block_head_ = 0; }
     block_refs_[b] = 1;
@@ -395,8 +396,19 @@ void QueryExpansion::release_block(uint32_t block) {
     if (--block_refs_[block] == 0) parked_blocks_.push_back(block);  // reusable once the current item is finished
 }
 
-void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d) {
+// Do this query's blocks carry live lists?  Decided once, with its first block: where the run knows that states thin out on
+// this index and the executor keeps lists.
+void QueryExpansion::decide_tracking() {
+    if (tracked_decided_) return;
+    tracked_decided_ = true;
+    if (!dense_.tracked_ok || dense_.tracked_force < 0) return;
+    tracked_ = dense_.tracked_force > 0 || (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse);
+}
+
+void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d0) {
     if (!dense_out_) throw std::logic_error("dense op without a dense table");
+    txq_dense_op d = d0;
+    if (tracked_) d.reserved |= TXQ_DENSE_TRACKED;
     dense_out_->push_back(d);
     dense_seen_ = dense_out_->size();
     emit(out, TXQ_DENSE_OP, (uint32_t)(dense_out_->size() - 1), 0, 0);
@@ -431,8 +443,9 @@ uint64_t QueryExpansion::shape_limit() const {
 
 // a list with many full-length states becomes (part of) a block: one scatter op per state now instead of
 // one op per state and residue at every later step
-void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
+void QueryExpansion::densify(NodeStates& ns, OpVec& out, bool may_hold_duplicates) {
     if (!dense_ok_ || ns.items.size() < dense_.min_states) return;
+    decide_tracking();
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     const uint64_t sym = enc_.symbol_mask();
     size_t full = 0;
@@ -443,21 +456,46 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out) {
         for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
     }
     if (full < dense_.min_states) return;
-    // the shape (the product of the per-position code sets) against the states it holds: shape_limit()
+    // the shape (the product of the per-position code sets) against the states it holds: shape_limit() — a tracked block
+    // costs what its living entries cost, whatever the shape
     uint64_t product = 1;
     for (unsigned j = 0; j < dense_pos_; ++j) product *= (uint64_t)__builtin_popcount(shape[j]);
-    const uint64_t limit = shape_limit();
-    if (limit == 0 || product > limit * full) return;
+    if (!tracked_) {
+        const uint64_t limit = shape_limit();
+        if (limit == 0 || product > limit * full) return;
+    }
     bool has_own = false;
     for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
     if (!has_own && !can_take_blocks(1)) return;
     DenseRef* own = owned_block(ns, out);
+    // States that all carry ONE mask and fill their shape exactly — the states behind a run of wildcards that have not been
+    // probed yet (they share ONES) — are spread by a single FILL.  (An append-only list may hold a key twice: no counting there.)
+    bool uniform = !may_hold_duplicates && product == full;
+    uint32_t the_slot = 0;
+    if (uniform) {
+        bool first = true;
+        for (const State& s : ns.items) {
+            if (s.gapped || s.shift < k - 1) continue;
+            if (first) { the_slot = s.slot; first = false; }
+            else if (s.slot != the_slot) { uniform = false; break; }
+        }
+    }
+    if (uniform) {
+        txq_dense_op f{};
+        f.kind = TXQ_DENSE_FILL;
+        f.dst = dense_slot(own->block, 0);
+        f.src = the_slot;
+        for (unsigned j = 0; j < dense_pos_; ++j) f.shape[j] = shape[j];
+        emit_dense(out, f);
+    }
     size_t kept = 0;
     for (size_t i = 0; i < ns.items.size(); ++i) {
         const State s = ns.items[i];
         if (s.gapped || s.shift < k - 1) { ns.items[kept++] = s; continue; }
-        const uint32_t e = dense_slot(own->block, dense_index(s.kmer));
-        emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
+        if (!uniform) {
+            const uint32_t e = dense_slot(own->block, dense_index(s.kmer));
+            emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
+        }
         drop(s.slot);
     }
     for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= shape[j];
@@ -609,7 +647,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         ns.items.swap(table_[item].items);
         ns.dense.swap(table_[item].dense);
         waiting_ -= ns.items.size();
-        if (densify_here) densify(ns, out);
+        if (densify_here) densify(ns, out, table_[item].append_only);
         for (const DenseRef& d : ns.dense)  // (densify has just added the list's own states to the shape)
             if (d.owned) shape_zero(d);
         table_[item].append_only = false;
@@ -951,6 +989,10 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
                     LevelScratch::Block& x = *block_of(d.src);
                     after(x.dw); after(x.sw);
                     if (x.dr < lvl) x.dr = lvl;
+                } else if (d.kind == TXQ_DENSE_FILL) {  // reads one ordinary slot
+                    LevelScratch::Slot& x = touch(d.src);
+                    after(x.wr); after(x.acc);
+                    if (x.rd < lvl) x.rd = lvl;
                 }
                 y.dw = lvl;
             }

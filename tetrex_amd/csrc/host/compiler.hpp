@@ -78,6 +78,13 @@ struct DenseOptions {
     // it is unknown, a query pauses once at its first list that could become a block and asks (QueryExpansion::observe).
     enum Evidence : int { kUnknown = 0, kDense = 1, kSparse = 2 };
     std::atomic<int>* evidence = nullptr;
+    // Tracked (sparse) blocks (include/txq_program.h): the executor keeps a live list per block and pushes steps from the
+    // live entries only, so a block costs what its LIVING states cost.  Where the run has learned that states thin out
+    // (kSparse) a query's lists then become blocks as soon as they hold min_states states, whatever their shape —
+    // at k = 6 a list of a few thousand states inside 21^5 suffixes.  0: the executor cannot (an HIBF whose steps are
+    // not fused, a test double without lists); -1 / +1 force it off / on for every query (tests, A/B).
+    bool tracked_ok = false;
+    int tracked_force = 0;
 };
 using DenseVec = std::vector<txq_dense_op>;
 // slots of one dense block, A^(k-1), for this encoder — 0 when dense blocks cannot be used with it (k too
@@ -155,6 +162,7 @@ class QueryExpansion {
     uint32_t n_slots() const { return high_water_; }
     // slots of the dense region (a multiple of the block size A^(k-1)); 0 while the query never went dense
     uint32_t n_dense_slots() const { return (uint32_t)(n_blocks_ * dense_n_); }
+    bool tracked() const { return tracked_; }  // its blocks carry live lists (TXQ_PROGRAM_TRACKED_BIT)
     uint64_t dense_steps() const { return dense_steps_; }
     uint64_t pool_taken() const { return pool_taken_; }  // bytes of the run's dense pool this query holds
     uint64_t dense_block_slots() const { return dense_n_; }  // A^(k-1), 0 when dense blocks are off for this query
@@ -238,6 +246,8 @@ class QueryExpansion {
     DenseOptions dense_;
     bool dense_ok_ = false;
     bool wants_evidence_ = false, evidence_asked_ = false;  // paused before the first list that could become a block
+    bool tracked_ = false, tracked_decided_ = false;        // decided with the query's first block
+    void decide_tracking();
     // per block: where its DENSE_ZERO sits in the stage's dense table, while that table is still being filled (see shape_zero)
     std::vector<uint32_t> zero_at_, zero_epoch_;
     uint32_t dense_epoch_ = 1;
@@ -257,7 +267,7 @@ class QueryExpansion {
     void release_block(uint32_t block);
     void emit_dense(OpVec& out, const txq_dense_op& d);
     DenseRef* owned_block(NodeStates& ns, OpVec& out);
-    void densify(NodeStates& ns, OpVec& out);
+    void densify(NodeStates& ns, OpVec& out, bool may_hold_duplicates);
     void shape_zero(const DenseRef& r);
     uint64_t shape_limit() const;
     void materialise(int32_t item, OpVec& out, bool all);
@@ -330,7 +340,7 @@ struct StagedOptions {
 
 struct StagedStats {
     size_t stages = 0;
-    uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0, dense_ops = 0;
+    uint64_t ops = 0, kmers = 0, states = 0, pruned = 0, feedback_queries = 0, dense_ops = 0, tracked_queries = 0;
     double expand_seconds = 0, execute_seconds = 0;  // host expansion vs. StageExecutor::stage
     int dense_evidence = DenseOptions::kUnknown;     // what this run knew / learned about the index (for the next run on it)
     double observed_fill = -1;                       // mean fraction of bits set in the masks it looked at (-1: it did not look)

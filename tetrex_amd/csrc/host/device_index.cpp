@@ -212,11 +212,13 @@ std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards,
     ShardedStageExecutor exec(shards, regexes.size(), aux);
     StagedOptions opt = options ? *options : StagedOptions{};
     opt.dense.enabled = true;
+    opt.dense.tracked_ok = true;
     opt.dense.slot_bytes = 0;
     for (txq_index* s : shards) {  // dense steps only where every shard can run them; budgets by the widest shard
         txq_index_info i{};
         txq_check(txq_index_get_info(s, &i), "txq_index_get_info");
         if (i.shard_words) opt.dense.enabled = opt.dense.enabled && txq_index_supports_dense(s) != 0;
+        if (i.shard_words) opt.dense.tracked_ok = opt.dense.tracked_ok && txq_index_supports_dense(s) == 2;
         opt.dense.slot_bytes = std::max<uint64_t>(opt.dense.slot_bytes, i.shard_words * 8);
     }
     uint64_t tag = 0;
@@ -241,6 +243,7 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     StagedOptions opt = options ? *options : StagedOptions{};
     // saturated state lists run as dense DP steps on the device where the index allows it (TETREX_DENSE=0 switches them off)
     opt.dense.enabled = txq_index_supports_dense(ix) != 0;
+    opt.dense.tracked_ok = txq_index_supports_dense(ix) == 2;  // fused steps: the session keeps live lists (tracked programs)
     opt.dense.slot_bytes = info.shard_words * 8;
     opt.feedback_bins = std::min<uint64_t>(info.user_bins, info.shard_words * 64);
     uint64_t tag = 0;

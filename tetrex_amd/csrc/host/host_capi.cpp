@@ -150,6 +150,8 @@ int txh_run_staged_dense(const char* const* regex, size_t n, int dna, unsigned k
             if (dense->max_blocks) opt.dense.max_blocks = dense->max_blocks;
             opt.dense.slot_bytes = dense->slot_bytes;
             if (dense->pool_bytes) opt.dense_pool_bytes = dense->pool_bytes;
+            opt.dense.tracked_ok = dense->tracked != 0;     // the executor keeps live lists (tracked programs, include/txq_program.h)
+            opt.dense.tracked_force = dense->tracked > 1 ? 1 : 0;  // 2: every query, whatever the run learns about the index
         }
         std::vector<int> st;
         std::vector<std::string> why;

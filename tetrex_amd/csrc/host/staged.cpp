@@ -112,7 +112,7 @@ class StagedRun {
     StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), lease_(threads_), pool_(lease_.pool()),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
-          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
+          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), tracked_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
           busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
@@ -125,6 +125,7 @@ class StagedRun {
         if (const char* e = std::getenv("TETREX_DENSE_MIN")) dense_.min_states = (uint32_t)std::max(1, std::atoi(e));
         if (const char* e = std::getenv("TETREX_DENSE_SPARSE_BELOW")) dense_.sparse_below = (uint32_t)std::max(0, std::atoi(e));
         if (const char* e = std::getenv("TETREX_DENSE_COOL")) dense_.cool_down = (uint32_t)std::max(0, std::atoi(e));
+        if (const char* e = std::getenv("TETREX_DENSE_TRACKED")) dense_.tracked_force = e[0] == '0' ? -1 : 1;  // A/B knob and tests: 0 never, 1 every query
         if (opt.gaps.dgram_loaded || dense_block_slots(enc, dense_) == 0) dense_.enabled = false;  // version-2 blobs, as before
         uint64_t pool_bytes = opt.dense_pool_bytes;
         if (const char* e = std::getenv("TETREX_DENSE_POOL_MB")) pool_bytes = (uint64_t)std::max(0LL, std::atoll(e)) << 20;  // device memory for dense blocks
@@ -167,6 +168,7 @@ class StagedRun {
         for (size_t i = 0; i < n_; ++i) {
             if (q_[i]) { st_.states += q_[i]->states(); st_.pruned += q_[i]->pruned(); }
             else { st_.states += fin_states_[i]; st_.pruned += fin_pruned_[i]; }
+            st_.tracked_queries += tracked_[i];
         }
         if (status) *status = status_;
         if (messages) *messages = why_;
@@ -278,6 +280,7 @@ class StagedRun {
             total.fetch_add(ops_[i].size(), std::memory_order_relaxed);
             slots_[i] = q_[i]->n_slots();
             dslots_[i] = q_[i]->n_dense_slots();
+            tracked_[i] = q_[i]->tracked();
             if (q_[i]->done()) {  // free the expansion's tables here, on the worker
                 fin_states_[i] = q_[i]->states();
                 fin_pruned_[i] = q_[i]->pruned();
@@ -404,13 +407,13 @@ class StagedRun {
         for (size_t i = 0; i < n_; ++i) {
             if (j < m && touched_[j] == i) {
                 const uint32_t nl = (uint32_t)levels_[i].size();
-                pr[i] = txq_program_v2{first_op[j], (uint32_t)ops_[i].size(), slots_[i], at_level, nl, dslots_[i]};
+                pr[i] = txq_program_v2{first_op[j], (uint32_t)ops_[i].size(), slots_[i], at_level, nl, dslots_[i] | (tracked_[i] ? TXQ_PROGRAM_TRACKED_BIT : 0u)};
                 if (nl) std::memcpy(lv + at_level, levels_[i].data(), (size_t)nl * 4);
                 at_level += nl;
                 ++j;
             } else {
                 if (released_[i]) dslots_[i] = 0;  // its dense region goes to the queries admitted now (see advance_stage)
-                pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, dslots_[i]};
+                pr[i] = txq_program_v2{(uint32_t)stage_ops, 0, slots_[i], at_level, 0, dslots_[i] | (tracked_[i] ? TXQ_PROGRAM_TRACKED_BIT : 0u)};
             }
         }
         h.n_levels = at_level;
@@ -538,6 +541,7 @@ class StagedRun {
     std::vector<KmerTable> tables_, dgram_tables_;
     std::vector<DenseVec> dense_ops_;  // per query: the dense ops of the stage being built (op.dst of a TXQ_DENSE_OP indexes it)
     std::vector<uint32_t> dslots_;     // per query: slots of its dense region
+    std::vector<uint8_t> tracked_;     // per query: its blocks carry live lists (TXQ_PROGRAM_TRACKED_BIT)
     DenseOptions dense_;
     std::atomic<int64_t> dense_pool_{0};
     std::atomic<int> evidence_{DenseOptions::kUnknown};  // see DenseOptions::evidence

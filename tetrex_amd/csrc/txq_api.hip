@@ -301,7 +301,8 @@ int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
 
 int txq_index_supports_dense(const txq_index* ix) {
     if (!ix || ix->ibf.empty() || ix->shard_words == 0) return 0;
-    return ix->is_hibf || (ix->ibf[0].bin_size >> 32) == 0 ? 1 : 0;  // HIBF: steps run as k-mer batches through the descent
+    if (!ix->is_hibf) return (ix->ibf[0].bin_size >> 32) == 0 ? 2 : 0;
+    return index_fuses_tree_steps(*ix) ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
 }
 
 int txq_index_free(txq_index* ix) {

@@ -55,13 +55,45 @@ __device__ __forceinline__ void slot_store(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// slot -> its W words: ordinary slots live in the program's slot region S, slots with TXQ_DENSE_SLOT_BIT in its dense region D
-__device__ __forceinline__ uint64_t* slot_ptr(uint64_t* S, uint64_t* D, uint32_t s, uint32_t W) {
-    return (s & TXQ_DENSE_SLOT_BIT) ? D + (size_t)(s & ~TXQ_DENSE_SLOT_BIT) * W : S + (size_t)s * W;
+// A dense block in HBM: [N][W] mask words, then its live list (include/txq_program.h, tracked programs): a 16-byte
+// header whose first word is the number of listed entries, a bitmap of N bits ("entry is listed"), the list itself.
+struct BlockMeta { uint32_t* count; uint64_t* bitmap; uint32_t* list; };
+__host__ __device__ __forceinline__ size_t block_meta_words(uint32_t N) { return 2 + ((size_t)N + 63) / 64 + ((size_t)N + 1) / 2; }
+__device__ __forceinline__ BlockMeta block_meta(uint64_t* block, uint32_t N, uint32_t W) {
+    uint64_t* m = block + (size_t)N * W;
+    return BlockMeta{reinterpret_cast<uint32_t*>(m), m + 2, reinterpret_cast<uint32_t*>(m + 2 + ((size_t)N + 63) / 64)};
+}
+// entry idx has received a bit: true for the one caller that makes it a listed entry
+__device__ __forceinline__ bool mark_live(const BlockMeta& m, uint32_t idx) {
+    const uint64_t bit = 1ULL << (idx & 63u);
+    return !(__hip_atomic_fetch_or(m.bitmap + (idx >> 6), bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & bit);
+}
+__device__ __forceinline__ void append_live(const BlockMeta& m, uint32_t idx) {
+    m.list[__hip_atomic_fetch_add(m.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = idx;
+}
+
+// Where a program's slots live: ordinary slots in its slot region S; slots with TXQ_DENSE_SLOT_BIT in its dense
+// blocks, found through its row BT of the stage's block table: BT[0] = flags (bit 0: tracked), BT[1 + b] = block b.
+struct DenseRow {
+    uint64_t* const* bt;
+    uint32_t N;  // slots per block (0: the session has no dense blocks)
+    __device__ __forceinline__ bool tracked() const { return (reinterpret_cast<uintptr_t>(bt[0]) & 1u) != 0; }
+};
+__device__ __forceinline__ uint64_t* slot_ptr(uint64_t* S, const DenseRow& D, uint32_t s, uint32_t W) {
+    if (!(s & TXQ_DENSE_SLOT_BIT)) return S + (size_t)s * W;
+    const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT, b = i / D.N;
+    return D.bt[1 + b] + (size_t)(i - b * D.N) * W;
+}
+// an ordinary op has ORed `x` into word w of dense slot s of a tracked program: the entry joins its block's live list
+__device__ __forceinline__ void note_dense_write(const DenseRow& D, uint32_t s, uint32_t W, uint64_t x) {
+    if (!x || !(s & TXQ_DENSE_SLOT_BIT) || !D.tracked()) return;
+    const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT, b = i / D.N, idx = i - b * D.N;
+    const BlockMeta m = block_meta(D.bt[1 + b], D.N, W);
+    if (mark_live(m, idx)) append_live(m, idx);
 }
 
 template <int G>
-__device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, uint64_t* D, const uint64_t* __restrict__ M, uint32_t W, uint32_t sub,
+__device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, const DenseRow& D, const uint64_t* __restrict__ M, uint32_t W, uint32_t sub,
                                         bool concurrent) {
     const bool accumulate = o.kmer == TXQ_NO_KMER && (o.dst == o.a || o.dst == o.b);
     uint64_t* pd = slot_ptr(S, D, o.dst, W);
@@ -70,6 +102,7 @@ __device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, uint64_t* D,
         for (uint32_t w = sub; w < W; w += G) {
             const uint64_t x = slot_load(ps + w);
             if (x) __hip_atomic_fetch_or(pd + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            note_dense_write(D, o.dst, W, x);
         }
         return;
     }
@@ -80,6 +113,7 @@ __device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, uint64_t* D,
         if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
         x |= slot_load(pb + w);
         slot_store(pd + w, x);
+        note_dense_write(D, o.dst, W, x);
     }
 }
 
@@ -89,14 +123,14 @@ __device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, uint64_t* D,
 template <int G>
 __global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict__ progs, const txq_op* __restrict__ ops,
                                                     const uint32_t* __restrict__ levels, uint64_t* const* __restrict__ slot_base,
-                                                    uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W) {
+                                                    uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t block_n) {
     const uint32_t sub = threadIdx.x % G;
     const uint32_t group = threadIdx.x / G, n_groups = blockDim.x / G;
     for (uint32_t p = blockIdx.x; p < n_programs; p += gridDim.x) {
         const DevProgram pr = progs[p];
         if (pr.n_ops == 0) continue;
         uint64_t* S = slot_base[p];  // [slots][W]
-        uint64_t* D = slot_base[n_programs + p];
+        const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + p]), block_n};
         const txq_op* op = ops + pr.first_op;
         if (pr.n_levels == 0) {
             if (group == 0)
@@ -125,11 +159,11 @@ static inline uint32_t unit_ops(uint32_t W) { return W >= kUnitWords ? 1u : kUni
 
 // g_log2: log2 of the lanes per op (a power of two <= 256)
 __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restrict__ ops, uint64_t* const* __restrict__ slot_base,
-                                         uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
+                                         uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2, uint32_t block_n) {
     const uint32_t G = 1u << g_log2;
     const uint32_t sub = threadIdx.x & (G - 1), group = threadIdx.x >> g_log2, n_groups = blockDim.x >> g_log2;
     uint64_t* S = slot_base[u.program];
-    uint64_t* D = slot_base[n_programs + u.program];
+    const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + u.program]), block_n};
     for (uint32_t i = u.begin + group; i < u.end; i += n_groups) {
         const txq_op o = ops[i];
         uint64_t* pd = slot_ptr(S, D, o.dst, W);
@@ -138,6 +172,7 @@ __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restr
             for (uint32_t w = sub; w < W; w += G) {
                 const uint64_t x = ps[w];
                 if (x) __hip_atomic_fetch_or(pd + w, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                note_dense_write(D, o.dst, W, x);
             }
         } else {
             const uint64_t* pa = slot_ptr(S, D, o.a, W);
@@ -147,6 +182,7 @@ __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restr
                 if (o.kmer != TXQ_NO_KMER) x &= M[(size_t)o.kmer * W + w];
                 x |= pb[w];
                 pd[w] = x;
+                note_dense_write(D, o.dst, W, x);
             }
         }
     }
@@ -154,13 +190,13 @@ __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restr
 
 __global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
                                                          uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                         const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
-    run_unit(units[blockIdx.x], ops, slot_base, n_programs, M, W, g_log2);
+                                                         const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2, uint32_t block_n) {
+    run_unit(units[blockIdx.x], ops, slot_base, n_programs, M, W, g_log2, block_n);
 }
 
 // The units of a level that also has dense tiles ride in the dense launch (its first `n_units` workgroups): the ordinary
 // and the dense ops of one level are independent, and a level costs one kernel boundary instead of two.
-struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M; uint32_t n_units, g_log2; };
+struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M; uint32_t n_units, g_log2, block_n; };
 
 // ---- dense DP steps ---------------------------------------------------------------------------
 // One workgroup per tile: `count` work entries of one dense op, starting at `first`.
@@ -176,6 +212,10 @@ struct DenseTile { uint32_t program, op, first, count; };
 struct TileGroup { uint32_t program, op, entries, per_tile; uint64_t first_tile; };
 static constexpr uint32_t kRootWordsLds = 4096;  // 32 KB of root verdicts per workgroup (TreeRowsByLane)
 struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; };
+// Where the blocks (and slots) of a stage's dense op live, resolved by the host side when it plans the stage:
+// dst = the block written (ZERO, STEP, FILL) or the slot accumulated into (REDUCE); src = the block read (STEP, REDUCE) or
+// the slot spread (FILL).  A tile reads this next to the op itself: no pointer chase through the program's tables.
+struct DenseOpPtr { uint64_t* dst; const uint64_t* src; };
 
 __global__ __launch_bounds__(256) void make_tiles_kernel(const TileGroup* __restrict__ groups, DenseTile* __restrict__ tiles) {
     const TileGroup g = groups[blockIdx.x];
@@ -237,14 +277,18 @@ struct FlatRows {
     IbfDev f;
     uint32_t c;
     __device__ __forceinline__ void prepare(uint32_t chunk) { c = chunk; }
+    // SRC = false: the rows only (the caller holds the predecessor's mask: pushed steps, sparse_kernel)
+    template <bool SRC = true>
     __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
-        l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+        if constexpr (SRC) l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+        else l.x[H] = ~L::zero();
 #pragma unroll
         for (int i = 0; i < H; ++i) {
             const uint64_t row = hash_row(value, kSeeds[i], f.hash_shift, f.bin_size);
             l.x[i] = L::load(f.words + row * f.stride + (size_t)c * L::kWords);
         }
     }
+    template <bool SRC = true>
     __device__ __forceinline__ void issue_late(Loads&) const {}
     __device__ __forceinline__ T combine(const Loads& l) const {
         T y = l.x[H];
@@ -285,6 +329,7 @@ struct TreeRows {
         r_word = (rec.packed >> 12) >> 6;
         r_bit = (rec.packed >> 12) & 63u;
     }
+    template <bool SRC = true>
     __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
         l.value = value;
         l.src = src_slot;
@@ -294,13 +339,15 @@ struct TreeRows {
         for (int i = 0; i < H; ++i)
             l.r[i] = (uint32_t)i < r_hf ? rw[hash_row_seeded(value * kSeeds[i], r_shift, root.bin_size) * r_stride + r_word] : ~0ULL;
     }
+    template <bool SRC = true>
     __device__ __forceinline__ void issue_late(Loads& l) const {
         uint64_t rb = l.r[0];
 #pragma unroll
         for (int h = 1; h < H; ++h) rb &= l.r[h];
         l.hit = (rb >> r_bit) & 1ULL;
         if (l.hit) {
-            l.x[H] = L::load(l.src + (size_t)c * L::kWords);
+            if constexpr (SRC) l.x[H] = L::load(l.src + (size_t)c * L::kWords);
+            else l.x[H] = ~L::zero();
 #pragma unroll
             for (int i = 0; i < H; ++i) {
                 if ((uint32_t)i < c_hf) l.x[i] = L::load(cw + ((hash_row_seeded(l.value * kSeeds[i], c_shift, c_rows) << wpr_log2) + col));
@@ -361,8 +408,10 @@ struct InterleavedRows {
         bit0 = children[word >> wpr_log2].packed >> 12;
         bit1 = WIDE ? children[(word + 1) >> wpr_log2].packed >> 12 : bit0;
     }
+    template <bool SRC = true>
     __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
-        l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+        if constexpr (SRC) l.x[H] = L::load(src_slot + (size_t)c * L::kWords);
+        else l.x[H] = ~L::zero();
         const uint64_t* rw = (const uint64_t*)root.words;
         const uint32_t r_hf = root.hash_funs(), r_stride = root.stride(), r_shift = root.hash_shift();
 #pragma unroll
@@ -373,6 +422,7 @@ struct InterleavedRows {
             l.r[i] = (uint32_t)i < r_hf ? rw[hash_row_seeded(sv, r_shift, root.bin_size) * r_stride] : ~0ULL;
         }
     }
+    template <bool SRC = true>
     __device__ __forceinline__ void issue_late(Loads&) const {}
     __device__ __forceinline__ T combine(const Loads& l) const {
         T y = l.x[H];
@@ -394,23 +444,22 @@ struct TreeRowsByLane : TreeRows<H, WIDE> {
 
 template <int H, bool WIDE, int UA, class ROWS>
 __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* __restrict__ tiles, const txq_dense_op* __restrict__ dops,
-                                                    uint64_t* const* __restrict__ slot_base, uint32_t n_programs, uint32_t W,
-                                                    uint32_t G, uint32_t SL, DenseParams P, LevelUnits U) {
+                                                    const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                    uint32_t W, uint32_t G, uint32_t SL, DenseParams P, LevelUnits U) {
     using L = Lane<WIDE>;
     using T = typename L::T;
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // [j < pos]: codes of shape[j]; [pos]: codes of r_mask
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     __shared__ uint64_t root_words[ROWS::kRootByLane ? kRootWordsLds : 1];  // [suffix of the pass][predecessor < 32][root word]
     if (blockIdx.x < U.n_units) {  // the whole workgroup: no barrier has been reached
-        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2, U.block_n);
         return;
     }
     const DenseTile t = tiles[blockIdx.x - U.n_units];
     const txq_dense_op d = dops[t.op];
-    uint64_t* S = slot_base[t.program];
-    uint64_t* D = slot_base[n_programs + t.program];
+    const DenseOpPtr q = optr[t.op];
     if (d.kind == TXQ_DENSE_ZERO && !d.r_mask) {  // the whole block: entries = consecutive slots
-        uint64_t* blk = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+        uint64_t* blk = q.dst;
         const size_t end = ((size_t)t.first + t.count) * W;
         for (size_t i = (size_t)t.first * W + threadIdx.x; i < end; i += blockDim.x) blk[i] = 0;
         return;
@@ -425,8 +474,9 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     }
     __syncthreads();
     const uint32_t end = t.first + t.count;
-    if (d.kind == TXQ_DENSE_ZERO) {  // the entries inside the shape
-        uint64_t* blk = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+    if (d.kind == TXQ_DENSE_ZERO || d.kind == TXQ_DENSE_FILL) {  // the entries inside the shape: := 0, or |= the slot that is spread
+        uint64_t* blk = q.dst;
+        const bool fill = d.kind == TXQ_DENSE_FILL;
         uint32_t wl = 1;
         while (wl < W && wl < blockDim.x) wl <<= 1;
         const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, groups = blockDim.x / wl;
@@ -436,13 +486,14 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
                 idx += (uint32_t)codes[j][r % cnt[j]] * P.pow_a[P.pos - 1 - j];
                 r /= cnt[j];
             }
-            for (uint32_t w = sub; w < W; w += wl) blk[(size_t)idx * W + w] = 0;
+            if (fill) for (uint32_t w = sub; w < W; w += wl) blk[(size_t)idx * W + w] |= q.src[w];
+            else for (uint32_t w = sub; w < W; w += wl) blk[(size_t)idx * W + w] = 0;
         }
         return;
     }
-    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
+    const uint64_t* src = q.src;
     if (d.kind == TXQ_DENSE_REDUCE) {
-        uint64_t* dst = slot_ptr(S, D, d.dst, W);
+        uint64_t* dst = q.dst;
         uint32_t wl = 1;
         while (wl < W && wl < blockDim.x) wl <<= 1;
         const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, groups = blockDim.x / wl;
@@ -463,7 +514,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     // STEP.  A destination suffix gets SL lane groups of G lanes: group `slice` takes every SL-th predecessor (three
     // at a time: 3 * (H row gathers + 1 source mask) loads in flight per lane), the slices are ORed with xor-shuffles.
     // One suffix per lane-group set and pass; a tile is short so that a level with few programs is not one long chain.
-    uint64_t* dstb = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+    uint64_t* dstb = q.dst;
     const uint32_t lanes = G * SL;  // per suffix, a power of two <= 64
     const uint32_t sub = threadIdx.x % G, slice = (threadIdx.x / G) % SL, grp = threadIdx.x / lanes, groups = blockDim.x / lanes;
     const uint32_t chunks = (W + L::kWords - 1) / L::kWords;
@@ -580,6 +631,249 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     }
 }
 
+__device__ __forceinline__ void dense_codes(const txq_dense_op& d, const DenseParams& P, uint8_t (*codes)[32], uint32_t* cnt);
+
+// ---- tracked (sparse) blocks: dense ops whose work follows the live list --------------------------
+// The dense ops of tracked programs (include/txq_program.h) are not cut into tiles by the host — how many entries a
+// block's list holds is known on the device only.  Per level: sparse_plan_kernel reads the counts of the level's
+// groups (one group per op), turns them into chunks of kSparseChunk entries and leaves counts and the running chunk
+// total in the stage's tables; sparse_kernel's workgroups share the chunks out evenly.  A ZERO's count is reset by
+// the plan kernel (the chunks work from the snapshot): nothing else of the level touches that block.
+struct SparseGroup { uint32_t op; uint32_t fixed; };  // fixed != kNotFixed: the host knows the entries (FILL: its shape)
+static constexpr uint32_t kNotFixed = 0xFFFFFFFFu;
+static constexpr uint32_t kSparseChunk = 64;
+static constexpr uint32_t kMaxSparseGroups = 1024;  // per launch (the chunk totals sit in LDS)
+
+__global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __restrict__ groups, uint32_t n_groups, const txq_dense_op* __restrict__ dops,
+                                                           const DenseOpPtr* __restrict__ optr, uint32_t N, uint32_t W, uint32_t* __restrict__ counts,
+                                                           uint32_t* __restrict__ prefix) {
+    __shared__ uint32_t scan[1024];
+    const uint32_t t = threadIdx.x;
+    uint32_t chunks = 0;
+    if (t < n_groups) {
+        const SparseGroup g = groups[t];
+        uint32_t n = g.fixed;
+        if (n == kNotFixed) {
+            const txq_dense_op d = dops[g.op];
+            uint64_t* blk = d.kind == TXQ_DENSE_ZERO ? optr[g.op].dst : const_cast<uint64_t*>(optr[g.op].src);
+            uint32_t* c = reinterpret_cast<uint32_t*>(blk + (size_t)N * W);
+            n = *c;
+            if (d.kind == TXQ_DENSE_ZERO) *c = 0;
+        }
+        counts[t] = n;
+        chunks = (n + kSparseChunk - 1) / kSparseChunk;
+    }
+    scan[t] = chunks;
+    __syncthreads();
+    for (uint32_t o = 1; o < 1024; o <<= 1) {
+        const uint32_t v = t >= o ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += v;
+        __syncthreads();
+    }
+    if (t < n_groups) prefix[t + 1] = scan[t];
+    if (t == 0) prefix[0] = 0;
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void atomic_or_chunk(uint64_t* p, typename Lane<WIDE>::T v) {
+    if constexpr (WIDE) {
+        const uint64_t lo = ((uint64_t)v.y << 32) | v.x, hi = ((uint64_t)v.w << 32) | v.z;
+        if (lo) __hip_atomic_fetch_or(p, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hi) __hip_atomic_fetch_or(p + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (v) __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// Entries that became live in this wave join the list with ONE atomic on the block's count: `n_new` per lane (most
+// lanes: 0), inclusive wave scan, the last lane reserves the range.  Returns the lane's first position.
+__device__ __forceinline__ uint32_t reserve_live(const BlockMeta& m, uint32_t n_new) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t incl = n_new;
+    for (uint32_t o = 1; o < 64; o <<= 1) {
+        const uint32_t v = (uint32_t)__shfl_up((int)incl, (int)o);
+        if (lane >= o) incl += v;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t base = 0;
+    if (lane == 63 && total) base = __hip_atomic_fetch_add(m.count, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    base = (uint32_t)__shfl((int)base, 63);
+    return base + incl - n_new;
+}
+
+template <int H, bool WIDE, class ROWS>
+__global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
+                                                     const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
+                                                     const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                     uint32_t W, uint32_t G, DenseParams P, LevelUnits U) {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    constexpr int UA = 3;  // residues in flight per lane: UA * H row gathers
+    __shared__ uint32_t pre[kMaxSparseGroups + 1];
+    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
+    __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2, U.block_n);
+        return;
+    }
+    for (uint32_t i = threadIdx.x; i <= n_groups; i += blockDim.x) pre[i] = prefix[i];
+    __syncthreads();
+    const uint32_t total = pre[n_groups];
+    const uint32_t j = blockIdx.x - U.n_units, J = gridDim.x - U.n_units;
+    const uint32_t lo = (uint32_t)((uint64_t)total * j / J), hi = (uint32_t)((uint64_t)total * (j + 1) / J);
+    if (lo >= hi) return;
+    uint32_t g = 0;  // the group of chunk lo: the last one that starts at or before it
+    for (uint32_t b = n_groups; b - g > 1;) {
+        const uint32_t m = (g + b) / 2;
+        if (pre[m] <= lo) g = m; else b = m;
+    }
+    const uint32_t N = P.pow_a[P.pos];
+    const uint32_t chunks_w = (W + L::kWords - 1) / L::kWords;
+    uint32_t loaded = 0xFFFFFFFFu;
+    for (uint32_t t = lo; t < hi; ++t) {
+        while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
+        const uint32_t first = (t - pre[g]) * kSparseChunk;
+        const uint32_t n = counts[g];
+        const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
+        const SparseGroup sg = groups[g];
+        const txq_dense_op d = dops[sg.op];
+        const DenseOpPtr q = optr[sg.op];
+        if (loaded != g && (d.kind == TXQ_DENSE_STEP || d.kind == TXQ_DENSE_FILL)) {
+            __syncthreads();  // the previous chunk has read its codes
+            dense_codes(d, P, codes, cnt);
+            loaded = g;
+        }
+        if (d.kind == TXQ_DENSE_ZERO) {  // the listed entries := 0, their bits in the bitmap cleared (the plan kernel has reset the count)
+            const BlockMeta m = block_meta(q.dst, N, W);
+            uint32_t wl = 1;
+            while (wl < W && wl < blockDim.x) wl <<= 1;
+            const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
+            for (uint32_t e = first + grp; e < end; e += ngrp) {
+                const uint32_t idx = m.list[e];
+                for (uint32_t w = sub; w < W; w += wl) q.dst[(size_t)idx * W + w] = 0;
+                if (sub == 0) __hip_atomic_fetch_and(m.bitmap + (idx >> 6), ~(1ULL << (idx & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+        if (d.kind == TXQ_DENSE_REDUCE) {  // slot dst |= OR of the listed entries
+            const BlockMeta m = block_meta(const_cast<uint64_t*>(q.src), N, W);
+            uint32_t wl = 1;
+            while (wl < W && wl < blockDim.x) wl <<= 1;
+            const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
+            for (uint32_t w = sub; w < W; w += wl) {
+                uint64_t acc = 0;
+                for (uint32_t e = first + grp; e < end; e += ngrp) acc |= q.src[(size_t)m.list[e] * W + w];
+                if (acc) __hip_atomic_fetch_or(q.dst + w, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            continue;
+        }
+        if (d.kind == TXQ_DENSE_FILL) {  // entries first .. end of the shape |= the slot; those that were empty join the list
+            const BlockMeta m = block_meta(q.dst, N, W);
+            uint32_t wl = 1;
+            while (wl < W && wl < 64u) wl <<= 1;  // the lanes of an entry stay within a wave (reserve_live)
+            const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
+            const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
+            for (uint32_t it = 0; it < rounds; ++it) {
+                const uint32_t e = first + it * ngrp + grp;
+                const bool live = e < end;
+                uint32_t r = live ? e : 0, idx = 0;
+                for (uint32_t jj = P.pos; jj-- > 0;) {
+                    idx += (uint32_t)codes[jj][r % cnt[jj]] * P.pow_a[P.pos - 1 - jj];
+                    r /= cnt[jj];
+                }
+                uint64_t any = 0;
+                if (live)
+                    for (uint32_t w = sub; w < W; w += wl) {
+                        const uint64_t v = q.src[w];
+                        if (v) q.dst[(size_t)idx * W + w] |= v;
+                        any |= v;
+                    }
+                for (uint32_t o = 1; o < wl; o <<= 1) any |= Lane<false>::shfl_xor(any, o);
+                const uint32_t fresh = live && sub == 0 && any && mark_live(m, idx) ? 1u : 0u;
+                const uint32_t at = reserve_live(m, fresh);
+                if (fresh) m.list[at] = idx;
+            }
+            continue;
+        }
+        // STEP, pushed: every listed entry (a, x1 .. x_{k-2}) of src is rolled forward by the residues of r_mask —
+        // dst[(x1 .. x_{k-2}, r)] |= src[entry] & M[k-mer(entry, r)] — G lanes per entry, UA residues in flight.  A product
+        // that is empty is not written (the collector's path_.none() pruning, include/otf_collector.h:383); a destination entry
+        // that receives its first bit joins dst's list.
+        const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), N, W), dm = block_meta(q.dst, N, W);
+        const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
+        const uint32_t n_r = cnt[P.pos];
+        const uint32_t a_stride = P.pow_a[P.pos - 1];
+        const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
+        for (uint32_t it = 0; it < rounds; ++it) {
+            const uint32_t e = first + it * ngrp + grp;
+            const bool live = e < end;
+            const uint32_t idx = live ? sm.list[e] : 0;
+            const uint32_t a = idx / a_stride, mid = idx - a * a_stride;
+            uint64_t mid_val = 0;
+            for (uint32_t tt = 0, m = mid; tt + 1 < P.pos; ++tt) {
+                mid_val |= (uint64_t)(m % P.A) << (P.bits * tt);
+                m /= P.A;
+            }
+            const uint64_t high = (((uint64_t)a << (P.bits * (P.pos - 1))) | mid_val) << P.bits;  // the k-mer without the residue rolled in
+            const size_t dst0 = (size_t)mid * P.A;
+            uint32_t hit = 0;  // bit i: residue codes[pos][i] left a bit in this lane's chunk
+            for (uint32_t c0 = 0; c0 < chunks_w; c0 += G) {
+                const uint32_t c = c0 + sub;
+                bool mine = live && c < chunks_w;
+                T sv = L::zero();
+                if (mine) {
+                    rows.prepare(c);
+                    sv = L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords);
+                    mine = L::any(sv);
+                }
+                if (!mine) continue;
+                uint32_t i = 0;
+                for (; i + UA <= n_r; i += UA) {
+                    typename ROWS::Loads x[UA];
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        uint64_t v = high | codes[P.pos][i + u];
+                        if (P.canonical) v = canonical_dna(v, P.k);
+                        rows.template issue<false>(nullptr, v, x[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) rows.template issue_late<false>(x[u]);
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        const T y = sv & rows.combine(x[u]);
+                        if (L::any(y)) {
+                            atomic_or_chunk<WIDE>(q.dst + (dst0 + codes[P.pos][i + u]) * W + (size_t)c * L::kWords, y);
+                            hit |= 1u << (i + u);
+                        }
+                    }
+                }
+                for (; i < n_r; ++i) {
+                    typename ROWS::Loads x0;
+                    uint64_t v = high | codes[P.pos][i];
+                    if (P.canonical) v = canonical_dna(v, P.k);
+                    rows.template issue<false>(nullptr, v, x0);
+                    rows.template issue_late<false>(x0);
+                    const T y = sv & rows.combine(x0);
+                    if (L::any(y)) {
+                        atomic_or_chunk<WIDE>(q.dst + (dst0 + codes[P.pos][i]) * W + (size_t)c * L::kWords, y);
+                        hit |= 1u << i;
+                    }
+                }
+            }
+            for (uint32_t o = 1; o < G; o <<= 1) hit |= (uint32_t)__shfl_xor((int)hit, (int)o);
+            uint32_t fresh = 0;  // the entry's first lane lists the destinations that were empty until now
+            if (sub == 0)
+                for (uint32_t h = hit; h; h &= h - 1) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(h);
+                    if (mark_live(dm, (uint32_t)dst0 + codes[P.pos][i])) fresh |= 1u << i;
+                }
+            uint32_t at = reserve_live(dm, (uint32_t)__builtin_popcount(fresh));
+            for (uint32_t h = fresh; h; h &= h - 1) dm.list[at++] = (uint32_t)dst0 + codes[P.pos][__builtin_ctz(h)];
+        }
+    }
+}
+
 // ---- dense steps on an HIBF --------------------------------------------------------------------
 // M[k-mer] of an HIBF is a tree descent (txq_hibf.hip), not h row gathers, so a step cannot be fused.  It runs as
 // three launches over a chunk of step tiles: the predecessor k-mers of every destination suffix are written out
@@ -635,16 +929,15 @@ __global__ __launch_bounds__(256) void dense_hibf_kmers_kernel(const DenseTile* 
 }
 
 __global__ __launch_bounds__(256) void dense_hibf_combine_kernel(const DenseTile* __restrict__ tiles, const uint32_t* __restrict__ pair_base,
-                                                                 const txq_dense_op* __restrict__ dops, uint64_t* const* __restrict__ slot_base,
-                                                                 uint32_t n_programs, uint32_t W, DenseParams P, const uint64_t* __restrict__ masks) {
+                                                                 const txq_dense_op* __restrict__ dops, const DenseOpPtr* __restrict__ optr,
+                                                                 uint32_t W, DenseParams P, const uint64_t* __restrict__ masks) {
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     const DenseTile t = tiles[blockIdx.x];
     const txq_dense_op d = dops[t.op];
     dense_codes(d, P, codes, cnt);
-    uint64_t* D = slot_base[n_programs + t.program];
-    const uint64_t* src = D + (size_t)(d.src & ~TXQ_DENSE_SLOT_BIT) * W;
-    uint64_t* dstb = D + (size_t)(d.dst & ~TXQ_DENSE_SLOT_BIT) * W;
+    const uint64_t* src = optr[t.op].src;
+    uint64_t* dstb = optr[t.op].dst;
     const uint64_t* M = masks + (size_t)pair_base[blockIdx.x] * W;
     uint32_t wl = 1;  // lanes per suffix: one word each
     while (wl < W && wl < blockDim.x) wl <<= 1;
@@ -733,6 +1026,7 @@ struct BlobView {
     std::vector<DevProgram> programs;
     std::vector<uint32_t> n_slots, n_dense_slots;
     std::vector<uint8_t> has_dense;  // the program has dense ops in this stage
+    std::vector<uint8_t> tracked;    // TXQ_PROGRAM_TRACKED_BIT
 };
 
 static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, BlobView* out) {
@@ -792,6 +1086,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     v.n_slots.resize(n_programs);
     v.n_dense_slots.assign(n_programs, 0);
     v.has_dense.assign(n_programs, 0);
+    v.tracked.assign(n_programs, 0);
     const txq_op* ops = (const txq_op*)(blob + v.ops_offset);
     const txq_dense_op* dops = v3 ? (const txq_dense_op*)(blob + v.dense_offset) : nullptr;
     const uint32_t* levels = v2 ? (const uint32_t*)(blob + v.levels_offset) : nullptr;
@@ -802,8 +1097,10 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             d = DevProgram{s.first_op, s.n_ops, s.first_level, s.n_levels};
             v.n_slots[p] = s.n_slots;
             if (v3) {
-                v.n_dense_slots[p] = s.reserved;
-                if (s.reserved % v.block_slots || s.reserved >= TXQ_DENSE_SLOT_BIT)
+                v.tracked[p] = (s.reserved & TXQ_PROGRAM_TRACKED_BIT) != 0;
+                const uint32_t dense_slots = s.reserved & ~TXQ_PROGRAM_TRACKED_BIT;
+                v.n_dense_slots[p] = dense_slots;
+                if (dense_slots % v.block_slots || dense_slots >= TXQ_DENSE_SLOT_BIT)
                     return fail(TXQ_ERR_PROGRAM, "program %u: dense slots not a multiple of the block size", p);
             }
         } else {
@@ -845,9 +1142,11 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
                 else {
                     const txq_dense_op& x = dops[o[i].dst];
                     const uint32_t code_mask = v.dense.A >= 32 ? 0xFFFFFFFFu : ((1u << v.dense.A) - 1u);
-                    bool ok = x.kind <= TXQ_DENSE_REDUCE;
+                    bool ok = x.kind <= TXQ_DENSE_FILL;
+                    if (ok) ok = ((x.reserved & TXQ_DENSE_TRACKED) != 0) == (v.tracked[p] != 0) && (x.reserved & ~TXQ_DENSE_TRACKED) == 0;
                     if (ok && x.kind != TXQ_DENSE_REDUCE) ok = block_ok(x.dst);
-                    if (ok && x.kind != TXQ_DENSE_ZERO) ok = block_ok(x.src);
+                    if (ok && (x.kind == TXQ_DENSE_STEP || x.kind == TXQ_DENSE_REDUCE)) ok = block_ok(x.src);
+                    if (ok && x.kind == TXQ_DENSE_FILL) ok = !(x.src & TXQ_DENSE_SLOT_BIT) && x.src < n_slots;
                     if (ok && (x.kind != TXQ_DENSE_ZERO || x.r_mask))
                         for (uint32_t j = 0; ok && j < v.dense.pos; ++j) ok = (x.shape[j] & ~code_mask) == 0;
                     if (ok && x.kind == TXQ_DENSE_STEP) ok = x.src != x.dst && (x.r_mask & ~code_mask) == 0;
@@ -899,6 +1198,9 @@ Session::~Session() {
         fprintf(stderr, "[txq]   dense work: %llu predecessor visits for %llu destination suffixes, %llu slots zeroed, %llu entries reduced; mask %u words\n",
                 (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
     if (std::getenv("TXQ_TRACE") && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
+    if (std::getenv("TXQ_TRACE") && n_blocks_made + n_block_memsets)
+        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB each), %zu cleared for tracked programs; %zu sparse launches (%zu groups)\n", n_blocks_made,
+                block_words * 8 / 1e6, n_block_memsets, n_sparse_launches, n_sparse_groups);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
@@ -956,7 +1258,8 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     s->W = (uint32_t)ix.shard_words;
     s->base.assign(2 * n_programs, nullptr);
     s->cap.assign(n_programs, 0);
-    s->dcap.assign(n_programs, 0);
+    s->blocks.assign(n_programs, {});
+    s->tracked.assign(n_programs, 0);
     Index::SessionCache& c = ix.session_cache;
     if (!c.in_use) {  // adopt the previous session's buffers
         c.in_use = true;
@@ -986,21 +1289,34 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 }
 
 // (re)size the programs' slot regions to what the stage needs; a grown region keeps its contents
-// (host side only: the caller uploads `moves` and the base table with the stage and launches move_regions_kernel)
-static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out) {
+// (host side only: the caller uploads `moves` and the base table with the stage and launches move_regions_kernel).
+// Dense blocks: a program that needs more blocks gets more (from the blocks finished programs gave back, or from the
+// arena); `to_clear` = blocks that go to a tracked program and must be all zero first (the caller memsets them on the
+// stage's stream).
+static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out,
+                             std::vector<uint64_t*>* to_clear) {
     std::vector<RegionMove>& moves = *moves_out;
-    // Regions given back two stages ago serve other programs now: whatever used them has finished (a stage waits for the
-    // stage before the previous one, whose staging set it takes over), so a recycled region ties its new owner to nobody.
-    for (const auto& r : s.given_back[1]) s.free_dense.emplace(r.first, r.second);
+    if (bv.block_slots) {
+        if (!s.block_slots) {
+            s.block_slots = bv.block_slots;
+            s.block_words = ((size_t)bv.block_slots * s.W + block_meta_words(bv.block_slots) + 1) & ~(size_t)1;
+        } else if (s.block_slots != bv.block_slots)
+            return fail(TXQ_ERR_PROGRAM, "the block size changed within a session (%u -> %u slots)", s.block_slots, bv.block_slots);
+    }
+    // Blocks given back two stages ago serve other programs now: whatever used them has finished (a stage waits for the
+    // stage before the previous one, whose staging set it takes over), so a recycled block ties its new owner to nobody.
+    s.free_blocks.insert(s.free_blocks.end(), s.given_back[1].begin(), s.given_back[1].end());
     s.given_back[1].swap(s.given_back[0]);
     s.given_back[0].clear();
     // a program that reports no dense slots any more is finished with its blocks
     if (bv.block_slots)
         for (size_t p = 0; p < s.n_programs; ++p)
-            if (bv.n_dense_slots[p] == 0 && s.dcap[p]) {
-                s.given_back[0].emplace_back(s.dcap[p], s.base[s.n_programs + p]);
+            if (bv.n_dense_slots[p] == 0 && !s.blocks[p].empty()) {
+                for (const Session::DenseBlock& b : s.blocks[p])
+                    s.given_back[0].push_back(Session::DenseBlock{b.p, (uint8_t)(s.tracked[p] ? Session::kListed : Session::kGarbage)});
+                s.n_blocks_live -= s.blocks[p].size();
+                s.blocks[p].clear();
                 s.base[s.n_programs + p] = nullptr;
-                s.dcap[p] = 0;
             }
     for (size_t p = 0; p < s.n_programs; ++p) {
         // a program gets its region with its first ops (a query of a later wave would otherwise get eight slots now and
@@ -1016,23 +1332,24 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             s.base[p] = region;
             s.cap[p] = cap;
         }
-        const uint32_t dneed = bv.n_dense_slots[p];
-        if (dneed > s.dcap[p]) {  // whole blocks; doubling keeps the copies (and the abandoned regions) within 2x
-            uint32_t cap = s.dcap[p] ? s.dcap[p] * 2 : dneed;
-            if (cap < dneed) cap = dneed;
-            uint64_t* region = nullptr;
-            auto recycled = s.free_dense.lower_bound(dneed);  // the smallest released region that is large enough, within reason
-            if (recycled != s.free_dense.end() && recycled->first <= 4 * (uint64_t)cap) {
-                cap = recycled->first;
-                region = recycled->second;
-                s.free_dense.erase(recycled);
-            } else if (int rc = arena_alloc(s, (size_t)cap * s.W, &region)) return rc;
-            if (s.dcap[p]) {
-                moves.push_back(RegionMove{region, s.base[s.n_programs + p], (size_t)s.dcap[p] * s.W});
-                s.given_back[0].emplace_back(s.dcap[p], s.base[s.n_programs + p]);  // this stage's move kernel still reads it
+        const size_t bneed = bv.block_slots ? bv.n_dense_slots[p] / bv.block_slots : 0;
+        if (bneed > s.blocks[p].size()) {
+            if (s.blocks[p].empty()) s.tracked[p] = bv.tracked[p];
+            else if (s.tracked[p] != bv.tracked[p]) return fail(TXQ_ERR_PROGRAM, "program %zu: tracked and untracked blocks in one program", p);
+            while (s.blocks[p].size() < bneed) {
+                Session::DenseBlock b{nullptr, Session::kGarbage};
+                if (!s.free_blocks.empty()) {
+                    b = s.free_blocks.back();
+                    s.free_blocks.pop_back();
+                } else {
+                    if (int rc = arena_alloc(s, s.block_words, &b.p)) return rc;
+                    ++s.n_blocks_made;
+                }
+                // (a kListed block could be cleared through its list instead; the memset is 0.1 ms per 500 MB)
+                if (s.tracked[p]) to_clear->push_back(b.p);
+                s.blocks[p].push_back(b);
+                ++s.n_blocks_live;
             }
-            s.base[s.n_programs + p] = region;
-            s.dcap[p] = cap;
         }
     }
     return TXQ_OK;
@@ -1042,29 +1359,45 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
 // their ops are cut into units per dependency level (units of level l, all programs, are contiguous in `units`),
 // their dense ops into tiles, and every level becomes one launch of each kind over the whole GPU.
 // Returns the number of programs left to exec_kernel.
-struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0; };
+struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0, sparse = 0, sparse_chunks = 0; };
 // hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
-// HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel
-static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
+// HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel.
+// The dense ops of tracked programs become sparse groups (one per op; sparse_kernel), and every dense op's blocks are
+// resolved to pointers here (`optr`, indexed like the stage's dense table).
+static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
                          std::vector<TileGroup>* groups, size_t* n_tiles, uint64_t (*work)[4], std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
-                         std::vector<LevelPlan>* plan) {
+                         std::vector<SparseGroup>* sparse, std::vector<DenseOpPtr>* optr, std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
     const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
     const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
     const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
+    optr->assign(bv.n_dense, DenseOpPtr{nullptr, nullptr});
     std::vector<std::vector<ExecUnit>> per_level;
     std::vector<std::vector<TileGroup>> groups_level;
     std::vector<std::vector<DenseTile>> hsteps_level;
+    std::vector<std::vector<SparseGroup>> sparse_level;
+    std::vector<size_t> sparse_chunks;
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
     static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
     const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
+    const uint32_t N = bv.block_slots;
     size_t n_small = 0;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
         DevProgram& d = bv.programs[p];
         const bool dense = bv.has_dense[p] != 0;
         // small = less work than a unit launch is worth: 2048 ops of a 1024-bin index, 32 ops at 65536 bins
         if (!dense && (d.n_levels == 0 || (uint64_t)d.n_ops * W < 2048u * 16u)) { n_small += d.n_ops != 0; continue; }
-        if (per_level.size() < d.n_levels) { per_level.resize(d.n_levels); groups_level.resize(d.n_levels); hsteps_level.resize(d.n_levels); }
+        if (per_level.size() < d.n_levels) {
+            per_level.resize(d.n_levels); groups_level.resize(d.n_levels); hsteps_level.resize(d.n_levels);
+            sparse_level.resize(d.n_levels); sparse_chunks.resize(d.n_levels, 0);
+        }
+        // (validate_blob has checked that block operands are block-aligned and inside the program's dense slots, and
+        // grow_slot_regions has given the program that many blocks)
+        auto block_of = [&](uint32_t slot) { return s.blocks[p][(slot & ~TXQ_DENSE_SLOT_BIT) / N].p; };
+        auto slot_of = [&](uint32_t slot) {
+            const uint32_t i = slot & ~TXQ_DENSE_SLOT_BIT;
+            return (slot & TXQ_DENSE_SLOT_BIT) ? s.blocks[p][i / N].p + (size_t)(i % N) * W : s.base[p] + (size_t)slot * W;
+        };
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
@@ -1081,19 +1414,32 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
                     cut(run, i);
                     run = i + 1;
                     const txq_dense_op& x = dops[o.dst];
+                    DenseOpPtr& q = (*optr)[o.dst];
+                    q.dst = x.kind == TXQ_DENSE_REDUCE ? slot_of(x.dst) : block_of(x.dst);
+                    q.src = x.kind == TXQ_DENSE_STEP || x.kind == TXQ_DENSE_REDUCE ? block_of(x.src) : x.kind == TXQ_DENSE_FILL ? slot_of(x.src) : nullptr;
+                    uint64_t shape_entries = 1;
+                    for (uint32_t j = 0; j < bv.dense.pos; ++j) shape_entries *= (uint64_t)__builtin_popcount(x.shape[j]);
+                    if (x.reserved & TXQ_DENSE_TRACKED) {  // work follows the block's live list (FILL: its shape)
+                        const bool fixed = x.kind == TXQ_DENSE_FILL;
+                        if (fixed && !shape_entries) continue;
+                        sparse_level[l].push_back(SparseGroup{o.dst, fixed ? (uint32_t)shape_entries : kNotFixed});
+                        // most chunks this group can turn out to have: a list never outgrows its block, nor (STEP, REDUCE: what is read) the op's shape
+                        const uint64_t most = x.kind == TXQ_DENSE_ZERO ? N : std::min<uint64_t>(N, std::max<uint64_t>(shape_entries, 1));
+                        sparse_chunks[l] += (size_t)((most + kSparseChunk - 1) / kSparseChunk);
+                        continue;
+                    }
                     uint64_t entries = 1, per_tile = step_tile;
-                    if (x.kind == TXQ_DENSE_ZERO) {
+                    if (x.kind == TXQ_DENSE_ZERO || x.kind == TXQ_DENSE_FILL) {
                         per_tile = std::max<uint64_t>(1, 8192 / W);
-                        if (!x.r_mask) entries = bv.block_slots;
-                        else for (uint32_t j = 0; j < bv.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
+                        entries = x.kind == TXQ_DENSE_ZERO && !x.r_mask ? bv.block_slots : shape_entries;
                     } else {
                         for (uint32_t j = x.kind == TXQ_DENSE_STEP ? 1 : 0; j < bv.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
                         if (x.kind == TXQ_DENSE_STEP) entries *= (uint64_t)__builtin_popcount(x.r_mask) * (__builtin_popcount(x.shape[0]) ? 1 : 0);
                         else per_tile = 1024;
                     }
                     if (x.kind == TXQ_DENSE_STEP) { (*work)[0] += entries * (uint64_t)__builtin_popcount(x.shape[0]); (*work)[1] += entries; }
-                    else if (x.kind == TXQ_DENSE_ZERO) (*work)[2] += entries;
-                    else (*work)[3] += entries;
+                    else if (x.kind == TXQ_DENSE_REDUCE) (*work)[3] += entries;
+                    else (*work)[2] += entries;
                     const bool hstep = hibf && x.kind == TXQ_DENSE_STEP;
                     if (hstep) per_tile = 256;  // 256 suffixes x up to 32 predecessors: at most 8192 k-mers per tile
                     if (!hstep) {
@@ -1121,6 +1467,9 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
         *n_tiles += level_tiles;
         groups->insert(groups->end(), groups_level[l].begin(), groups_level[l].end());
         (*plan)[l].hsteps = hsteps_level[l].size();
+        (*plan)[l].sparse = sparse_level[l].size();
+        (*plan)[l].sparse_chunks = sparse_chunks[l];
+        sparse->insert(sparse->end(), sparse_level[l].begin(), sparse_level[l].end());
         units->insert(units->end(), per_level[l].begin(), per_level[l].end());
         for (const DenseTile& t : hsteps_level[l]) {
             hsteps->push_back(t);
@@ -1132,8 +1481,8 @@ static size_t plan_units(BlobView& bv, const unsigned char* blob, uint32_t W, ui
 
 // rows_of(H) makes the kernel's row source for H hash functions (FlatRows / TreeRows)
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
-static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, uint64_t* const* base,
-                               uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, const LevelUnits& U, hipStream_t st) {
+static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, const DenseOpPtr* optr,
+                               uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, const LevelUnits& U, hipStream_t st) {
     const size_t grid = n_tiles + U.n_units;
     // predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
     static const int ua = std::getenv("TXQ_DENSE_UNROLL") ? std::atoi(std::getenv("TXQ_DENSE_UNROLL")) : 3;
@@ -1141,9 +1490,9 @@ static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        if (ua >= 6) dense_kernel<H, WIDE, 6, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
-        else if (ua <= 2) dense_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
-        else dense_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, base, n_programs, W, G, SL, P, U); \
+        if (ua >= 6) dense_kernel<H, WIDE, 6, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
+        else if (ua <= 2) dense_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
+        else dense_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
     } while (0)
     switch (hash_funs) {
         case 1: TXQ_DENSE(1); break;
@@ -1154,6 +1503,29 @@ static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile
         default: return hipErrorInvalidValue;
     }
 #undef TXQ_DENSE
+    return hipGetLastError();
+}
+
+// the level's sparse groups [groups, groups + n_groups) (n_groups <= kMaxSparseGroups): `grid` workgroups share their chunks out
+template <bool WIDE, template <int, bool> class ROWS, class MAKE>
+static hipError_t launch_sparse(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
+                                size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G,
+                                const DenseParams& P, const LevelUnits& U, hipStream_t st) {
+#define TXQ_SPARSE(H) \
+    do { \
+        ROWS<H, WIDE> rows{}; \
+        rows_of(rows); \
+        sparse_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U); \
+    } while (0)
+    switch (hash_funs) {
+        case 1: TXQ_SPARSE(1); break;
+        case 2: TXQ_SPARSE(2); break;
+        case 3: TXQ_SPARSE(3); break;
+        case 4: TXQ_SPARSE(4); break;
+        case 5: TXQ_SPARSE(5); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TXQ_SPARSE
     return hipGetLastError();
 }
 
@@ -1191,18 +1563,21 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             continues = continues || s.last_stage[p] + 1 == s.n_stages;
             s.last_stage[p] = (uint32_t)s.n_stages;
         }
+    // dense steps on a regular two-level HIBF run fused, too (TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
+    const bool tree = index_fuses_tree_steps(ix);
+    bool any_tracked = false;
+    for (size_t p = 0; p < s.n_programs; ++p) any_tracked |= bv.tracked[p] != 0 && bv.has_dense[p] != 0;
+    if (any_tracked && ix.is_hibf && !tree)
+        return fail(TXQ_ERR_PROGRAM, "tracked blocks need an index whose dense steps run fused (txq_index_supports_dense() == 2)");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
-    if (int rc = grow_slot_regions(s, bv, &fresh, &moves)) return rc;
+    std::vector<uint64_t*> to_clear;
+    if (int rc = grow_slot_regions(s, bv, &fresh, &moves, &to_clear)) return rc;
     s.t_grow += now_s() - t0;
     for (size_t i = 0; i < n_q; ++i)
         if (!s.base[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: program %u has not run an op yet", i, q_prog[i]);
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
-    // (a regular two-level HIBF runs its steps fused, too: TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
-    const bool tree_allowed = !(std::getenv("TXQ_DENSE_TREE") && std::getenv("TXQ_DENSE_TREE")[0] == '0');
-    const bool tree = ix.is_hibf && ix.d_children && ix.n_children && tree_allowed && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
-                      (uint64_t)ix.n_children * ix.child_row_words == W;
     if (any_dense) s.row_source = tree ? "regular tree, fused" : ix.is_hibf ? "HIBF descent" : "flat IBF, fused";
     if (any_dense && tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && !std::getenv("TXQ_DENSE_TREE"))
         s.row_source = "regular tree, interleaved children, fused";
@@ -1223,8 +1598,22 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<DenseTile> hsteps;
     std::vector<uint32_t> hstep_na;
     std::vector<LevelPlan> plan;
+    std::vector<SparseGroup> sparse_groups;
+    std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    const size_t n_small = plan_units(bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na, &plan);
+    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
+                                      &sparse_groups, &optr, &plan);
+    size_t n_sparse_launches = 0;
+    for (const LevelPlan& lp : plan) n_sparse_launches += (lp.sparse + kMaxSparseGroups - 1) / kMaxSparseGroups;
+    // the stage's block table: per program with blocks a row [flags | block 0 | block 1 | ..] (DenseRow)
+    std::vector<uint64_t*> block_table;
+    std::vector<size_t> row_of(s.n_programs, 0);
+    for (size_t p = 0; p < s.n_programs; ++p)
+        if (!s.blocks[p].empty()) {
+            row_of[p] = block_table.size();
+            block_table.push_back(reinterpret_cast<uint64_t*>((uintptr_t)(s.tracked[p] ? 1 : 0)));
+            for (const Session::DenseBlock& b : s.blocks[p]) block_table.push_back(b.p);
+        }
     s.n_step_pairs += work[0]; s.n_step_suffixes += work[1]; s.n_zero_slots += work[2]; s.n_reduce_entries += work[3];
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
     // never across a level; pair_base[tile] = first pair of the tile within its chunk
@@ -1274,6 +1663,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const size_t at_units = place(units.size() * sizeof(ExecUnit)), at_tiles = place(n_tiles * sizeof(DenseTile)), at_groups = place(tile_groups.size() * sizeof(TileGroup));
     const size_t at_hsteps = place(hsteps.size() * sizeof(DenseTile)), at_pair_base = place(hsteps.size() * 4);
     const size_t at_moves = place(moves.size() * sizeof(RegionMove)), at_base = place(2 * s.n_programs * sizeof(uint64_t*));
+    const size_t at_optr = place(optr.size() * sizeof(DenseOpPtr)), at_bt = place(block_table.size() * sizeof(uint64_t*));
+    const size_t at_sgroups = place(sparse_groups.size() * sizeof(SparseGroup)), at_scounts = place(sparse_groups.size() * 4);
+    const size_t at_sprefix = place((sparse_groups.size() + n_sparse_launches) * 4);
     // a small stage (a single query: a few hundred bytes of blob, a dozen small tables) travels as ONE copy: the blob
     // rides behind the tables in `aux`
     const bool packed = aux_bytes + bytes <= ((size_t)256 << 10);
@@ -1282,6 +1674,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (int rc = ensure((void**)&S.d_blob, &S.cap_blob, (bytes + 7) & ~(size_t)7)) return rc;
     if (int rc = ensure((void**)&S.d_aux, &S.cap_aux, aux_bytes + 16)) return rc;
     const unsigned char* dblob = packed ? S.d_aux + at_blob : S.d_blob;
+    for (size_t p = 0; p < s.n_programs; ++p)  // (the aux buffer has its final address now)
+        s.base[s.n_programs + p] = s.blocks[p].empty() ? nullptr : reinterpret_cast<uint64_t*>(reinterpret_cast<uint64_t**>(S.d_aux + at_bt) + row_of[p]);
     const size_t nk = h->n_kmers;
     // scratch the kernels in flight may still use: replacing it drains the device (ensure), so replace it generously
     auto ensure_scratch = [&](uint64_t** p, size_t* cap, size_t need) -> int {
@@ -1306,6 +1700,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         put(at_pair_base, pair_base.data(), hsteps.size() * 4);
         put(at_moves, moves.data(), moves.size() * sizeof(RegionMove));
         put(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*));
+        put(at_optr, optr.data(), optr.size() * sizeof(DenseOpPtr));
+        put(at_bt, block_table.data(), block_table.size() * sizeof(uint64_t*));
+        put(at_sgroups, sparse_groups.data(), sparse_groups.size() * sizeof(SparseGroup));
         put(at_blob, blob, bytes);
         TXQ_HIP(hipMemcpyAsync(S.d_aux, hb, aux_bytes, hipMemcpyHostToDevice, up));
     } else {
@@ -1323,6 +1720,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         TXQ_HIP(send(at_pair_base, pair_base.data(), hsteps.size() * 4));
         TXQ_HIP(send(at_moves, moves.data(), moves.size() * sizeof(RegionMove)));
         TXQ_HIP(send(at_base, s.base.data(), 2 * s.n_programs * sizeof(uint64_t*)));
+        TXQ_HIP(send(at_optr, optr.data(), optr.size() * sizeof(DenseOpPtr)));
+        TXQ_HIP(send(at_bt, block_table.data(), block_table.size() * sizeof(uint64_t*)));
+        TXQ_HIP(send(at_sgroups, sparse_groups.data(), sparse_groups.size() * sizeof(SparseGroup)));
     }
     DevProgram* d_progs = (DevProgram*)(S.d_aux + at_progs);
     uint32_t* d_fresh = (uint32_t*)(S.d_aux + at_fresh);
@@ -1333,6 +1733,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     DenseTile* d_tiles = (DenseTile*)(S.d_aux + at_tiles);
     DenseTile* d_hsteps = (DenseTile*)(S.d_aux + at_hsteps);
     uint32_t* d_pair_base = (uint32_t*)(S.d_aux + at_pair_base);
+    const DenseOpPtr* d_optr = (const DenseOpPtr*)(S.d_aux + at_optr);
+    const SparseGroup* d_sgroups = (const SparseGroup*)(S.d_aux + at_sgroups);
+    uint32_t* d_scounts = (uint32_t*)(S.d_aux + at_scounts);
+    uint32_t* d_sprefix = (uint32_t*)(S.d_aux + at_sprefix);
     s.d_base = (uint64_t**)(S.d_aux + at_base);
     if (!hsteps.empty()) {
         if (int rc = ensure_scratch(&ix.scratch_dense_kmers, &ix.cap_dense_kmers, most_pairs * 8)) return rc;
@@ -1355,6 +1759,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (!tile_groups.empty()) {
         make_tiles_kernel<<<(unsigned)tile_groups.size(), 256, 0, st>>>((const TileGroup*)(S.d_aux + at_groups), d_tiles);
         TXQ_HIP(hipGetLastError());
+    }
+    for (uint64_t* b : to_clear) {  // blocks a tracked program takes over: all zero, list empty
+        TXQ_HIP(hipMemsetAsync(b, 0, s.block_words * 8, st));
+        ++s.n_block_memsets;
     }
     if (!moves.empty()) {  // after everything earlier stages launched on the regions, before anything of this stage
         move_regions_kernel<<<dim3((unsigned)moves.size(), 16), 256, 0, st>>>((const RegionMove*)(S.d_aux + at_moves));
@@ -1395,7 +1803,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, d_masks, W)
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, d_masks, W, s.block_slots)
             switch (g) {
                 case 1: TXQ_EXEC(1); break;
                 case 2: TXQ_EXEC(2); break;
@@ -1411,15 +1819,19 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             }
 #undef TXQ_EXEC
         }
-        size_t first = 0, first_tile = 0, first_hstep = 0, chunk = 0;
+        size_t first = 0, first_tile = 0, first_hstep = 0, chunk = 0, first_sparse = 0, sparse_launch = 0;
+        uint32_t wpr_log2 = 0;
+        while (tree && (1u << wpr_log2) < ix.child_row_words) ++wpr_log2;
         for (size_t l = 0; l < plan.size(); ++l) {
             const size_t cnt = plan[l].units;
             ++s.n_levels;
-            // a flat index runs the level's units inside its dense launch (below); otherwise they are a launch of their own
+            // a flat index runs the level's units inside its dense launch (below), or its sparse launch when it has no tiles;
+            // otherwise they are a launch of their own
             const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree);
-            if (cnt && !ride) {
+            const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree);
+            if (cnt && !ride && !ride_sparse) {
                 ++s.n_unit_launches;
-                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2);
+                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2, s.block_slots);
             }
             s.n_units += cnt;
             // HIBF: the level's steps, chunk by chunk: k-mers of all (suffix, predecessor) pairs -> tree descent -> combine
@@ -1430,41 +1842,69 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     dense_hibf_kmers_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, bv.dense, ix.scratch_dense_kmers);
                     TXQ_HIP(hipGetLastError());
                     if (int rc = hibf_probe(ix, ix.scratch_dense_kmers, pairs, ix.scratch_dense_masks, nullptr, st)) return rc;
-                    dense_hibf_combine_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, s.d_base, np, W, bv.dense, ix.scratch_dense_masks);
+                    dense_hibf_combine_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, d_optr, W, bv.dense, ix.scratch_dense_masks);
                     TXQ_HIP(hipGetLastError());
                 }
                 first_hstep = c1;
                 s.n_dense_tiles += c1 - c0;
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
-                const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
+                const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2, s.block_slots};
                 hipError_t e;
                 if (tree) {
-                    uint32_t wpr_log2 = 0;
-                    while ((1u << wpr_log2) < ix.child_row_words) ++wpr_log2;
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
                     const bool by_lane = (256u / (g_dense * sl_dense)) * 32u * ix.root_node.stride() <= kRootWordsLds && !(tree_knob && tree_knob[0] == '1');
                     if (interleaved) {
                         auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_dense<true, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                     } else if (by_lane)
-                        e = wide ? launch_dense<true, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                     else
-                        e = wide ? launch_dense<true, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 } else {  // (an irregular HIBF only has ZERO / REDUCE tiles here: its steps are `hsteps`)
                     auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                    e = wide ? launch_dense<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                             : launch_dense<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                    e = wide ? launch_dense<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                             : launch_dense<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 }
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
                 s.n_dense_tiles += plan[l].tiles;
                 ++s.n_dense_launches;
             }
+            // the level's sparse groups (dense ops of tracked programs): plan (counts -> chunks), then the chunks
+            for (size_t off = 0; off < plan[l].sparse; off += kMaxSparseGroups, ++sparse_launch) {
+                const uint32_t ng = (uint32_t)std::min<size_t>(kMaxSparseGroups, plan[l].sparse - off);
+                const SparseGroup* gr = d_sgroups + first_sparse + off;
+                uint32_t* counts = d_scounts + first_sparse + off;
+                uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
+                sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, s.block_slots, W, counts, prefix);
+                TXQ_HIP(hipGetLastError());
+                const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && off == 0 ? (uint32_t)cnt : 0u, g_units_log2, s.block_slots};
+                // as many workgroups as the chunks could be at most, within what the device holds at a time
+                const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(plan[l].sparse_chunks, 2048));
+                hipError_t e;
+                if (interleaved) {
+                    auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                    e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                             : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                } else if (tree) {
+                    auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                    e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                             : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                } else {
+                    auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
+                    e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                             : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                }
+                if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
+                ++s.n_sparse_launches;
+                s.n_sparse_groups += ng;
+            }
+            first_sparse += plan[l].sparse;
             first += cnt;
         }
     }

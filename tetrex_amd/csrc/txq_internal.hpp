@@ -3,7 +3,6 @@
 #include "txq_kernels.hpp"
 #include "../../include/txq.h"
 #include <cstdlib>
-#include <map>
 #include <vector>
 
 namespace txq {
@@ -127,6 +126,15 @@ struct Index {
     void release();
 };
 
+// Does a session on this index run dense steps fused on the tree (txq_exec.hip TreeRows / InterleavedRows)?  A regular
+// two-level HIBF whose children tile this shard's mask columns.  TXQ_DENSE_TREE=0 (A/B and tests) sends steps through
+// the generic HIBF path instead.
+inline bool index_fuses_tree_steps(const Index& ix) {
+    const char* knob = std::getenv("TXQ_DENSE_TREE");
+    return ix.is_hibf && ix.d_children && ix.n_children && !(knob && knob[0] == '0') && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
+           (uint64_t)ix.n_children * ix.child_row_words == ix.shard_words;
+}
+
 // Normalised program descriptor the executor kernel reads (both blob versions map onto it).
 struct DevProgram { uint32_t first_op, n_ops, first_level, n_levels; };
 
@@ -138,12 +146,24 @@ struct Session {
     uint32_t W = 0;
     std::vector<Index::ArenaChunk> chunks;  // arena chunks; bump allocation in chunks[cur]
     size_t cur = 0, chunk_used = 0, arena_words = 0;
-    std::vector<uint64_t*> base;    // [2 * n_programs]: per program its slot region [cap][W], then its dense region [dcap][W]
+    std::vector<uint64_t*> base;    // [2 * n_programs]: per program its slot region [cap][W], then (device address of) its row of the stage's block table
     std::vector<uint32_t> cap;      // per program: slots allocated
-    std::vector<uint32_t> dcap;     // per program: dense slots allocated (include/txq_program.h, version 3)
-    std::multimap<uint32_t, uint64_t*> free_dense;  // dense regions given back by finished programs / outgrown: capacity in slots -> region
+    // Dense blocks (include/txq_program.h, version 3): block b of program p is blocks[p][b], an allocation of its own —
+    // [N][W] mask words, then the block's live list (tracked programs): count | bitmap of N bits | list of N entries.
+    // A program that needs more blocks just gets more (nothing ever moves); kernels find a block through the stage's
+    // block table (ordinary ops on dense slots) or through the per-op pointers the host side resolves (DenseOpPtr).
+    // What a block holds when it is handed on: kGarbage (fresh arena memory, or left by an untracked program),
+    // kListed (left by a tracked program: all zero except the entries in its list, which is intact).
+    struct DenseBlock { uint64_t* p; uint8_t state; };
+    enum : uint8_t { kGarbage = 0, kListed = 1 };
+    std::vector<std::vector<DenseBlock>> blocks;  // per program
+    std::vector<uint8_t> tracked;                 // per program: TXQ_PROGRAM_TRACKED_BIT (fixed with its first block)
+    std::vector<DenseBlock> free_blocks;          // blocks of finished programs, reusable ...
     // ... two stages after they were given back: the stage before the current one may still be running, on another stream
-    std::vector<std::pair<uint32_t, uint64_t*>> given_back[2];
+    std::vector<DenseBlock> given_back[2];
+    uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet)
+    size_t block_words = 0;         // words of one block allocation (masks + live list)
+    size_t n_blocks_live = 0, n_blocks_made = 0, n_block_memsets = 0, n_sparse_launches = 0, n_sparse_groups = 0;
     std::vector<uint32_t> last_stage;  // per program: the last stage (1-based) that had ops for it
     hipStream_t side = nullptr;        // a stage that continues nothing of the stage in flight runs beside it, on the other stream
     int stream_of_last = 0;            // 0: the caller's stream, 1: `side`

@@ -118,7 +118,7 @@ def dgram_values(seq, min_gap, max_gap):
 
 class DenseOptions(C.Structure):
     _fields_ = [("enabled", C.c_int), ("min_states", C.c_uint32), ("sparse_below", C.c_uint32), ("max_blocks", C.c_uint32),
-                ("slot_bytes", C.c_uint64), ("pool_bytes", C.c_uint64)]
+                ("slot_bytes", C.c_uint64), ("pool_bytes", C.c_uint64), ("tracked", C.c_int)]
 
 
 def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=0, ops_per_stage=0, gaps=None, dense=None):
@@ -126,8 +126,8 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
 
     stage(blob: bytes, query_program: list, query_slot: list) -> iterable of answers: False/0 = the slot has no bit set,
     True/1 = alive, or 1 + floor(log2(bits set)) as txq_session_stage answers (what the expansion reads mask fills from).
-    dense: None, or dict(min_states=, sparse_below=, max_blocks=, slot_bytes=, pool_bytes=) to switch dense DP
-    steps on (the executor then gets version-3 blobs)."""
+    dense: None, or dict(min_states=, sparse_below=, max_blocks=, slot_bytes=, pool_bytes=, tracked=) to switch dense DP
+    steps on (the executor then gets version-3 blobs); tracked: 1 = the executor keeps live lists, 2 = every query uses them."""
     L = lib()
     L.txh_run_staged_dense.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
                                        C.c_size_t, C.POINTER(GapOptions), C.POINTER(DenseOptions), STAGE_FN, C.c_void_p,
@@ -135,7 +135,7 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
     d = None
     if dense is not None:
         d = DenseOptions(1, dense.get("min_states", 0), dense.get("sparse_below", 0), dense.get("max_blocks", 0),
-                         dense.get("slot_bytes", 0), dense.get("pool_bytes", 0))
+                         dense.get("slot_bytes", 0), dense.get("pool_bytes", 0), int(dense.get("tracked", 0)))
     g = None
     if gaps is not None:  # dict(augment=, dgram_loaded=, min_gap=, max_gap=)
         g = GapOptions(int(gaps.get("augment", 0)), int(gaps.get("dgram_loaded", 0)), gaps.get("min_gap", 0), gaps.get("max_gap", 0))
