@@ -98,6 +98,8 @@ int txe_query_masks_sharded(void* const* handles, void* const* aux_handles, size
 const char* txe_last_error(void);
 /* dense DP ops (include/txq_program.h version 3) the calling thread's last txe_query_masks* run sent to the device */
 uint64_t txe_last_dense_ops(void);
+/* queries of that run whose blocks carried live lists (tracked programs, include/txq_program.h) */
+uint64_t txe_last_tracked_queries(void);
 
 /* The verification matcher (host/matcher.hpp; stands where the reference has RE2, include/query.h:103,148): successive
  * non-overlapping matches of `pattern` in text[0..len), the RE2::FindAndConsume loop of src/query.cpp:206-216.

@@ -97,7 +97,8 @@ typedef struct {
     uint32_t reserved;
 } txq_program_v2;
 
-/* Version 3 — dense DP steps (blob version TXQ_PROGRAM_VERSION_DENSE; a superset of version 2).
+/* Version 4 — dense DP steps (blob version TXQ_PROGRAM_VERSION_DENSE; a superset of version 2; version 3 numbered
+ * dense slots block * N + index and is no longer accepted).
  *
  * Where a query's state set saturates (a run of wildcards or residue classes makes every (k-1)-symbol
  * suffix a live state: 20^(k-1) states, and 20 times as many ops for the next wildcard) the host stops
@@ -110,13 +111,17 @@ typedef struct {
  * for every r in R and every (x1 .. x_{k-2}) in shape[1] x .. x shape[k-2]; M[.] is bulk_contains of the
  * (for DNA: canonical) k-mer, evaluated inside the kernel — these masks never touch HBM.
  *
- * Slots with TXQ_DENSE_SLOT_BIT set address the dense region: slot = BIT | (block * N + index).  Ordinary ops
- * may read and write them (scattering enumerated states into a block, copying block entries out).
+ * Slots with TXQ_DENSE_SLOT_BIT set address the program's dense blocks: slot = BIT | block << 22 | index, at most 256
+ * blocks of at most 2^22 entries.  Ordinary ops may read and write them (scattering enumerated states into a block,
+ * copying block entries out).
  * A dense op sits in the op stream as  { kmer = TXQ_DENSE_OP, dst = index into the dense table, a = b = 0 }
  * and obeys the level rules with its blocks as operands (a step reads all of src, reads and writes all of dst).
  * On a flat IBF a step is one fused kernel; on an HIBF the predecessor k-mers are written out, descended as one
  * batch and combined (txq_exec.hip). */
-#define TXQ_PROGRAM_VERSION_DENSE 3u
+#define TXQ_PROGRAM_VERSION_DENSE 4u
+#define TXQ_DENSE_BLOCK_SHIFT 22u
+#define TXQ_DENSE_INDEX_MASK 0x3FFFFFu
+#define TXQ_DENSE_MAX_BLOCKS 256u
 #define TXQ_DENSE_OP 0xFFFFFFFEu
 #define TXQ_DENSE_SLOT_BIT 0x40000000u
 #define TXQ_DENSE_MAX_POSITIONS 11u /* k - 1 <= 11 */
@@ -136,15 +141,23 @@ enum { TXQ_DENSE_ZERO = 0,   /* r_mask == 0: dst block := 0; r_mask != 0: only i
  * a ZERO clears them — cost proportional to the states that are ALIVE, not to the shape.  This is what makes blocks
  * pay at k >= 6 (21^5 suffixes, of which an index of real sequences keeps a few thousand alive): the collector's
  * path_.none() pruning (reference include/otf_collector.h:383) happens on the device, entry by entry.
- * Every dense op of a tracked program carries TXQ_DENSE_TRACKED in `reserved`; entries outside a ZERO's shape are
- * zero in a tracked block (the device keeps them so), so shape[] of a tracked ZERO is not used. */
+ * Every dense op of a tracked program carries TXQ_DENSE_TRACKED in `reserved`.
+ *
+ * A tracked block is also SMALLER than A^(k-1): it is laid out inside its GEOMETRY, per suffix position the set of codes
+ * that can occur there at all (the host derives it from the k-graph: the residue classes of the motif around that
+ * place), entry index = the mixed-radix number of the codes' ranks within those sets (oldest position most significant).
+ * A tracked ZERO (re)creates its block: shape[] = the geometry, src = the block's capacity in entries (>= the product of
+ * the sets' sizes; a block id keeps its capacity for as long as the program lives).  The other tracked ops find the
+ * geometry of their blocks on the device; their shape[] is a hint.  At k = 6 a list behind `[LIVM]-x-x-[DE]-A` is a
+ * block of 4*20*20*2*1 entries, not 21^5.  Untracked blocks have the full geometry (every code at every position). */
 #define TXQ_PROGRAM_TRACKED_BIT 0x80000000u
 #define TXQ_DENSE_TRACKED 1u
 
 typedef struct {
     uint32_t kind;
     uint32_t dst;     /* ZERO, STEP, FILL: first slot of the block (dense slot id); REDUCE: any writable slot */
-    uint32_t src;     /* STEP, REDUCE: first slot of the block read; FILL: the ordinary slot whose mask is spread */
+    uint32_t src;     /* STEP, REDUCE: first slot of the block read; FILL: the ordinary slot whose mask is spread;
+                         tracked ZERO: the block's capacity in entries                                            */
     uint32_t r_mask;  /* STEP: bit c set <=> residue code c is rolled in                                    */
     uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; /* per suffix position (oldest first): codes worth visiting    */
     uint32_t reserved; /* bit 0: TXQ_DENSE_TRACKED */
@@ -152,7 +165,7 @@ typedef struct {
 
 typedef struct {
     txq_blob_header_v2 v2;   /* version = TXQ_PROGRAM_VERSION_DENSE; txq_program_v2.reserved = the program's
-                                dense slots (a multiple of N; bit 31: TXQ_PROGRAM_TRACKED_BIT)                                            */
+                                dense blocks (ids 0 .. n-1 are in use; bit 31: TXQ_PROGRAM_TRACKED_BIT)                                            */
     uint64_t dense_offset;   /* txq_dense_op[n_dense]                                                       */
     uint32_t n_dense;
     uint32_t k;              /* k-mer length                                                                */

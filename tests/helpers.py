@@ -141,10 +141,13 @@ def ones_mask(user_bins, word0=0, words=None):
 class SessionSimulator:
     """CPU stand-in for a txq session (test double): keeps every program's slot masks, runs a
     stage's ops with numpy over oracle-probed masks and answers the alive questions.  Understands
-    version-3 blobs (dense DP steps, include/txq_program.h): a program's dense region is one array."""
+    version-4 blobs (dense DP steps, include/txq_program.h): a program's dense blocks are arrays of their own, laid out
+    inside their geometry (untracked blocks: the whole alphabet at every position; tracked blocks: what their ZERO says)."""
 
     DENSE_OP = 0xFFFFFFFE
     DENSE_BIT = 0x40000000
+    BLOCK_SHIFT = 22
+    INDEX_MASK = 0x3FFFFF
 
     def __init__(self, oracle_index, n_programs, dgram_index=None):
         from tetrex_amd import host
@@ -154,19 +157,27 @@ class SessionSimulator:
         self.W = oracle_index.words_per_mask
         self.ones = ones_mask(oracle_index.bins)
         self.slots = [dict() for _ in range(n_programs)]
-        self.dense = [np.zeros((0, self.W), dtype=np.uint64) for _ in range(n_programs)]
-        # which dense slots hold defined values: a shaped DENSE_ZERO leaves the rest of its block undefined, and nothing may touch them
-        self.dense_valid = [np.zeros(0, dtype=bool) for _ in range(n_programs)]
+        # per program: block id -> dict(arr [cap, W], valid [cap] (which entries hold defined values: a shaped DENSE_ZERO of an
+        # untracked block leaves the rest undefined, and nothing may touch them), geom = per position the sorted codes)
+        self.blocks = [dict() for _ in range(n_programs)]
         self.stages = 0
         self.dense_steps = 0
         self.dense_kinds = [0, 0, 0, 0]  # ZERO, STEP, REDUCE, FILL ops seen
         self.tracked = [False] * n_programs  # TXQ_PROGRAM_TRACKED_BIT: the program's blocks carry live lists
         self.tracked_ops = 0
+        self.block_entries = []  # capacities of the tracked blocks created
+
+    def _entry(self, p, s):
+        blk = self.blocks[p][(s & ~self.DENSE_BIT) >> self.BLOCK_SHIFT]
+        i = s & self.INDEX_MASK
+        assert i < blk["arr"].shape[0], "dense slot beyond the capacity of its block"
+        return blk, i
 
     def _get(self, p, s):
         if s & self.DENSE_BIT:
-            assert self.dense_valid[p][s & ~self.DENSE_BIT], "ordinary op reads a dense slot outside the zeroed shape of its block"
-            return self.dense[p][s & ~self.DENSE_BIT]
+            blk, i = self._entry(p, s)
+            assert blk["valid"][i], "ordinary op reads a dense slot outside the zeroed shape of its block"
+            return blk["arr"][i]
         if s == 0:
             return np.zeros(self.W, dtype=np.uint64)
         if s == 1:
@@ -175,8 +186,9 @@ class SessionSimulator:
 
     def _set(self, p, s, v):
         if s & self.DENSE_BIT:
-            assert self.dense_valid[p][s & ~self.DENSE_BIT], "ordinary op writes a dense slot outside the zeroed shape of its block"
-            self.dense[p][s & ~self.DENSE_BIT] = v
+            blk, i = self._entry(p, s)
+            assert blk["valid"][i], "ordinary op writes a dense slot outside the zeroed shape of its block"
+            blk["arr"][i] = v
         else:
             self.slots[p][s] = v
 
@@ -192,82 +204,124 @@ class SessionSimulator:
             f >>= np.uint64(2)
         return np.minimum(fwd, rc)
 
+    @staticmethod
+    def _ranks(geom):
+        """per position: code -> rank within the geometry's set (-1: not in it)"""
+        out = []
+        for cs in geom:
+            r = np.full(32, -1, dtype=np.int64)
+            r[np.array(cs, dtype=np.int64)] = np.arange(len(cs))
+            out.append(r)
+        return out
+
+    def _indices(self, blk, code_lists):
+        """entries of the product code_lists[0] x .. x code_lists[pos-1] in the block, and their packed k-mer bits"""
+        rk = self._ranks(blk["geom"])
+        idx = np.zeros(1, dtype=np.int64)
+        for j, cs in enumerate(code_lists):
+            c = np.array(cs, dtype=np.int64)
+            assert (rk[j][c] >= 0).all(), "code outside the geometry of the block"
+            idx = (idx[:, None] * len(blk["geom"][j]) + rk[j][c][None, :]).reshape(-1)
+        return idx
+
     def _dense_op(self, p, par, row):
         kind, dst, src, r_mask = (int(x) for x in row[:4])
         k, bits, A = par["k"], par["bits"], par["alphabet"]
         pos = k - 1
         N = A ** pos
-        D = self.dense[p]
+        B = self.blocks[p]
         self.dense_kinds[kind] += 1
         # every dense op of a tracked program says so, and only those (include/txq_program.h TXQ_DENSE_TRACKED)
         assert int(row[15]) == (1 if self.tracked[p] else 0), "dense op and program disagree about tracking"
         self.tracked_ops += int(row[15])
-        if kind == 0:  # ZERO: the whole block, or (r_mask != 0) the entries inside the shape
-            b = dst & ~self.DENSE_BIT
-            assert b % N == 0 and b + N <= D.shape[0]
-            V = self.dense_valid[p]
-            if not r_mask or self.tracked[p]:  # (a tracked block is kept zero outside its live entries: its ZERO leaves all of it zero)
-                D[b:b + N] = 0
-                V[b:b + N] = True
-                return
-            shape = [self._codes(int(row[4 + j])) for j in range(pos)]
-            assert all(c < A for cs in shape for c in cs)
-            idx = np.zeros(1, dtype=np.int64)
-            for cs in shape:
-                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
-            D[b:b + N] = np.uint64(0xFFFFFFFFFFFFFFFF)  # nobody may touch the rest: undefined (and poisoned, should a check miss it)
-            D[b + idx] = 0
-            V[b:b + N] = False
-            V[b + idx] = True
-            return
         shape = [self._codes(int(row[4 + j])) for j in range(pos)]
         assert all(c < A for cs in shape for c in cs)
+
+        def block_of(s):
+            assert (s & self.DENSE_BIT) and (s & self.INDEX_MASK) == 0, "dense op on something that is not a block"
+            return B[(s & ~self.DENSE_BIT) >> self.BLOCK_SHIFT]
+
+        if kind == 0:  # ZERO
+            b = (dst & ~self.DENSE_BIT) >> self.BLOCK_SHIFT
+            assert (dst & self.DENSE_BIT) and (dst & self.INDEX_MASK) == 0
+            if self.tracked[p]:  # (re)creates the block inside the geometry its shape gives; src = capacity
+                entries = int(np.prod([len(cs) for cs in shape]))
+                assert all(shape) and entries <= src <= (1 << self.BLOCK_SHIFT), "tracked ZERO: capacity below its geometry"
+                assert b not in B or B[b]["arr"].shape[0] == src, "a block id changed its capacity"
+                B[b] = dict(arr=np.zeros((src, self.W), dtype=np.uint64), valid=np.zeros(src, dtype=bool), geom=shape)
+                B[b]["valid"][:entries] = True
+                self.block_entries.append(src)
+                return
+            blk = B[b]
+            if not r_mask:
+                blk["arr"][:] = 0
+                blk["valid"][:] = True
+                return
+            idx = self._indices(blk, shape)
+            blk["arr"][:] = np.uint64(0xFFFFFFFFFFFFFFFF)  # nobody may touch the rest: undefined (and poisoned, should a check miss it)
+            blk["arr"][idx] = 0
+            blk["valid"][:] = False
+            blk["valid"][idx] = True
+            return
         if kind == 3:  # FILL: every entry inside the shape |= the ordinary slot src
-            b = dst & ~self.DENSE_BIT
-            assert (dst & self.DENSE_BIT) and b % N == 0 and b + N <= D.shape[0] and not (src & self.DENSE_BIT)
-            idx = np.zeros(1, dtype=np.int64)
-            for cs in shape:
-                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
+            blk = block_of(dst)
+            assert not (src & self.DENSE_BIT)
+            idx = self._indices(blk, shape)
             v = self._get(p, src)
             assert v is not None, "DENSE_FILL spreads a slot that was never written"
-            assert self.dense_valid[p][b + idx].all(), "DENSE_FILL writes outside the zeroed shape of its block"
-            D[b + idx] |= v
+            assert blk["valid"][idx].all(), "DENSE_FILL writes outside the zeroed shape of its block"
+            blk["arr"][idx] |= v
             return
-        sb = src & ~self.DENSE_BIT
-        assert (src & self.DENSE_BIT) and sb % N == 0 and sb + N <= D.shape[0]
+        sblk = block_of(src)
+        if self.tracked[p]:
+            shape = sblk["geom"]  # the work follows the live list: whatever the block holds, inside its geometry
         if kind == 2:  # REDUCE: slot dst |= OR of the entries inside the shape
-            idx = np.zeros(1, dtype=np.int64)
-            for cs in shape:
-                idx = (idx[:, None] * A + np.array(cs, dtype=np.int64)[None, :]).reshape(-1)
-            assert self.dense_valid[p][sb + idx].all(), "DENSE_REDUCE reads outside the zeroed shape of its block"
-            acc = np.bitwise_or.reduce(D[sb + idx], axis=0) if idx.size else np.zeros(self.W, dtype=np.uint64)
+            idx = self._indices(sblk, shape)
+            assert sblk["valid"][idx].all(), "DENSE_REDUCE reads outside the zeroed shape of its block"
+            acc = np.bitwise_or.reduce(sblk["arr"][idx], axis=0) if idx.size else np.zeros(self.W, dtype=np.uint64)
             cur = self._get(p, dst)
             assert cur is not None
             self._set(p, dst, cur | acc)
             return
         assert kind == 1
         self.dense_steps += 1
-        db = dst & ~self.DENSE_BIT
-        assert (dst & self.DENSE_BIT) and db % N == 0 and db + N <= D.shape[0] and db != sb
-        mid = np.zeros(1, dtype=np.int64)   # block index of (x1 .. x_{k-2})
-        midv = np.zeros(1, dtype=np.uint64)  # its k-mer bits
+        dblk = block_of(dst)
+        assert dblk is not sblk
+        # (x1 .. x_{k-2}) over shape[1:]: codes per position as flat arrays
+        mids = [np.zeros(1, dtype=np.int64)] * 0
+        grid = np.zeros((1, 0), dtype=np.int64)
         for cs in shape[1:]:
             c = np.array(cs, dtype=np.int64)
-            mid = (mid[:, None] * A + c[None, :]).reshape(-1)
-            midv = ((midv[:, None] << np.uint64(bits)) | c.astype(np.uint64)[None, :]).reshape(-1)
-        if mid.size == 0 or not shape[0]:
+            grid = np.concatenate([np.repeat(grid, c.size, axis=0), np.tile(c, grid.shape[0])[:, None]], axis=1)
+        if grid.shape[0] == 0 or not shape[0]:
             return
-        a = np.array(shape[0], dtype=np.int64)
+        midv = np.zeros(grid.shape[0], dtype=np.uint64)
+        for j in range(grid.shape[1]):
+            midv = (midv << np.uint64(bits)) | grid[:, j].astype(np.uint64)
+        srk, drk = self._ranks(sblk["geom"]), self._ranks(dblk["geom"])
+        sn = [len(cs) for cs in sblk["geom"]]
+        dn = [len(cs) for cs in dblk["geom"]]
+        smid = np.zeros(grid.shape[0], dtype=np.int64)   # rank number of (x1 .. x_{k-2}) at positions 1 .. pos-1 of src
+        dmid = np.zeros(grid.shape[0], dtype=np.int64)   # ... at positions 0 .. pos-2 of dst
+        for j in range(grid.shape[1]):
+            assert (srk[j + 1][grid[:, j]] >= 0).all()
+            smid = smid * sn[j + 1] + srk[j + 1][grid[:, j]]
+            dr = drk[j][grid[:, j]]
+            assert (dr >= 0).all(), "DENSE_STEP leaves the geometry of its destination block"
+            dmid = dmid * dn[j] + dr
+        s_stride0 = int(np.prod(sn[1:])) if pos > 1 else 1
         for r in self._codes(r_mask):
-            assert r < A
-            acc = np.zeros((mid.size, self.W), dtype=np.uint64)
-            for ai in a:
+            assert r < A and drk[pos - 1][r] >= 0
+            acc = np.zeros((grid.shape[0], self.W), dtype=np.uint64)
+            for ai in shape[0]:
                 fwd = (np.uint64(ai) << np.uint64(bits * (k - 1))) | (midv << np.uint64(bits)) | np.uint64(r)
                 val = self._canonical(fwd, k) if par["canonical"] else fwd
-                assert self.dense_valid[p][sb + ai * A ** (pos - 1) + mid].all(), "DENSE_STEP reads outside the zeroed shape of its source block"
-                acc |= D[sb + ai * A ** (pos - 1) + mid] & self.ox.probe(val)
-            assert self.dense_valid[p][db + mid * A + r].all(), "DENSE_STEP accumulates outside the zeroed shape of its destination block"
-            D[db + mid * A + r] |= acc
+                si = int(srk[0][ai]) * s_stride0 + smid
+                assert sblk["valid"][si].all(), "DENSE_STEP reads outside the zeroed shape of its source block"
+                acc |= sblk["arr"][si] & self.ox.probe(val)
+            di = dmid * dn[pos - 1] + int(drk[pos - 1][r])
+            assert dblk["valid"][di].all(), "DENSE_STEP accumulates outside the zeroed shape of its destination block"
+            dblk["arr"][di] |= acc
 
     def _check_level_races(self, blob, progs, dense):
         """The device runs the ops of one dependency level concurrently (txq_program.h, version 2/3 rules): within a level
@@ -278,7 +332,7 @@ class SessionSimulator:
         if levels is None:
             return
         BIT, DOP = self.DENSE_BIT, self.DENSE_OP
-        N = dense[0]["alphabet"] ** (dense[0]["k"] - 1) if dense is not None else 0
+        N = 1 << self.BLOCK_SHIFT  # a block's slot numbers
         for p, ((n_slots, ops), ends) in enumerate(zip(progs, levels)):
             begin = 0
             for end in ends:
@@ -329,15 +383,18 @@ class SessionSimulator:
         dense = self.host.blob_dense(blob)
         self._check_level_races(blob, progs, dense)
         if dense is not None:
+            A, pos = dense[0]["alphabet"], dense[0]["k"] - 1
             for p, want in enumerate(dense[2]):
-                if self.dense[p].shape[0] == 0:
+                if not self.blocks[p]:
                     self.tracked[p] = bool(want & 0x80000000)
                 assert (not (want & 0x7FFFFFFF)) or self.tracked[p] == bool(want & 0x80000000), "a program changed its tracking"
                 want &= 0x7FFFFFFF
-                have = self.dense[p].shape[0]
-                if want > have:
-                    self.dense[p] = np.concatenate([self.dense[p], np.zeros((want - have, self.W), dtype=np.uint64)])
-                    self.dense_valid[p] = np.concatenate([self.dense_valid[p], np.zeros(want - have, dtype=bool)])
+                assert want <= 256
+                if not self.tracked[p]:  # untracked blocks exist from the moment the program counts them: A^(k-1) entries, full geometry
+                    for b in range(want):
+                        if b not in self.blocks[p]:
+                            self.blocks[p][b] = dict(arr=np.zeros((A ** pos, self.W), dtype=np.uint64), valid=np.zeros(A ** pos, dtype=bool),
+                                                     geom=[list(range(A))] * pos)
         n_aux = self.host.blob_aux_kmers(blob)
         n_main = kmers.size - n_aux
         M = self.ox.probe(kmers[:n_main]) if n_main else np.zeros((0, self.W), dtype=np.uint64)

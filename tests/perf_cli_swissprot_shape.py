@@ -63,6 +63,9 @@ def main():
             f.write("M%03d\t%s\n" % (i, m))
     r, t_batch = run("query", "-S", "-f", "sp.ibf", "motifs.tsv")
     assert r.returncode == 0, r.stderr[-2000:]
+    if os.environ.get("PERF_STDERR"):  # the batch run's stderr (TETREX_TRACE / TXQ_TRACE output) for whoever profiles it
+        with open(os.environ["PERF_STDERR"], "w") as f:
+            f.write(r.stderr)
     bstats = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")]
     print(json.dumps({
         "scenario": "Swissprot-shaped synthetic data through the tetrex CLI (HIBF, k=6, h=3, fpr 0.05)",

@@ -43,16 +43,21 @@ def _wants(ox, queries):
     return out
 
 
+TRACKED = [0]  # tracked queries of the last _check
+
+
 def _check(capi, ox, queries, dna, k, reduction=0, shards=(1,), wants=None, per_query=0):
     sh = ox.shape()
     wants = wants if wants is not None else _wants(ox, queries)
     checked, dense_ops = 0, 0
+    TRACKED[0] = 0
     for R in shards:
         for r in range(R):
             ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=R)
             lo, nw = int(ix.info.shard_word0), ix.shard_words
             got, status, stats = ix.query_masks(queries, dna, k, reduction, per_query)
             dense_ops += stats["dense_ops"]
+            TRACKED[0] += stats["tracked_queries"]
             for q, g, w, st in zip(queries, got, wants, status):
                 if w is False:
                     assert st != 0, q
@@ -429,7 +434,7 @@ def test_tracked_blocks_vs_oracle(capi, oracle, monkeypatch):
     qs = PEPTIDE_QUERIES + random_prosite_motifs(60, 7, wildcard=0.1, ranges=0.05)
     wants = _wants(ox, qs)
     checked, dense_ops = _check(capi, ox, qs, False, 4, shards=(1, 4), wants=wants)
-    assert checked > 300 and dense_ops > 50
+    assert checked > 300 and dense_ops > 50 and TRACKED[0] > 100
     monkeypatch.setenv("TETREX_DENSE_MIN", "32")
     monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "16")
     checked, dense_ops = _check(capi, ox, qs, False, 4, wants=wants)
@@ -454,7 +459,7 @@ def test_tracked_blocks_on_odd_and_wide_masks_dna_and_reduced_alphabets(capi, or
         ox = _oracle_index(oracle, bins=256, m=8191, h=2, k=5, dna=False, per_bin=1500, seed=red, reduction=red)
         rq = ["LMA(E|Q)GLYN", "LMAEGLYNK", "W[LIVM]D.FYLK", "LMAE(GL|YN)K.DE", "KRDEG..NLMA"]
         checked, dense_ops = _check(capi, ox, rq, False, 5, red)
-        assert checked >= 3 and dense_ops > 5
+        assert checked >= 3 and dense_ops > 5 and TRACKED[0] >= 2
 
 
 def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
@@ -468,7 +473,7 @@ def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
     qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "CLM.{2,4}C...[LIVMFYWC]", "LMK.{0,2}C.{0,2}D.{0,2}EK"] * 6
     for per_query in (3, 40, 0):
         checked, dense_ops = _check(capi, ox, qs, False, 4, per_query=per_query)
-        assert checked == len(qs) and dense_ops > 30
+        assert checked == len(qs) and dense_ops > 30 and TRACKED[0] >= 20
 
 
 def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
@@ -495,7 +500,7 @@ def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
     sh = ox.shape()
     ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
     got, status, stats = ix.query_masks(qs, False, k, 0, 0)
-    assert stats["dense_ops"] > 10 and stats["ops"] < 200000
+    assert stats["dense_ops"] > 10 and stats["ops"] < 200000 and stats["tracked_queries"] >= 4
     monkeypatch.setenv("TETREX_DENSE", "0")
     plain, status0, stats0 = ix.query_masks(qs, False, k, 0, 0)
     for q, g, p0, w, st in zip(qs, got, plain, wants, status):

@@ -326,7 +326,8 @@ class Index:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
         keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
         Lq.txe_last_dense_ops.restype = C.c_uint64
-        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
+        Lq.txe_last_tracked_queries.restype = C.c_uint64
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
 
     def query_masks(self, regexes, dna, k, reduction=0, ops_per_query_per_stage=0):
         """Whole queries on this GPU-resident index through the C++ host (libtetrex_query.so):
@@ -343,7 +344,8 @@ class Index:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
         keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
         Lq.txe_last_dense_ops.restype = C.c_uint64
-        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
+        Lq.txe_last_tracked_queries.restype = C.c_uint64
+        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
 
     def run_programs(self, blob, n_programs):
         buf = np.frombuffer(blob, dtype=np.uint8)
@@ -374,7 +376,8 @@ def query_masks_sharded(shards, regexes, dna, k, reduction=0, ops_per_query_per_
         raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
     keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
     Lq.txe_last_dense_ops.restype = C.c_uint64
-    return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()))
+    Lq.txe_last_tracked_queries.restype = C.c_uint64
+    return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
 
 
 def _aligned(blob):

@@ -121,8 +121,7 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     if (const uint64_t n = gaps_.dgram_loaded ? 0 : tetrex::dense_block_slots(enc_, dense_)) {
         dense_ok_ = true;
         dense_n_ = n;
-        const uint64_t room = (TXQ_DENSE_SLOT_BIT - 1) / n;  // blocks that fit the dense slot numbers
-        if (dense_.max_blocks > room) dense_.max_blocks = (uint32_t)room;
+        if (dense_.max_blocks > TXQ_DENSE_MAX_BLOCKS) dense_.max_blocks = TXQ_DENSE_MAX_BLOCKS;  // block ids are 8 bits of a dense slot number
     }
     if (gaps_.augment) g_.augment();
     const int32_t n = n_nodes_ = g_.size();
@@ -204,8 +203,65 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     input_of_.assign(items, KGraph::kNone);
     readers_.assign(join_of.size(), 0);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
+    if (dense_ok_) compute_static_shapes();
     OpVec none;
     hand_on(n, State{0, TXQ_SLOT_ONES, 0, 0, 0, 0, 0}, none);
+}
+
+// Which codes can stand at each position of the (k-1)-suffix of a full-length state waiting at an item: the residues of
+// the nodes k-1 .. 1 steps back along any path.  One pass in topological order: a residue node shifts the sets of its
+// input by one position and puts its own code last; joins, Match and '$' pass them on; the entry and Gap nodes (a state
+// restarts its k-mer there) contribute nothing — a state that leaves them is not full-length before it has passed k-1
+// residue nodes, each of which then puts its code where it belongs.
+void QueryExpansion::compute_static_shapes() {
+    const size_t items = table_.size();
+    static_shape_.assign(items, Geometry{});
+    auto feed = [&](int32_t to, const Geometry& out) {
+        if (to == KGraph::kNone) return;
+        for (unsigned j = 0; j < dense_pos_; ++j) static_shape_[to][j] |= out[j];
+    };
+    auto forward_all = [&](int32_t item, const Geometry& out) {
+        if (item > n_nodes_) { for (uint32_t i = fan_first_[item - n_nodes_ - 1]; i < fan_first_[item - n_nodes_]; ++i) feed(fan_[i], out); }
+        else feed(forward_[item], out);
+    };
+    forward_all(n_nodes_, Geometry{});
+    for (const int32_t item : order_) {
+        Geometry out{};
+        if (item > n_nodes_) out = static_shape_[item];
+        else {
+            const int32_t lab = g_.label[item];
+            if (lab == KGraph::kMatch) continue;
+            if (lab == KGraph::kGap) out = Geometry{};
+            else if (lab < 256) {
+                for (unsigned j = 0; j + 1 < dense_pos_; ++j) out[j] = static_shape_[item][j + 1];
+                out[dense_pos_ - 1] = 1u << enc_.code((unsigned char)lab);
+            } else out = static_shape_[item];
+        }
+        forward_all(item, out);
+    }
+}
+
+// the geometry of the blocks of the list at `item`: tracked programs lay a block out inside the list's static shape,
+// untracked ones over the whole alphabet (entry index = the suffix as a number in base A, as the step kernel of
+// untracked blocks computes it)
+QueryExpansion::Geometry QueryExpansion::geometry_of(int32_t item) const {
+    Geometry g{};
+    if (tracked_) {
+        g = static_shape_[item];
+        for (unsigned j = 0; j < dense_pos_; ++j)
+            if (!g[j]) g[j] = 1u;  // a position nothing can reach yet: one (never used) code keeps the radix non-zero
+    } else
+        for (unsigned j = 0; j < dense_pos_; ++j) g[j] = dense_a_ >= 32 ? 0xFFFFFFFFu : ((1u << dense_a_) - 1u);
+    return g;
+}
+
+uint32_t QueryExpansion::capacity_of(const Geometry& g) const {
+    if (!tracked_) return (uint32_t)dense_n_;
+    uint64_t n = 1;
+    for (unsigned j = 0; j < dense_pos_; ++j) n *= (uint64_t)__builtin_popcount(g[j]);
+    uint64_t cap = 64;
+    while (cap < n) cap <<= 1;
+    return (uint32_t)std::min<uint64_t>(cap, (uint64_t)1 << TXQ_DENSE_BLOCK_SHIFT);  // (n <= A^(k-1) <= 2^22)
 }
 
 // a state leaves item `from` (a residue node or the entry): to its join or only target
@@ -326,12 +382,22 @@ void QueryExpansion::adopt_storage(NodeStates& ns) {
 
 // ---- dense blocks (include/txq_program.h, version 3) -----------------------------------------
 
-uint64_t QueryExpansion::dense_index(uint64_t kmer) const {
+// entry of a suffix in a block: the ranks of its codes within the block's geometry, as a mixed-radix number
+uint64_t QueryExpansion::index_of_codes(uint32_t block, const unsigned* code) const {
+    const Geometry& g = block_geom_[block];
+    uint64_t idx = 0;
+    for (unsigned j = 0; j < dense_pos_; ++j) {
+        if (!((g[j] >> code[j]) & 1u)) throw std::logic_error("state outside the geometry of its dense block");
+        idx = idx * (uint64_t)__builtin_popcount(g[j]) + (uint64_t)__builtin_popcount(g[j] & ((1u << code[j]) - 1u));
+    }
+    return idx;
+}
+uint64_t QueryExpansion::dense_index(uint32_t block, uint64_t kmer) const {
     const unsigned bits = enc_.bits_per_symbol();
     const uint64_t sym = enc_.symbol_mask();
-    uint64_t idx = 0;
-    for (unsigned j = 0; j < dense_pos_; ++j) idx = idx * dense_a_ + ((kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
-    return idx;
+    unsigned code[TXQ_DENSE_MAX_POSITIONS];
+    for (unsigned j = 0; j < dense_pos_; ++j) code[j] = (unsigned)((kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
+    return index_of_codes(block, code);
 }
 
 uint64_t QueryExpansion::shape_entries(const DenseRef& r) const {
@@ -340,40 +406,67 @@ uint64_t QueryExpansion::shape_entries(const DenseRef& r) const {
     return n;
 }
 
-// makes sure the next `n` new_block() calls succeed (blocks come from the free list or extend the region)
-bool QueryExpansion::can_take_blocks(size_t n) {
+// makes sure that the next new_block() calls for blocks of these capacities succeed (blocks come from the free list of
+// their capacity or get a new id)
+bool QueryExpansion::can_take_blocks(const std::vector<uint32_t>& caps) {
+    if (caps.empty()) return true;
     // The most recently released blocks stay out of circulation while new ones can be had: a recycled block must be zeroed
     // AFTER its last reader, which puts its DENSE_ZERO one level behind the step that read it and the next step one more
     // level behind that — a chain of steps ping-ponging between two blocks needs two levels per step instead of one.
-    const size_t in_list = free_blocks_.size() - free_block_head_;
-    size_t available = in_list > dense_.cool_down ? in_list - dense_.cool_down : 0;
-    if (n <= available) return true;
-    const size_t more = n - available;
-    if (n_blocks_ + more > dense_.max_blocks) return n <= in_list;  // at the cap: the cooling ones will do, if there are enough
-    const int64_t bytes = (int64_t)(more * dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128));
+    std::map<uint32_t, size_t> want;
+    for (uint32_t c : caps) ++want[c];
+    size_t more_ids = 0;
+    int64_t bytes = 0;
+    bool cooling_will_do = true;
+    for (const auto& [cap, n] : want) {
+        const auto it = free_by_cap_.find(cap);
+        const size_t in_list = it == free_by_cap_.end() ? 0 : it->second.ids.size() - it->second.head;
+        const size_t available = in_list > dense_.cool_down ? in_list - dense_.cool_down : 0;
+        if (n > available) {
+            more_ids += n - available;
+            bytes += (int64_t)((n - available) * (uint64_t)cap * (dense_.slot_bytes ? dense_.slot_bytes : 128));
+        }
+        cooling_will_do = cooling_will_do && n <= in_list;
+    }
+    if (!more_ids) return true;
+    if (n_blocks_ + more_ids > dense_.max_blocks) return cooling_will_do;  // at the cap: the cooling ones will do, if there are enough
     if (dense_.pool) {
         if (dense_.pool->fetch_sub(bytes, std::memory_order_relaxed) - bytes < 0) {
             dense_.pool->fetch_add(bytes, std::memory_order_relaxed);
-            return n <= in_list;  // no memory for new blocks: the cooling ones will do
+            return cooling_will_do;  // no memory for new blocks
         }
         pool_taken_ += (uint64_t)bytes;  // the stage driver hands them back once the device has run the query's last ops
     }
-    for (size_t i = 0; i < more; ++i) {  // new blocks go to the FRONT: they are taken before the released ones that are still cooling
-        free_blocks_.insert(free_blocks_.begin() + (std::ptrdiff_t)free_block_head_, (uint32_t)n_blocks_++);
-        block_refs_.push_back(0);
+    for (const auto& [cap, n] : want) {
+        FreeList& fl = free_by_cap_[cap];
+        const size_t in_list = fl.ids.size() - fl.head;
+        const size_t available = in_list > dense_.cool_down ? in_list - dense_.cool_down : 0;
+        for (size_t i = available; i < n; ++i) {  // new blocks go to the FRONT: they are taken before the released ones that are still cooling
+            fl.ids.insert(fl.ids.begin() + (std::ptrdiff_t)fl.head, (uint32_t)n_blocks_++);
+            block_refs_.push_back(0);
+            block_cap_.push_back(cap);
+            block_geom_.push_back(Geometry{});
+        }
     }
     return true;
 }
 
-uint32_t QueryExpansion::new_block(OpVec& out) {
-    if (free_block_head_ >= free_blocks_.size()) throw std::logic_error("dense block taken without a reservation");
-    decide_tracking();
-    const uint32_t b = free_blocks_[free_block_head_++];
-    if (free_block_head_ == free_blocks_.size()) { free_blocks_.clear(); free_block_head_ = 0; }
+uint32_t QueryExpansion::new_block(OpVec& out, const Geometry& geom) {
+    const uint32_t cap = capacity_of(geom);
+    FreeList& fl = free_by_cap_[cap];
+    if (fl.head >= fl.ids.size()) throw std::logic_error("dense block taken without a reservation");
+    const uint32_t b = fl.ids[fl.head++];
+    if (fl.head == fl.ids.size()) { fl.ids.clear(); fl.head = 0; }
     block_refs_[b] = 1;
+    block_geom_[b] = geom;
     txq_dense_op z{};
     z.kind = TXQ_DENSE_ZERO;
     z.dst = dense_slot(b, 0);
+    if (tracked_) {  // (re)creates the block inside this geometry
+        z.src = cap;
+        z.r_mask = 1;
+        for (unsigned j = 0; j < dense_pos_; ++j) z.shape[j] = geom[j];
+    }
     emit_dense(out, z);
     if (zero_at_.size() <= b) { zero_at_.resize(b + 1, 0); zero_epoch_.resize(b + 1, 0); }
     zero_at_[b] = (uint32_t)(dense_out_->size() - 1);
@@ -385,6 +478,7 @@ uint32_t QueryExpansion::new_block(OpVec& out) {
 // an entry outside it.  If the block's DENSE_ZERO is still in the stage's table, it is told to zero that shape instead
 // of all A^(k-1) slots (31.8 M slots = 4 GB per 1000-motif batch otherwise, a sixth of the dense kernel's bytes).
 void QueryExpansion::shape_zero(const DenseRef& r) {
+    if (tracked_) return;  // a tracked ZERO carries the block's geometry, and clears what is listed
     if (!dense_out_ || r.block >= zero_at_.size() || zero_epoch_[r.block] != dense_epoch_ || zero_at_[r.block] >= dense_out_->size()) return;
     txq_dense_op& z = (*dense_out_)[zero_at_[r.block]];
     if (z.kind != TXQ_DENSE_ZERO || z.dst != dense_slot(r.block, 0)) return;
@@ -402,7 +496,11 @@ void QueryExpansion::decide_tracking() {
     if (tracked_decided_) return;
     tracked_decided_ = true;
     if (!dense_.tracked_ok || dense_.tracked_force < 0) return;
-    tracked_ = dense_.tracked_force > 0 || (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse);
+    // ... and wherever an untracked block (A^(k-1) entries) would be tens of megabytes: 21^5 masks of 128 bytes are half a
+    // gigabyte, a tracked block of the same list a few hundred kilobytes — pushing from a full list costs little more than
+    // pulling, allocating (and zeroing) gigabytes per query costs seconds
+    const bool huge = dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128) >= ((uint64_t)64 << 20);
+    tracked_ = dense_.tracked_force > 0 || huge || (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse);
 }
 
 void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d0) {
@@ -416,11 +514,11 @@ void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d0) {
 }
 
 // the block this list accumulates into (created on first use; the caller has reserved it)
-QueryExpansion::DenseRef* QueryExpansion::owned_block(NodeStates& ns, OpVec& out) {
+QueryExpansion::DenseRef* QueryExpansion::owned_block(int32_t item, NodeStates& ns, OpVec& out) {
     for (DenseRef& r : ns.dense)
         if (r.owned) return &r;
     DenseRef r{};
-    r.block = new_block(out);
+    r.block = new_block(out, geometry_of(item));
     r.owned = 1;
     ns.dense.push_back(r);
     return &ns.dense.back();
@@ -443,7 +541,7 @@ uint64_t QueryExpansion::shape_limit() const {
 
 // a list with many full-length states becomes (part of) a block: one scatter op per state now instead of
 // one op per state and residue at every later step
-void QueryExpansion::densify(NodeStates& ns, OpVec& out, bool may_hold_duplicates) {
+void QueryExpansion::densify(int32_t item, NodeStates& ns, OpVec& out, bool may_hold_duplicates) {
     if (!dense_ok_ || ns.items.size() < dense_.min_states) return;
     decide_tracking();
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
@@ -466,8 +564,11 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out, bool may_hold_duplicate
     }
     bool has_own = false;
     for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
-    if (!has_own && !can_take_blocks(1)) return;
-    DenseRef* own = owned_block(ns, out);
+    if (!has_own) {
+        caps_scratch_.assign(1, capacity_of(geometry_of(item)));
+        if (!can_take_blocks(caps_scratch_)) return;
+    }
+    DenseRef* own = owned_block(item, ns, out);
     // States that all carry ONE mask and fill their shape exactly — the states behind a run of wildcards that have not been
     // probed yet (they share ONES) — are spread by a single FILL.  (An append-only list may hold a key twice: no counting there.)
     bool uniform = !may_hold_duplicates && product == full;
@@ -480,6 +581,8 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out, bool may_hold_duplicate
             else if (s.slot != the_slot) { uniform = false; break; }
         }
     }
+    for (unsigned j = 0; j < dense_pos_; ++j)
+        if (shape[j] & ~block_geom_[own->block][j]) throw std::logic_error("state list outside the geometry of its dense block");
     if (uniform) {
         txq_dense_op f{};
         f.kind = TXQ_DENSE_FILL;
@@ -493,7 +596,7 @@ void QueryExpansion::densify(NodeStates& ns, OpVec& out, bool may_hold_duplicate
         const State s = ns.items[i];
         if (s.gapped || s.shift < k - 1) { ns.items[kept++] = s; continue; }
         if (!uniform) {
-            const uint32_t e = dense_slot(own->block, dense_index(s.kmer));
+            const uint32_t e = dense_slot(own->block, dense_index(own->block, s.kmer));
             emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
         }
         drop(s.slot);
@@ -520,8 +623,9 @@ void QueryExpansion::materialise(int32_t item, OpVec& out, bool all) {
             code[j] = (unsigned)__builtin_ctz(r.shape[j]);
         }
         while (!empty) {
-            uint64_t idx = 0, kmer = 0;
-            for (unsigned j = 0; j < dense_pos_; ++j) { idx = idx * dense_a_ + code[j]; kmer = (kmer << bits) | code[j]; }
+            uint64_t kmer = 0;
+            for (unsigned j = 0; j < dense_pos_; ++j) kmer = (kmer << bits) | code[j];
+            const uint64_t idx = index_of_codes(r.block, code);
             const uint32_t d = fresh();
             emit(out, TXQ_NO_KMER, d, dense_slot(r.block, idx), TXQ_SLOT_ZERO);
             arrive(item, State{kmer, d, (uint8_t)k, 0, 0, 0, 0}, out);
@@ -542,7 +646,7 @@ void QueryExpansion::materialise(int32_t item, OpVec& out, bool all) {
 void QueryExpansion::dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out) {
     if (receiver == KGraph::kNone || !r_mask) return;
     NodeStates& rs = table_[receiver];
-    DenseRef* own = owned_block(rs, out);
+    DenseRef* own = owned_block(receiver, rs, out);
     txq_dense_op d{};
     d.kind = TXQ_DENSE_STEP;
     d.dst = dense_slot(own->block, 0);
@@ -552,6 +656,8 @@ void QueryExpansion::dense_step(const DenseRef& src, uint32_t r_mask, int32_t re
     emit_dense(out, d);
     for (unsigned j = 0; j + 1 < dense_pos_; ++j) own->shape[j] |= src.shape[j + 1];
     own->shape[dense_pos_ - 1] |= r_mask;
+    for (unsigned j = 0; j < dense_pos_; ++j)
+        if (own->shape[j] & ~block_geom_[own->block][j]) throw std::logic_error("dense step leaves the geometry of its destination block");
 }
 
 // the lists that dense steps out of `item` accumulate into
@@ -595,7 +701,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             parked_.clear();
         }
         if (!parked_blocks_.empty()) {
-            free_blocks_.insert(free_blocks_.end(), parked_blocks_.begin(), parked_blocks_.end());
+            for (uint32_t b : parked_blocks_) free_by_cap_[block_cap_[b]].ids.push_back(b);
             parked_blocks_.clear();
         }
         bool densify_here = false;
@@ -628,16 +734,18 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 // (still unknown after asking: as if they saturate; what the run has learned sets the bar in densify())
             }
             if (!cur.dense.empty() || may_densify) {
+                if (go_dense) decide_tracking();
                 dense_receivers(next, receivers_scratch_);
-                size_t need = 0;
+                caps_scratch_.clear();
                 for (int32_t r : receivers_scratch_) {
                     bool has = false;
                     for (const DenseRef& d : table_[r].dense) has |= d.owned != 0;
-                    need += !has;
+                    if (!has) caps_scratch_.push_back(capacity_of(geometry_of(r)));
                 }
                 bool own = false;
                 for (const DenseRef& d : cur.dense) own |= d.owned != 0;
-                const bool ok = go_dense && can_take_blocks(need + (may_densify && !own ? 1 : 0));
+                if (may_densify && !own) caps_scratch_.push_back(capacity_of(geometry_of(next)));
+                const bool ok = go_dense && can_take_blocks(caps_scratch_);
                 densify_here = ok && may_densify;
                 if (!ok && !cur.dense.empty()) materialise(next, out, true);
             }
@@ -647,7 +755,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         ns.items.swap(table_[item].items);
         ns.dense.swap(table_[item].dense);
         waiting_ -= ns.items.size();
-        if (densify_here) densify(ns, out, table_[item].append_only);
+        if (densify_here) densify(item, ns, out, table_[item].append_only);
         for (const DenseRef& d : ns.dense)  // (densify has just added the list's own states to the shape)
             if (d.owned) shape_zero(d);
         table_[item].append_only = false;
@@ -939,10 +1047,8 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
                                            uint32_t kmer_add, uint32_t dgram_add, const DenseSchedule* dn) {
     std::vector<uint32_t> ends;
     if (ops.empty()) return ends;
-    const uint32_t n_dense_slots = dn ? dn->n_dense_slots : 0;
-    const uint64_t block_n = dn && dn->block_slots ? dn->block_slots : 1;
     if (sc.slot.size() < (size_t)n_slots) sc.slot.resize((size_t)n_slots, LevelScratch::Slot{0, 0, 0, 0});
-    if (n_dense_slots && sc.block.size() < n_dense_slots / block_n + 1) sc.block.resize(n_dense_slots / block_n + 1, LevelScratch::Block{0, 0, 0, 0, 0, 0});
+    if (dn && sc.block.size() < TXQ_DENSE_MAX_BLOCKS) sc.block.resize(TXQ_DENSE_MAX_BLOCKS, LevelScratch::Block{0, 0, 0, 0, 0, 0});
     if (++sc.epoch == 0) {
         for (auto& s : sc.slot) s.stamp = 0;
         for (auto& b : sc.block) b.stamp = 0;
@@ -957,7 +1063,8 @@ std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, L
     // dw / dr = last level a dense op wrote / read the block, sw / sr = last level an ordinary op wrote / read a slot of it
     auto block_of = [&](uint32_t s) -> LevelScratch::Block* {
         if (!(s & TXQ_DENSE_SLOT_BIT)) return nullptr;
-        LevelScratch::Block& b = sc.block[(s & ~TXQ_DENSE_SLOT_BIT) / block_n];
+        if (!dn) throw std::logic_error("dense slot without a dense table");
+        LevelScratch::Block& b = sc.block[(s & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT];
         if (b.stamp != sc.epoch) b = LevelScratch::Block{sc.epoch, 0, 0, 0, 0, 0};
         return &b;
     };

@@ -24,7 +24,9 @@
 #include "kgraph.hpp"
 #include "../../../include/txq_program.h"
 
+#include <array>
 #include <atomic>
+#include <map>
 #include <cstdint>
 #include <functional>
 #include <string>
@@ -160,8 +162,8 @@ class QueryExpansion {
     void advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams = nullptr, bool verified_only = false,
                  DenseVec* dense = nullptr);
     uint32_t n_slots() const { return high_water_; }
-    // slots of the dense region (a multiple of the block size A^(k-1)); 0 while the query never went dense
-    uint32_t n_dense_slots() const { return (uint32_t)(n_blocks_ * dense_n_); }
+    // dense blocks the query addresses; 0 while it never went dense
+    uint32_t n_dense_blocks() const { return (uint32_t)n_blocks_; }  // block ids 0 .. n-1 are in use
     bool tracked() const { return tracked_; }  // its blocks carry live lists (TXQ_PROGRAM_TRACKED_BIT)
     uint64_t dense_steps() const { return dense_steps_; }
     uint64_t pool_taken() const { return pool_taken_; }  // bytes of the run's dense pool this query holds
@@ -256,18 +258,32 @@ class QueryExpansion {
     uint32_t dense_a_ = 0;        // alphabet size A
     uint64_t dense_n_ = 0;        // A^(k-1)
     uint64_t n_blocks_ = 0, pool_taken_ = 0, dense_steps_ = 0;
-    std::vector<uint32_t> block_refs_, free_blocks_, parked_blocks_;
-    size_t free_block_head_ = 0;
+    // A block id keeps its capacity (entries) for the life of the query; released ids wait in the list of their capacity.
+    // Untracked blocks: A^(k-1) entries, full geometry.  Tracked blocks: laid out inside the geometry of the list they
+    // belong to (static_shape_), capacity = the product of its sets rounded up to a power of two.
+    using Geometry = std::array<uint32_t, TXQ_DENSE_MAX_POSITIONS>;
+    struct FreeList { std::vector<uint32_t> ids; size_t head = 0; };
+    std::map<uint32_t, FreeList> free_by_cap_;
+    std::vector<uint32_t> block_refs_, block_cap_, parked_blocks_;
+    std::vector<Geometry> block_geom_;
+    // per item: the codes that can occur at each position of the (k-1)-suffix of a full-length state waiting there (a
+    // superset, from one pass over the derived graph)
+    std::vector<Geometry> static_shape_;
+    void compute_static_shapes();
+    Geometry geometry_of(int32_t item) const;
+    uint32_t capacity_of(const Geometry& g) const;
     DenseVec* dense_out_ = nullptr;
-    uint32_t dense_slot(uint32_t block, uint64_t index) const { return TXQ_DENSE_SLOT_BIT | (uint32_t)(block * dense_n_ + index); }
-    uint64_t dense_index(uint64_t kmer) const;
+    static uint32_t dense_slot(uint32_t block, uint64_t index) { return TXQ_DENSE_SLOT_BIT | (block << TXQ_DENSE_BLOCK_SHIFT) | (uint32_t)index; }
+    uint64_t dense_index(uint32_t block, uint64_t kmer) const;
+    uint64_t index_of_codes(uint32_t block, const unsigned* code) const;
     uint64_t shape_entries(const DenseRef& r) const;
-    bool can_take_blocks(size_t n);
-    uint32_t new_block(OpVec& out);
+    bool can_take_blocks(const std::vector<uint32_t>& caps);
+    std::vector<uint32_t> caps_scratch_;
+    uint32_t new_block(OpVec& out, const Geometry& geom);
     void release_block(uint32_t block);
     void emit_dense(OpVec& out, const txq_dense_op& d);
-    DenseRef* owned_block(NodeStates& ns, OpVec& out);
-    void densify(NodeStates& ns, OpVec& out, bool may_hold_duplicates);
+    DenseRef* owned_block(int32_t item, NodeStates& ns, OpVec& out);
+    void densify(int32_t item, NodeStates& ns, OpVec& out, bool may_hold_duplicates);
     void shape_zero(const DenseRef& r);
     uint64_t shape_limit() const;
     void materialise(int32_t item, OpVec& out, bool all);
@@ -305,7 +321,7 @@ std::vector<uint32_t> schedule_levels(OpVec& ops, uint32_t n_slots, LevelScratch
 // Same, but leaves `ops` alone and writes the reordered ops to `dst` (room for ops.size()), adding
 // `kmer_add` to every k-mer index and `dgram_add` to every (flag-stripped) d-gram index on the way.
 // dense ops of the program (op.dst indexes `table`; `index_add` rebases it into the stage's table)
-struct DenseSchedule { const txq_dense_op* table; uint32_t index_add; uint32_t n_dense_slots; uint64_t block_slots; };
+struct DenseSchedule { const txq_dense_op* table; uint32_t index_add; uint32_t n_blocks; };
 std::vector<uint32_t> schedule_levels_into(const OpVec& ops, uint32_t n_slots, LevelScratch& scratch, txq_op* dst,
                                            uint32_t kmer_add, uint32_t dgram_add, const DenseSchedule* dense = nullptr);
 

@@ -8,7 +8,7 @@ using namespace tetrex;
 
 namespace {
 thread_local std::string g_qerr;
-thread_local uint64_t g_dense_ops = 0;
+thread_local uint64_t g_dense_ops = 0, g_tracked = 0;
 
 }  // namespace
 
@@ -16,6 +16,7 @@ extern "C" {
 
 const char* txe_last_error(void) { return g_qerr.c_str(); }
 uint64_t txe_last_dense_ops(void) { return g_dense_ops; }
+uint64_t txe_last_tracked_queries(void) { return g_tracked; }
 
 int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6) {
@@ -39,6 +40,7 @@ int txe_query_masks_gapped(void* handle, void* aux_handle, const txh_gap_options
         const std::vector<uint64_t> out = run_queries(ix, enc, rx, &st, &why, &s, &opt, aux);
         std::copy(out.begin(), out.end(), masks);
         g_dense_ops = s.dense_ops;
+        g_tracked = s.tracked_queries;
         int failures = 0;
         for (size_t i = 0; i < n; ++i) {
             if (status) status[i] = st[i];
@@ -74,6 +76,7 @@ int txe_query_masks_sharded(void* const* handles, void* const* aux_handles, size
         const std::vector<uint64_t> out = run_queries_sharded(shards, enc, rx, &st, &why, &s, &opt, aux);
         std::copy(out.begin(), out.end(), masks);
         g_dense_ops = s.dense_ops;
+        g_tracked = s.tracked_queries;
         int failures = 0;
         for (size_t i = 0; i < n; ++i) {
             if (status) status[i] = st[i];

@@ -131,7 +131,9 @@ class StagedRun {
         if (const char* e = std::getenv("TETREX_DENSE_POOL_MB")) pool_bytes = (uint64_t)std::max(0LL, std::atoll(e)) << 20;  // device memory for dense blocks
         dense_pool_.store((int64_t)std::min<uint64_t>(pool_bytes, (uint64_t)INT64_MAX));
         dense_total_ = dense_pool_.load();
-        admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)INT64_MAX / 4);
+        // (tracked blocks are laid out inside their lists' geometries — typically far smaller than A^(k-1) entries; a query that
+        // does need more takes it from the pool like everybody else)
+        admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)256 << 20);
         dense_.pool = &dense_pool_;
         evidence_.store(opt.dense_evidence);
         if (const char* e = std::getenv("TETREX_DENSE_EVIDENCE"))  // A/B knob and tests: dense / sparse / ask
@@ -205,7 +207,6 @@ class StagedRun {
     void build_one(size_t i) {  // throws what the front-end throws
         const std::string postfix = preprocess_query(regexes_[i], enc_);
         q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps, dense_);
-        if (q_[i]->dense_block_slots()) dense_block_slots_.store(q_[i]->dense_block_slots(), std::memory_order_relaxed);
     }
 
     // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned query is
@@ -279,7 +280,7 @@ class StagedRun {
             }
             total.fetch_add(ops_[i].size(), std::memory_order_relaxed);
             slots_[i] = q_[i]->n_slots();
-            dslots_[i] = q_[i]->n_dense_slots();
+            dslots_[i] = q_[i]->n_dense_blocks();
             tracked_[i] = q_[i]->tracked();
             if (q_[i]->done()) {  // free the expansion's tables here, on the worker
                 fin_states_[i] = q_[i]->states();
@@ -385,7 +386,6 @@ class StagedRun {
         uint8_t* blob = blob_store_.ensure(h.levels_offset + stage_ops * 4 + 8,
                                            sizeof(txq_blob_header_v3) + n_ * sizeof(txq_program_v2) + most_ops * (sizeof(txq_op) + 4 + 8));
         txq_dense_op* blob_dense = reinterpret_cast<txq_dense_op*>(blob + h3.dense_offset);
-        const uint64_t block_slots = dense_block_slots_.load(std::memory_order_relaxed);
         uint64_t* blob_kmers = reinterpret_cast<uint64_t*>(blob + h.kmers_offset);
         txq_op* blob_ops = reinterpret_cast<txq_op*>(blob + h.ops_offset);
         pool_.run(m, [&](size_t j, int t) {
@@ -396,7 +396,7 @@ class StagedRun {
             if (!dg.empty()) std::memcpy(blob_kmers + dbase[j], dg.data(), dg.size() * 8);
             const DenseVec& dn = dense_ops_[i];
             if (!dn.empty()) std::memcpy(blob_dense + first_dense[j], dn.data(), dn.size() * sizeof(txq_dense_op));
-            const DenseSchedule ds{dn.data(), first_dense[j], dslots_[i], block_slots};
+            const DenseSchedule ds{dn.data(), first_dense[j], dslots_[i]};
             levels_[i] = schedule_levels_into(ops_[i], slots_[i], scratch_[t], blob_ops + first_op[j], base[j], dbase[j], v3 ? &ds : nullptr);
         });
         lap("levels");
@@ -540,12 +540,11 @@ class StagedRun {
     // by two queries is simply probed twice (a probe costs far less than a shared-table miss)
     std::vector<KmerTable> tables_, dgram_tables_;
     std::vector<DenseVec> dense_ops_;  // per query: the dense ops of the stage being built (op.dst of a TXQ_DENSE_OP indexes it)
-    std::vector<uint32_t> dslots_;     // per query: slots of its dense region
+    std::vector<uint32_t> dslots_;     // per query: dense blocks it addresses (ids 0 .. n-1)
     std::vector<uint8_t> tracked_;     // per query: its blocks carry live lists (TXQ_PROGRAM_TRACKED_BIT)
     DenseOptions dense_;
     std::atomic<int64_t> dense_pool_{0};
     std::atomic<int> evidence_{DenseOptions::kUnknown};  // see DenseOptions::evidence
-    std::atomic<uint64_t> dense_block_slots_{0};
     std::vector<LevelScratch> scratch_;               // per thread
     std::vector<std::vector<uint8_t>> dead_scratch_;  // per thread
     std::vector<std::vector<uint32_t>> levels_, asks_;

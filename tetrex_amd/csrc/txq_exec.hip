@@ -55,13 +55,15 @@ __device__ __forceinline__ void slot_store(uint64_t* p, uint64_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
-// A dense block in HBM: [N][W] mask words, then its live list (include/txq_program.h, tracked programs): a 16-byte
-// header whose first word is the number of listed entries, a bitmap of N bits ("entry is listed"), the list itself.
-struct BlockMeta { uint32_t* count; uint64_t* bitmap; uint32_t* list; };
-__host__ __device__ __forceinline__ size_t block_meta_words(uint32_t N) { return 2 + ((size_t)N + 63) / 64 + ((size_t)N + 1) / 2; }
-__device__ __forceinline__ BlockMeta block_meta(uint64_t* block, uint32_t N, uint32_t W) {
-    uint64_t* m = block + (size_t)N * W;
-    return BlockMeta{reinterpret_cast<uint32_t*>(m), m + 2, reinterpret_cast<uint32_t*>(m + 2 + ((size_t)N + 63) / 64)};
+// A dense block in HBM: [cap][W] mask words, then its live list (include/txq_program.h, tracked programs): a 64-byte
+// header — number of listed entries, capacity, the block's geometry —, a bitmap of cap bits ("entry is listed"), the list.
+struct BlockMeta { uint32_t* count; uint32_t* geom; uint64_t* bitmap; uint32_t* list; };
+static constexpr uint32_t kBlockHeaderWords = 8;
+__host__ __device__ __forceinline__ size_t block_meta_words(uint32_t cap) { return kBlockHeaderWords + ((size_t)cap + 63) / 64 + ((size_t)cap + 1) / 2; }
+__device__ __forceinline__ BlockMeta block_meta(uint64_t* block, uint32_t cap, uint32_t W) {
+    uint64_t* m = block + (size_t)cap * W;
+    uint32_t* h = reinterpret_cast<uint32_t*>(m);
+    return BlockMeta{h, h + 2, m + kBlockHeaderWords, reinterpret_cast<uint32_t*>(m + kBlockHeaderWords + ((size_t)cap + 63) / 64)};
 }
 // entry idx has received a bit: true for the one caller that makes it a listed entry
 __device__ __forceinline__ bool mark_live(const BlockMeta& m, uint32_t idx) {
@@ -72,23 +74,23 @@ __device__ __forceinline__ void append_live(const BlockMeta& m, uint32_t idx) {
     m.list[__hip_atomic_fetch_add(m.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = idx;
 }
 
-// Where a program's slots live: ordinary slots in its slot region S; slots with TXQ_DENSE_SLOT_BIT in its dense
-// blocks, found through its row BT of the stage's block table: BT[0] = flags (bit 0: tracked), BT[1 + b] = block b.
+// Where a program's slots live: ordinary slots in its slot region S; slots with TXQ_DENSE_SLOT_BIT (BIT | block << 22 |
+// index) in its dense blocks, found through its row of the stage's block table: bt[0] = flags (bit 0: tracked),
+// bt[1 + 2 b] = block b, bt[2 + 2 b] = its capacity in entries.
 struct DenseRow {
     uint64_t* const* bt;
-    uint32_t N;  // slots per block (0: the session has no dense blocks)
     __device__ __forceinline__ bool tracked() const { return (reinterpret_cast<uintptr_t>(bt[0]) & 1u) != 0; }
 };
 __device__ __forceinline__ uint64_t* slot_ptr(uint64_t* S, const DenseRow& D, uint32_t s, uint32_t W) {
     if (!(s & TXQ_DENSE_SLOT_BIT)) return S + (size_t)s * W;
-    const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT, b = i / D.N;
-    return D.bt[1 + b] + (size_t)(i - b * D.N) * W;
+    const uint32_t b = (s & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT;
+    return D.bt[1 + 2 * b] + (size_t)(s & TXQ_DENSE_INDEX_MASK) * W;
 }
 // an ordinary op has ORed `x` into word w of dense slot s of a tracked program: the entry joins its block's live list
 __device__ __forceinline__ void note_dense_write(const DenseRow& D, uint32_t s, uint32_t W, uint64_t x) {
     if (!x || !(s & TXQ_DENSE_SLOT_BIT) || !D.tracked()) return;
-    const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT, b = i / D.N, idx = i - b * D.N;
-    const BlockMeta m = block_meta(D.bt[1 + b], D.N, W);
+    const uint32_t b = (s & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT, idx = s & TXQ_DENSE_INDEX_MASK;
+    const BlockMeta m = block_meta(D.bt[1 + 2 * b], (uint32_t)reinterpret_cast<uintptr_t>(D.bt[2 + 2 * b]), W);
     if (mark_live(m, idx)) append_live(m, idx);
 }
 
@@ -123,14 +125,14 @@ __device__ __forceinline__ void run_op(const txq_op o, uint64_t* S, const DenseR
 template <int G>
 __global__ __launch_bounds__(1024) void exec_kernel(const DevProgram* __restrict__ progs, const txq_op* __restrict__ ops,
                                                     const uint32_t* __restrict__ levels, uint64_t* const* __restrict__ slot_base,
-                                                    uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t block_n) {
+                                                    uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W) {
     const uint32_t sub = threadIdx.x % G;
     const uint32_t group = threadIdx.x / G, n_groups = blockDim.x / G;
     for (uint32_t p = blockIdx.x; p < n_programs; p += gridDim.x) {
         const DevProgram pr = progs[p];
         if (pr.n_ops == 0) continue;
         uint64_t* S = slot_base[p];  // [slots][W]
-        const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + p]), block_n};
+        const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + p])};
         const txq_op* op = ops + pr.first_op;
         if (pr.n_levels == 0) {
             if (group == 0)
@@ -159,11 +161,11 @@ static inline uint32_t unit_ops(uint32_t W) { return W >= kUnitWords ? 1u : kUni
 
 // g_log2: log2 of the lanes per op (a power of two <= 256)
 __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restrict__ ops, uint64_t* const* __restrict__ slot_base,
-                                         uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2, uint32_t block_n) {
+                                         uint32_t n_programs, const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
     const uint32_t G = 1u << g_log2;
     const uint32_t sub = threadIdx.x & (G - 1), group = threadIdx.x >> g_log2, n_groups = blockDim.x >> g_log2;
     uint64_t* S = slot_base[u.program];
-    const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + u.program]), block_n};
+    const DenseRow D{reinterpret_cast<uint64_t* const*>(slot_base[n_programs + u.program])};
     for (uint32_t i = u.begin + group; i < u.end; i += n_groups) {
         const txq_op o = ops[i];
         uint64_t* pd = slot_ptr(S, D, o.dst, W);
@@ -190,13 +192,13 @@ __device__ __forceinline__ void run_unit(const ExecUnit u, const txq_op* __restr
 
 __global__ __launch_bounds__(256) void exec_units_kernel(const ExecUnit* __restrict__ units, const txq_op* __restrict__ ops,
                                                          uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                         const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2, uint32_t block_n) {
-    run_unit(units[blockIdx.x], ops, slot_base, n_programs, M, W, g_log2, block_n);
+                                                         const uint64_t* __restrict__ M, uint32_t W, uint32_t g_log2) {
+    run_unit(units[blockIdx.x], ops, slot_base, n_programs, M, W, g_log2);
 }
 
 // The units of a level that also has dense tiles ride in the dense launch (its first `n_units` workgroups): the ordinary
 // and the dense ops of one level are independent, and a level costs one kernel boundary instead of two.
-struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M; uint32_t n_units, g_log2, block_n; };
+struct LevelUnits { const ExecUnit* units; const txq_op* ops; const uint64_t* M; uint32_t n_units, g_log2; };
 
 // ---- dense DP steps ---------------------------------------------------------------------------
 // One workgroup per tile: `count` work entries of one dense op, starting at `first`.
@@ -215,7 +217,7 @@ struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DEN
 // Where the blocks (and slots) of a stage's dense op live, resolved by the host side when it plans the stage:
 // dst = the block written (ZERO, STEP, FILL) or the slot accumulated into (REDUCE); src = the block read (STEP, REDUCE) or
 // the slot spread (FILL).  A tile reads this next to the op itself: no pointer chase through the program's tables.
-struct DenseOpPtr { uint64_t* dst; const uint64_t* src; };
+struct DenseOpPtr { uint64_t* dst; const uint64_t* src; uint32_t dst_cap, src_cap; };  // (capacities of the blocks: where their live lists sit)
 
 __global__ __launch_bounds__(256) void make_tiles_kernel(const TileGroup* __restrict__ groups, DenseTile* __restrict__ tiles) {
     const TileGroup g = groups[blockIdx.x];
@@ -452,7 +454,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     __shared__ uint64_t root_words[ROWS::kRootByLane ? kRootWordsLds : 1];  // [suffix of the pass][predecessor < 32][root word]
     if (blockIdx.x < U.n_units) {  // the whole workgroup: no barrier has been reached
-        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2, U.block_n);
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
     }
     const DenseTile t = tiles[blockIdx.x - U.n_units];
@@ -645,7 +647,7 @@ static constexpr uint32_t kSparseChunk = 64;
 static constexpr uint32_t kMaxSparseGroups = 1024;  // per launch (the chunk totals sit in LDS)
 
 __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __restrict__ groups, uint32_t n_groups, const txq_dense_op* __restrict__ dops,
-                                                           const DenseOpPtr* __restrict__ optr, uint32_t N, uint32_t W, uint32_t* __restrict__ counts,
+                                                           const DenseOpPtr* __restrict__ optr, uint32_t W, uint32_t pos, uint32_t* __restrict__ counts,
                                                            uint32_t* __restrict__ prefix) {
     __shared__ uint32_t scan[1024];
     const uint32_t t = threadIdx.x;
@@ -655,10 +657,15 @@ __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __
         uint32_t n = g.fixed;
         if (n == kNotFixed) {
             const txq_dense_op d = dops[g.op];
-            uint64_t* blk = d.kind == TXQ_DENSE_ZERO ? optr[g.op].dst : const_cast<uint64_t*>(optr[g.op].src);
-            uint32_t* c = reinterpret_cast<uint32_t*>(blk + (size_t)N * W);
-            n = *c;
-            if (d.kind == TXQ_DENSE_ZERO) *c = 0;
+            const DenseOpPtr q = optr[g.op];
+            if (d.kind == TXQ_DENSE_ZERO) {  // (re)creates the block: what it listed is cleared by this level's chunks, its geometry is the op's shape from now on
+                uint32_t* h = reinterpret_cast<uint32_t*>(q.dst + (size_t)q.dst_cap * W);
+                n = h[0];
+                h[0] = 0;
+                h[1] = q.dst_cap;
+                for (uint32_t j = 0; j < TXQ_DENSE_MAX_POSITIONS; ++j) h[2 + j] = j < pos ? d.shape[j] : 0u;
+            } else
+                n = *reinterpret_cast<const uint32_t*>(q.src + (size_t)q.src_cap * W);
         }
         counts[t] = n;
         chunks = (n + kSparseChunk - 1) / kSparseChunk;
@@ -702,6 +709,32 @@ __device__ __forceinline__ uint32_t reserve_live(const BlockMeta& m, uint32_t n_
     return base + incl - n_new;
 }
 
+// A block's geometry as the chunks use it: per position the codes in rank order (entry -> suffix) and the rank of every
+// code (suffix -> entry), and the mixed-radix strides.
+struct GeomTables {
+    uint8_t code[TXQ_DENSE_MAX_POSITIONS][32];
+    uint8_t rank[TXQ_DENSE_MAX_POSITIONS][32];  // 0xFF: the code is not in the set
+    uint32_t cnt[TXQ_DENSE_MAX_POSITIONS], stride[TXQ_DENSE_MAX_POSITIONS];
+};
+__device__ __forceinline__ void load_geometry(GeomTables& g, const uint32_t* __restrict__ geom, uint32_t pos) {
+    if (threadIdx.x < pos) {
+        const uint32_t j = threadIdx.x, mask = geom[j];
+        uint32_t n = 0;
+        for (uint32_t c = 0; c < 32; ++c) {
+            const bool in = (mask >> c) & 1u;
+            g.rank[j][c] = in ? (uint8_t)n : (uint8_t)0xFF;
+            if (in) g.code[j][n++] = (uint8_t)c;
+        }
+        g.cnt[j] = n;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t st = 1;
+        for (uint32_t j = pos; j-- > 0;) { g.stride[j] = st; st *= g.cnt[j]; }
+    }
+    __syncthreads();
+}
+
 template <int H, bool WIDE, class ROWS>
 __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                      const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
@@ -711,10 +744,11 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     using T = typename L::T;
     constexpr int UA = 3;  // residues in flight per lane: UA * H row gathers
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
-    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
+    __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // of the op's shape (FILL) and, [pos], of its r_mask (STEP)
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
+    __shared__ GeomTables sg, dg;  // geometry of the block read / written
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
-        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2, U.block_n);
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
     }
     for (uint32_t i = threadIdx.x; i <= n_groups; i += blockDim.x) pre[i] = prefix[i];
@@ -728,7 +762,6 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const uint32_t m = (g + b) / 2;
         if (pre[m] <= lo) g = m; else b = m;
     }
-    const uint32_t N = P.pow_a[P.pos];
     const uint32_t chunks_w = (W + L::kWords - 1) / L::kWords;
     uint32_t loaded = 0xFFFFFFFFu;
     for (uint32_t t = lo; t < hi; ++t) {
@@ -736,16 +769,18 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const uint32_t first = (t - pre[g]) * kSparseChunk;
         const uint32_t n = counts[g];
         const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
-        const SparseGroup sg = groups[g];
-        const txq_dense_op d = dops[sg.op];
-        const DenseOpPtr q = optr[sg.op];
+        const SparseGroup sgr = groups[g];
+        const txq_dense_op d = dops[sgr.op];
+        const DenseOpPtr q = optr[sgr.op];
         if (loaded != g && (d.kind == TXQ_DENSE_STEP || d.kind == TXQ_DENSE_FILL)) {
-            __syncthreads();  // the previous chunk has read its codes
+            __syncthreads();  // the previous chunk has read its tables
             dense_codes(d, P, codes, cnt);
+            load_geometry(dg, block_meta(q.dst, q.dst_cap, W).geom, P.pos);
+            if (d.kind == TXQ_DENSE_STEP) load_geometry(sg, block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W).geom, P.pos);
             loaded = g;
         }
         if (d.kind == TXQ_DENSE_ZERO) {  // the listed entries := 0, their bits in the bitmap cleared (the plan kernel has reset the count)
-            const BlockMeta m = block_meta(q.dst, N, W);
+            const BlockMeta m = block_meta(q.dst, q.dst_cap, W);
             uint32_t wl = 1;
             while (wl < W && wl < blockDim.x) wl <<= 1;
             const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
@@ -757,7 +792,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             continue;
         }
         if (d.kind == TXQ_DENSE_REDUCE) {  // slot dst |= OR of the listed entries
-            const BlockMeta m = block_meta(const_cast<uint64_t*>(q.src), N, W);
+            const BlockMeta m = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W);
             uint32_t wl = 1;
             while (wl < W && wl < blockDim.x) wl <<= 1;
             const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
@@ -769,19 +804,22 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             continue;
         }
         if (d.kind == TXQ_DENSE_FILL) {  // entries first .. end of the shape |= the slot; those that were empty join the list
-            const BlockMeta m = block_meta(q.dst, N, W);
+            const BlockMeta m = block_meta(q.dst, q.dst_cap, W);
             uint32_t wl = 1;
             while (wl < W && wl < 64u) wl <<= 1;  // the lanes of an entry stay within a wave (reserve_live)
             const uint32_t sub = threadIdx.x % wl, grp = threadIdx.x / wl, ngrp = blockDim.x / wl;
             const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
             for (uint32_t it = 0; it < rounds; ++it) {
                 const uint32_t e = first + it * ngrp + grp;
-                const bool live = e < end;
+                bool live = e < end;
                 uint32_t r = live ? e : 0, idx = 0;
-                for (uint32_t jj = P.pos; jj-- > 0;) {
-                    idx += (uint32_t)codes[jj][r % cnt[jj]] * P.pow_a[P.pos - 1 - jj];
+                for (uint32_t jj = P.pos; jj-- > 0;) {  // entry number e of the shape -> its codes -> their ranks in the block's geometry
+                    const uint32_t rk = dg.rank[jj][codes[jj][r % cnt[jj]]];
+                    live = live && rk != 0xFFu;
+                    idx += rk * dg.stride[jj];
                     r /= cnt[jj];
                 }
+                live = live && idx < q.dst_cap;
                 uint64_t any = 0;
                 if (live)
                     for (uint32_t w = sub; w < W; w += wl) {
@@ -799,24 +837,29 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         // STEP, pushed: every listed entry (a, x1 .. x_{k-2}) of src is rolled forward by the residues of r_mask —
         // dst[(x1 .. x_{k-2}, r)] |= src[entry] & M[k-mer(entry, r)] — G lanes per entry, UA residues in flight.  A product
         // that is empty is not written (the collector's path_.none() pruning, include/otf_collector.h:383); a destination entry
-        // that receives its first bit joins dst's list.
-        const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), N, W), dm = block_meta(q.dst, N, W);
+        // that receives its first bit joins dst's list.  Entries are numbered inside the blocks' geometries (sg, dg).
+        const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W), dm = block_meta(q.dst, q.dst_cap, W);
         const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
         const uint32_t n_r = cnt[P.pos];
-        const uint32_t a_stride = P.pow_a[P.pos - 1];
         const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
         for (uint32_t it = 0; it < rounds; ++it) {
             const uint32_t e = first + it * ngrp + grp;
-            const bool live = e < end;
+            bool live = e < end;
             const uint32_t idx = live ? sm.list[e] : 0;
-            const uint32_t a = idx / a_stride, mid = idx - a * a_stride;
-            uint64_t mid_val = 0;
-            for (uint32_t tt = 0, m = mid; tt + 1 < P.pos; ++tt) {
-                mid_val |= (uint64_t)(m % P.A) << (P.bits * tt);
-                m /= P.A;
+            uint64_t high = 0;   // the k-mer without the residue rolled in
+            uint32_t dst0 = 0;   // the destination entry without that residue's rank
+            for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
+                const uint32_t c = sg.code[jj][rest % sg.cnt[jj]];
+                rest /= sg.cnt[jj];
+                high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
+                if (jj > 0) {
+                    const uint32_t rk = dg.rank[jj - 1][c];
+                    live = live && rk != 0xFFu;
+                    dst0 += rk * dg.stride[jj - 1];
+                }
             }
-            const uint64_t high = (((uint64_t)a << (P.bits * (P.pos - 1))) | mid_val) << P.bits;  // the k-mer without the residue rolled in
-            const size_t dst0 = (size_t)mid * P.A;
+            high <<= P.bits;
+            live = live && idx < q.src_cap;
             uint32_t hit = 0;  // bit i: residue codes[pos][i] left a bit in this lane's chunk
             for (uint32_t c0 = 0; c0 < chunks_w; c0 += G) {
                 const uint32_t c = c0 + sub;
@@ -842,8 +885,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
                         const T y = sv & rows.combine(x[u]);
-                        if (L::any(y)) {
-                            atomic_or_chunk<WIDE>(q.dst + (dst0 + codes[P.pos][i + u]) * W + (size_t)c * L::kWords, y);
+                        const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i + u]];
+                        if (L::any(y) && rk != 0xFFu) {
+                            atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
                             hit |= 1u << (i + u);
                         }
                     }
@@ -855,8 +899,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
                     rows.template issue<false>(nullptr, v, x0);
                     rows.template issue_late<false>(x0);
                     const T y = sv & rows.combine(x0);
-                    if (L::any(y)) {
-                        atomic_or_chunk<WIDE>(q.dst + (dst0 + codes[P.pos][i]) * W + (size_t)c * L::kWords, y);
+                    const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
+                    if (L::any(y) && rk != 0xFFu) {
+                        atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
                         hit |= 1u << i;
                     }
                 }
@@ -866,10 +911,10 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             if (sub == 0)
                 for (uint32_t h = hit; h; h &= h - 1) {
                     const uint32_t i = (uint32_t)__builtin_ctz(h);
-                    if (mark_live(dm, (uint32_t)dst0 + codes[P.pos][i])) fresh |= 1u << i;
+                    if (mark_live(dm, dst0 + dg.rank[P.pos - 1][codes[P.pos][i]])) fresh |= 1u << i;
                 }
             uint32_t at = reserve_live(dm, (uint32_t)__builtin_popcount(fresh));
-            for (uint32_t h = fresh; h; h &= h - 1) dm.list[at++] = (uint32_t)dst0 + codes[P.pos][__builtin_ctz(h)];
+            for (uint32_t h = fresh; h; h &= h - 1) dm.list[at++] = dst0 + dg.rank[P.pos - 1][codes[P.pos][__builtin_ctz(h)]];
         }
     }
 }
@@ -1024,7 +1069,7 @@ struct BlobView {
     DenseParams dense{};
     uint32_t block_slots = 0;  // A^(k-1) when the blob is version 3
     std::vector<DevProgram> programs;
-    std::vector<uint32_t> n_slots, n_dense_slots;
+    std::vector<uint32_t> n_slots, n_blocks;  // per program: ordinary slots; dense blocks (ids 0 .. n-1)
     std::vector<uint8_t> has_dense;  // the program has dense ops in this stage
     std::vector<uint8_t> tracked;    // TXQ_PROGRAM_TRACKED_BIT
 };
@@ -1034,7 +1079,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     if ((uintptr_t)blob % 8) return fail(TXQ_ERR_PROGRAM, "blob must be 8-byte aligned");
     const txq_blob_header* h1 = (const txq_blob_header*)blob;
     if (h1->magic != TXQ_PROGRAM_MAGIC) return fail(TXQ_ERR_PROGRAM, "bad blob magic");
-    const bool v3 = h1->version == TXQ_PROGRAM_VERSION_DENSE;
+    const bool v3 = h1->version == TXQ_PROGRAM_VERSION_DENSE;  // (levels + dense ops)
     const bool v2 = v3 || h1->version == TXQ_PROGRAM_VERSION_LEVELS;
     if (!v2 && h1->version != TXQ_PROGRAM_VERSION) return fail(TXQ_ERR_PROGRAM, "unsupported blob version %u", h1->version);
     if (bytes < (v3 ? sizeof(txq_blob_header_v3) : v2 ? sizeof(txq_blob_header_v2) : sizeof(txq_blob_header)))
@@ -1084,7 +1129,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     }
     v.programs.resize(n_programs);
     v.n_slots.resize(n_programs);
-    v.n_dense_slots.assign(n_programs, 0);
+    v.n_blocks.assign(n_programs, 0);
     v.has_dense.assign(n_programs, 0);
     v.tracked.assign(n_programs, 0);
     const txq_op* ops = (const txq_op*)(blob + v.ops_offset);
@@ -1098,10 +1143,8 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             v.n_slots[p] = s.n_slots;
             if (v3) {
                 v.tracked[p] = (s.reserved & TXQ_PROGRAM_TRACKED_BIT) != 0;
-                const uint32_t dense_slots = s.reserved & ~TXQ_PROGRAM_TRACKED_BIT;
-                v.n_dense_slots[p] = dense_slots;
-                if (dense_slots % v.block_slots || dense_slots >= TXQ_DENSE_SLOT_BIT)
-                    return fail(TXQ_ERR_PROGRAM, "program %u: dense slots not a multiple of the block size", p);
+                v.n_blocks[p] = s.reserved & ~TXQ_PROGRAM_TRACKED_BIT;
+                if (v.n_blocks[p] > TXQ_DENSE_MAX_BLOCKS) return fail(TXQ_ERR_PROGRAM, "program %u: more than %u dense blocks", p, TXQ_DENSE_MAX_BLOCKS);
             }
         } else {
             const txq_program& s = ((const txq_program*)(blob + programs_offset))[p];
@@ -1128,12 +1171,18 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
     struct Bad { uint32_t program = 0xFFFFFFFFu, op = 0; int kind = 0; };
     auto check_program = [&](uint32_t p, Bad& bad) {
         const DevProgram& d = v.programs[p];
-        const uint32_t n_slots = v.n_slots[p], n_dense_slots = v.n_dense_slots[p];
+        const uint32_t n_slots = v.n_slots[p], n_blocks = v.n_blocks[p];
+        const bool tracked = v.tracked[p] != 0;
         const txq_op* o = ops + d.first_op;
-        auto slot_ok = [&](uint32_t s) { return (s & TXQ_DENSE_SLOT_BIT) ? (s & ~TXQ_DENSE_SLOT_BIT) < n_dense_slots : s < n_slots; };
+        // a dense slot: an existing block id; its index inside A^(k-1) for untracked blocks (a tracked block's capacity is only
+        // known to the session: plan_units checks those)
+        auto slot_ok = [&](uint32_t s) {
+            if (s & 0x80000000u) return false;
+            if (!(s & TXQ_DENSE_SLOT_BIT)) return s < n_slots;
+            return ((s & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT) < n_blocks && (tracked || (s & TXQ_DENSE_INDEX_MASK) < v.block_slots);
+        };
         auto block_ok = [&](uint32_t s) {
-            const uint32_t i = s & ~TXQ_DENSE_SLOT_BIT;
-            return (s & TXQ_DENSE_SLOT_BIT) && i % v.block_slots == 0 && i < n_dense_slots;  // n_dense_slots is a multiple of the block size
+            return !(s & 0x80000000u) && (s & TXQ_DENSE_SLOT_BIT) && (s & TXQ_DENSE_INDEX_MASK) == 0 && ((s & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT) < n_blocks;
         };
         for (uint32_t i = 0; i < d.n_ops; ++i) {
             int kind = 0;
@@ -1150,13 +1199,22 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
                     if (ok && (x.kind != TXQ_DENSE_ZERO || x.r_mask))
                         for (uint32_t j = 0; ok && j < v.dense.pos; ++j) ok = (x.shape[j] & ~code_mask) == 0;
                     if (ok && x.kind == TXQ_DENSE_STEP) ok = x.src != x.dst && (x.r_mask & ~code_mask) == 0;
-                    if (ok && x.kind == TXQ_DENSE_REDUCE) ok = slot_ok(x.dst) && x.dst != TXQ_SLOT_ZERO && x.dst != TXQ_SLOT_ONES;
+                    if (ok && x.kind == TXQ_DENSE_REDUCE) ok = slot_ok(x.dst) && x.dst != TXQ_SLOT_ZERO && x.dst != TXQ_SLOT_ONES && !(tracked && (x.dst & TXQ_DENSE_SLOT_BIT));
+                    if (ok && x.kind == TXQ_DENSE_ZERO && tracked) {  // (re)creates the block: geometry in shape[], capacity in src
+                        uint64_t entries = 1;
+                        for (uint32_t j = 0; j < v.dense.pos; ++j) entries *= (uint64_t)__builtin_popcount(x.shape[j]);
+                        ok = entries >= 1 && entries <= x.src && x.src <= (1u << TXQ_DENSE_BLOCK_SHIFT);
+                    }
                     if (!ok) kind = 4;
                     v.has_dense[p] = 1;
                 }
             } else if (!slot_ok(o[i].dst) || !slot_ok(o[i].a) || !slot_ok(o[i].b)) kind = 1;
             else if (o[i].dst == TXQ_SLOT_ZERO || o[i].dst == TXQ_SLOT_ONES) kind = 2;
             else if (o[i].kmer != TXQ_NO_KMER && o[i].kmer >= v.n_kmers) kind = 3;
+            else if ((o[i].dst | o[i].a | o[i].b) & TXQ_DENSE_SLOT_BIT) {  // an ordinary op on block entries: the program runs level by level, like one with dense ops
+                if (d.n_levels == 0) kind = 4;
+                v.has_dense[p] = 1;
+            }
             if (kind) { if (p < bad.program) bad = Bad{p, i, kind}; return; }
         }
     };
@@ -1199,8 +1257,8 @@ Session::~Session() {
                 (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
     if (std::getenv("TXQ_TRACE") && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
     if (std::getenv("TXQ_TRACE") && n_blocks_made + n_block_memsets)
-        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB each), %zu cleared for tracked programs; %zu sparse launches (%zu groups)\n", n_blocks_made,
-                block_words * 8 / 1e6, n_block_memsets, n_sparse_launches, n_sparse_groups);
+        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all), %zu cleared for tracked programs; %zu sparse launches (%zu groups)\n", n_blocks_made,
+                block_bytes_made / 1e6, n_block_memsets, n_sparse_launches, n_sparse_groups);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
@@ -1290,34 +1348,54 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 
 // (re)size the programs' slot regions to what the stage needs; a grown region keeps its contents
 // (host side only: the caller uploads `moves` and the base table with the stage and launches move_regions_kernel).
-// Dense blocks: a program that needs more blocks gets more (from the blocks finished programs gave back, or from the
-// arena); `to_clear` = blocks that go to a tracked program and must be all zero first (the caller memsets them on the
-// stage's stream).
-static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out,
-                             std::vector<uint64_t*>* to_clear) {
+// Dense blocks: an untracked program gets the blocks it counts (A^(k-1) entries each); a tracked program gets a block
+// when a ZERO of this stage creates it, with the capacity the op names (a block id keeps its capacity).  Blocks come
+// from those that finished programs gave back, or from the arena; `to_clear` = blocks that go to a tracked program and
+// must be all zero first (the caller memsets them on the stage's stream).
+static size_t block_alloc_words(uint32_t cap, uint32_t W) { return ((size_t)cap * W + block_meta_words(cap) + 1) & ~(size_t)1; }
+
+static int take_block(Session& s, uint32_t cap, Session::DenseBlock* out) {
+    auto it = s.free_blocks.find(cap);
+    if (it != s.free_blocks.end()) {
+        *out = it->second;
+        s.free_blocks.erase(it);
+        return TXQ_OK;
+    }
+    Session::DenseBlock b{nullptr, cap, Session::kGarbage};
+    if (int rc = arena_alloc(s, block_alloc_words(cap, s.W), &b.p)) return rc;
+    ++s.n_blocks_made;
+    s.block_bytes_made += block_alloc_words(cap, s.W) * 8;
+    *out = b;
+    return TXQ_OK;
+}
+
+static int grow_slot_regions(Session& s, const BlobView& bv, const unsigned char* blob, std::vector<uint32_t>* fresh, std::vector<RegionMove>* moves_out,
+                             std::vector<std::pair<uint64_t*, size_t>>* to_clear) {
     std::vector<RegionMove>& moves = *moves_out;
     if (bv.block_slots) {
-        if (!s.block_slots) {
-            s.block_slots = bv.block_slots;
-            s.block_words = ((size_t)bv.block_slots * s.W + block_meta_words(bv.block_slots) + 1) & ~(size_t)1;
-        } else if (s.block_slots != bv.block_slots)
+        if (!s.block_slots) s.block_slots = bv.block_slots;
+        else if (s.block_slots != bv.block_slots)
             return fail(TXQ_ERR_PROGRAM, "the block size changed within a session (%u -> %u slots)", s.block_slots, bv.block_slots);
     }
     // Blocks given back two stages ago serve other programs now: whatever used them has finished (a stage waits for the
     // stage before the previous one, whose staging set it takes over), so a recycled block ties its new owner to nobody.
-    s.free_blocks.insert(s.free_blocks.end(), s.given_back[1].begin(), s.given_back[1].end());
+    for (const Session::DenseBlock& b : s.given_back[1]) s.free_blocks.emplace(b.cap, b);
     s.given_back[1].swap(s.given_back[0]);
     s.given_back[0].clear();
-    // a program that reports no dense slots any more is finished with its blocks
+    // a program that reports no dense blocks any more is finished with them
     if (bv.block_slots)
         for (size_t p = 0; p < s.n_programs; ++p)
-            if (bv.n_dense_slots[p] == 0 && !s.blocks[p].empty()) {
+            if (bv.n_blocks[p] == 0 && !s.blocks[p].empty()) {
                 for (const Session::DenseBlock& b : s.blocks[p])
-                    s.given_back[0].push_back(Session::DenseBlock{b.p, (uint8_t)(s.tracked[p] ? Session::kListed : Session::kGarbage)});
-                s.n_blocks_live -= s.blocks[p].size();
+                    if (b.p) {
+                        s.given_back[0].push_back(Session::DenseBlock{b.p, b.cap, (uint8_t)(s.tracked[p] ? Session::kListed : Session::kGarbage)});
+                        --s.n_blocks_live;
+                    }
                 s.blocks[p].clear();
                 s.base[s.n_programs + p] = nullptr;
             }
+    const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
+    const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
     for (size_t p = 0; p < s.n_programs; ++p) {
         // a program gets its region with its first ops (a query of a later wave would otherwise get eight slots now and
         // outgrow them — a move, tied to this stage's init kernel — the moment it begins)
@@ -1332,24 +1410,34 @@ static int grow_slot_regions(Session& s, const BlobView& bv, std::vector<uint32_
             s.base[p] = region;
             s.cap[p] = cap;
         }
-        const size_t bneed = bv.block_slots ? bv.n_dense_slots[p] / bv.block_slots : 0;
-        if (bneed > s.blocks[p].size()) {
-            if (s.blocks[p].empty()) s.tracked[p] = bv.tracked[p];
-            else if (s.tracked[p] != bv.tracked[p]) return fail(TXQ_ERR_PROGRAM, "program %zu: tracked and untracked blocks in one program", p);
-            while (s.blocks[p].size() < bneed) {
-                Session::DenseBlock b{nullptr, Session::kGarbage};
-                if (!s.free_blocks.empty()) {
-                    b = s.free_blocks.back();
-                    s.free_blocks.pop_back();
-                } else {
-                    if (int rc = arena_alloc(s, s.block_words, &b.p)) return rc;
-                    ++s.n_blocks_made;
+        const size_t bneed = bv.block_slots ? bv.n_blocks[p] : 0;
+        if (!bneed) continue;
+        if (s.blocks[p].empty()) s.tracked[p] = bv.tracked[p];
+        else if (s.tracked[p] != bv.tracked[p]) return fail(TXQ_ERR_PROGRAM, "program %zu: tracked and untracked blocks in one program", p);
+        if (s.blocks[p].size() < bneed) s.blocks[p].resize(bneed, Session::DenseBlock{nullptr, 0, Session::kGarbage});
+        if (!s.tracked[p]) {
+            for (Session::DenseBlock& b : s.blocks[p])
+                if (!b.p) {
+                    if (int rc = take_block(s, bv.block_slots, &b)) return rc;
+                    ++s.n_blocks_live;
                 }
-                // (a kListed block could be cleared through its list instead; the memset is 0.1 ms per 500 MB)
-                if (s.tracked[p]) to_clear->push_back(b.p);
-                s.blocks[p].push_back(b);
-                ++s.n_blocks_live;
+            continue;
+        }
+        if (!bv.has_dense[p]) continue;
+        const DevProgram& d = bv.programs[p];
+        for (uint32_t i = 0; i < d.n_ops; ++i) {
+            const txq_op& o = ops[d.first_op + i];
+            if (o.kmer != TXQ_DENSE_OP || dops[o.dst].kind != TXQ_DENSE_ZERO) continue;
+            const txq_dense_op& z = dops[o.dst];
+            Session::DenseBlock& b = s.blocks[p][(z.dst & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT];
+            if (b.p) {
+                if (b.cap != z.src) return fail(TXQ_ERR_PROGRAM, "program %zu: a tracked block changed its capacity (%u -> %u entries)", p, b.cap, z.src);
+                continue;
             }
+            if (int rc = take_block(s, z.src, &b)) return rc;
+            ++s.n_blocks_live;
+            // (a kListed block could be cleared through its list instead of whole)
+            to_clear->emplace_back(b.p, block_alloc_words(b.cap, s.W) * 8);
         }
     }
     return TXQ_OK;
@@ -1371,7 +1459,7 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
     const uint32_t* levels_host = bv.n_levels ? (const uint32_t*)(blob + bv.levels_offset) : nullptr;
     const txq_op* ops = (const txq_op*)(blob + bv.ops_offset);
     const txq_dense_op* dops = bv.n_dense ? (const txq_dense_op*)(blob + bv.dense_offset) : nullptr;
-    optr->assign(bv.n_dense, DenseOpPtr{nullptr, nullptr});
+    optr->assign(bv.n_dense, DenseOpPtr{nullptr, nullptr, 0, 0});
     std::vector<std::vector<ExecUnit>> per_level;
     std::vector<std::vector<TileGroup>> groups_level;
     std::vector<std::vector<DenseTile>> hsteps_level;
@@ -1380,8 +1468,8 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
     static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
     const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
-    const uint32_t N = bv.block_slots;
     size_t n_small = 0;
+    int bad_program = -1;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
         DevProgram& d = bv.programs[p];
         const bool dense = bv.has_dense[p] != 0;
@@ -1391,13 +1479,20 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
             per_level.resize(d.n_levels); groups_level.resize(d.n_levels); hsteps_level.resize(d.n_levels);
             sparse_level.resize(d.n_levels); sparse_chunks.resize(d.n_levels, 0);
         }
-        // (validate_blob has checked that block operands are block-aligned and inside the program's dense slots, and
-        // grow_slot_regions has given the program that many blocks)
-        auto block_of = [&](uint32_t slot) { return s.blocks[p][(slot & ~TXQ_DENSE_SLOT_BIT) / N].p; };
-        auto slot_of = [&](uint32_t slot) {
-            const uint32_t i = slot & ~TXQ_DENSE_SLOT_BIT;
-            return (slot & TXQ_DENSE_SLOT_BIT) ? s.blocks[p][i / N].p + (size_t)(i % N) * W : s.base[p] + (size_t)slot * W;
+        // (validate_blob has checked that block operands name existing block ids; grow_slot_regions has given the program its
+        // blocks — a tracked block exists once a ZERO has created it: an op on one that was never created is refused here)
+        auto block_of = [&](uint32_t slot) -> const Session::DenseBlock& {
+            const Session::DenseBlock& b = s.blocks[p][(slot & ~TXQ_DENSE_SLOT_BIT) >> TXQ_DENSE_BLOCK_SHIFT];
+            if (!b.p) bad_program = (int)p;
+            return b;
         };
+        auto slot_of = [&](uint32_t slot) -> uint64_t* {
+            if (!(slot & TXQ_DENSE_SLOT_BIT)) return s.base[p] + (size_t)slot * W;
+            const Session::DenseBlock& b = block_of(slot);
+            if ((slot & TXQ_DENSE_INDEX_MASK) >= b.cap) bad_program = (int)p;
+            return b.p + (size_t)(slot & TXQ_DENSE_INDEX_MASK) * W;
+        };
+        const bool check_slots = dense && bv.tracked[p];  // ordinary ops on dense slots of tracked blocks: inside the block's capacity?
         uint32_t begin = 0;
         for (uint32_t l = 0; l < d.n_levels; ++l) {
             const uint32_t end = levels_host[d.first_level + l];
@@ -1410,21 +1505,28 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
                 uint32_t run = begin;
                 for (uint32_t i = begin; i < end; ++i) {
                     const txq_op& o = ops[d.first_op + i];
-                    if (o.kmer != TXQ_DENSE_OP) continue;
+                    if (o.kmer != TXQ_DENSE_OP) {
+                        if (check_slots)
+                            for (uint32_t operand : {o.dst, o.a, o.b})
+                                if (operand & TXQ_DENSE_SLOT_BIT) (void)slot_of(operand);
+                        continue;
+                    }
                     cut(run, i);
                     run = i + 1;
                     const txq_dense_op& x = dops[o.dst];
                     DenseOpPtr& q = (*optr)[o.dst];
-                    q.dst = x.kind == TXQ_DENSE_REDUCE ? slot_of(x.dst) : block_of(x.dst);
-                    q.src = x.kind == TXQ_DENSE_STEP || x.kind == TXQ_DENSE_REDUCE ? block_of(x.src) : x.kind == TXQ_DENSE_FILL ? slot_of(x.src) : nullptr;
+                    if (x.kind == TXQ_DENSE_REDUCE) q.dst = slot_of(x.dst);
+                    else { const Session::DenseBlock& b = block_of(x.dst); q.dst = b.p; q.dst_cap = b.cap; }
+                    if (x.kind == TXQ_DENSE_STEP || x.kind == TXQ_DENSE_REDUCE) { const Session::DenseBlock& b = block_of(x.src); q.src = b.p; q.src_cap = b.cap; }
+                    else if (x.kind == TXQ_DENSE_FILL) q.src = slot_of(x.src);
                     uint64_t shape_entries = 1;
                     for (uint32_t j = 0; j < bv.dense.pos; ++j) shape_entries *= (uint64_t)__builtin_popcount(x.shape[j]);
                     if (x.reserved & TXQ_DENSE_TRACKED) {  // work follows the block's live list (FILL: its shape)
                         const bool fixed = x.kind == TXQ_DENSE_FILL;
                         if (fixed && !shape_entries) continue;
                         sparse_level[l].push_back(SparseGroup{o.dst, fixed ? (uint32_t)shape_entries : kNotFixed});
-                        // most chunks this group can turn out to have: a list never outgrows its block, nor (STEP, REDUCE: what is read) the op's shape
-                        const uint64_t most = x.kind == TXQ_DENSE_ZERO ? N : std::min<uint64_t>(N, std::max<uint64_t>(shape_entries, 1));
+                        // most chunks this group can turn out to have: a list never outgrows its block
+                        const uint64_t most = fixed ? shape_entries : x.kind == TXQ_DENSE_ZERO ? q.dst_cap : q.src_cap;
                         sparse_chunks[l] += (size_t)((most + kSparseChunk - 1) / kSparseChunk);
                         continue;
                     }
@@ -1454,6 +1556,10 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
             begin = end;
         }
         d.n_ops = 0;  // the per-program kernel skips it
+    }
+    if (bad_program >= 0) {
+        (void)fail(TXQ_ERR_PROGRAM, "program %d: an op on a dense block that no ZERO has created, or beyond its capacity", bad_program);
+        return (size_t)-1;
     }
     plan->resize(per_level.size());
     for (size_t l = 0; l < per_level.size(); ++l) {
@@ -1571,8 +1677,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         return fail(TXQ_ERR_PROGRAM, "tracked blocks need an index whose dense steps run fused (txq_index_supports_dense() == 2)");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
-    std::vector<uint64_t*> to_clear;
-    if (int rc = grow_slot_regions(s, bv, &fresh, &moves, &to_clear)) return rc;
+    std::vector<std::pair<uint64_t*, size_t>> to_clear;
+    if (int rc = grow_slot_regions(s, bv, blob, &fresh, &moves, &to_clear)) return rc;
     s.t_grow += now_s() - t0;
     for (size_t i = 0; i < n_q; ++i)
         if (!s.base[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: program %u has not run an op yet", i, q_prog[i]);
@@ -1603,16 +1709,20 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     double t1 = now_s();
     const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
+    if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
     size_t n_sparse_launches = 0;
     for (const LevelPlan& lp : plan) n_sparse_launches += (lp.sparse + kMaxSparseGroups - 1) / kMaxSparseGroups;
-    // the stage's block table: per program with blocks a row [flags | block 0 | block 1 | ..] (DenseRow)
+    // the stage's block table: per program with blocks a row [flags | block 0 | its capacity | block 1 | ..] (DenseRow)
     std::vector<uint64_t*> block_table;
     std::vector<size_t> row_of(s.n_programs, 0);
     for (size_t p = 0; p < s.n_programs; ++p)
         if (!s.blocks[p].empty()) {
             row_of[p] = block_table.size();
             block_table.push_back(reinterpret_cast<uint64_t*>((uintptr_t)(s.tracked[p] ? 1 : 0)));
-            for (const Session::DenseBlock& b : s.blocks[p]) block_table.push_back(b.p);
+            for (const Session::DenseBlock& b : s.blocks[p]) {
+                block_table.push_back(b.p);
+                block_table.push_back(reinterpret_cast<uint64_t*>((uintptr_t)b.cap));
+            }
         }
     s.n_step_pairs += work[0]; s.n_step_suffixes += work[1]; s.n_zero_slots += work[2]; s.n_reduce_entries += work[3];
     // HIBF steps run in chunks of tiles whose masks fit the scratch (2 GiB): chunk c = tiles [chunk_first[c], chunk_first[c+1]),
@@ -1760,8 +1870,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         make_tiles_kernel<<<(unsigned)tile_groups.size(), 256, 0, st>>>((const TileGroup*)(S.d_aux + at_groups), d_tiles);
         TXQ_HIP(hipGetLastError());
     }
-    for (uint64_t* b : to_clear) {  // blocks a tracked program takes over: all zero, list empty
-        TXQ_HIP(hipMemsetAsync(b, 0, s.block_words * 8, st));
+    for (const auto& b : to_clear) {  // blocks a tracked program takes over: all zero, list empty
+        TXQ_HIP(hipMemsetAsync(b.first, 0, b.second, st));
         ++s.n_block_memsets;
     }
     if (!moves.empty()) {  // after everything earlier stages launched on the regions, before anything of this stage
@@ -1803,7 +1913,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const uint32_t np = (uint32_t)s.n_programs;
         if (n_small) {
             size_t blocks = s.n_programs < 4096 ? s.n_programs : 4096;
-#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, d_masks, W, s.block_slots)
+#define TXQ_EXEC(G) exec_kernel<G><<<(unsigned)blocks, 1024, 0, st>>>(d_progs, d_ops, d_levels, s.d_base, np, d_masks, W)
             switch (g) {
                 case 1: TXQ_EXEC(1); break;
                 case 2: TXQ_EXEC(2); break;
@@ -1831,7 +1941,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree);
             if (cnt && !ride && !ride_sparse) {
                 ++s.n_unit_launches;
-                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2, s.block_slots);
+                exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2);
             }
             s.n_units += cnt;
             // HIBF: the level's steps, chunk by chunk: k-mers of all (suffix, predecessor) pairs -> tree descent -> combine
@@ -1849,7 +1959,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 s.n_dense_tiles += c1 - c0;
             }
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
-                const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2, s.block_slots};
+                const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
                 hipError_t e;
                 if (tree) {
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
@@ -1881,9 +1991,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 const SparseGroup* gr = d_sgroups + first_sparse + off;
                 uint32_t* counts = d_scounts + first_sparse + off;
                 uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
-                sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, s.block_slots, W, counts, prefix);
+                sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, counts, prefix);
                 TXQ_HIP(hipGetLastError());
-                const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && off == 0 ? (uint32_t)cnt : 0u, g_units_log2, s.block_slots};
+                const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && off == 0 ? (uint32_t)cnt : 0u, g_units_log2};
                 // as many workgroups as the chunks could be at most, within what the device holds at a time
                 const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(plan[l].sparse_chunks, 2048));
                 hipError_t e;

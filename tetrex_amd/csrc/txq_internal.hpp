@@ -3,6 +3,7 @@
 #include "txq_kernels.hpp"
 #include "../../include/txq.h"
 #include <cstdlib>
+#include <map>
 #include <vector>
 
 namespace txq {
@@ -154,15 +155,15 @@ struct Session {
     // block table (ordinary ops on dense slots) or through the per-op pointers the host side resolves (DenseOpPtr).
     // What a block holds when it is handed on: kGarbage (fresh arena memory, or left by an untracked program),
     // kListed (left by a tracked program: all zero except the entries in its list, which is intact).
-    struct DenseBlock { uint64_t* p; uint8_t state; };
+    struct DenseBlock { uint64_t* p; uint32_t cap; uint8_t state; };  // cap: entries ([cap][W] mask words, then the live list)
     enum : uint8_t { kGarbage = 0, kListed = 1 };
-    std::vector<std::vector<DenseBlock>> blocks;  // per program
+    std::vector<std::vector<DenseBlock>> blocks;  // per program, by block id (p == nullptr: a tracked block no ZERO has created yet)
     std::vector<uint8_t> tracked;                 // per program: TXQ_PROGRAM_TRACKED_BIT (fixed with its first block)
-    std::vector<DenseBlock> free_blocks;          // blocks of finished programs, reusable ...
+    std::multimap<uint32_t, DenseBlock> free_blocks;  // blocks of finished programs by capacity, reusable ...
     // ... two stages after they were given back: the stage before the current one may still be running, on another stream
     std::vector<DenseBlock> given_back[2];
-    uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet)
-    size_t block_words = 0;         // words of one block allocation (masks + live list)
+    uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet): the capacity of untracked blocks
+    size_t block_bytes_made = 0;
     size_t n_blocks_live = 0, n_blocks_made = 0, n_block_memsets = 0, n_sparse_launches = 0, n_sparse_groups = 0;
     std::vector<uint32_t> last_stage;  // per program: the last stage (1-based) that had ops for it
     hipStream_t side = nullptr;        // a stage that continues nothing of the stage in flight runs beside it, on the other stream

@@ -127,7 +127,7 @@ def run_staged(regexes, dna, k, reduction, bins, stage, ops_per_query_per_stage=
     stage(blob: bytes, query_program: list, query_slot: list) -> iterable of answers: False/0 = the slot has no bit set,
     True/1 = alive, or 1 + floor(log2(bits set)) as txq_session_stage answers (what the expansion reads mask fills from).
     dense: None, or dict(min_states=, sparse_below=, max_blocks=, slot_bytes=, pool_bytes=, tracked=) to switch dense DP
-    steps on (the executor then gets version-3 blobs); tracked: 1 = the executor keeps live lists, 2 = every query uses them."""
+    steps on (the executor then gets version-4 blobs); tracked: 1 = the executor keeps live lists, 2 = every query uses them."""
     L = lib()
     L.txh_run_staged_dense.argtypes = [C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_uint, C.c_uint, C.c_uint64, C.c_size_t,
                                        C.c_size_t, C.POINTER(GapOptions), C.POINTER(DenseOptions), STAGE_FN, C.c_void_p,
@@ -214,11 +214,11 @@ def record_values_array(seq, k, dna=True, reduction=0, wraparound=False):
 
 
 def parse_blob(blob):
-    """Decode a txq_program.h blob (version 1, 2 or 3): (kmers uint64[], [(n_slots, ops array [n,4] =
-    kmer,dst,a,b)]).  Version-2/3 ops are in level order, which is also a valid sequential order.
-    The dense table of a version-3 blob: blob_dense()."""
+    """Decode a txq_program.h blob (version 1, 2 or 4): (kmers uint64[], [(n_slots, ops array [n,4] =
+    kmer,dst,a,b)]).  Version-2/4 ops are in level order, which is also a valid sequential order.
+    The dense table of a version-4 blob: blob_dense()."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
-    assert magic == 0x50515854 and ver in (1, 2, 3)
+    assert magic == 0x50515854 and ver in (1, 2, 4)
     if ver == 1:
         _, _, n_prog, n_kmers, n_ops, _, k_off, p_off, o_off = struct.unpack_from("<6I3Q", blob, 0)
         stride = 4
@@ -246,10 +246,10 @@ DENSE_SLOT_BIT = 0x40000000
 
 
 def blob_dense(blob):
-    """Dense part of a version-3 blob: (params dict(k, bits, alphabet, canonical), table uint32[n, 16] =
+    """Dense part of a version-4 blob: (params dict(k, bits, alphabet, canonical), table uint32[n, 16] =
     kind, dst, src, r_mask, shape[11], reserved, per-program dense slot counts); None for older versions."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
-    if ver != 3:
+    if ver != 4:
         return None
     _, _, n_prog, _, _, _, _, p_off, _, _, _, d_off, n_dense, k, bits, alphabet, canonical, _ = struct.unpack_from("<6I5QQ6I", blob, 0)
     table = np.frombuffer(blob, dtype="<u4", count=n_dense * 16, offset=d_off).reshape(n_dense, 16)
@@ -258,7 +258,7 @@ def blob_dense(blob):
 
 
 def blob_levels(blob):
-    """Level tables of a version-2/3 blob: list of per-program end-index lists."""
+    """Level tables of a version-2/4 blob: list of per-program end-index lists."""
     magic, ver = struct.unpack_from("<2I", blob, 0)
     if ver < 2:
         return None
