@@ -298,7 +298,7 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
                            "op": "all_gather of the final masks (%d x %d words per rank)" % (len(motifs), int(ix.shard_words))}} if world > 1 else {}),
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
                   "warmup": "one batch of the same size and mix from another seed", "first_batch_seconds": local["first_batch_s"],
-                  "k": k, **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
+                  "k": k, "refused_fraction": float(sum(1 for s_ in status if s_)) / len(motifs), **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
         "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
                                "failed": int(sum(1 for s in plain_status if s)), **plain_stats},
         "single_query": {"motif": single, "median_latency_ms": float(np.median(lat)) * 1e3,
@@ -363,12 +363,108 @@ def hibf_end_to_end(capi, torch, args):
         else:
             os.environ["TXQ_DENSE_TREE"] = knob
     ix.free()
+    if not (np.array_equal(best[2], ref_masks) and list(best[3]) == list(ref_status)):
+        raise SystemExit("bench: the HIBF batch gives other masks with fused dense steps than through the generic HIBF descent")
+    # ... and against the CPU oracle's HIBF (membership_for restated, oracle/txo_ibf.hpp) on the first motifs, for a few seconds
+    import oracle as O
+    ox = O.Index.hibf(user_bins, dna=False, k=4)
+    for d in descs:
+        ox.add_ibf(d["bins"], d["bin_size"], d["hash_funs"], d["next_ibf_id"], d["tb_to_user"], words=d["words"])
+    compared, t0 = 0, time.perf_counter()
+    for i, rx in enumerate(motifs):
+        try:
+            want = ox.expected_mask(rx)[0]
+        except Exception:  # noqa: BLE001 - a motif the reference path cannot search either
+            continue
+        if not np.array_equal(want, best[2][i]):
+            raise SystemExit("bench: the candidate-bin mask of %r on the HIBF differs from the CPU oracle" % rx)
+        compared += 1
+        if time.perf_counter() - t0 > 4.0:
+            break
     return {"workload": "BASELINE configs[2]: %d PROSITE-style motifs on a 1024-user-bin HIBF (16 x 64 bins, k=4, h=3, %d values per bin)" % (len(motifs), per_bin),
+            "k": 4, "oracle_masks_compared": compared, "refused_fraction": float(sum(1 for x in best[3] if x)) / len(motifs),
             "queries_per_s": len(motifs) / best[0], "seconds": best[0], "failed": int(sum(1 for x in best[3] if x)),
             "mean_candidate_bins": float(np.unpackbits(best[2].view(np.uint8), axis=1).sum(axis=1).mean()), **best[1],
             "checked_against": "the same batch with its dense steps through the generic HIBF descent (TXQ_DENSE_TREE=0)",
             "masks_identical": bool(np.array_equal(best[2], ref_masks) and list(best[3]) == list(ref_status)),
             "generic_descent_seconds": ref_dt}
+
+
+def k6_end_to_end(capi, torch, args):
+    """The reference's DEFAULT k (include/arg_parse.h:12: k = 6; the README's Swissprot scenario, README.md:84-109): a
+    1024-bin flat IBF over Swissprot-SHAPED content — per bin the 6-mers of 200 000 uniform random residues, inserted on
+    the device with the real hash (h = 3, rows for fpr 0.05) — and a batch of 200 PROSITE-style motifs with wildcards and
+    x(m,n) gaps (the batch of tests/perf_cli_swissprot_shape.py).  At k = 6 a block of suffixes has 21^5 entries of which
+    such an index keeps a few alive: the expansion keeps wildcard lists as TRACKED blocks (include/txq_program.h: live
+    lists, steps pushed from the live entries, blocks laid out inside their lists' geometries).  Checks inside this run:
+    the same batch with dense blocks switched off (TETREX_DENSE=0: every state enumerated and pruned by the host) must give
+    identical masks, and the CPU oracle is compared on the motifs it answers within its budget.  N = 1 only."""
+    from motifs import random_prosite_motifs
+    import oracle as O
+    bins, per_bin, h, k = 1024, 200000, 3, 6
+    m = compute_bitcount(per_bin, 0.05)
+    ix = capi.Index.create_ibf(bins, m, h)
+    rng = np.random.default_rng(11)
+    base_code = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19], dtype=np.uint64)  # "ACDEFGHIKLMNPQRSTVWY" in the Base alphabet
+    for b0 in range(0, bins, 64):  # 64 bins at a time: 12.8 M values
+        nb = min(64, bins - b0)
+        codes = base_code[rng.integers(0, 20, size=(nb, per_bin))]
+        vals = np.zeros((nb, per_bin - k + 1), dtype=np.uint64)
+        for j in range(k):
+            vals = (vals << np.uint64(5)) | codes[:, j:per_bin - k + 1 + j]
+        bins_of = np.repeat(np.arange(b0, b0 + nb, dtype=np.uint32), vals.shape[1])
+        dv = torch.from_numpy(vals.reshape(-1).view(np.int64)).cuda()
+        db = torch.from_numpy(bins_of.view(np.int32)).cuda()
+        ix.emplace_device(dv.data_ptr(), db.data_ptr(), vals.size, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+    motifs = random_prosite_motifs(200, 3, wildcard=0.05, ranges=0.02, min_len=8, max_len=14)
+    ix.query_masks(random_prosite_motifs(200, 4, wildcard=0.05, ranges=0.02, min_len=8, max_len=14), False, k)  # warm: arena, staging sets
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        masks, status, stats = ix.query_masks(motifs, False, k)
+        dt = time.perf_counter() - t0
+        if best is None or dt < best[0]:
+            best = (dt, stats, masks, status)
+    knob = os.environ.get("TETREX_DENSE")
+    os.environ["TETREX_DENSE"] = "0"
+    try:
+        t0 = time.perf_counter()
+        ref_masks, ref_status, ref_stats = ix.query_masks(motifs, False, k)
+        ref_dt = time.perf_counter() - t0
+    finally:
+        if knob is None:
+            del os.environ["TETREX_DENSE"]
+        else:
+            os.environ["TETREX_DENSE"] = knob
+    if not (np.array_equal(best[2], ref_masks) and list(best[3]) == list(ref_status)):
+        raise SystemExit("bench: the k = 6 batch gives other masks with tracked blocks than with enumerated states")
+    # CPU oracle on the motifs whose leading residues are fixed (it enumerates every state: a wildcard in front costs it minutes)
+    ox = O.Index.ibf(bins, m, h, dna=False, k=k)
+    ox.set_words(ix.download_words_rows(m))
+    compared, t0 = 0, time.perf_counter()
+    for i, rx in enumerate(motifs):
+        if "." in rx[:10]:
+            continue
+        try:
+            want = ox.expected_mask(rx)[0]
+        except Exception:  # noqa: BLE001 - a motif the reference path cannot search either
+            continue
+        if not np.array_equal(want, best[2][i]):
+            raise SystemExit("bench: the candidate-bin mask of %r (k = 6) differs from the CPU oracle" % rx)
+        compared += 1
+        if time.perf_counter() - t0 > 5.0:
+            break
+    cpu_dt = time.perf_counter() - t0
+    ix.free()
+    refused = int(sum(1 for x in best[3] if x))
+    return {"workload": "%d PROSITE-style motifs (5 %% wildcards, 2 %% x(m,n)) at k = 6 on a 1024-bin flat IBF of Swissprot-shaped bins "
+                        "(6-mers of %d random residues per bin, h = 3, %d rows)" % (len(motifs), per_bin, m),
+            "k": k, "queries_per_s": len(motifs) / best[0], "seconds": best[0], "refused": refused, "refused_fraction": refused / len(motifs),
+            "mean_candidate_bins": float(np.unpackbits(best[2].view(np.uint8), axis=1).sum(axis=1).mean()), **best[1],
+            "enumerated_states": {"what": "the same batch with TETREX_DENSE=0 (no blocks: states enumerated and pruned through host feedback)",
+                                  "seconds": ref_dt, "ops": ref_stats["ops"], "masks_identical": True},
+            "cpu_oracle": {"masks_compared": compared, "seconds": cpu_dt, "sample": "motifs of the batch without a wildcard among their first residues"}}
 
 
 def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
@@ -467,6 +563,7 @@ def main():
     ap.add_argument("--no-queries", action="store_true", help="skip the end-to-end queries/s leg")
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--no-hibf", action="store_true", help="skip the HIBF descent leg")
+    ap.add_argument("--no-k6", action="store_true", help="skip the k = 6 end-to-end leg (end_to_end.k6_batch)")
     ap.add_argument("--hibf-kmers", type=int, default=1 << 20)
     ap.add_argument("--hibf-per-bin", type=int, default=300)
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
@@ -622,6 +719,11 @@ def main():
                 out["end_to_end"]["hibf_batch"] = hibf_end_to_end(capi, torch, args)
             except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
                 out["end_to_end"]["hibf_batch"] = {"error": repr(e)}
+        if world == 1 and not args.no_k6 and "error" not in out["end_to_end"]:
+            try:
+                out["end_to_end"]["k6_batch"] = k6_end_to_end(capi, torch, args)
+            except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
+                out["end_to_end"]["k6_batch"] = {"error": repr(e)}
 
     ix.free()
     if not args.no_hbm_leg and not strong and cache_resident:

@@ -509,3 +509,36 @@ def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
         assert np.array_equal(g, w), q
     assert any(int(np.bitwise_or.reduce(g)) for g in got)
     ix.free()
+
+
+def test_k6_motif_batch_tracked_blocks_equal_enumerated_states(capi, oracle, monkeypatch):
+    """A batch of PROSITE-style motifs with wildcards and x(m,n) gaps at k = 6 on 1024 bins of random sequences (the shape
+    of tests/perf_cli_swissprot_shape.py, smaller): nothing is told about the index — the run asks, learns that states thin
+    out, and keeps wildcard lists as tracked blocks.  Masks identical to the run without dense blocks (every state
+    enumerated and pruned by the host), and to the oracle where it answers quickly."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "ask")
+    k = 6
+    from tetrex_amd import host as H
+    ox = oracle.Index.ibf(1024, 60013, 3, dna=False, k=k)
+    rng = np.random.default_rng(67)
+    for b in range(1024):
+        s = "".join("ACDEFGHIKLMNPQRSTVWY"[i] for i in rng.integers(0, 20, size=3000))
+        ox.emplace(H.record_values_array(s, k, dna=False), b)
+    qs = random_prosite_motifs(120, 3, wildcard=0.08, ranges=0.04, min_len=8, max_len=14)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    got, status, stats = ix.query_masks(qs, False, k, 0, 0)
+    assert stats["tracked_queries"] >= 10 and stats["dense_ops"] > 50
+    monkeypatch.setenv("TETREX_DENSE", "0")
+    plain, status0, stats0 = ix.query_masks(qs, False, k, 0, 0)
+    assert list(status) == list(status0)
+    assert np.array_equal(got, plain)
+    assert stats["ops"] * 20 < stats0["ops"]
+    compared = 0
+    for q, g, st in zip(qs, got, status):
+        if "." in q[:10] or st:
+            continue
+        assert np.array_equal(g, ox.expected_mask(q)[0]), q
+        compared += 1
+    assert compared > 30
+    ix.free()
