@@ -481,7 +481,7 @@ def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
     index keeps a few alive.  With the run told that states thin out (what it learns by asking) wildcard motifs become
     tracked blocks — a handful of ops instead of one per state and residue — and give the oracle's masks, identical to the
     run without dense blocks."""
-    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "sparse")
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "thin")
     k = 6
     ox = oracle.Index.ibf(1024, 20011, 3, dna=False, k=k)
     rng = np.random.default_rng(66)

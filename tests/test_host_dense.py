@@ -216,9 +216,9 @@ def test_a_run_of_unprobed_wildcard_states_is_one_fill(host, oracle):
 
 
 def test_sparse_evidence_turns_queries_to_tracked_blocks(host, oracle, monkeypatch):
-    """TETREX_DENSE_EVIDENCE=sparse (what a run learns on an index where states thin out) and an executor that keeps live
+    """TETREX_DENSE_EVIDENCE=thin (what a run learns on an index where states die out) and an executor that keeps live
     lists: lists become tracked blocks regardless of their shape; the same run on an executor without lists enumerates."""
-    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "sparse")
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "thin")
     ox = _index(oracle, bins=128, m=4099, h=2, k=5, dna=False, per_bin=600, seed=22)
     qs = ["LMK..A[DE]..GK", "WKL.[LIVM]D..[FY]", "CLM.{2,4}C...[LIVMFYWC]"]
     checked, with_lists, sim = _run(host, ox, qs, False, 5, dict(tracked=1))

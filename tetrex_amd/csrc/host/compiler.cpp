@@ -500,7 +500,7 @@ void QueryExpansion::decide_tracking() {
     // gigabyte, a tracked block of the same list a few hundred kilobytes — pushing from a full list costs little more than
     // pulling, allocating (and zeroing) gigabytes per query costs seconds
     const bool huge = dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128) >= ((uint64_t)64 << 20);
-    tracked_ = dense_.tracked_force > 0 || huge || (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse);
+    tracked_ = dense_.tracked_force > 0 || huge || (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kThin);
 }
 
 void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d0) {
@@ -534,7 +534,7 @@ QueryExpansion::DenseRef* QueryExpansion::owned_block(int32_t item, NodeStates& 
 uint64_t QueryExpansion::shape_limit() const {
     const double t_dev = (double)(dense_.slot_bytes ? dense_.slot_bytes : 128) / 1000.0;
     double per_state = (dense_.host_ns_per_op + t_dev) / t_dev;
-    if (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) == DenseOptions::kSparse) per_state /= 4;
+    if (dense_.evidence && dense_.evidence->load(std::memory_order_relaxed) >= DenseOptions::kSparse) per_state /= 4;
     if (per_state < 1) return 0;
     return std::min<uint64_t>((uint64_t)per_state, dense_.max_shape_per_state);
 }

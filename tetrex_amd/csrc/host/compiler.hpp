@@ -78,11 +78,13 @@ struct DenseOptions {
     // What the run knows about the index (shared by its queries; null = kDense): do the masks of probed states stay full
     // (lists saturate: blocks pay) or thin out (states die within a few residues: enumerating and pruning pays)?  While
     // it is unknown, a query pauses once at its first list that could become a block and asks (QueryExpansion::observe).
-    enum Evidence : int { kUnknown = 0, kDense = 1, kSparse = 2 };
+    // kThin: states do not just thin out, they are down to a handful of bins after their first probe (fewer than
+    // StagedOptions::thin_bits bits per probed state) — most die within a residue or two
+    enum Evidence : int { kUnknown = 0, kDense = 1, kSparse = 2, kThin = 3 };
     std::atomic<int>* evidence = nullptr;
     // Tracked (sparse) blocks (include/txq_program.h): the executor keeps a live list per block and pushes steps from the
-    // live entries only, so a block costs what its LIVING states cost.  Where the run has learned that states thin out
-    // (kSparse) a query's lists then become blocks as soon as they hold min_states states, whatever their shape —
+    // live entries only, so a block costs what its LIVING states cost.  Where the run has learned that states die out
+    // (kThin) a query's lists then become blocks as soon as they hold min_states states, whatever their shape —
     // at k = 6 a list of a few thousand states inside 21^5 suffixes.  0: the executor cannot (an HIBF whose steps are
     // not fused, a test double without lists); -1 / +1 force it off / on for every query (tests, A/B).
     bool tracked_ok = false;
@@ -352,6 +354,7 @@ struct StagedOptions {
     int dense_evidence = DenseOptions::kUnknown;  // what earlier runs learned about this index (StagedStats::dense_evidence); kUnknown: ask
     uint64_t feedback_bins = 0;              // bins the executor's answers count bits over (a column shard); 0 = all bins
     double dense_min_fill = 0.25;            // masks of probed states at least this full on average: lists saturate, blocks pay
+    double thin_bits = 16;                   // ... fewer bits than this per probed state on average: states die out (DenseOptions::kThin), tracked blocks
 };
 
 struct StagedStats {

@@ -137,7 +137,7 @@ class StagedRun {
         dense_.pool = &dense_pool_;
         evidence_.store(opt.dense_evidence);
         if (const char* e = std::getenv("TETREX_DENSE_EVIDENCE"))  // A/B knob and tests: dense / sparse / ask
-            evidence_.store(e[0] == 'd' ? DenseOptions::kDense : e[0] == 's' ? DenseOptions::kSparse : DenseOptions::kUnknown);
+            evidence_.store(e[0] == 'd' ? DenseOptions::kDense : e[0] == 's' ? DenseOptions::kSparse : e[0] == 't' ? DenseOptions::kThin : DenseOptions::kUnknown);
         dense_.evidence = &evidence_;
         wave_ops_ = opt.wave_ops;
         if (const char* e = std::getenv("TETREX_WAVE_OPS")) wave_ops_ = (size_t)std::max(0LL, std::atoll(e));  // A/B knob; 0 = one wave
@@ -513,9 +513,11 @@ class StagedRun {
         if (look && seen_states.load() >= 16) {  // a handful of states is no basis: the next stage looks again
             const double fill = std::min(1.0, (double)seen_bits.load() / ((double)seen_states.load() * (double)std::max<uint64_t>(opt_.feedback_bins ? opt_.feedback_bins : bins_, 1)));
             st_.observed_fill = fill;
-            evidence_.store(fill >= opt_.dense_min_fill ? DenseOptions::kDense : DenseOptions::kSparse);
-            if (trace_) std::fprintf(stderr, "[tetrex] masks of %llu probed states are %.1f %% full: %s\n", (unsigned long long)seen_states.load(), fill * 100,
-                                     fill >= opt_.dense_min_fill ? "lists saturate, dense steps" : "states thin out, enumerate and prune");
+            const double bits_per_state = (double)seen_bits.load() / (double)seen_states.load();
+            const int verdict = fill >= opt_.dense_min_fill ? DenseOptions::kDense : bits_per_state < opt_.thin_bits ? DenseOptions::kThin : DenseOptions::kSparse;
+            evidence_.store(verdict);
+            if (trace_) std::fprintf(stderr, "[tetrex] masks of %llu probed states are %.1f %% full (%.1f bits): %s\n", (unsigned long long)seen_states.load(), fill * 100,
+                                     bits_per_state, verdict == DenseOptions::kDense ? "lists saturate, dense steps" : verdict == DenseOptions::kThin ? "states die out, tracked blocks where the executor keeps lists" : "states thin out, fewer blocks");
         }
         lap("prune");
     }

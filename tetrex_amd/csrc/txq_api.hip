@@ -204,7 +204,12 @@ int txq_init(int n_devices, const int* device_ids) {
             return fail(TXQ_ERR_STATE, "device %d is %s; this library is built for gfx950 (MI355X) only", dev, prop.gcnArchName);
         devices.push_back(dev);
     }
-    TXQ_HIP(hipSetDevice(devices[0]));
+    for (size_t i = devices.size(); i-- > 0;) {  // load the kernels now, not inside the first query (ends on devices[0])
+        TXQ_HIP(hipSetDevice(devices[i]));
+        preload_exec_kernels();
+        preload_probe_kernels();
+        preload_hibf_kernels();
+    }
     g_devices = devices;
     return TXQ_OK;
 }

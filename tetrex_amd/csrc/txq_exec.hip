@@ -2055,6 +2055,12 @@ int session_finish(Session& s, uint64_t* d_final, hipStream_t st) {
     return TXQ_OK;
 }
 
+void preload_exec_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&gather_result_kernel));
+    (void)hipGetLastError();
+}
+
 int run_programs(Index& ix, const void* blob, size_t bytes, size_t n_programs, uint64_t* d_final, hipStream_t st) {
     Session* s = nullptr;
     if (int rc = session_begin(ix, n_programs, &s)) return rc;

@@ -924,6 +924,12 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     return true;
 }
 
+void preload_hibf_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&hibf_clamp_kernel));
+    (void)hipGetLastError();
+}
+
 int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     if (n == 0) return TXQ_OK;

@@ -185,6 +185,13 @@ struct Session {
     ~Session();
 };
 
+// The device code of a translation unit is loaded when one of its kernels is first needed — 14 ms for the executor's
+// kernels, which a single `tetrex query` would pay inside its query time.  txq_init asks for them right away (the CLI
+// calls it on a helper thread while the index file is parsed).
+void preload_exec_kernels();
+void preload_probe_kernels();
+void preload_hibf_kernels();
+
 int fail(int code, const char* fmt, ...);
 int fail_hip(hipError_t e, const char* what);
 int ensure(void** p, size_t* cap, size_t bytes);

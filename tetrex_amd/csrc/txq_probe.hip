@@ -255,6 +255,12 @@ static hipError_t launch_lpk(const IbfDev& f, const uint64_t* k, size_t n, uint6
         default: return hipErrorInvalidValue;                              \
     }
 
+void preload_probe_kernels() {
+    hipFuncAttributes a;
+    (void)hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&emplace_kernel));
+    (void)hipGetLastError();
+}
+
 hipError_t launch_probe(const IbfDev& f, const uint64_t* k, size_t n, uint64_t* m, uint64_t* a, hipStream_t s) {
     if (n == 0 || f.shard_words == 0) return hipSuccess;
     if (f.bin_size >> 32) {
