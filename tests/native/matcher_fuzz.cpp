@@ -65,16 +65,19 @@ static Gen gen(const std::string& alphabet, int depth) {
 
 // POSIX oracle: the leftmost position where anything matches, and the longest match from there; then on from its end
 static std::vector<std::pair<size_t, size_t>> longest_by_brute_force(const std::string& text, const std::regex& rx) {
+    // (FindAndConsume searches the REMAINING text as if it were the whole text: `^` holds again where a non-empty match ended)
     std::vector<std::pair<size_t, size_t>> out;
     size_t pos = 0;
+    bool fresh = false;
     while (pos <= text.size()) {
         bool found = false;
         for (size_t s = pos; s <= text.size() && !found; ++s)
             for (size_t e = text.size() + 1; e-- > s;)
                 if (std::regex_match(text.begin() + (std::ptrdiff_t)s, text.begin() + (std::ptrdiff_t)e, rx,
-                                     (s ? std::regex_constants::match_not_bol | std::regex_constants::match_prev_avail : std::regex_constants::match_default) |
+                                     (s && !(fresh && s == pos) ? std::regex_constants::match_not_bol | std::regex_constants::match_prev_avail : std::regex_constants::match_default) |
                                          (e < text.size() ? std::regex_constants::match_not_eol : std::regex_constants::match_default))) {
                     out.emplace_back(s, e - s);
+                    fresh = e > s;
                     pos = e > s ? e : s + 1;
                     found = true;
                     break;
@@ -87,12 +90,14 @@ static std::vector<std::pair<size_t, size_t>> longest_by_brute_force(const std::
 static std::vector<std::pair<size_t, size_t>> with_std(const std::string& text, const std::regex& rx) {
     std::vector<std::pair<size_t, size_t>> out;
     size_t pos = 0;
+    bool fresh = false;  // pos is where a non-empty match ended: the beginning of the text as far as the next search is concerned
     std::smatch m;
     while (pos <= text.size()) {
         if (!std::regex_search(text.begin() + (std::ptrdiff_t)pos, text.end(), m, rx,
-                               pos ? std::regex_constants::match_prev_avail : std::regex_constants::match_default)) break;
+                               pos && !fresh ? std::regex_constants::match_prev_avail : std::regex_constants::match_default)) break;
         const size_t start = pos + (size_t)m.position(0), len = (size_t)m.length(0);
         out.emplace_back(start, len);
+        fresh = len != 0;
         pos = start + (len ? len : 1);
     }
     return out;

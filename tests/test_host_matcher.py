@@ -19,15 +19,20 @@ def host():
 
 
 def _consume_loop(finditer_like, text):
-    """The FindAndConsume loop of src/query.cpp:206-216 on top of a 'first match at or after pos' function."""
-    out, pos = [], 0
+    """The FindAndConsume loop of src/query.cpp:206-216 on top of a 'first match at or after pos' function.  Each call of
+    FindAndConsume searches the REMAINING text as if it were the whole text (`^` holds at its beginning): the text is
+    cut where a non-empty match ended."""
+    out, pos, base = [], 0, 0
     while pos <= len(text):
-        m = finditer_like(text, pos)
+        m = finditer_like(text[base:], pos - base)
         if m is None:
             break
-        s, e = m
+        s, e = m[0] + base, m[1] + base
         out.append((s, e - s))
-        pos = e if e > s else s + 1
+        if e > s:
+            pos = base = e
+        else:
+            pos = s + 1
     return out
 
 
@@ -40,9 +45,11 @@ def test_leftmost_first_equals_pythons_re_on_the_readme_and_prosite_motifs(host)
     for rx, text in cases:
         pat = re.compile("(" + rx + ")")
         want = _consume_loop(lambda t, pos: (lambda m: m.span() if m else None)(pat.search(t, pos)), text)
-        # Python's `^` with a start offset still means position 0, like a search in the remaining input would NOT — the
-        # reference consumes the input, so `^` can only ever match at the very beginning: same thing for these cases
         assert host.regex_find_all("(" + rx + ")", text, posix=False) == want, rx
+    # the reference consumes the input: what is left after a match is a text of its own, `^` holds at its beginning
+    assert host.regex_find_all("(^M.K)", "MAKMAKXMAK", posix=False) == [(0, 3), (3, 3)]
+    assert host.regex_find_all("(^M.K)", "MAKMAKXMAK", posix=True) == [(0, 3), (3, 3)]
+    assert host.regex_find_all("(^AC|GT)", "ACACGTACGT", posix=False) == [(0, 2), (2, 2), (4, 2), (6, 2), (8, 2)]
 
 
 def test_leftmost_longest_differs_from_leftmost_first_where_it_should(host):

@@ -191,6 +191,7 @@ Matcher::Matcher(const std::string& pattern, Semantics semantics) : semantics_(s
     };
     build(false, fwd_);
     build(true, rev_);
+    for (const Inst& in : fwd_.inst) has_begin_ = has_begin_ || in.op == kBegin;
 }
 
 // epsilon closure of `seeds` in priority order: the Char and Match instructions reachable without consuming a byte
@@ -306,48 +307,52 @@ void Matcher::match_starts(std::string_view text, Cache& c) const {
     }
 }
 
-size_t Matcher::match_end(std::string_view text, size_t start, Cache& c) const {
-    if (semantics_ == Semantics::LeftmostFirst) return pike_end(text, start, c);
+size_t Matcher::match_end(std::string_view text, size_t start, Cache& c, bool at_begin, bool* matched) const {
+    if (semantics_ == Semantics::LeftmostFirst) return pike_end(text, start, c, at_begin, matched);
     Cache::Dfa& d = c.fwd;
     if (d.sets.size() > 20000) d = Cache::Dfa{};
     if (!d.ready) dfa_init(fwd_, false, d, c);
     const size_t n = text.size();
     const unsigned char* t = reinterpret_cast<const unsigned char*>(text.data());
-    uint32_t state = start == 0 ? d.start_begin : d.start_mid;
+    uint32_t state = at_begin ? d.start_begin : d.start_mid;
     size_t last = start;
+    bool any = false;
     for (size_t pos = start; state != kDead; ++pos) {
         const uint8_t f = d.flags[state];
-        if ((f & 1) || (pos == n && (f & 2))) last = pos;
+        if ((f & 1) || (pos == n && (f & 2))) { last = pos; any = true; }
         if (pos == n) break;
         const uint32_t cls = class_of_[t[pos]];
         uint32_t to = d.next[(size_t)state * n_classes_ + cls];
         if (to == kUnknown) to = dfa_step(fwd_, d, state, cls, c);
         state = to;
     }
+    if (matched) *matched = any;
     return last;
 }
 
 // Pike VM anchored at `start`: threads in priority order (alternatives left to right, quantifiers greedy); the match of the
 // highest-priority thread that reaches Match wins, and cuts off everything of lower priority (RE2 default / Perl semantics).
-size_t Matcher::pike_end(std::string_view text, size_t start, Cache& c) const {
+size_t Matcher::pike_end(std::string_view text, size_t start, Cache& c, bool at_begin, bool* matched) const {
     const Prog& p = fwd_;
     const size_t n = text.size();
     std::vector<uint32_t>& cur = c.clist;
     std::vector<uint32_t>& nxt = c.nlist;
     std::vector<uint32_t> seeds{p.start};
-    closure(p, seeds, start == 0, start == n, cur, c);
+    closure(p, seeds, at_begin, start == n, cur, c);
     size_t last = start;
+    bool any = false;
     for (size_t pos = start;; ++pos) {
         seeds.clear();
         for (uint32_t pc : cur) {
             const Inst& in = p.inst[pc];
-            if (in.op == kMatch) { last = pos; break; }  // lower-priority threads are cut off
+            if (in.op == kMatch) { last = pos; any = true; break; }  // lower-priority threads are cut off
             if (pos < n && ((sets_[in.x][(unsigned char)text[pos] >> 6] >> ((unsigned char)text[pos] & 63)) & 1)) seeds.push_back(in.y);
         }
         if (pos >= n || seeds.empty()) break;
         closure(p, seeds, false, pos + 1 == n, nxt, c);
         cur.swap(nxt);
     }
+    if (matched) *matched = any;
     return last;
 }
 

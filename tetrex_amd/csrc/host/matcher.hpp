@@ -52,16 +52,30 @@ class Matcher {
     };
 
     // successive non-overlapping matches, each searched in what the previous one left (the FindAndConsume loop of
-    // src/query.cpp:206-216); fn(start, length)
+    // src/query.cpp:206-216); fn(start, length).  FindAndConsume hands RE2 the REMAINING text as the whole text, so `^`
+    // holds again right behind a (non-empty) match: `^M.K` finds MAK twice in MAKMAK.  The starts are collected with `^` at
+    // the record's beginning only; where the pattern has a `^`, the position a match ended at is tried under that rule first.
     template <class Fn>
     void find_all(std::string_view text, Cache& cache, Fn&& fn) const {
         match_starts(text, cache);
         size_t pos = 0;
-        for (size_t i = cache.starts.size(); i-- > 0;) {  // starts are collected right to left
-            const size_t s = cache.starts[i];
-            if (s < pos) continue;
-            const size_t e = match_end(text, s, cache);
+        bool fresh_begin = false;  // `pos` is where a non-empty match ended: the beginning of what FindAndConsume searches next
+        size_t i = cache.starts.size();  // starts are collected right to left
+        for (;;) {
+            size_t s, e;
+            bool found = false;
+            if (has_begin_ && fresh_begin && pos <= text.size()) {
+                e = match_end(text, pos, cache, true, &found);
+                s = pos;
+            }
+            if (!found) {
+                while (i > 0 && cache.starts[i - 1] < pos) --i;
+                if (i == 0) return;
+                s = cache.starts[--i];
+                e = match_end(text, s, cache, s == 0 || (fresh_begin && s == pos));
+            }
             fn(s, e - s);
+            fresh_begin = e > s;
             pos = e > s ? e : s + 1;
         }
     }
@@ -78,6 +92,7 @@ class Matcher {
         uint32_t unanchored = 0;  // entry behind a leading any-byte loop
     };
     Semantics semantics_;
+    bool has_begin_ = false;                     // the pattern has a `^`
     std::vector<std::array<uint64_t, 4>> sets_;  // byte sets of the pattern
     std::array<uint8_t, 256> class_of_{};        // byte -> equivalence class
     std::vector<std::vector<uint8_t>> set_has_class_;  // [set][class]
@@ -85,8 +100,9 @@ class Matcher {
     Prog fwd_, rev_;
 
     void match_starts(std::string_view text, Cache& cache) const;
-    size_t match_end(std::string_view text, size_t start, Cache& cache) const;
-    size_t pike_end(std::string_view text, size_t start, Cache& cache) const;
+    // end of the match that starts at `start` (at_begin: `^` holds there); *matched = is there one at all
+    size_t match_end(std::string_view text, size_t start, Cache& cache, bool at_begin, bool* matched = nullptr) const;
+    size_t pike_end(std::string_view text, size_t start, Cache& cache, bool at_begin, bool* matched) const;
     // DFA plumbing
     void dfa_init(const Prog& p, bool unanchored, Cache::Dfa& d, Cache& c) const;
     uint32_t dfa_state(const Prog& p, Cache::Dfa& d, std::vector<uint32_t>& seeds, bool at_begin, Cache& c) const;
