@@ -4,6 +4,11 @@ CXX     ?= g++
 ARCH    ?= gfx950
 CSRC    := tetrex_amd/csrc
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function
+# `make EXPERIMENTS=1` (after `make clean`): timing experiments that deliberately compute WRONG masks (TXQ_HIBF_STORE bits 4/5,
+# tools/ab_hibf*.sh) are compiled in.  The product build does not contain them.
+ifdef EXPERIMENTS
+HIPFLAGS += -DTXQ_EXPERIMENTS
+endif
 HIP_SRCS := $(CSRC)/txq_api.hip $(CSRC)/txq_probe.hip $(CSRC)/txq_hibf.hip $(CSRC)/txq_exec.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)
 HIP_HDRS := $(wildcard $(CSRC)/*.hpp) include/txq.h include/txq_program.h

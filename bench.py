@@ -44,6 +44,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def usable_cpus():
+    """CPUs this process (and its sibling ranks) may use: affinity mask and the container's CPU quota (cgroup v2 cpu.max,
+    v1 cpu.cfs_quota_us) — whichever is smaller."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cpus = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cpus = min(cpus, max(1, round(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                cpus = min(cpus, max(1, round(q / p)))
+        except (OSError, ValueError):
+            pass
+    return cpus
+
+
 def splitmix64(seed, n, start=0):
     with np.errstate(over="ignore"):
         x = np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) + np.uint64(start)) * np.uint64(0x9E3779B97F4A7C15)
@@ -594,10 +616,7 @@ def main():
     args.coll_device = "cpu" if args.rehearse_single_device else "cuda"
     if world > 1:
         # the ranks of a node share its CPUs: each rank's expansion threads = its share (at most 16, at least 2)
-        try:
-            cpus = len(os.sched_getaffinity(0))
-        except AttributeError:
-            cpus = os.cpu_count() or 1
+        cpus = usable_cpus()
         os.environ.setdefault("TETREX_THREADS", str(max(2, min(16, cpus // world))))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_single_device:

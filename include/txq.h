@@ -39,6 +39,19 @@ extern "C" {
 
 #define TXQ_VERSION 1
 
+/* Environment variables.  Every one selects between code paths that give the SAME results (A/B measurements, tests that
+ * run one input through every path); none is needed in production.  They are read at txq_init, txq_index_upload,
+ * txq_session_begin, txq_run_programs* and txq_probe* — never while a stage runs — and a session keeps the values it began with.
+ *   TXQ_TRACE, TXQ_TRACE_STAGES, TXQ_TRACE_SYNC      timers and per-stage notes on stderr
+ *   TXQ_DENSE_TREE=0|1|2                              dense steps on a regular HIBF: generic descent | TreeRows | TreeRowsByLane
+ *   TXQ_DENSE_UNROLL, TXQ_DENSE_SLICES, TXQ_DENSE_TILE_ROUNDS   shape of a dense step's tiles
+ *   TXQ_FUSE_UNITS=0, TXQ_ONE_STREAM                  one launch per kind and level; no second stream
+ *   TXQ_HIBF_INTERLEAVE=0, TXQ_HIBF_INTERLEAVE_PROBE=0, TXQ_HIBF_LEVELS=1, TXQ_HIBF_STATIONARY=0, TXQ_HIBF_SMALL=0,
+ *   TXQ_HIBF_LANE_HASH, TXQ_HIBF_STEPS_PER_GROUP, TXQ_HIBF_TILE, TXQ_HIBF_UNROLL, TXQ_HIBF_STORE_KIND, TXQ_HIBF_WAVES
+ *                                                     which HIBF descent kernel runs, and its tiling
+ *   TXQ_PROBE_BLOCKS_PER_CU, TXQ_PROBE_UNROLL, TXQ_PROBE_NT   grid and variant of the flat probe kernel
+ * (tests/test_gpu_knobs.py runs a workload under each of them against the oracle.) */
+
 typedef enum {
     TXQ_OK = 0,
     TXQ_ERR_ARG = -1,      /* invalid argument / inconsistent descriptor            */

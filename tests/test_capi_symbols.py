@@ -41,3 +41,16 @@ def test_header_cites_reference_seams():
     for cite in ["include/index_base.h:104-107", "include/index_ibf.h:146-150", "include/index_hibf.h:132-147",
                  "include/otf_collector.h:341-393"]:
         assert cite in text
+
+
+def test_product_library_has_no_result_changing_experiment_switch():
+    """TXQ_HIBF_STORE bits 4/5 (no row gathers / no stores: wrong masks, for timing experiments) are compiled only with
+    -DTXQ_EXPERIMENTS (`make EXPERIMENTS=1`, tools/ab_hibf*.sh); the product library does not know the variable at all.
+    Every variable it does read is listed in include/txq.h."""
+    lib = open(os.path.join(ROOT, "tetrex_amd", "libtxq.so"), "rb").read()
+    names = set(m.decode() for m in re.findall(rb"TXQ_[A-Z0-9_]{3,}", lib))
+    assert "TXQ_HIBF_STORE" not in names and "TXQ_HIBF_STORE_KIND" in names
+    header = open(os.path.join(ROOT, "include", "txq.h")).read()
+    knobs = {n for n in names if not n.startswith("TXQ_ERR") and n not in ("TXQ_OK", "TXQ_HIP")}
+    missing = sorted(n for n in knobs if n not in header)
+    assert not missing, missing

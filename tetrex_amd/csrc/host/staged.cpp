@@ -24,6 +24,7 @@
 #include <future>
 #include <memory>
 #include <stdexcept>
+#include <sched.h>
 #include <thread>
 
 namespace tetrex {
@@ -37,7 +38,39 @@ bool env_is(const char* name, char value) {
     return e && e[0] == value;
 }
 
-// default: the hardware threads, but at most 16 — one GPU's CPU share on a multi-GPU node
+// CPUs this process may actually use: the hardware threads, its affinity mask, and the container's CPU quota
+// (cgroup v2 cpu.max / v1 cpu.cfs_quota_us) — 8 ranks of a node that each start "all hardware threads" would
+// oversubscribe it eight times
+int usable_cpus() {
+    int n = (int)std::thread::hardware_concurrency();
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) {
+        const int a = CPU_COUNT(&set);
+        if (a > 0 && (n <= 0 || a < n)) n = a;
+    }
+    auto read_two = [](const char* path, double* a, double* b) {
+        std::FILE* f = std::fopen(path, "r");
+        if (!f) return 0;
+        char x[64] = {0}, y[64] = {0};
+        const int got = std::fscanf(f, "%63s %63s", x, y);
+        std::fclose(f);
+        if (got >= 1) *a = std::strcmp(x, "max") == 0 ? -1.0 : std::atof(x);
+        if (got >= 2) *b = std::atof(y);
+        return got;
+    };
+    double quota = -1, period = 100000;
+    if (read_two("/sys/fs/cgroup/cpu.max", &quota, &period) < 1) {
+        double q = -1, p = 100000, unused = 0;
+        if (read_two("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", &q, &unused) >= 1 && read_two("/sys/fs/cgroup/cpu/cpu.cfs_period_us", &p, &unused) >= 1) { quota = q; period = p; }
+    }
+    if (quota > 0 && period > 0) {
+        const int c = (int)(quota / period + 0.5);
+        if (c >= 1 && (n <= 0 || c < n)) n = c;
+    }
+    return n < 1 ? 1 : n;
+}
+
+// default: the CPUs this process may use, but at most 16 — one GPU's CPU share on a multi-GPU node
 // (override with StagedOptions::threads or the TETREX_THREADS environment variable)
 int expansion_threads(const StagedOptions& opt, size_t n_queries) {
     int threads = opt.threads;
@@ -45,7 +78,7 @@ int expansion_threads(const StagedOptions& opt, size_t n_queries) {
         if (const char* env = std::getenv("TETREX_THREADS")) threads = std::atoi(env);
     }
     if (threads <= 0) {
-        threads = (int)std::thread::hardware_concurrency();
+        threads = usable_cpus();
         if (threads > 16) threads = 16;
     }
     if (threads < 1) threads = 1;

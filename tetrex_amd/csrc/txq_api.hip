@@ -4,6 +4,7 @@
 #include "../../include/txq.h"
 #include "txq_internal.hpp"
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -15,6 +16,44 @@ namespace txq {
 
 static thread_local std::string g_err;
 static std::vector<int> g_devices;  // txq_init: shard r of an index lives on g_devices[r % size]
+
+static Knobs g_knobs;
+const Knobs& knobs() { return g_knobs; }
+void read_knobs() {
+    auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
+    auto is = [](const char* name, char c) { const char* e = std::getenv(name); return e && e[0] == c; };
+    auto num = [](const char* name, long long otherwise) { const char* e = std::getenv(name); return e && *e ? std::atoll(e) : otherwise; };
+    Knobs k;
+    k.trace = flag("TXQ_TRACE");
+    k.trace_stages = flag("TXQ_TRACE_STAGES");
+    k.trace_sync = flag("TXQ_TRACE_SYNC");
+    k.dense_tree = (int)num("TXQ_DENSE_TREE", -1);
+    k.dense_unroll = (int)num("TXQ_DENSE_UNROLL", 3);
+    k.dense_slices = (int)std::max(1LL, num("TXQ_DENSE_SLICES", 2));
+    k.dense_tile_rounds = (int)std::max(1LL, num("TXQ_DENSE_TILE_ROUNDS", 2));
+    k.fuse_units = !is("TXQ_FUSE_UNITS", '0');
+    k.one_stream = flag("TXQ_ONE_STREAM");
+    k.hibf_interleave = !is("TXQ_HIBF_INTERLEAVE", '0');
+    k.hibf_interleave_probe = !is("TXQ_HIBF_INTERLEAVE_PROBE", '0');
+    k.hibf_levels = is("TXQ_HIBF_LEVELS", '1');
+    k.hibf_stationary = !is("TXQ_HIBF_STATIONARY", '0');
+    k.hibf_small = !is("TXQ_HIBF_SMALL", '0');
+    k.hibf_lane_hash = flag("TXQ_HIBF_LANE_HASH");
+    k.hibf_steps_per_group = (int)std::max(0LL, num("TXQ_HIBF_STEPS_PER_GROUP", 0));
+    k.hibf_tile = (int)std::max(0LL, num("TXQ_HIBF_TILE", 0));
+    k.hibf_unroll = (int)num("TXQ_HIBF_UNROLL", 1);
+    k.hibf_store = (int)num("TXQ_HIBF_STORE_KIND", 0) & 3;  // which store instruction writes the rows
+#ifdef TXQ_EXPERIMENTS
+    // timing experiments of tools/ab_hibf*.sh (`make EXPERIMENTS=1`): bit 4 no row gathers, bit 5 (almost) no stores — WRONG masks,
+    // which is why the product build does not contain them
+    k.hibf_store |= (int)num("TXQ_HIBF_STORE", 0) & 48;
+#endif
+    k.hibf_waves = std::max(0LL, num("TXQ_HIBF_WAVES", 0));
+    k.probe_blocks_per_cu = (int)std::max(1LL, num("TXQ_PROBE_BLOCKS_PER_CU", 256));
+    k.probe_unroll = (int)num("TXQ_PROBE_UNROLL", 2);
+    k.probe_nt = flag("TXQ_PROBE_NT");
+    g_knobs = k;
+}
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -186,6 +225,7 @@ int txq_device_count(void) {
 }
 
 int txq_init(int n_devices, const int* device_ids) {
+    read_knobs();
     if (n_devices < 1 || n_devices > 64) return fail(TXQ_ERR_ARG, "n_devices must be 1..64 (got %d)", n_devices);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
@@ -220,6 +260,7 @@ int txq_shutdown(void) {
 }
 
 int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out) {
+    read_knobs();
     if (int rc = require_init()) return rc;
     if (!desc || !out || !desc->ibf || desc->n_ibf == 0) return fail(TXQ_ERR_ARG, "null descriptor");
     if (n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) return fail(TXQ_ERR_ARG, "bad shard %d/%d", shard_rank, n_shards);
@@ -305,6 +346,7 @@ int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
 }
 
 int txq_index_supports_dense(const txq_index* ix) {
+    read_knobs();
     if (!ix || ix->ibf.empty() || ix->shard_words == 0) return 0;
     if (!ix->is_hibf) return (ix->ibf[0].bin_size >> 32) == 0 ? 2 : 0;
     return index_fuses_tree_steps(*ix) ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
@@ -345,6 +387,7 @@ int txq_index_download_words(const txq_index* ix, uint64_t* words, size_t n_word
 }
 
 int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, void* stream) {
+    read_knobs();
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(ix)) return rc;
     if (!ix || (n && (!d_kmers || !d_masks))) return fail(TXQ_ERR_ARG, "null argument");
@@ -441,6 +484,7 @@ int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* 
 }
 
 int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final_masks, void* stream) {
+    read_knobs();
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(ix)) return rc;
     if (!ix || !blob || (n_programs && !d_final_masks)) return fail(TXQ_ERR_ARG, "null argument");
@@ -448,6 +492,7 @@ int txq_run_programs_device(txq_index* ix, const void* blob, size_t blob_bytes, 
 }
 
 int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* final_masks) {
+    read_knobs();
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(ix)) return rc;
     if (!ix || !blob || (n_programs && !final_masks)) return fail(TXQ_ERR_ARG, "null argument");
@@ -460,6 +505,7 @@ int txq_run_programs(txq_index* ix, const void* blob, size_t blob_bytes, size_t 
 }
 
 int txq_session_begin(txq_index* ix, size_t n_programs, txq_session** out) {
+    read_knobs();
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(ix)) return rc;
     if (!ix || !out) return fail(TXQ_ERR_ARG, "null argument");

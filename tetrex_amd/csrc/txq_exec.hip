@@ -1246,17 +1246,17 @@ static double now_s() {
 }
 
 Session::~Session() {
-    if (std::getenv("TXQ_TRACE"))
+    if (kn.trace)
         fprintf(stderr, "[txq] session: %zu programs, %zu stages, %.1f MB uploaded, %.1f MB of slots; validate %.3f s, upload %.3f s, device+sync %.3f s; "
                         "(regions %.3f, plan %.3f, wait for the staging set %.3f, buffers %.3f) "
                         "%zu levels, %zu unit launches (%zu units), %zu dense launches (%zu tiles), step rows: %s\n",
                 n_programs, n_stages, bytes_uploaded / 1e6, arena_words * 8 / 1e6, t_validate, t_upload, t_device, t_grow, t_plan, t_wait, t_alloc, n_levels, n_unit_launches, n_units,
                 n_dense_launches, n_dense_tiles, row_source);
-    if (std::getenv("TXQ_TRACE") && n_step_pairs)
+    if (kn.trace && n_step_pairs)
         fprintf(stderr, "[txq]   dense work: %llu predecessor visits for %llu destination suffixes, %llu slots zeroed, %llu entries reduced; mask %u words\n",
                 (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
-    if (std::getenv("TXQ_TRACE") && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
-    if (std::getenv("TXQ_TRACE") && n_blocks_made + n_block_memsets)
+    if (kn.trace && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
+    if (kn.trace && n_blocks_made + n_block_memsets)
         fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all), %zu cleared for tracked programs; %zu sparse launches (%zu groups)\n", n_blocks_made,
                 block_bytes_made / 1e6, n_block_memsets, n_sparse_launches, n_sparse_groups);
     if (aux) --aux->open_sessions;
@@ -1311,6 +1311,7 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     Session* s = new (std::nothrow) Session();
     if (!s) return fail(TXQ_ERR_NOMEM, "out of host memory");
     s->ix = &ix;
+    s->kn = knobs();
     ++ix.open_sessions;
     s->n_programs = n_programs;
     s->W = (uint32_t)ix.shard_words;
@@ -1466,8 +1467,7 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
     std::vector<std::vector<SparseGroup>> sparse_level;
     std::vector<size_t> sparse_chunks;
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
-    static const uint32_t tile_rounds = std::getenv("TXQ_DENSE_TILE_ROUNDS") ? std::max(1, std::atoi(std::getenv("TXQ_DENSE_TILE_ROUNDS"))) : 2;
-    const uint32_t step_tile = tile_rounds * (256 / (G_dense ? G_dense : 1));
+    const uint32_t step_tile = (uint32_t)s.kn.dense_tile_rounds * (256 / (G_dense ? G_dense : 1));
     size_t n_small = 0;
     int bad_program = -1;
     for (size_t p = 0; p < bv.programs.size(); ++p) {
@@ -1587,11 +1587,10 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
 
 // rows_of(H) makes the kernel's row source for H hash functions (FlatRows / TreeRows)
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
-static hipError_t launch_dense(uint32_t hash_funs, MAKE rows_of, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, const DenseOpPtr* optr,
+static hipError_t launch_dense(int ua, uint32_t hash_funs, MAKE rows_of, const DenseTile* tiles, size_t n_tiles, const txq_dense_op* dops, const DenseOpPtr* optr,
                                uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G, uint32_t SL, const DenseParams& P, const LevelUnits& U, hipStream_t st) {
     const size_t grid = n_tiles + U.n_units;
-    // predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
-    static const int ua = std::getenv("TXQ_DENSE_UNROLL") ? std::atoi(std::getenv("TXQ_DENSE_UNROLL")) : 3;
+    // ua: predecessors in flight per lane (TXQ_DENSE_UNROLL: A/B knob)
 #define TXQ_DENSE(H) \
     do { \
         ROWS<H, WIDE> rows{}; \
@@ -1685,16 +1684,16 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
     if (any_dense) s.row_source = tree ? "regular tree, fused" : ix.is_hibf ? "HIBF descent" : "flat IBF, fused";
-    if (any_dense && tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && !std::getenv("TXQ_DENSE_TREE"))
+    if (any_dense && tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && s.kn.dense_tree < 0)
         s.row_source = "regular tree, interleaved children, fused";
-    const char* tree_knob = std::getenv("TXQ_DENSE_TREE");  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; default: best fit
-    const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && !tree_knob;
+    const int tree_knob = s.kn.dense_tree;  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; -1 (default): best fit
+    const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && tree_knob < 0;
     const bool wide = W % 2 == 0 && (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0);
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
     // 1 / 2 / 4 / 8 slices took 34 / 30 / 34 / 44+ ms end to end: more slices shorten a tile's load chain but multiply the tiles)
-    static const uint32_t want_slices = std::getenv("TXQ_DENSE_SLICES") ? (uint32_t)std::atoi(std::getenv("TXQ_DENSE_SLICES")) : 2u;
+    const uint32_t want_slices = (uint32_t)s.kn.dense_slices;
     uint32_t sl_dense = 1;
     while (sl_dense * 2 <= want_slices && g_dense * sl_dense * 2 <= 64) sl_dense <<= 1;
     std::vector<ExecUnit> units;
@@ -1856,13 +1855,13 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     s.t_upload += now_s() - t0;
     t0 = now_s();
 
-    const bool one_stream = std::getenv("TXQ_ONE_STREAM") != nullptr;  // A/B knob (read per stage: tests flip it)
+    const bool one_stream = s.kn.one_stream;  // A/B knob
     const Index::StagingSet& prev = s.set[s.n_stages & 1];
     const bool beside = !continues && moves.empty() && hsteps.empty() && prev.pending && s.n_stages > 1 && !one_stream;
     const int which = beside ? 1 - s.stream_of_last : s.stream_of_last;
     s.stream_of_last = which;
     if (beside) ++s.n_beside;
-    if (std::getenv("TXQ_TRACE_STAGES"))
+    if (s.kn.trace_stages)
         fprintf(stderr, "[txq] stage %zu: continues %d (questions %zu), moves %zu, previous pending %d -> stream %d\n", s.n_stages, (int)continues, n_q, moves.size(),
                 (int)prev.pending, which);
     hipStream_t st = which ? s.side : caller_stream;
@@ -1906,7 +1905,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         const int g_units = g < 256 ? g : 256;
         uint32_t g_units_log2 = 0;
         while ((1 << g_units_log2) < g_units) ++g_units_log2;
-        const bool fuse_units = !(std::getenv("TXQ_FUSE_UNITS") && std::getenv("TXQ_FUSE_UNITS")[0] == '0');  // A/B knob
+        const bool fuse_units = s.kn.fuse_units;  // A/B knob
         const txq_op* d_ops = (const txq_op*)(dblob + h->ops_offset);
         const uint32_t* d_levels = h->n_levels ? (const uint32_t*)(dblob + h->levels_offset) : nullptr;
         const txq_dense_op* d_dops = h->n_dense ? (const txq_dense_op*)(dblob + h->dense_offset) : nullptr;
@@ -1964,21 +1963,21 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 if (tree) {
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
-                    const bool by_lane = (256u / (g_dense * sl_dense)) * 32u * ix.root_node.stride() <= kRootWordsLds && !(tree_knob && tree_knob[0] == '1');
+                    const bool by_lane = (256u / (g_dense * sl_dense)) * 32u * ix.root_node.stride() <= kRootWordsLds && tree_knob != 1;
                     if (interleaved) {
                         auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_dense<true, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, InterleavedRows>(ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, InterleavedRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, InterleavedRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_il, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                     } else if (by_lane)
-                        e = wide ? launch_dense<true, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, TreeRowsByLane>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, TreeRowsByLane>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRowsByLane>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                     else
-                        e = wide ? launch_dense<true, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                                 : launch_dense<false, TreeRows>(ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                        e = wide ? launch_dense<true, TreeRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                                 : launch_dense<false, TreeRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 } else {  // (an irregular HIBF only has ZERO / REDUCE tiles here: its steps are `hsteps`)
                     auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                    e = wide ? launch_dense<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
-                             : launch_dense<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                    e = wide ? launch_dense<true, FlatRows>(s.kn.dense_unroll, ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                             : launch_dense<false, FlatRows>(s.kn.dense_unroll, ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 }
                 if (e != hipSuccess) return fail_hip(e, "dense kernel launch");
                 first_tile += plan[l].tiles;
@@ -2030,8 +2029,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     }
     TXQ_HIP(hipEventRecord(S.done, st));
     S.pending = true;
-    static const bool trace_sync = std::getenv("TXQ_TRACE_SYNC") != nullptr;  // charges the device time to the stage that caused it
-    if (trace_sync) (void)hipStreamSynchronize(st);
+    if (s.kn.trace_sync)  // charges the device time to the stage that caused it (void)hipStreamSynchronize(st);
     s.t_device += now_s() - t0;
     return TXQ_OK;
 }

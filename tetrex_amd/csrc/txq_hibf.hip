@@ -513,7 +513,11 @@ __global__ __launch_bounds__(256) void hibf_children_kernel(const ChildRec* __re
 #pragma unroll
                     for (uint32_t j = 0; j < 5; ++j) seeded[j] = j < h_max ? v * kSeeds[j] : 0;
                 }
-                hit[u] = valid && ((cmw[i * cm_words] >> (tb & 63u)) & 1u) && !(store_flavour & 16);  // bit 4: timing experiment, no row gathers
+#ifdef TXQ_EXPERIMENTS
+                hit[u] = valid && ((cmw[i * cm_words] >> (tb & 63u)) & 1u) && !(store_flavour & 16);  // bit 4: timing experiment, no row gathers (wrong masks)
+#else
+                hit[u] = valid && ((cmw[i * cm_words] >> (tb & 63u)) & 1u);
+#endif
 #pragma unroll
                 for (uint32_t j = 0; j < 5; ++j) {
                     if (j >= h_max) continue;
@@ -535,7 +539,11 @@ __global__ __launch_bounds__(256) void hibf_children_kernel(const ChildRec* __re
                     for (uint32_t j = 1; j < 5; ++j) if (j < h_max) acc &= x[u][j];
                 }
                 const size_t i = i0 + u < last ? i0 + u : last - 1;
-                if (valid && (!(store_flavour & 32) || (acc.x == 0x12345u && acc.y == 0x54321u)))  // bit 5: timing experiment, (almost) no stores
+#ifdef TXQ_EXPERIMENTS
+                if (valid && (!(store_flavour & 32) || (acc.x == 0x12345u && acc.y == 0x54321u)))  // bit 5: timing experiment, (almost) no stores (wrong masks)
+#else
+                if (valid)
+#endif
                     store_row16(reinterpret_cast<hu32x4*>(out + i * w_out), acc, store_flavour & 15);
                 if (alive) {
                     const bool some = __ballot((acc.x | acc.y | acc.z | acc.w) != 0u) != 0;
@@ -755,8 +763,7 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
             ix.root_node.bins = root.bins;
             ix.tree_hash_max = 1;
             for (const IbfDev& f : ix.ibf) ix.tree_hash_max = std::max(ix.tree_hash_max, f.hash_funs);
-            const char* il = std::getenv("TXQ_HIBF_INTERLEAVE");  // A/B knob: 0 = never
-            if (ix.children_uniform && root.bins <= 64 && ix.shard_words <= 32 && !(il && il[0] == '0')) {
+            if (ix.children_uniform && root.bins <= 64 && ix.shard_words <= 32 && knobs().hibf_interleave) {  // (TXQ_HIBF_INTERLEAVE=0: never)
                 const IbfDev& c0 = ix.ibf[by_column[ix.shard_word0 / wpr]];
                 IbfDev f{};
                 f.bin_size = c0.bin_size;
@@ -807,29 +814,28 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2;
     const size_t wave_bytes = wave_words * 8;
     const size_t lds_budget = 64u << 10;
-    const char* force = std::getenv("TXQ_HIBF_LEVELS");
-    if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || (force && force[0] == '1')) return false;
+    const Knobs& kn = knobs();
+    if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || kn.hibf_levels) return false;
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
     const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_descend, ix.d_merged_off, (const HibfNode*)ix.d_nodes, (uint32_t)ix.hibf_total_tbs};
     *rc = TXQ_OK;
     // regular two-level trees: the children stay put in L2, the k-mers stream past (TXQ_HIBF_STATIONARY=0: A/B against the kernels below)
     {
-        const char* off = std::getenv("TXQ_HIBF_STATIONARY");
         // (narrow masks, <= 16 words, are better off with one lane per k-mer: hibf_small_kernel)
-        if (ix.d_children && ix.n_children && ix.child_row_words >= 2 && w_out > 16 && !(off && off[0] == '0')) {
+        if (ix.d_children && ix.n_children && ix.child_row_words >= 2 && w_out > 16 && kn.hibf_stationary) {
             const uint32_t wpr = ix.child_row_words, lpc = wpr / 2, cps = 64 / lpc;
             const uint32_t n_steps = (ix.n_children + cps - 1) / cps;
             // a group = whole wave steps whose children fit ~2 MB (half an XCD's L2); at least 8 groups when there are 8 steps
             const uint64_t per_step = ix.children_bytes / n_steps + 1;
             uint32_t spg = (uint32_t)std::max<uint64_t>(1, ((uint64_t)2 << 20) / per_step);
             if (n_steps >= 8 && (n_steps + spg - 1) / spg < 8) spg = n_steps / 8;
-            if (const char* e = std::getenv("TXQ_HIBF_STEPS_PER_GROUP")) spg = std::max(1, std::atoi(e));
+            if (kn.hibf_steps_per_group) spg = (uint32_t)kn.hibf_steps_per_group;
             const uint32_t n_groups = (n_steps + spg - 1) / spg;
             const uint32_t gpp = n_groups < 8 ? n_groups : 8;
             const uint32_t phases = (n_groups + gpp - 1) / gpp;
             uint32_t tile = 2048;
-            if (const char* e = std::getenv("TXQ_HIBF_TILE")) tile = std::max(64, std::atoi(e));
+            if (kn.hibf_tile) tile = (uint32_t)std::max(64, kn.hibf_tile);
             const size_t n_tiles = (n + tile - 1) / tile;
             if ((size_t)phases * n_tiles * gpp < ((size_t)1 << 31) && n_tiles < ((size_t)1 << 31)) {
                 const IbfDev& root = ix.ibf[0];
@@ -842,8 +848,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
                 rn.bins = root.bins;
                 size_t rb = (n + 255) / 256;
                 if (rb > 256 * 32) rb = 256 * 32;
-                static const bool force_lanes = std::getenv("TXQ_HIBF_LANE_HASH") != nullptr;  // A/B: per-lane hashing on a uniform tree
-                const bool uniform = ix.children_uniform && !force_lanes;
+                const bool uniform = ix.children_uniform && !kn.hibf_lane_hash;  // (A/B: per-lane hashing on a uniform tree)
                 uint32_t* d_child_rows = nullptr;
                 const IbfDev& c0 = ix.ibf[1];  // uniform: every child looks like this one
                 if (uniform) {
@@ -857,8 +862,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
                     if (e != hipSuccess) { *rc = fail_hip(e, "hipMemsetAsync(alive)"); return true; }
                 }
                 const unsigned grid = (unsigned)((size_t)phases * n_tiles * gpp);
-                static const int unroll = std::getenv("TXQ_HIBF_UNROLL") ? std::atoi(std::getenv("TXQ_HIBF_UNROLL")) : 1;
-                static const int store_flavour = std::getenv("TXQ_HIBF_STORE") ? std::atoi(std::getenv("TXQ_HIBF_STORE")) : 0;
+                const int unroll = kn.hibf_unroll, store_flavour = kn.hibf_store;
 #define TXQ_CHILDREN(U, UNI) hibf_children_kernel<U, UNI><<<grid, 256, 0, s>>>((const ChildRec*)ix.d_children, ix.n_children, lpc, d_kmers, n, ix.scratch_cm, \
                                                                                 cm_words, d_masks, w_out, n_steps, spg, gpp, (uint32_t)n_tiles, tile, h_max, d_alive, store_flavour, d_child_rows)
                 if (uniform) {
@@ -881,8 +885,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
         }
     }
     // small trees: one lane per k-mer (TXQ_HIBF_SMALL=0 keeps them on the wave-per-k-mer kernel, for A/B runs)
-    const char* small = std::getenv("TXQ_HIBF_SMALL");
-    if (ix.max_stride <= 4 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && !(small && small[0] == '0')) {
+    if (ix.max_stride <= 4 && ix.ibf.size() <= kSmallStack && ix.hibf_total_tbs < 0xFFFF && w_out <= 16 && kn.hibf_small) {
         const size_t lds_bytes = (size_t)w_out * kSmallPitch * 8 + (size_t)kSmallStack * kSmallThreads * 2;
         size_t blocks = (n + kSmallThreads - 1) / kSmallThreads;
         if (blocks > 256 * 8) blocks = 256 * 8;
@@ -896,7 +899,7 @@ static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint6
     // 64 waves per CU are launched: with an 8 KiB row the LDS keeps 16 of them resident and the rest queue up,
     // with the short rows of a column shard more are resident and the finer grain is worth 14 % (TXQ_HIBF_WAVES overrides)
     size_t want_waves = (size_t)256 * 64;
-    if (const char* e = std::getenv("TXQ_HIBF_WAVES")) want_waves = std::atoll(e) > 0 ? (size_t)std::atoll(e) : want_waves;
+    if (kn.hibf_waves > 0) want_waves = (size_t)kn.hibf_waves;
     const size_t total_waves = n < want_waves ? n : want_waves;
     const unsigned grid = (unsigned)((total_waves + waves - 1) / waves);
     const uint32_t quads = (ix.max_stride + 3) / 4;  // a lane owns four row words

@@ -8,6 +8,35 @@
 
 namespace txq {
 
+// Every environment variable libtxq.so reads (all of them A/B and test switches between code paths that give the
+// SAME results; listed in include/txq.h).  They are parsed in ONE place (txq_api.hip read_knobs) at the library's entry
+// points — txq_init, txq_index_upload, txq_session_begin and the probe calls — and everything below works from
+// that snapshot: nothing in the library reads the environment while it runs a stage.
+struct Knobs {
+    bool trace = false, trace_stages = false, trace_sync = false;  // TXQ_TRACE, TXQ_TRACE_STAGES, TXQ_TRACE_SYNC
+    // executor (txq_exec.hip)
+    int dense_tree = -1;        // TXQ_DENSE_TREE: 0 generic HIBF steps, 1 TreeRows, 2 TreeRowsByLane where it applies; -1: best fit
+    int dense_unroll = 3;       // TXQ_DENSE_UNROLL: predecessors in flight per lane (2, 3, 6)
+    int dense_slices = 2;       // TXQ_DENSE_SLICES: lane groups sharing the predecessors of one suffix
+    int dense_tile_rounds = 2;  // TXQ_DENSE_TILE_ROUNDS: destination suffixes per lane-group set and tile
+    bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
+    bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
+    // HIBF (txq_hibf.hip)
+    bool hibf_interleave = true;        // TXQ_HIBF_INTERLEAVE=0: no interleaved copy of uniform children (at upload)
+    bool hibf_interleave_probe = true;  // TXQ_HIBF_INTERLEAVE_PROBE=0: plain probes descend the tree
+    bool hibf_levels = false;           // TXQ_HIBF_LEVELS=1: level-synchronous descent
+    bool hibf_stationary = true;        // TXQ_HIBF_STATIONARY=0: no child-stationary descent
+    bool hibf_small = true;             // TXQ_HIBF_SMALL=0: no lane-per-k-mer kernel for small trees
+    bool hibf_lane_hash = false;        // TXQ_HIBF_LANE_HASH: per-lane hashing on a uniform tree
+    int hibf_steps_per_group = 0, hibf_tile = 0, hibf_unroll = 1, hibf_store = 0;  // TXQ_HIBF_STEPS_PER_GROUP / _TILE / _UNROLL / _STORE_KIND (store instruction: 0-3)
+    long long hibf_waves = 0;           // TXQ_HIBF_WAVES
+    // probe (txq_probe.hip)
+    int probe_blocks_per_cu = 256, probe_unroll = 2;  // TXQ_PROBE_BLOCKS_PER_CU, TXQ_PROBE_UNROLL
+    bool probe_nt = false;                            // TXQ_PROBE_NT
+};
+const Knobs& knobs();  // the snapshot taken at the last entry point
+void read_knobs();     // take it (txq_api.hip)
+
 // Everything about one IBF of an HIBF tree in one 32-byte record (txq_hibf.hip: nodes[e] = the child behind merged
 // technical bin e; the dense steps on a regular tree take the root as a kernel argument).
 struct HibfNode {  // 32 bytes = two 16-byte loads per lane
@@ -66,9 +95,8 @@ struct Index {
     IbfDev interleaved{};
     // plain k-mer probes go to the interleaved children too (TXQ_HIBF_INTERLEAVE_PROBE=0: the tree descent kernels; A/B and tests)
     bool probes_interleaved() const {
-        const char* off = std::getenv("TXQ_HIBF_INTERLEAVE_PROBE");
         return is_hibf && interleaved.words && interleaved.stride >= 2 && !(interleaved.stride & 1) && interleaved.shard_words == shard_words &&
-               root_node.bins <= 64 && !(off && off[0] == '0');
+               root_node.bins <= 64 && knobs().hibf_interleave_probe;
     }
     HibfNode root_node{};            // host copy of the root's record
     uint32_t tree_hash_max = 0;      // most hash functions of any IBF of the regular tree
@@ -131,8 +159,7 @@ struct Index {
 // two-level HIBF whose children tile this shard's mask columns.  TXQ_DENSE_TREE=0 (A/B and tests) sends steps through
 // the generic HIBF path instead.
 inline bool index_fuses_tree_steps(const Index& ix) {
-    const char* knob = std::getenv("TXQ_DENSE_TREE");
-    return ix.is_hibf && ix.d_children && ix.n_children && !(knob && knob[0] == '0') && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
+    return ix.is_hibf && ix.d_children && ix.n_children && knobs().dense_tree != 0 && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
            (uint64_t)ix.n_children * ix.child_row_words == ix.shard_words;
 }
 
@@ -143,6 +170,7 @@ struct DevProgram { uint32_t first_op, n_ops, first_level, n_levels; };
 struct Session {
     Index* ix = nullptr;
     Index* aux = nullptr;  // optional d-gram index (flat IBF, same bins and shard as ix)
+    Knobs kn;              // the environment switches as they were when the session began
     size_t n_programs = 0;
     uint32_t W = 0;
     std::vector<Index::ArenaChunk> chunks;  // arena chunks; bump allocation in chunks[cur]

@@ -208,7 +208,7 @@ static inline unsigned grid_for(size_t work_items, unsigned per_block) {
     // Up to 256 blocks per CU before the kernels start to grid-stride: letting the dispatcher hand out
     // short blocks balances slightly better than 8 long ones per CU (1024-bin index: +0.6 % cache-resident,
     // within the noise on matrices that miss the Infinity Cache).  TXQ_PROBE_BLOCKS_PER_CU is the A/B knob.
-    static const size_t per_cu = std::getenv("TXQ_PROBE_BLOCKS_PER_CU") ? (size_t)std::atoi(std::getenv("TXQ_PROBE_BLOCKS_PER_CU")) : 256;
+    const size_t per_cu = (size_t)knobs().probe_blocks_per_cu;
     const size_t cap = 256u * (per_cu ? per_cu : 1);
     if (blocks > cap) blocks = cap;
     if (blocks == 0) blocks = 1;
@@ -223,8 +223,8 @@ static hipError_t launch_lpk(const IbfDev& f, const uint64_t* k, size_t n, uint6
     // supplies the memory-level parallelism, and 4 steps cost 124 VGPRs = half the waves per SIMD;
     // non-temporal ROW loads cost 20 % on a cache-resident matrix and gain nothing on an 8 GB one.
     // Default: 2 steps in flight, 8 waves/SIMD, plain row loads.)
-    static const int unroll = std::getenv("TXQ_PROBE_UNROLL") ? std::atoi(std::getenv("TXQ_PROBE_UNROLL")) : 2;
-    static const bool nt = std::getenv("TXQ_PROBE_NT") != nullptr;
+    const int unroll = knobs().probe_unroll;
+    const bool nt = knobs().probe_nt;
     if (f.hash_funs == 3 && LPK == 8 && (unroll != 2 || nt)) {
         if (unroll == 1 && !nt) probe_kernel<LPK, 3, 1, false><<<grid, 256, 0, s>>>(f, k, n, m, a);
         else if (unroll == 4 && !nt) probe_kernel<LPK, 3, 4, false><<<grid, 256, 0, s>>>(f, k, n, m, a);
