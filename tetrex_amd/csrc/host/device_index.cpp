@@ -239,7 +239,11 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     if (status) status->assign(regexes.size(), 0);
     if (messages) messages->assign(regexes.size(), std::string());
     if (regexes.empty()) return masks;
+    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     TxqStageExecutor exec(ix, regexes.size(), aux);
+    if (trace)
+        std::fprintf(stderr, "[tetrex] session begin %.2f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_begin).count());
     StagedOptions opt = options ? *options : StagedOptions{};
     // saturated state lists run as dense DP steps on the device where the index allows it (TETREX_DENSE=0 switches them off)
     opt.dense.enabled = txq_index_supports_dense(ix) != 0;
@@ -249,7 +253,6 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     uint64_t tag = 0;
     (void)txq_index_get_tag(ix, &tag);
     if (opt.dense_evidence == DenseOptions::kUnknown) opt.dense_evidence = (int)(tag & 3);  // what earlier runs learned about the index
-    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     const StagedStats st = run_staged(enc, info.user_bins, regexes, exec, opt, status, messages);
     if (st.dense_evidence != DenseOptions::kUnknown) (void)txq_index_set_tag(ix, (tag & ~(uint64_t)3) | (uint64_t)st.dense_evidence);
