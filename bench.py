@@ -489,6 +489,90 @@ def k6_end_to_end(capi, torch, args):
             "cpu_oracle": {"masks_compared": compared, "seconds": cpu_dt, "sample": "motifs of the batch without a wildcard among their first residues"}}
 
 
+def verified_end_to_end(args):
+    """End-to-end queries/s INCLUDING verification, timed like the reference times a query: wall-clock from after the index is
+    loaded to the last output byte (include/query.h:256,287-289) — candidate masks on the GPU, then the candidate bins'
+    FASTA files read from local disk and searched with the motif (host/verify.cpp: iter_disk_search / verify_fasta_hit of
+    src/query.cpp:194-315 with this project's linear-time matcher; OpenMP over the candidate bins like the reference).
+    The README's scenario (README.md:84-109) on synthetic data of its shape: 1024 FASTA bins of 200 000 uniform random
+    residues (360-residue records), `tetrex index -k 6 -i` (flat IBF, h = 3, fpr 0.05), 200 PROSITE-style motifs through
+    `tetrex query -f` with -t 1 and -t 16.  cpu_baseline: the CPU oracle's mask stage on the same index file (the motifs it
+    answers in its budget; it enumerates every state, so motifs with a wildcard among their first residues are left out)
+    plus the same verification single-threaded.  N = 1 only; does not touch `value`."""
+    import subprocess
+    import tempfile
+    import oracle as O
+    from motifs import random_prosite_motifs
+    from tetrex_amd import host as H
+    tetrex = os.path.join(os.path.dirname(os.path.abspath(__file__)), "bin", "tetrex")
+    bins, per_bin, k = 1024, 200000, 6
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    rng = np.random.default_rng(11)
+    out = {}
+    with tempfile.TemporaryDirectory(prefix="tetrex_bench_") as work:
+        files = []
+        for b in range(bins):
+            seq = aa[rng.integers(0, 20, size=per_bin)]
+            path = os.path.join(work, "bin%04d.fa" % b)
+            with open(path, "wb") as f:
+                for i, start in enumerate(range(0, per_bin, 360)):
+                    f.write(b">sp|%04d_%d\n" % (b, i))
+                    f.write(seq[start:start + 360].tobytes())
+                    f.write(b"\n")
+            files.append(path)
+        motifs = random_prosite_motifs(200, 3, wildcard=0.05, ranges=0.02, min_len=8, max_len=14)
+        with open(os.path.join(work, "motifs.tsv"), "w") as f:
+            for i, m in enumerate(motifs):
+                f.write("M%03d\t%s\n" % (i, m))
+        r = subprocess.run([tetrex, "index", "-k", str(k), "-i", "sp", *files], capture_output=True, text=True, cwd=work)
+        if r.returncode != 0:
+            return {"error": "tetrex index failed: " + r.stderr[-500:]}
+        runs = {}
+        for threads in (1, 16):
+            best = None
+            for _ in range(2):  # the second run reads the FASTA files from the page cache, like a server that has seen them before
+                r = subprocess.run([tetrex, "query", "-S", "-f", "-t", str(threads), "sp.ibf", "motifs.tsv"], capture_output=True, text=True, cwd=work)
+                if r.returncode != 0:
+                    return {"error": "tetrex query failed: " + r.stderr[-500:]}
+                stats = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")]
+                whole = [x for x in stats if "batch_seconds" in x][-1]
+                mask = [x for x in stats if "mask_seconds" in x][-1]
+                if best is None or whole["batch_seconds"] < best[0]["batch_seconds"]:
+                    best = (whole, mask)
+            whole, mask = best
+            hits = sum(1 for i in range(len(motifs)) if os.path.getsize(os.path.join(work, "M%03d.tsv" % i)) > 0) if all(
+                os.path.exists(os.path.join(work, "M%03d.tsv" % i)) for i in range(len(motifs))) else None
+            runs["threads_%d" % threads] = {"queries_per_s": len(motifs) / whole["batch_seconds"], "seconds": whole["batch_seconds"],
+                                            "mask_seconds": mask["mask_seconds"], "verify_seconds": whole["verify_seconds"],
+                                            "refused_fraction": whole["refused"] / len(motifs), "motifs_with_verified_matches": hits}
+        # CPU baseline: the oracle's mask stage on the index file the CLI wrote, plus the single-threaded verification measured above
+        img = H.IndexFile.load(os.path.join(work, "sp.ibf"))
+        d = img.describe()
+        ibf = d["ibfs"][0]
+        ox = O.Index.ibf(int(ibf["bins"]), int(ibf["bin_size"]), int(ibf["hash_funs"]), dna=False, k=k)
+        ox.set_words(img.words(0))
+        done, t0 = 0, time.perf_counter()
+        for rx in motifs:
+            if "." in rx[:10]:
+                continue
+            try:
+                ox.query(rx)
+            except Exception:  # noqa: BLE001
+                pass
+            done += 1
+            if time.perf_counter() - t0 > 5.0:
+                break
+        cpu_mask_per_query = (time.perf_counter() - t0) / max(done, 1)
+        per_query = cpu_mask_per_query + runs["threads_1"]["verify_seconds"] / len(motifs)
+        out = {"metric": "end-to-end queries/sec INCLUDING verification (regex -> candidate bins -> verified matches on disk)",
+               "workload": "%d PROSITE-style motifs, k = %d, %d FASTA bins of %d residues on local disk (flat IBF written by `tetrex index -i`)" % (len(motifs), k, bins, per_bin),
+               "k": k, **runs,
+               "cpu_baseline": {"value": 1.0 / per_query, "unit": "queries/s", "cores": 1, "kind": "port",
+                                "sample": "oracle mask stage on %d motifs of the batch (%.4f s per query) + the same verification with one thread (%.4f s per query)"
+                                          % (done, cpu_mask_per_query, runs["threads_1"]["verify_seconds"] / len(motifs))}}
+    return out
+
+
 def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
     """Third figure (BASELINE configs[4] shape, SURVEY.md §8d S-HIBF-65536): k-mers/s of the HIBF
     descent — root IBF of 256 merged bins over 256 child IBFs of 256 user bins each, h = 2, sizes from
@@ -586,6 +670,7 @@ def main():
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--no-hibf", action="store_true", help="skip the HIBF descent leg")
     ap.add_argument("--no-k6", action="store_true", help="skip the k = 6 end-to-end leg (end_to_end.k6_batch)")
+    ap.add_argument("--no-verification", action="store_true", help="skip the end-to-end leg that includes verification (end_to_end.with_verification)")
     ap.add_argument("--hibf-kmers", type=int, default=1 << 20)
     ap.add_argument("--hibf-per-bin", type=int, default=300)
     ap.add_argument("--rows", type=int, default=0, help="override bin_size (rows); >0 selects an out-of-cache variant")
@@ -743,6 +828,11 @@ def main():
                 out["end_to_end"]["k6_batch"] = k6_end_to_end(capi, torch, args)
             except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
                 out["end_to_end"]["k6_batch"] = {"error": repr(e)}
+        if world == 1 and not args.no_verification and "error" not in out["end_to_end"]:
+            try:
+                out["end_to_end"]["with_verification"] = verified_end_to_end(args)
+            except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
+                out["end_to_end"]["with_verification"] = {"error": repr(e)}
 
     ix.free()
     if not args.no_hbm_leg and not strong and cache_resident:

@@ -199,6 +199,7 @@ int cmd_query(int argc, char** argv) {
         const std::vector<uint64_t> masks = dev.query_masks(motifs, &status, &why, &st, &sopt);
         print_stats(st, motifs.size(), now() - t0);
         const double batch = (now() - t0) / std::max<size_t>(1, motifs.size());
+        const double t_verify = now();
         int failed = 0;
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
@@ -209,6 +210,11 @@ int cmd_query(int argc, char** argv) {
             }
             run_one(motifs[i], masks.data() + i * W, ids[i] + ".tsv", true, now() - batch);
         }
+        // -S: the whole batch as the reference times a query — from after the index is loaded to the last output byte
+        // (include/query.h:256,287-289): candidate masks + verification of the candidate bins
+        if (a.has("stats"))
+            std::cerr << "{\"batch_seconds\": " << (now() - t0) << ", \"verify_seconds\": " << (now() - t_verify) << ", \"threads\": " << vopt.threads
+                      << ", \"refused\": " << failed << "}" << std::endl;
         return failed ? 1 : 0;
     }
     if (conj) {
