@@ -573,6 +573,48 @@ def verified_end_to_end(args):
     return out
 
 
+def one_process_n_devices(capi, torch, args, world, bins_total, m, h, value_bits, motifs_k):
+    """The C++ product deployment of the sharded index: ONE process drives all N devices — txq_init(N, ids),
+    shard r on device r, one frontier expansion feeding every shard's session (ShardedStageExecutor, host/device_index.cpp),
+    the shards' masks joined on the host (txe_query_masks_sharded; the seam of run_collection / run_multiple_queries,
+    reference include/query.h:250-290,329-346).  Runs on rank 0 alone after the distributed legs, while the other ranks
+    wait at a barrier; the index is the weak-scaling index of this run (bins_total bins), rebuilt shard by shard on the
+    devices.  Reports the batch time and what the shards' stages took."""
+    from motifs import random_prosite_motifs
+    capi.init_devices(list(range(world)))
+    shards = []
+    t0 = time.perf_counter()
+    try:
+        bins_local = bins_total // world
+        for r in range(world):
+            torch.cuda.set_device(r)
+            shards.append(build_index(capi, torch, bins_total, bins_local, m, h, r, world, args.per_bin, value_bits))
+        build_s = time.perf_counter() - t0
+        devices = [int(s.info.device) for s in shards]
+        motifs = random_prosite_motifs(args.motifs, 6)
+        capi.query_masks_sharded(shards, random_prosite_motifs(args.motifs, 8), False, motifs_k)  # warm, like the other legs
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            masks, status, stats = capi.query_masks_sharded(shards, motifs, False, motifs_k)
+            dt = time.perf_counter() - t1
+            if best is None or dt < best[0]:
+                best = (dt, stats, masks, status)
+        # the same batch on shard 0 alone must give shard 0's columns of the joined masks
+        part, _, _ = shards[0].query_masks(motifs, False, motifs_k)
+        w0, nw = int(shards[0].info.shard_word0), shards[0].shard_words
+        if not np.array_equal(part, best[2][:, w0:w0 + nw]):
+            raise RuntimeError("joined masks differ from shard 0's own run in its columns")
+        return {"what": "one process, %d devices: txe_query_masks_sharded (one expansion, %d shard sessions, host-side join)" % (world, world),
+                "devices": devices, "queries_per_s": len(motifs) / best[0], "seconds": best[0], "k": motifs_k,
+                "refused_fraction": float(sum(1 for x in best[3] if x)) / len(motifs), **best[1], "index_build_s": round(build_s, 1),
+                "mask_words": int(best[2].shape[1])}
+    finally:
+        for s in shards:
+            s.free()
+        torch.cuda.set_device(0)
+
+
 def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
     """Third figure (BASELINE configs[4] shape, SURVEY.md §8d S-HIBF-65536): k-mers/s of the HIBF
     descent — root IBF of 256 merged bins over 256 child IBFs of 256 user bins each, h = 2, sizes from
@@ -850,6 +892,17 @@ def main():
         except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
             out.setdefault("hibf", {"error": repr(e)})
             out.setdefault("hibf_1024", {"error": repr(e)})
+    if world > 1 and not strong and not args.no_queries and not args.rehearse_single_device:
+        # both deployments of the sharded index are measured at first contact with a multi-GPU node: after the one-process-
+        # per-GPU legs above, rank 0 alone drives all N devices; everybody else waits (a failure must not cost the line)
+        dist.barrier()
+        if rank == 0:
+            try:
+                out.setdefault("end_to_end", {})["one_process_n_devices"] = one_process_n_devices(
+                    capi, torch, args, world, bins_total, m, h, value_bits, max(2, args.kmer_bits // 5))
+            except Exception as e:  # noqa: BLE001
+                out.setdefault("end_to_end", {})["one_process_n_devices"] = {"error": repr(e)}
+        dist.barrier()
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -145,3 +145,42 @@ def test_shards_of_a_fresh_index_are_asked_together(capi, oracle, monkeypatch):
     assert stats["dense_ops"] > 0 and shards[0].tag & 3 == 1
     for s in shards:
         s.free()
+
+
+def test_shards_on_real_devices_when_the_box_has_several(oracle, monkeypatch):
+    """txq_init(N, ids) with N real devices: shard r lives on device r, every session call binds the calling thread to the
+    device of its index, the stage-submission threads (one per shard) talk to different GPUs at the same time.  Skipped on a
+    one-GPU box (there every shard lands on the one device: the tests above)."""
+    from tetrex_amd import capi as c
+    n = c.device_count_safe()
+    if n < 2:
+        pytest.skip("one GPU: nothing to deal shards over")
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    c.init_devices(list(range(n)))
+    try:
+        ox = _oracle_index(oracle, bins=64 * 4 * n, m=4099, h=3, k=4, dna=False, per_bin=1200, seed=15)
+        sh = ox.shape()
+        qs = PEPTIDE_QUERIES + random_prosite_motifs(40, 12, wildcard=0.1, ranges=0.05)
+        shards = [c.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=n) for r in range(n)]
+        assert sorted(int(s.info.device) for s in shards) == list(range(n))
+        full, status, stats = c.query_masks_sharded(shards, qs, False, 4)
+        checked = 0
+        for q, g, st in zip(qs, full, status):
+            try:
+                want, quirks = ox.expected_mask(q)
+            except Exception:
+                assert st != 0
+                continue
+            assert st == 0 and np.array_equal(g, want), q
+            checked += 1
+        assert checked > 50
+        # plain probes of every shard on its own device
+        kmers = np.random.default_rng(3).integers(0, 1 << 20, size=4000, dtype=np.uint64)
+        want = ox.probe(kmers)
+        for s in shards:
+            w0, nw = int(s.info.shard_word0), s.shard_words
+            assert np.array_equal(s.probe(kmers), want[:, w0:w0 + nw])
+        for s in shards:
+            s.free()
+    finally:
+        c.init(0)

@@ -116,6 +116,12 @@ def init(device=0):
     check(lib().txq_init(1, C.byref(dev)))
 
 
+def init_devices(devices):
+    """One process, several GPUs (txq_init(N, ids)): shard r of an index lives on devices[r % N]."""
+    ids = (C.c_int * len(devices))(*[int(d) for d in devices])
+    check(lib().txq_init(len(devices), ids))
+
+
 def shutdown():
     check(lib().txq_shutdown())
 
