@@ -126,47 +126,86 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     if (gaps_.augment) g_.augment();
     const int32_t n = n_nodes_ = g_.size();
     const std::vector<int32_t> topo = g_.topological_order();
-    // closure[v] of epsilon nodes, successors first
-    std::vector<std::vector<int32_t>> closure(n);
+    // closure[v] of epsilon nodes, successors first: sorted, duplicate-free lists in ONE arena (a 20-way wildcard union is
+    // a tree of 19 Split nodes over 20 residues: per-node vectors were a third of this constructor's time)
+    std::vector<int32_t> arena;
+    arena.reserve((size_t)n * 8);
+    std::vector<uint32_t> c_off(n, 0), c_len(n, 0);
     std::vector<uint8_t> hole(n, 0);
-    auto through = [&](int32_t t, std::vector<int32_t>& out, uint8_t& dang) {
+    // the target list behind successor slot t: {t} itself for a residue / Match node, closure[t] for an epsilon node
+    auto list_of = [&](int32_t t, const int32_t** p, uint32_t* len, int32_t* self, uint8_t& dang) {
+        *len = 0;
         if (t == KGraph::kNone) { dang = 1; return; }
-        if (!is_epsilon(g_.label[t])) { out.push_back(t); return; }
-        out.insert(out.end(), closure[t].begin(), closure[t].end());
+        if (!is_epsilon(g_.label[t])) { *self = t; *p = self; *len = 1; return; }
+        *p = arena.data() + c_off[t];
+        *len = c_len[t];
         dang |= hole[t];
-    };
-    auto unique = [](std::vector<int32_t>& v) {
-        std::sort(v.begin(), v.end());
-        v.erase(std::unique(v.begin(), v.end()), v.end());
     };
     for (size_t i = topo.size(); i-- > 0;) {
         const int32_t v = topo[i];
         if (!is_epsilon(g_.label[v])) continue;
-        through(g_.next_a[v], closure[v], hole[v]);
-        if (g_.label[v] == KGraph::kSplit) through(g_.next_b[v], closure[v], hole[v]);
-        unique(closure[v]);
+        const int32_t *pa = nullptr, *pb = nullptr;
+        uint32_t la = 0, lb = 0;
+        int32_t sa = 0, sb = 0;
+        list_of(g_.next_a[v], &pa, &la, &sa, hole[v]);
+        if (g_.label[v] == KGraph::kSplit) list_of(g_.next_b[v], &pb, &lb, &sb, hole[v]);
+        const size_t at = arena.size();
+        if (arena.capacity() < at + la + lb) {  // (pa / pb may point into the arena: re-derive them after growing)
+            const size_t oa = pa && pa != &sa ? (size_t)(pa - arena.data()) : 0, ob = pb && pb != &sb ? (size_t)(pb - arena.data()) : 0;
+            arena.reserve(std::max(arena.capacity() * 2, at + la + lb));
+            if (pa && pa != &sa) pa = arena.data() + oa;
+            if (pb && pb != &sb) pb = arena.data() + ob;
+        }
+        arena.resize(at + la + lb);
+        int32_t* out = arena.data() + at;  // merge of two sorted lists, duplicates dropped
+        uint32_t x = 0, y = 0, m = 0;
+        while (x < la || y < lb) {
+            int32_t w;
+            if (y >= lb || (x < la && pa[x] <= pb[y])) { w = pa[x]; if (y < lb && pb[y] == w) ++y; ++x; }
+            else w = pb[y++];
+            out[m++] = w;
+        }
+        arena.resize(at + m);
+        c_off[v] = (uint32_t)at;
+        c_len[v] = m;
     }
-    // per source item (residue nodes and the entry n): its target set -> join or single target
+    // per source item (residue nodes and the entry n): its target set -> join or single target.  Equal sets share a join:
+    // found through a hash of the list (open addressing), verified by comparing the lists.
     forward_.assign(n + 1, KGraph::kNone);
     dangling_.assign(n + 1, 0);
     fan_first_.assign(1, 0);
-    std::map<std::vector<int32_t>, int32_t> join_of;
+    size_t table_size = 16;
+    while (table_size < (size_t)n * 2 + 2) table_size <<= 1;
+    std::vector<int32_t> join_slot(table_size, -1);  // -> index of the join (0-based)
+    size_t n_joins = 0;
     for (int32_t u = 0; u <= n; ++u) {
-        std::vector<int32_t> t;
-        if (u == n) through(0, t, dangling_[u]);
-        else if (!is_epsilon(g_.label[u]) && g_.label[u] != KGraph::kMatch) through(g_.next_a[u], t, dangling_[u]);  // residues and gaps
+        const int32_t* t = nullptr;
+        uint32_t len = 0;
+        int32_t self = 0;
+        if (u == n) list_of(0, &t, &len, &self, dangling_[u]);
+        else if (!is_epsilon(g_.label[u]) && g_.label[u] != KGraph::kMatch) list_of(g_.next_a[u], &t, &len, &self, dangling_[u]);  // residues and gaps
         else continue;
-        unique(t);
-        if (t.empty()) continue;
-        if (t.size() == 1) { forward_[u] = t[0]; continue; }
-        auto [it, fresh_join] = join_of.emplace(t, n + 1 + (int32_t)join_of.size());
-        if (fresh_join) {
-            fan_.insert(fan_.end(), t.begin(), t.end());
+        if (len == 0) continue;
+        if (len == 1) { forward_[u] = t[0]; continue; }
+        uint64_t hsh = 0xcbf29ce484222325ULL;
+        for (uint32_t i = 0; i < len; ++i) hsh = (hsh ^ (uint64_t)(uint32_t)t[i]) * 0x100000001b3ULL;
+        size_t at = (size_t)(hsh * 0x9E3779B97F4A7C15ULL >> 20) & (table_size - 1);
+        int32_t found = -1;
+        for (;; at = (at + 1) & (table_size - 1)) {
+            const int32_t j = join_slot[at];
+            if (j < 0) break;
+            const uint32_t lo = fan_first_[j], hi = fan_first_[j + 1];
+            if (hi - lo == len && std::equal(t, t + len, fan_.begin() + lo)) { found = j; break; }
+        }
+        if (found < 0) {
+            found = (int32_t)n_joins++;
+            join_slot[at] = found;
+            fan_.insert(fan_.end(), t, t + len);
             fan_first_.push_back((uint32_t)fan_.size());
         }
-        forward_[u] = it->second;
+        forward_[u] = n + 1 + found;
     }
-    const int32_t items = n + 1 + (int32_t)join_of.size();
+    const int32_t items = n + 1 + (int32_t)n_joins;
     forward_.resize(items, KGraph::kNone);
     dangling_.resize(items, 0);
     // topological order of the derived graph (Kahn): edges u -> forward_[u], join -> its targets
@@ -201,7 +240,7 @@ QueryExpansion::QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimi
     // state keys are (k-1) symbols plus the length marker bit: small enough for a directly indexed merge table?
     direct_key_bits_ = (enc_.k() - 1) * enc_.bits_per_symbol() + 1 <= 20 ? (enc_.k() - 1) * enc_.bits_per_symbol() + 1 : 0;
     input_of_.assign(items, KGraph::kNone);
-    readers_.assign(join_of.size(), 0);
+    readers_.assign(n_joins, 0);
     refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
     if (dense_ok_) compute_static_shapes();
     OpVec none;

@@ -150,11 +150,12 @@ struct Fragment {
     uint64_t paths = 1;          // Subgraph::paths (include/construction_tools.h:76)
     std::set<uint64_t> lengths;  // Subgraph::lengths
     bool single() const { return pending || entry == exit; }
-    static Fragment residue(int32_t node, bool pending) {
+    // with_stats: the path statistics (paths, lengths) are kept — only KGraph::augment() (-a) reads what comes of them
+    static Fragment residue(int32_t node, bool pending, bool with_stats) {
         Fragment f;
         f.entry = f.exit = node;
         f.pending = pending;
-        f.lengths = {1};
+        if (with_stats) f.lengths = {1};
         return f;
     }
     static Fragment span(int32_t entry, int32_t exit) {
@@ -167,7 +168,7 @@ struct Fragment {
 
 class Builder {
   public:
-    Builder(unsigned k, bool reduced) : k_(k), reduced_(reduced) {}
+    Builder(unsigned k, bool reduced, bool path_stats) : k_(k), reduced_(reduced), stats_(path_stats) {}
 
     KGraph finish(const std::string& postfix) {
         const int32_t start = g_.add(KGraph::kGhost);
@@ -210,6 +211,7 @@ class Builder {
     KGraph g_;
     unsigned k_;
     bool reduced_;
+    bool stats_;  // keep path statistics (for -a)
     std::vector<Fragment> stack_;
     std::vector<int32_t> symbols_;  // reduced builder: residues waiting to become nodes
 
@@ -242,15 +244,15 @@ class Builder {
         const int32_t s = waiting_symbol();
         symbols_.pop_back();
         const int32_t n = g_.add(s);
-        f = Fragment::residue(n, false);
+        f = Fragment::residue(n, false, stats_);
     }
 
     void symbol(int32_t s) {
         if (reduced_) {
             symbols_.push_back(s);
-            stack_.push_back(Fragment::residue(KGraph::kNone, true));
+            stack_.push_back(Fragment::residue(KGraph::kNone, true, stats_));
         } else {
-            stack_.push_back(Fragment::residue(g_.add(s), false));
+            stack_.push_back(Fragment::residue(g_.add(s), false, stats_));
         }
     }
 
@@ -260,10 +262,12 @@ class Builder {
         realise(left);
         g_.link(left.exit, right.entry);
         Fragment both = Fragment::span(left.entry, right.exit);
-        both.paths = left.paths * right.paths;
-        for (uint64_t x : left.lengths) for (uint64_t y : right.lengths) both.lengths.insert(x + y);
-        if (right.paths >= 15 || (both.paths >= 690000u && right.entry != right.exit))
-            g_.catsites.push_back(CatSite{left.exit, right.entry, right.exit, right.lengths});
+        if (stats_) {
+            both.paths = left.paths * right.paths;
+            for (uint64_t x : left.lengths) for (uint64_t y : right.lengths) both.lengths.insert(x + y);
+            if (right.paths >= 15 || (both.paths >= 690000u && right.entry != right.exit))
+                g_.catsites.push_back(CatSite{left.exit, right.entry, right.exit, right.lengths});
+        }
         stack_.push_back(both);
     }
 
@@ -288,9 +292,11 @@ class Builder {
         g_.link(left.exit, join);
         g_.link(right.exit, join);
         Fragment either = Fragment::span(fork, join);
-        either.paths = left.paths + right.paths;
-        either.lengths = left.lengths;
-        either.lengths.insert(right.lengths.begin(), right.lengths.end());
+        if (stats_) {
+            either.paths = left.paths + right.paths;
+            either.lengths = left.lengths;
+            either.lengths.insert(right.lengths.begin(), right.lengths.end());
+        }
         stack_.push_back(either);
     }
 
@@ -303,16 +309,18 @@ class Builder {
         g_.link(fork, join);
         g_.link(body.exit, join);
         Fragment maybe = Fragment::span(fork, join);
-        maybe.paths = body.paths + 1;
-        maybe.lengths = body.lengths;
-        maybe.lengths.insert(0);
+        if (stats_) {
+            maybe.paths = body.paths + 1;
+            maybe.lengths = body.lengths;
+            maybe.lengths.insert(0);
+        }
         stack_.push_back(maybe);
     }
 
     // duplicate the sub-graph between f.entry and f.exit (nodes on some entry->exit path)
     Fragment duplicate(const Fragment& f) {
         if (f.single()) {
-            Fragment copy = Fragment::residue(g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]), false);
+            Fragment copy = Fragment::residue(g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]), false, stats_);
             copy.paths = f.paths;
             copy.lengths = f.lengths;
             return copy;
@@ -376,8 +384,10 @@ class Builder {
             tail = copy.exit;
         }
         Fragment loop = Fragment::span(fork, join);
-        loop.paths = body.paths * depth;
-        for (uint64_t i = 0; i < depth; ++i) for (uint64_t l : body.lengths) loop.lengths.insert(i * l);
+        if (stats_) {
+            loop.paths = body.paths * depth;
+            for (uint64_t i = 0; i < depth; ++i) for (uint64_t l : body.lengths) loop.lengths.insert(i * l);
+        }
         stack_.push_back(loop);
     }
 
@@ -430,8 +440,8 @@ class Builder {
 
 }  // namespace
 
-KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet) {
-    return Builder(k, reduced_alphabet).finish(postfix);
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats) {
+    return Builder(k, reduced_alphabet, path_stats).finish(postfix);
 }
 
 }  // namespace tetrex

@@ -55,6 +55,8 @@ struct KGraph {
 // builder (symbols are buffered and identical reduced letters of a union collapse).
 // Throws std::runtime_error where the reference would run into undefined behaviour
 // (stack underflow, empty symbol buffer) instead of reproducing it.
-KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet);
+// path_stats: keep the reference's path statistics (Subgraph::paths / lengths) and record the concatenations that -a would
+// bypass (catsites) — only KGraph::augment() needs them; a graph built without them cannot be augmented
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats = true);
 
 }  // namespace tetrex

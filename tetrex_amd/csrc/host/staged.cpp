@@ -106,21 +106,32 @@ struct BlobStore {
 
 // Expansion threads are kept from run to run (spawning and joining 15 threads is half a millisecond of a 7 ms batch): a
 // run borrows the idle pool of its size, or starts its own when that one is busy (runs on several indexes at once).
+// With the threads come the buffers whose FIRST TOUCH is what costs: the stage blob (tens of MB for a 10 000-motif batch:
+// thousands of page faults per run otherwise — 30 ms of a 100 ms batch) and the level scheduler's per-thread slot records.
+struct RunBuffers {
+    BlobStore blob;
+    std::vector<LevelScratch> scratch;  // per thread
+};
 class PoolLease {
   public:
     explicit PoolLease(int threads) {
         {
             std::lock_guard<std::mutex> lk(mutex());
             for (Kept& k : kept())
-                if (!k.busy && k.pool->threads() == threads) { k.busy = true; pool_ = k.pool.get(); return; }
+                if (!k.busy && k.pool->threads() == threads) { k.busy = true; pool_ = k.pool.get(); buffers_ = k.buffers.get(); return; }
             if (kept().size() < 8) {
-                kept().push_back(Kept{std::make_unique<ThreadPool>(threads), true});
+                kept().push_back(Kept{std::make_unique<ThreadPool>(threads), std::make_unique<RunBuffers>(), true});
                 pool_ = kept().back().pool.get();
+                buffers_ = kept().back().buffers.get();
+                buffers_->scratch.resize((size_t)threads);
                 return;
             }
         }
         own_ = std::make_unique<ThreadPool>(threads);
+        own_buffers_ = std::make_unique<RunBuffers>();
+        own_buffers_->scratch.resize((size_t)threads);
         pool_ = own_.get();
+        buffers_ = own_buffers_.get();
     }
     ~PoolLease() {
         if (own_) return;
@@ -131,13 +142,16 @@ class PoolLease {
     PoolLease(const PoolLease&) = delete;
     PoolLease& operator=(const PoolLease&) = delete;
     ThreadPool& pool() { return *pool_; }
+    RunBuffers& buffers() { return *buffers_; }
 
   private:
-    struct Kept { std::unique_ptr<ThreadPool> pool; bool busy; };
+    struct Kept { std::unique_ptr<ThreadPool> pool; std::unique_ptr<RunBuffers> buffers; bool busy; };
     static std::mutex& mutex() { static std::mutex m; return m; }
     static std::vector<Kept>& kept() { static std::vector<Kept> v; return v; }
     ThreadPool* pool_ = nullptr;
+    RunBuffers* buffers_ = nullptr;
     std::unique_ptr<ThreadPool> own_;
+    std::unique_ptr<RunBuffers> own_buffers_;
 };
 
 class StagedRun {
@@ -145,7 +159,7 @@ class StagedRun {
     StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), lease_(threads_), pool_(lease_.pool()),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
-          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), tracked_(n_, 0), scratch_(threads_), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
+          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), tracked_(n_, 0), scratch_(lease_.buffers().scratch), blob_store_(lease_.buffers().blob), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
           busy_(threads_, 0.0) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
@@ -239,7 +253,7 @@ class StagedRun {
     }
     void build_one(size_t i) {  // throws what the front-end throws
         const std::string postfix = preprocess_query(regexes_[i], enc_);
-        q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base), opt_.limits, opt_.gaps, dense_);
+        q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base, opt_.gaps.augment), opt_.limits, opt_.gaps, dense_);
     }
 
     // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned query is
@@ -580,7 +594,7 @@ class StagedRun {
     DenseOptions dense_;
     std::atomic<int64_t> dense_pool_{0};
     std::atomic<int> evidence_{DenseOptions::kUnknown};  // see DenseOptions::evidence
-    std::vector<LevelScratch> scratch_;               // per thread
+    std::vector<LevelScratch>& scratch_;              // per thread (kept with the thread pool from run to run)
     std::vector<std::vector<uint8_t>> dead_scratch_;  // per thread
     std::vector<std::vector<uint32_t>> levels_, asks_;
     std::vector<uint64_t> fin_states_, fin_pruned_;   // statistics of the queries freed early
@@ -595,7 +609,7 @@ class StagedRun {
     std::atomic<int64_t> admitted_{0};
     size_t carried_ = 0;                              // ops those produced
     std::vector<double> busy_;
-    BlobStore blob_store_;
+    BlobStore& blob_store_;                           // (kept with the thread pool from run to run)
     StagedStats st_;
     size_t run_on_budget_ = 0, feedback_budget_ = 0;  // the latter: what a query that asks gets per stage (advance_stage sets it)
     size_t wave_ops_ = 0;
