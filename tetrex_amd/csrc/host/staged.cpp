@@ -159,9 +159,9 @@ class StagedRun {
     StagedRun(const KmerEncoder& enc, uint64_t bins, const std::vector<std::string>& regexes, StageExecutor& exec, const StagedOptions& opt)
         : enc_(enc), bins_(bins), regexes_(regexes), exec_(exec), opt_(opt), n_(regexes.size()), threads_(expansion_threads(opt, n_)), lease_(threads_), pool_(lease_.pool()),
           status_(n_, 0), why_(n_), q_(n_), passthrough_(n_, 0), ops_(n_), slots_(n_, TXQ_SLOT_FIRST_FREE), tables_(n_, KmerTable(false)),
-          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), tracked_(n_, 0), scratch_(lease_.buffers().scratch), blob_store_(lease_.buffers().blob), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
+          dgram_tables_(n_, KmerTable(false)), dense_ops_(n_), dslots_(n_, 0), tracked_(n_, 0), scratch_(lease_.buffers().scratch), dead_scratch_(threads_), levels_(n_), asks_(n_), fin_states_(n_, 0),
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
-          busy_(threads_, 0.0) {
+          busy_(threads_, 0.0), blob_store_(lease_.buffers().blob) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
