@@ -249,6 +249,11 @@ int txq_init(int n_devices, const int* device_ids) {
         preload_exec_kernels();
         preload_probe_kernels();
         preload_hibf_kernels();
+        // (the first non-default stream of a process costs what the runtime has put off until then — 17 ms with this library's
+        // kernels; a session creates two: have it happen here)
+        hipStream_t first = nullptr;
+        if (hipStreamCreateWithFlags(&first, hipStreamNonBlocking) == hipSuccess) (void)hipStreamDestroy(first);
+        (void)hipGetLastError();
     }
     g_devices = devices;
     return TXQ_OK;
