@@ -90,6 +90,63 @@ def random_hibf(O, seed, user_bins=300, tmax=128, h=2, n_values=40, value_bits=2
     return ox, descs, values
 
 
+def layout_hibf(O, seed, user_bins, tmax=64, h=2, n_values=20, value_bits=20, direct=6, fpr=0.05, k=4):
+    """An HIBF shaped like the layouts seqan::hibf computes (reference include/index_hibf.h:114-129 hands the layout to it):
+    every IBF has at most `tmax` technical bins; user bins are taken in a SHUFFLED order (the layout sorts them by size, so
+    the user bins of a leaf are no run of ids); an IBF that cannot hold its user bins directly keeps a few of them as
+    technical bins of its own (`direct`, every third one split over two or three bins) and merges the rest into evenly
+    sized children — as many levels as that takes.  Returns (oracle index, upload descriptors, values per user bin)."""
+    rng = np.random.default_rng(seed)
+    values = [rng.integers(0, 1 << value_bits, size=n_values, dtype=np.uint64) for _ in range(user_bins)]
+    ibfs = []
+
+    def build(ubs):
+        my = len(ibfs)
+        ibfs.append(None)
+        entries = []  # per technical bin: (user bin or MERGED, child, values)
+        def direct_bins(lst):
+            for j, ub in enumerate(lst):
+                parts = 1 if j % 3 else int(rng.integers(2, 4))
+                for c in np.array_split(values[ub], parts):
+                    entries.append((ub, 0, c))
+        if len(ubs) * 1.4 <= tmax:
+            direct_bins(ubs)
+        else:
+            mine, rest = ubs[:direct], ubs[direct:]
+            direct_bins(mine)
+            room = tmax - len(entries)
+            for part in np.array_split(np.array(rest, dtype=np.int64), room):
+                if len(part) == 0:
+                    continue
+                part = [int(x) for x in part]
+                if len(part) == 1:
+                    entries.append((part[0], 0, values[part[0]]))
+                else:
+                    child = build(part)
+                    entries.append((MERGED, child, np.concatenate([values[u] for u in part])))
+        order = rng.permutation(len(entries))
+        tbs = [entries[i] for i in order]
+        n_max = max(len(t[2]) for t in tbs)
+        bin_size = max(8, int(np.ceil(-max(n_max, 1) * np.log(fpr) / np.log(2) ** 2)))
+        ibfs[my] = dict(bins=len(tbs), bin_size=bin_size, hash_funs=h, tbs=tbs)
+        return my
+
+    build([int(x) for x in rng.permutation(user_bins)])
+    ox = O.Index.hibf(user_bins, dna=False, k=k)
+    descs = []
+    for f in ibfs:
+        nxt = np.array([t[1] if t[0] == MERGED else 0 for t in f["tbs"]], dtype=np.uint64)
+        tbu = np.array([t[0] for t in f["tbs"]], dtype=np.uint64)
+        i = ox.add_ibf(f["bins"], f["bin_size"], f["hash_funs"], nxt, tbu)
+        for tb, t in enumerate(f["tbs"]):
+            if len(t[2]):
+                ox.hibf_emplace(i, t[2], tb)
+        descs.append(dict(bins=f["bins"], bin_size=f["bin_size"], hash_funs=f["hash_funs"], words=None, next_ibf_id=nxt, tb_to_user=tbu))
+    for i, d in enumerate(descs):
+        d["words"] = ox.hibf_words(i)
+    return ox, descs, values
+
+
 NO_KMER = 0xFFFFFFFF
 
 

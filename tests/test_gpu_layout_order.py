@@ -1,0 +1,111 @@
+"""Sessions on GENERAL HIBFs — three and more levels, user bins next to merged bins, split bins, user bins in any order:
+what seqan::hibf's layout produces (reference include/index_hibf.h:114-129,132-147) — work in LAYOUT ORDER
+(csrc/txq_internal.hpp VChunk; csrc/txq_hibf.hip hibf_layout_level_kernel; csrc/txq_exec.hip PathRows): masks are the rows
+of the tree's own technical bins, written segment by segment, dense steps gather a lane's bytes from one IBF behind its
+ancestors' gates, and only the final masks are converted to user-bin order.  Every mask must equal the CPU oracle's
+collect() over membership_for — and the masks of the same queries in user-bin order (TXQ_HIBF_LAYOUT_ORDER=0: the descent
+kernels, the path the earlier rounds pinned)."""
+import numpy as np
+import pytest
+
+from helpers import layout_hibf, random_hibf
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from tetrex_amd import capi as c
+    c.init(0)
+    return c
+
+
+def _spell(v, k=4):
+    return "".join("ACDEFGHIKLMNPQRSTVWY"[(int(v) >> (5 * (k - 1 - j))) & 31] for j in range(k))
+
+
+def _queries(values, k=4):
+    ok = [v for b in range(0, len(values), max(1, len(values) // 40)) for v in values[b][:2] if all(((int(v) >> (5 * j)) & 31) < 20 for j in range(k))]
+    planted = [_spell(v, k) for v in ok]
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "CLM.{2,4}C...[LIVMFYWC]", "LMA(E|Q)GLYN", "A.CD", "K[RK]DE"]
+    qs += planted[:16] + [p[0] + "." + p[2:] for p in planted[:8]] + [p[:2] + "[" + "".join(sorted(set(p[2] + "AK"))) + "]" + p[3:] for p in planted[8:16]]
+    qs += [p[:1] + ".." + p[3:] for p in planted[16:22]] + [p + ".{0,2}" + q for p, q in zip(planted[22:26], planted[26:30])]
+    return qs
+
+
+@pytest.mark.parametrize("tree", ["random-2", "random-3", "random-4", "layout-64", "layout-16-deep", "layout-200-h3"])
+def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tree):
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    kind, _, arg = tree.partition("-")
+    if kind == "random":
+        ox, descs, values = random_hibf(oracle, 40 + int(arg), user_bins=420, levels=int(arg), n_values=60)
+        ub = 420
+    elif arg == "64":
+        ox, descs, values = layout_hibf(oracle, 5, user_bins=3000, tmax=64, n_values=30)
+        ub = 3000
+    elif arg == "16-deep":
+        ox, descs, values = layout_hibf(oracle, 6, user_bins=900, tmax=16, n_values=30, direct=3)  # four levels
+        ub = 900
+    else:
+        ox, descs, values = layout_hibf(oracle, 7, user_bins=5000, tmax=200, h=3, n_values=25)
+        ub = 5000
+    qs = _queries(values)
+    wants = [ox.query(q, with_stats=True) for q in qs]
+    ix = capi.Index.upload_hibf(ub, descs)
+    assert ix.supports_dense() == 2  # fused steps: the index has a layout order
+    results = {}
+    for way in ("layout", "layout-blocks", "layout-tracked", "user-order"):
+        monkeypatch.delenv("TETREX_DENSE_MIN", raising=False)
+        monkeypatch.delenv("TETREX_DENSE_SPARSE_BELOW", raising=False)
+        monkeypatch.delenv("TETREX_DENSE_TRACKED", raising=False)
+        monkeypatch.delenv("TXQ_HIBF_LAYOUT_ORDER", raising=False)
+        if way != "layout":
+            monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+            monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+        if way == "layout-tracked":
+            monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+        if way == "user-order":
+            monkeypatch.setenv("TXQ_HIBF_LAYOUT_ORDER", "0")
+        got, status, stats = ix.query_masks(qs, False, 4)
+        results[way] = got
+        hits = 0
+        for q, g, st, (want, ost) in zip(qs, got, status, wants):
+            assert st == 0, q
+            if not ost["quirk_merges"]:
+                assert np.array_equal(g, want), (q, way)
+                hits += int(want.any())
+        assert hits >= 10, way
+        if way != "layout":
+            assert stats["dense_ops"] > 0
+        if way == "layout-tracked":
+            assert stats["tracked_queries"] > 0
+    for way, got in results.items():
+        assert np.array_equal(got, results["user-order"]), way
+    # plain probes keep user-bin order (the public contract of txq_probe)
+    kmers = np.concatenate([v[:1] for v in values[:500]] + [np.random.default_rng(1).integers(0, 1 << 20, size=500, dtype=np.uint64)])
+    assert np.array_equal(ix.probe(kmers), ox.probe(kmers))
+    ix.free()
+
+
+def test_a_65536_bin_three_level_tree(capi, oracle, monkeypatch):
+    """BASELINE configs[4]'s size on a tree as a layout algorithm would shape it: 65 536 user bins, at most 64 technical bins
+    per IBF -> three levels, some 3 700 IBFs, user bins scattered over the leaves.  Queries in layout order against the
+    oracle, and against the user-order run."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    ox, descs, values = layout_hibf(oracle, 9, user_bins=65536, tmax=64, n_values=12)
+    qs = _queries(values)[:40]
+    wants = [ox.query(q, with_stats=True) for q in qs]
+    ix = capi.Index.upload_hibf(65536, descs)
+    assert ix.supports_dense() == 2
+    got, status, stats = ix.query_masks(qs, False, 4)
+    monkeypatch.setenv("TXQ_HIBF_LAYOUT_ORDER", "0")
+    ref, status0, _ = ix.query_masks(qs, False, 4)
+    assert list(status) == list(status0) and np.array_equal(got, ref)
+    hits = 0
+    for q, g, st, (want, ost) in zip(qs, got, status, wants):
+        assert st == 0, q
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+            hits += int(want.any())
+    assert hits >= 10
+    ix.free()

@@ -353,6 +353,10 @@ class Index:
         Lq.txe_last_tracked_queries.restype = C.c_uint64
         return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
 
+    def supports_dense(self):
+        """txq_index_supports_dense: 0 no dense steps, 1 through the descent, 2 fused (tracked programs, too)."""
+        return int(lib().txq_index_supports_dense(self._h))
+
     def run_programs(self, blob, n_programs):
         buf = np.frombuffer(blob, dtype=np.uint8)
         # 8-byte aligned copy

@@ -39,6 +39,7 @@ void read_knobs() {
     k.hibf_stationary = !is("TXQ_HIBF_STATIONARY", '0');
     k.hibf_small = !is("TXQ_HIBF_SMALL", '0');
     k.hibf_lane_hash = flag("TXQ_HIBF_LANE_HASH");
+    k.hibf_layout_order = !is("TXQ_HIBF_LAYOUT_ORDER", '0');
     k.hibf_steps_per_group = (int)std::max(0LL, num("TXQ_HIBF_STEPS_PER_GROUP", 0));
     k.hibf_tile = (int)std::max(0LL, num("TXQ_HIBF_TILE", 0));
     k.hibf_unroll = (int)num("TXQ_HIBF_UNROLL", 1);
@@ -170,6 +171,11 @@ void Index::release() {
                     (void*)session_cache.set[0].d_masks, (void*)session_cache.set[1].d_masks})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
+    for (void* p : {(void*)d_vchunks, (void*)d_vpaths, (void*)d_vleaf, (void*)d_vuser, (void*)d_vgroups})
+        if (p) (void)hipFree(p);
+    d_vchunks = nullptr; d_vpaths = nullptr; d_vleaf = nullptr; d_vuser = nullptr; d_vgroups = nullptr;
+    v_words = n_vchunks = 0;
+    vlevels.clear();
     if (d_children) (void)hipFree(d_children);
     if (interleaved.words) (void)hipFree(interleaved.words);
     interleaved = IbfDev{};
@@ -354,7 +360,7 @@ int txq_index_supports_dense(const txq_index* ix) {
     read_knobs();
     if (!ix || ix->ibf.empty() || ix->shard_words == 0) return 0;
     if (!ix->is_hibf) return (ix->ibf[0].bin_size >> 32) == 0 ? 2 : 0;
-    return index_fuses_tree_steps(*ix) ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
+    return index_fuses_tree_steps(*ix) || ix->layout_order() ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
 }
 
 int txq_index_free(txq_index* ix) {
@@ -528,6 +534,11 @@ int txq_session_set_aux_index(txq_session* s, txq_index* aux) {
             aux->device != s->ix->device)
             return fail(TXQ_ERR_ARG, "the auxiliary index must cover the same bins and the same shard (on the same device) as the main index");
     }
+    if (aux && s->vspace) {  // d-gram masks come in user-bin order: the session cannot work in layout order then
+        if (s->n_stages) return fail(TXQ_ERR_STATE, "attach the auxiliary index before the session's first stage");
+        s->vspace = false;
+        s->W = (uint32_t)s->ix->shard_words;
+    }
     if (s->aux) --s->aux->open_sessions;
     s->aux = aux;
     if (aux) ++aux->open_sessions;
@@ -548,7 +559,7 @@ int txq_session_end(txq_session* s, uint64_t* final_masks) {
     if (rc != TXQ_OK) { delete static_cast<Session*>(s); return rc; }
     if (final_masks && s->n_programs && s->W) {
         Index& ix = *s->ix;
-        const size_t bytes = s->n_programs * (size_t)s->W * 8;
+        const size_t bytes = s->n_programs * (size_t)ix.shard_words * 8;  // (a layout-order session hands out user-bin masks too)
         rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);
         if (rc == TXQ_OK) rc = session_finish(*s, ix.scratch_final, nullptr);
         if (rc == TXQ_OK) {

@@ -276,6 +276,7 @@ struct FlatRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; };
     static constexpr bool kRootByLane = false;
+    static constexpr int kPushUnroll = 3;
     IbfDev f;
     uint32_t c;
     __device__ __forceinline__ void prepare(uint32_t chunk) { c = chunk; }
@@ -313,6 +314,7 @@ struct TreeRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; uint64_t r[H]; uint64_t value; const uint64_t* src; bool hit; };
     static constexpr bool kRootByLane = false;
+    static constexpr int kPushUnroll = 3;
     HibfNode root;
     const ChildRec* children;
     uint32_t wpr_log2;
@@ -399,6 +401,7 @@ struct InterleavedRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; uint64_t r[H]; };
     static constexpr bool kRootByLane = false;
+    static constexpr int kPushUnroll = 3;
     IbfDev f;  // the interleaved children
     HibfNode root;
     const ChildRec* children;
@@ -442,6 +445,93 @@ struct InterleavedRows {
 template <int H, bool WIDE>
 struct TreeRowsByLane : TreeRows<H, WIDE> {
     static constexpr bool kRootByLane = true;
+};
+
+// A general HIBF in layout order (txq_internal.hpp VChunk): the lane's 16 bytes are two row words of ONE IBF of the tree, and
+// M[k-mer] there = that IBF's rows ANDed, if the k-mer gets that far — if, in every ancestor from the root down, the rows
+// ANDed have the bit of the merged bin that leads towards it (membership_for(·, 1), reference include/index_hibf.h:132-147,
+// restated per technical bin).  Two rounds of loads like TreeRows: the gate words of all ancestors (8 bytes each; the lanes
+// of a sub-tree read the same ones), then — where every gate is open — the predecessor's chunk and the IBF's own rows.
+template <int H, bool WIDE>
+struct PathRows {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    struct Loads { T x[H + 1]; uint64_t g[kMaxVDepth][H]; uint64_t sv[H]; const uint64_t* src; bool hit; };
+    static constexpr bool kRootByLane = false;
+    static constexpr int kPushUnroll = 1;  // (a lane keeps its ancestors' gates in registers: one residue's loads at a time)
+    const VChunk* chunks;
+    const VPath* paths;
+    // the lane's chunk: its IBF and the ancestors' gates
+    const uint64_t* cw;
+    uint32_t c, c_rows, c_packed, col, depth;
+    const uint64_t* aw[kMaxVDepth];
+    uint32_t a_rows[kMaxVDepth], a_packed[kMaxVDepth], a_word[kMaxVDepth], a_bit[kMaxVDepth];
+    __device__ __forceinline__ void prepare(uint32_t chunk) {
+        c = chunk;
+        const VChunk rec = chunks[chunk];
+        cw = (const uint64_t*)rec.words;
+        c_rows = rec.bin_size;
+        c_packed = rec.packed;
+        col = rec.col;
+        const VPath* p = paths + rec.ibf;
+        depth = p->depth;
+#pragma unroll
+        for (uint32_t a = 0; a < kMaxVDepth; ++a) {
+            aw[a] = (const uint64_t*)p->anc[a].words;
+            a_rows[a] = p->anc[a].bin_size;
+            a_packed[a] = p->anc[a].packed;
+            a_word[a] = p->anc[a].word;
+            a_bit[a] = p->anc[a].bit;
+        }
+    }
+    template <bool SRC = true>
+    __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        l.src = src_slot;
+#pragma unroll
+        for (int i = 0; i < H; ++i) l.sv[i] = value * kSeeds[i];
+#pragma unroll
+        for (uint32_t a = 0; a < kMaxVDepth; ++a)
+#pragma unroll
+            for (int i = 0; i < H; ++i) {
+                l.g[a][i] = ~0ULL;
+                if (a < depth && (uint32_t)i < ((a_packed[a] >> 26) & 7u))
+                    l.g[a][i] = aw[a][hash_row_seeded32(l.sv[i], (a_packed[a] >> 20) & 63u, a_rows[a]) * (a_packed[a] & 0xFFFFFu) + a_word[a]];
+            }
+    }
+    template <bool SRC = true>
+    __device__ __forceinline__ void issue_late(Loads& l) const {
+        bool open = true;
+#pragma unroll
+        for (uint32_t a = 0; a < kMaxVDepth; ++a) {
+            uint64_t gw = l.g[a][0];
+#pragma unroll
+            for (int i = 1; i < H; ++i) gw &= l.g[a][i];
+            if (a < depth) open = open && ((gw >> a_bit[a]) & 1ULL);
+        }
+        l.hit = open;
+        if (!open) return;
+        if constexpr (SRC) l.x[H] = L::load(l.src + (size_t)c * L::kWords);
+        else l.x[H] = ~L::zero();
+        const uint32_t stride = c_packed & 0xFFFFFu, shift = (c_packed >> 20) & 63u, hf = (c_packed >> 26) & 7u;
+        const bool single = (c_packed >> 29) & 1u;
+#pragma unroll
+        for (int i = 0; i < H; ++i) {
+            l.x[i] = ~L::zero();
+            if ((uint32_t)i >= hf) continue;
+            const uint64_t* p = cw + (size_t)hash_row_seeded32(l.sv[i], shift, c_rows) * stride + col;
+            if constexpr (WIDE) {
+                if (single) { const uint64_t w = *p; l.x[i] = T{(uint32_t)w, (uint32_t)(w >> 32), 0u, 0u}; }
+                else l.x[i] = L::load(p);
+            } else l.x[i] = L::load(p);
+        }
+    }
+    __device__ __forceinline__ T combine(const Loads& l) const {
+        if (!l.hit) return L::zero();
+        T y = l.x[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) y &= l.x[h];
+        return y;
+    }
 };
 
 template <int H, bool WIDE, int UA, class ROWS>
@@ -742,7 +832,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
                                                      uint32_t W, uint32_t G, DenseParams P, LevelUnits U) {
     using L = Lane<WIDE>;
     using T = typename L::T;
-    constexpr int UA = 3;  // residues in flight per lane: UA * H row gathers
+    constexpr int UA = ROWS::kPushUnroll;  // residues in flight per lane: UA * H row gathers
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // of the op's shape (FILL) and, [pos], of its r_mask (STEP)
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
@@ -1014,7 +1104,7 @@ __global__ __launch_bounds__(256) void move_regions_kernel(const RegionMove* __r
 
 // constants of programs that just received their first slot region
 __global__ __launch_bounds__(256) void init_slots_kernel(uint64_t* const* __restrict__ slot_base, const uint32_t* __restrict__ which,
-                                                         uint32_t n, uint32_t W, uint64_t user_bins, uint64_t word0) {
+                                                         uint32_t n, uint32_t W, uint64_t user_bins, uint64_t word0, const uint64_t* __restrict__ ones_words) {
     const size_t total = (size_t)n * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const uint32_t p = which[i / W], w = (uint32_t)(i % W);
@@ -1023,6 +1113,7 @@ __global__ __launch_bounds__(256) void init_slots_kernel(uint64_t* const* __rest
         const uint64_t first_bin = (word0 + w) * 64;
         uint64_t ones = 0;
         if (first_bin < user_bins) ones = (user_bins - first_bin >= 64) ? ~0ULL : ((1ULL << (user_bins - first_bin)) - 1ULL);
+        if (ones_words) ones = ones_words[w];  // a layout-order session: the technical bins that are user bins
         S[(size_t)TXQ_SLOT_ZERO * W + w] = 0;
         S[(size_t)TXQ_SLOT_ONES * W + w] = ones;
         S[(size_t)TXQ_SLOT_RESULT * W + w] = 0;
@@ -1314,7 +1405,8 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     s->kn = knobs();
     ++ix.open_sessions;
     s->n_programs = n_programs;
-    s->W = (uint32_t)ix.shard_words;
+    s->vspace = ix.layout_order();  // a general HIBF: the session's masks are rows in layout order (txq_internal.hpp VChunk)
+    s->W = s->vspace ? ix.v_words : (uint32_t)ix.shard_words;
     s->base.assign(2 * n_programs, nullptr);
     s->cap.assign(n_programs, 0);
     s->blocks.assign(n_programs, {});
@@ -1662,7 +1754,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // Does this stage continue anything the previous stage — possibly still running — works on?  Programs with ops in both,
     // feedback questions, grown regions (moves), an HIBF that is descended or a d-gram index (scratch of the index) tie it
     // to the previous stage's stream; a stage of other programs only (the next wave of queries) runs beside it.
-    bool continues = n_q != 0 || (ix.is_hibf && !ix.probes_interleaved()) || s.aux != nullptr;
+    bool continues = n_q != 0 || (ix.is_hibf && !ix.probes_interleaved() && !s.vspace) || s.aux != nullptr;
     for (size_t p = 0; p < s.n_programs; ++p)
         if (bv.programs[p].n_ops) {
             continues = continues || s.last_stage[p] + 1 == s.n_stages;
@@ -1672,7 +1764,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const bool tree = index_fuses_tree_steps(ix);
     bool any_tracked = false;
     for (size_t p = 0; p < s.n_programs; ++p) any_tracked |= bv.tracked[p] != 0 && bv.has_dense[p] != 0;
-    if (any_tracked && ix.is_hibf && !tree)
+    const bool vspace = s.vspace;
+    if (any_tracked && ix.is_hibf && !tree && !vspace)
         return fail(TXQ_ERR_PROGRAM, "tracked blocks need an index whose dense steps run fused (txq_index_supports_dense() == 2)");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
@@ -1683,12 +1776,12 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (!s.base[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: program %u has not run an op yet", i, q_prog[i]);
 
     // dense steps: 16-byte lanes where masks and rows allow it, G lanes per destination suffix
-    if (any_dense) s.row_source = tree ? "regular tree, fused" : ix.is_hibf ? "HIBF descent" : "flat IBF, fused";
+    if (any_dense) s.row_source = tree ? "regular tree, fused" : vspace ? "general tree in layout order, fused" : ix.is_hibf ? "HIBF descent" : "flat IBF, fused";
     if (any_dense && tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && s.kn.dense_tree < 0)
         s.row_source = "regular tree, interleaved children, fused";
     const int tree_knob = s.kn.dense_tree;  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; -1 (default): best fit
     const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && tree_knob < 0;
-    const bool wide = W % 2 == 0 && (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0);
+    const bool wide = W % 2 == 0 && (vspace || (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0));
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
@@ -1706,7 +1799,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<SparseGroup> sparse_groups;
     std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
+    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
     size_t n_sparse_launches = 0;
@@ -1880,13 +1973,15 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     if (!fresh.empty()) {
         size_t blocks = (fresh.size() * W + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0);
+        init_slots_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, d_fresh, (uint32_t)fresh.size(), W, ix.user_bins, ix.shard_word0, s.vspace ? ix.d_vleaf : nullptr);
     }
     const uint64_t* d_kmers = (const uint64_t*)(dblob + h->kmers_offset);
     const size_t n_aux = (size_t)h->n_aux_kmers, n_main = nk - n_aux;
     if (n_aux && !s.aux) return fail(TXQ_ERR_STATE, "the blob has auxiliary (d-gram) k-mers but the session has no auxiliary index");
     if (n_main) {
-        if (ix.is_hibf) {
+        if (vspace) {
+            if (int rc = hibf_probe_layout_order(ix, d_kmers, n_main, d_masks, st)) return rc;
+        } else if (ix.is_hibf) {
             if (int rc = hibf_probe(ix, d_kmers, n_main, d_masks, nullptr, st)) return rc;
         } else {
             hipError_t e = launch_probe(ix.ibf[0], d_kmers, n_main, d_masks, nullptr, st);
@@ -1936,8 +2031,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             ++s.n_levels;
             // a flat index runs the level's units inside its dense launch (below), or its sparse launch when it has no tiles;
             // otherwise they are a launch of their own
-            const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree);
-            const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree);
+            const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree || vspace);
+            const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree || vspace);
             if (cnt && !ride && !ride_sparse) {
                 ++s.n_unit_launches;
                 exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2);
@@ -1960,7 +2055,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             if (plan[l].tiles) {  // ordinary and dense ops of one level are independent of each other: no order implied
                 const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
                 hipError_t e;
-                if (tree) {
+                if (vspace) {  // (rows are whole 16-byte chunks: WIDE; two predecessors in flight — a lane keeps its ancestors' gates in registers)
+                    auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
+                    e = launch_dense<true, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                } else if (tree) {
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
                     const bool by_lane = (256u / (g_dense * sl_dense)) * 32u * ix.root_node.stride() <= kRootWordsLds && tree_knob != 1;
@@ -1996,7 +2094,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 // as many workgroups as the chunks could be at most, within what the device holds at a time
                 const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(plan[l].sparse_chunks, 2048));
                 hipError_t e;
-                if (interleaved) {
+                if (vspace) {
+                    auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
+                    e = launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                } else if (interleaved) {
                     auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
                              : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
@@ -2047,9 +2148,15 @@ int session_finish(Session& s, uint64_t* d_final, hipStream_t st) {
         }
     size_t blocks = (s.n_programs * W + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    gather_result_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, (uint32_t)s.n_programs, W, d_final);
+    uint64_t* gathered = d_final;
+    if (s.vspace) {  // RESULT slots are rows in layout order: gathered into scratch, then converted to user-bin order
+        if (int rc = ensure((void**)&s.ix->scratch_slots, &s.ix->cap_slots, s.n_programs * (size_t)W * 8)) return rc;
+        gathered = s.ix->scratch_slots;
+    }
+    gather_result_kernel<<<(unsigned)blocks, 256, 0, st>>>(s.d_base, (uint32_t)s.n_programs, W, gathered);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail_hip(e, "gather kernel launch");
+    if (s.vspace) return hibf_layout_to_user(*s.ix, gathered, s.n_programs, d_final, st);
     return TXQ_OK;
 }
 

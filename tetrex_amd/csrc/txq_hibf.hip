@@ -573,11 +573,209 @@ __global__ __launch_bounds__(256) void mask_alive_kernel(const uint64_t* __restr
     }
 }
 
+// ---- layout order (txq_internal.hpp VChunk): the rows of a general HIBF, level by level, child-stationary ----------
+// One launch per level of the tree.  A workgroup = a tile of k-mers x one GROUP of the level's chunks (consecutive
+// chunks whose IBFs' rows fit an XCD's L2: workgroup b takes group b % 8 of its phase, and the dispatcher deals
+// workgroups round-robin over the 8 XCDs, so an XCD keeps probing the same few MB — a speed assumption only).
+// A lane owns one 16-byte chunk of the row (two words of one IBF) for the whole tile: its IBF's parameters stay in
+// registers, the k-mers stream past.  Per k-mer: the gate (the bit of the parent's row that leads to this IBF, written
+// by the previous level's launch), then — only where it is set — h row gathers, AND, and one coalesced store (a wave
+// covers 1 KiB of the row).  Chunks of IBFs that were not reached get zeros: every byte of the row is written once.
+__global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __restrict__ chunks, const uint32_t* __restrict__ group_first,
+                                                                uint32_t n_groups, const uint64_t* __restrict__ kmers, size_t n,
+                                                                uint64_t* __restrict__ rows, uint32_t v_words, uint32_t n_tiles, uint32_t tile) {
+    constexpr int U = 4;  // k-mers in flight per lane: U gates, then up to U * h row gathers
+    const uint32_t gsel = blockIdx.x % 8u, t = (blockIdx.x / 8u) % n_tiles, phase = blockIdx.x / (8u * n_tiles);
+    const uint32_t g = phase * 8u + gsel;
+    if (g >= n_groups) return;
+    const uint32_t c0 = group_first[g], c1 = group_first[g + 1];
+    const size_t k0 = (size_t)t * tile, k1 = k0 + tile < n ? k0 + tile : n;
+    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+        const VChunk rec = chunks[c];
+        const uint64_t* words = (const uint64_t*)rec.words;
+        const uint32_t stride = rec.packed & 0xFFFFFu, shift = (rec.packed >> 20) & 63u, hf = (rec.packed >> 26) & 7u;
+        const bool single = (rec.packed >> 29) & 1u;
+        for (size_t i0 = k0; i0 < k1; i0 += U) {
+            uint64_t v[U];
+            bool pass[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const size_t i = i0 + u < k1 ? i0 + u : k1 - 1;
+                v[u] = kmers[i];
+                pass[u] = i0 + u < k1;
+                if (pass[u] && rec.gate_word != kNoGate) pass[u] = (gload(rows + i * v_words + rec.gate_word) >> rec.gate_bit) & 1ULL;
+            }
+            ulonglong2 x[U][5];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (uint32_t j = 0; j < 5; ++j) {
+                    x[u][j] = ulonglong2{~0ULL, ~0ULL};
+                    if (j >= hf || !pass[u]) continue;
+                    const uint64_t r = hash_row_seeded32(v[u] * kSeeds[j], shift, rec.bin_size);
+                    if (single) x[u][j].x = gload(words + r);
+                    else x[u][j] = gload2(words + r * stride + rec.col);
+                }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (i0 + u >= k1) break;
+                hu32x4 acc{0u, 0u, 0u, 0u};
+                if (pass[u]) {
+                    uint64_t a = ~0ULL, b = ~0ULL;
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; ++j) { a &= x[u][j].x; b &= x[u][j].y; }
+                    if (single) b = 0;
+                    acc = hu32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+                }
+                store_row16(reinterpret_cast<hu32x4*>(rows + (i0 + u) * v_words + (size_t)c * 2), acc, 0);
+            }
+        }
+    }
+}
+
+// final masks of a layout-order session -> user-bin order (split bins: several technical bins, one user bin: ORed)
+__global__ __launch_bounds__(256) void hibf_layout_to_user_kernel(const uint64_t* __restrict__ rows, size_t n, uint32_t v_words, const uint64_t* __restrict__ leaf,
+                                                                  const uint32_t* __restrict__ vuser, uint64_t* __restrict__ out, uint32_t w_out) {
+    const size_t total = n * (size_t)v_words;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t p = i / v_words;
+        const uint32_t w = (uint32_t)(i % v_words);
+        for (uint64_t x = rows[i] & leaf[w]; x; x &= x - 1) {
+            const uint32_t ub = vuser[(size_t)w * 64 + (uint32_t)__builtin_ctzll(x)];
+            atomicOr((unsigned long long*)(out + p * w_out + (ub >> 6)), 1ULL << (ub & 63u));
+        }
+    }
+}
+
 #define TXQ_HIP(call)                                        \
     do {                                                     \
         hipError_t e_ = (call);                              \
         if (e_ != hipSuccess) return fail_hip(e_, #call);    \
     } while (0)
+
+// Layout order for a tree that is not regular (txq_internal.hpp VChunk): the rows of all IBFs, levels ascending, each IBF
+// padded to whole 16-byte chunks; per chunk its record, per IBF its ancestors, which bits are user bins, and the user
+// bin behind every bit.  Single shard only (a column shard of the USER bins does not cut the layout-order row in one piece).
+static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::vector<int>& level, const std::vector<uint64_t>& next,
+                              const std::vector<uint64_t>& tbu, const std::vector<uint64_t>& off) {
+    const uint64_t n = desc.n_ibf;
+    if (ix.shard_words != ix.mask_words || ix.shard_word0 != 0 || ix.depth > kMaxVDepth + 1 || desc.user_bins >= kNoGate) return TXQ_OK;
+    for (const IbfDev& f : ix.ibf)
+        if ((f.bin_size >> 32) || f.stride >= (1u << 20) || f.hash_funs > 5) return TXQ_OK;
+    // IBFs by level (BFS order within a level), their segments in the row
+    std::vector<std::vector<uint64_t>> by_level(ix.depth);
+    for (uint64_t i = 0; i < n; ++i) by_level[level[i]].push_back(i);
+    std::vector<uint64_t> seg(n, 0), parent(n, UINT64_MAX), parent_tb(n, 0);
+    for (uint64_t i = 0; i < n; ++i)
+        for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+            if (tbu[off[i] + b] == TXQ_MERGED_BIN) { parent[next[off[i] + b]] = i; parent_tb[next[off[i] + b]] = b; }
+    uint64_t words = 0;
+    for (auto& lv : by_level)
+        for (uint64_t i : lv) { seg[i] = words; words += (desc.ibf[i].bin_words + 1) & ~(uint64_t)1; }
+    if (words >= (1u << 26)) return TXQ_OK;
+    std::vector<VChunk> chunks;
+    std::vector<VPath> paths(n);
+    std::vector<uint64_t> leaf(words, 0);
+    std::vector<uint32_t> vuser(words * 64, kNoGate);
+    std::vector<uint32_t> groups;  // per level: first chunk of each group, then the level's end
+    ix.vlevels.clear();
+    auto packed_of = [](const IbfDev& f) { return f.stride | (f.hash_shift << 20) | (f.hash_funs << 26) | ((uint32_t)(f.stride == 1) << 29); };
+    for (auto& lv : by_level) {
+        VLevel L;
+        L.first_chunk = (uint32_t)chunks.size();
+        uint64_t group_bytes = 0;
+        for (uint64_t i : lv) {
+            const IbfDev& f = ix.ibf[i];
+            const uint64_t bytes = f.bin_size * (uint64_t)f.stride * 8;
+            if (L.group_first.empty() || group_bytes + bytes > ((uint64_t)2 << 20)) { L.group_first.push_back((uint32_t)chunks.size()); group_bytes = 0; }
+            group_bytes += bytes;
+            const uint64_t padded = (desc.ibf[i].bin_words + 1) & ~(uint64_t)1;
+            for (uint64_t c = 0; c < padded; c += 2) {
+                VChunk r{};
+                r.words = (uint64_t)(uintptr_t)f.words;
+                r.bin_size = (uint32_t)f.bin_size;
+                r.packed = packed_of(f);
+                r.col = (uint32_t)c;
+                r.gate_word = parent[i] == UINT64_MAX ? kNoGate : (uint32_t)(seg[parent[i]] + (parent_tb[i] >> 6));
+                r.gate_bit = (uint32_t)(parent_tb[i] & 63);
+                r.ibf = (uint32_t)i;
+                chunks.push_back(r);
+            }
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+                if (tbu[off[i] + b] != TXQ_MERGED_BIN) {
+                    leaf[seg[i] + (b >> 6)] |= 1ULL << (b & 63);
+                    vuser[(seg[i] + (b >> 6)) * 64 + (b & 63)] = (uint32_t)tbu[off[i] + b];
+                }
+            VPath& p = paths[i];
+            p.depth = 0;
+            std::vector<uint64_t> chain;  // i's ancestors, nearest first
+            for (uint64_t a = i; parent[a] != UINT64_MAX; a = parent[a]) chain.push_back(a);
+            for (size_t at = chain.size(); at-- > 0;) {  // root first
+                const uint64_t child = chain[at], a = parent[child];
+                const IbfDev& fa = ix.ibf[a];
+                auto& slot = p.anc[p.depth++];
+                slot.words = (uint64_t)(uintptr_t)fa.words;
+                slot.bin_size = (uint32_t)fa.bin_size;
+                slot.packed = packed_of(fa);
+                slot.word = (uint32_t)(parent_tb[child] >> 6);
+                slot.bit = (uint32_t)(parent_tb[child] & 63);
+            }
+        }
+        L.n_chunks = (uint32_t)chunks.size() - L.first_chunk;
+        L.group_first.push_back((uint32_t)chunks.size());
+        ix.vlevels.push_back(L);
+    }
+    for (VLevel& L : ix.vlevels) {  // the groups of all levels in one device array; group_first becomes offsets into it
+        const uint32_t at = (uint32_t)groups.size();
+        groups.insert(groups.end(), L.group_first.begin(), L.group_first.end());
+        const uint32_t ng = (uint32_t)L.group_first.size() - 1;
+        L.group_first.assign({at, ng});
+    }
+    TXQ_HIP(hipMalloc((void**)&ix.d_vchunks, chunks.size() * sizeof(VChunk)));
+    TXQ_HIP(hipMalloc((void**)&ix.d_vpaths, paths.size() * sizeof(VPath)));
+    TXQ_HIP(hipMalloc((void**)&ix.d_vleaf, leaf.size() * 8));
+    TXQ_HIP(hipMalloc((void**)&ix.d_vuser, vuser.size() * 4));
+    TXQ_HIP(hipMalloc((void**)&ix.d_vgroups, groups.size() * 4));
+    TXQ_HIP(hipMemcpy(ix.d_vchunks, chunks.data(), chunks.size() * sizeof(VChunk), hipMemcpyHostToDevice));
+    TXQ_HIP(hipMemcpy(ix.d_vpaths, paths.data(), paths.size() * sizeof(VPath), hipMemcpyHostToDevice));
+    TXQ_HIP(hipMemcpy(ix.d_vleaf, leaf.data(), leaf.size() * 8, hipMemcpyHostToDevice));
+    TXQ_HIP(hipMemcpy(ix.d_vuser, vuser.data(), vuser.size() * 4, hipMemcpyHostToDevice));
+    TXQ_HIP(hipMemcpy(ix.d_vgroups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
+    ix.v_words = (uint32_t)words;
+    ix.n_vchunks = (uint32_t)chunks.size();
+    ix.v_depth = ix.depth - 1;
+    ix.tree_hash_max = 1;
+    for (const IbfDev& f : ix.ibf) ix.tree_hash_max = std::max(ix.tree_hash_max, f.hash_funs);
+    ix.device_bytes += chunks.size() * sizeof(VChunk) + paths.size() * sizeof(VPath) + leaf.size() * 8 + vuser.size() * 4;
+    return TXQ_OK;
+}
+
+int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_rows, hipStream_t s) {
+    if (!ix.d_vchunks) return fail(TXQ_ERR_STATE, "the index has no layout order");
+    if (!n) return TXQ_OK;
+    const uint32_t tile = 2048;
+    const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+    for (const VLevel& L : ix.vlevels) {
+        const uint32_t at = L.group_first[0], ng = L.group_first[1];
+        const uint32_t phases = (ng + 7) / 8;
+        if ((uint64_t)phases * n_tiles * 8 >= ((uint64_t)1 << 31)) return fail(TXQ_ERR_ARG, "too many k-mers for one layout-order probe");
+        hibf_layout_level_kernel<<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return fail_hip(e, "layout-order level kernel launch");
+    }
+    return TXQ_OK;
+}
+
+int hibf_layout_to_user(const Index& ix, const uint64_t* d_rows, size_t n, uint64_t* d_out, hipStream_t s) {
+    if (!n || !ix.shard_words) return TXQ_OK;
+    TXQ_HIP(hipMemsetAsync(d_out, 0, n * ix.shard_words * 8, s));
+    size_t blocks = (n * ix.v_words + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hibf_layout_to_user_kernel<<<(unsigned)blocks, 256, 0, s>>>(d_rows, n, ix.v_words, ix.d_vleaf, ix.d_vuser, d_out, (uint32_t)ix.shard_words);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail_hip(e, "layout-to-user kernel launch");
+    return TXQ_OK;
+}
 
 int hibf_upload(Index& ix, const txq_index_desc& desc) {
     const uint64_t n = desc.n_ibf;
@@ -787,6 +985,9 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
             ix.device_bytes += recs.size() * sizeof(ChildRec);
         }
     }
+    // any other tree: sessions work in layout order
+    if (!ix.d_children)
+        if (int rc = build_layout_order(ix, desc, level, next, tbu, off)) return rc;
     return TXQ_OK;
 }
 

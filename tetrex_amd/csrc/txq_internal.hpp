@@ -28,6 +28,7 @@ struct Knobs {
     bool hibf_stationary = true;        // TXQ_HIBF_STATIONARY=0: no child-stationary descent
     bool hibf_small = true;             // TXQ_HIBF_SMALL=0: no lane-per-k-mer kernel for small trees
     bool hibf_lane_hash = false;        // TXQ_HIBF_LANE_HASH: per-lane hashing on a uniform tree
+    bool hibf_layout_order = true;      // TXQ_HIBF_LAYOUT_ORDER=0: sessions on general trees work in user-bin order (descent kernels)
     int hibf_steps_per_group = 0, hibf_tile = 0, hibf_unroll = 1, hibf_store = 0;  // TXQ_HIBF_STEPS_PER_GROUP / _TILE / _UNROLL / _STORE_KIND (store instruction: 0-3)
     long long hibf_waves = 0;           // TXQ_HIBF_WAVES
     // probe (txq_probe.hip)
@@ -63,6 +64,34 @@ struct ChildRec {   // 16 bytes, one per child in mask-column order
     uint32_t packed;    // hash_shift (bits 0-7) | hash_funs (8-11) | root technical bin (12-31)
 };
 static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
+
+// General HIBFs in LAYOUT ORDER (sessions on trees that are not regular: three and more levels, user bins next to merged
+// bins, split bins, user bins in any order — what seqan::hibf's layout produces, reference include/index_hibf.h:114-129).
+// A session on such a tree does not work on masks in user-bin order but on rows in the order of the tree's own
+// technical bins: the row of every IBF, one after the other (levels ascending, every IBF padded to an even number of
+// words), W_v words in all.  In that order every IBF owns an aligned segment of the row, so a k-mer's mask is written
+// segment by segment with coalesced stores and no atomics (child-stationary, level by level), and a dense step gathers a
+// lane's 16 bytes from ONE IBF.  Every operation of the collector is bin-wise, so the order of the bins does not matter
+// until the final masks are handed out: those are converted to user-bin order (split bins ORed) once per query.
+// Merged bins keep their bits in the rows (the next level reads them as its gates); they never reach a result because
+// the ONES slot of a layout-order session only has the bits of technical bins that ARE user bins.
+struct VChunk {          // one 16-byte chunk (two row words) of the layout-order row
+    uint64_t words;      // the IBF's rows
+    uint32_t bin_size;   // rows (< 2^32)
+    uint32_t packed;     // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | single-word rows (29)
+    uint32_t col;        // word column of the chunk within the IBF's row
+    uint32_t gate_word;  // layout-order word that holds the parent's merged bin leading here (kNoGate: the root)
+    uint32_t gate_bit;
+    uint32_t ibf;        // IBF id (its VPath)
+};
+static_assert(sizeof(VChunk) == 32, "two 16-byte loads per lane");
+static constexpr uint32_t kNoGate = 0xFFFFFFFFu;
+static constexpr uint32_t kMaxVDepth = 3;  // ancestors a fused dense step follows (trees of up to 4 levels)
+struct VPath {           // the ancestors of an IBF, root first: whose merged bin (row word, bit) leads towards it
+    uint32_t depth, pad;
+    struct { uint64_t words; uint32_t bin_size, packed, word, bit; } anc[kMaxVDepth];
+};
+struct VLevel { uint32_t first_chunk, n_chunks; std::vector<uint32_t> group_first; };  // groups: chunk ranges whose IBFs share an L2's worth of rows
 
 // One HIBF work item: k-mer `kmer` (index into the batch) must be looked up in IBF `ibf`.
 struct WorkItem { uint32_t kmer; uint32_t ibf; };
@@ -104,6 +133,15 @@ struct Index {
     uint64_t children_bytes = 0;     // their matrices
     uint32_t* scratch_crows = nullptr; size_t cap_crows = 0;  // uniform children: per k-mer its row indexes in a child
     uint64_t* scratch_cm = nullptr; size_t cap_cm = 0;  // root pass output: per k-mer the root row (which children to visit)
+    // layout order (see VChunk): built at upload for trees that are not regular, one shard, fewer than 2^32 rows per IBF
+    VChunk* d_vchunks = nullptr;
+    VPath* d_vpaths = nullptr;
+    uint64_t* d_vleaf = nullptr;     // [v_words] bits of technical bins that are user bins (the ONES of a layout-order session)
+    uint32_t* d_vuser = nullptr;     // [v_words * 64] user bin of a layout-order bit (kNoGate: none)
+    uint32_t* d_vgroups = nullptr;   // per level its groups' first chunks, concatenated (+ end)
+    uint32_t v_words = 0, n_vchunks = 0, v_depth = 0;
+    std::vector<VLevel> vlevels;
+    bool layout_order() const;       // sessions on this index work in layout order
     uint32_t depth = 1;              // levels of the tree
     uint64_t hibf_total_tbs = 0;     // technical bins over all IBFs of the tree
     uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
@@ -158,6 +196,9 @@ struct Index {
 // Does a session on this index run dense steps fused on the tree (txq_exec.hip TreeRows / InterleavedRows)?  A regular
 // two-level HIBF whose children tile this shard's mask columns.  TXQ_DENSE_TREE=0 (A/B and tests) sends steps through
 // the generic HIBF path instead.
+inline bool Index::layout_order() const {
+    return is_hibf && d_vchunks && v_words && knobs().hibf_layout_order && shard_words == mask_words && shard_word0 == 0;
+}
 inline bool index_fuses_tree_steps(const Index& ix) {
     return ix.is_hibf && ix.d_children && ix.n_children && knobs().dense_tree != 0 && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
            (uint64_t)ix.n_children * ix.child_row_words == ix.shard_words;
@@ -172,7 +213,8 @@ struct Session {
     Index* aux = nullptr;  // optional d-gram index (flat IBF, same bins and shard as ix)
     Knobs kn;              // the environment switches as they were when the session began
     size_t n_programs = 0;
-    uint32_t W = 0;
+    uint32_t W = 0;        // words of a slot mask: the shard's mask words, or (vspace) the words of a layout-order row
+    bool vspace = false;   // the index is a general HIBF: masks are rows in layout order, final masks are converted (Index::layout_order)
     std::vector<Index::ArenaChunk> chunks;  // arena chunks; bump allocation in chunks[cur]
     size_t cur = 0, chunk_used = 0, arena_words = 0;
     std::vector<uint64_t*> base;    // [2 * n_programs]: per program its slot region [cap][W], then (device address of) its row of the stage's block table
@@ -234,6 +276,10 @@ hipError_t launch_emplace(const IbfDev& f, const uint64_t* values, const uint32_
 // txq_hibf.hip
 int hibf_upload(Index& ix, const txq_index_desc& desc);
 int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s);
+// layout-order rows of n k-mers: d_rows[n][v_words]
+int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_rows, hipStream_t s);
+// final masks of a layout-order session -> user-bin order: d_out[n][shard_words] (zeroed here)
+int hibf_layout_to_user(const Index& ix, const uint64_t* d_rows, size_t n, uint64_t* d_out, hipStream_t s);
 
 // txq_exec.hip
 int run_programs(Index& ix, const void* blob, size_t blob_bytes, size_t n_programs, uint64_t* d_final, hipStream_t s);
