@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Measurement: a GENERAL HIBF of 65 536 user bins (helpers.layout_hibf: at most `tmax` technical bins per IBF, user bins
+scattered over the leaves, split bins, user bins next to merged bins — three levels at tmax = 64), the shape seqan::hibf's
+layout gives the reference's index (include/index_hibf.h:114-129).
+  * txq_probe_device (masks in user-bin order, the public contract): the k-mer-stationary descent kernels;
+  * the same k-mers as ONE session stage (rows in layout order: csrc/txq_hibf.hip hibf_layout_level_kernel) — what every
+    query on such an index runs on;
+  * a batch of PROSITE-style motifs, in layout order and (TXQ_HIBF_LAYOUT_ORDER=0) in user-bin order; masks must agree.
+Prints one JSON line.  Usage: perf_hibf_ragged.py [kmers] [tmax] [user_bins]"""
+import json
+import os
+import struct
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def probe_blob(kmers):
+    """a version-2 blob (include/txq_program.h): the k-mer table and one program with the op RESULT |= ONES & M[0]"""
+    n = kmers.size
+    k_off = 64
+    p_off = k_off + n * 8
+    o_off = p_off + 24
+    l_off = o_off + 16
+    head = struct.pack("<6I5Q", 0x50515854, 2, 1, n, 1, 1, k_off, p_off, o_off, l_off, 0)
+    return head + kmers.tobytes() + struct.pack("<6I", 0, 1, 3, 0, 1, 0) + struct.pack("<4I", 0, 2, 1, 2) + struct.pack("<2I", 1, 0)
+
+
+def main():
+    import torch
+    import oracle as O
+    from helpers import layout_hibf
+    from motifs import random_prosite_motifs
+    from tetrex_amd import capi
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    tmax = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    user_bins = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    capi.init(0)
+    t0 = time.perf_counter()
+    ox, descs, values = layout_hibf(O, 9, user_bins=user_bins, tmax=tmax, n_values=12)
+    build_s = time.perf_counter() - t0
+    ix = capi.Index.upload_hibf(user_bins, descs)
+    rng = np.random.default_rng(3)
+    kmers = np.concatenate([np.concatenate([v[:2] for v in values[:4096]]), rng.integers(0, 1 << 20, size=n - 8192, dtype=np.uint64)]) if n > 8192 else rng.integers(0, 1 << 20, size=n, dtype=np.uint64)
+    W = ix.shard_words
+    d_kmers = torch.from_numpy(kmers.view(np.int64)).cuda()
+    d_masks = torch.empty((n, W), dtype=torch.int64, device="cuda")
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def user_order():
+        ix.probe_device(d_kmers.data_ptr(), n, d_masks.data_ptr(), 0, stream)
+        torch.cuda.synchronize()
+    user_order()
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter()
+        user_order()
+        ts.append(time.perf_counter() - t)
+    t_user = min(ts)
+    got = d_masks[:2048].cpu().numpy().view(np.uint64)
+    if not os.environ.get("PERF_HIBF_NO_CHECK") and not np.array_equal(got, ox.probe(kmers[:2048])):
+        raise SystemExit("user-order masks differ from the oracle")
+    del d_masks
+    blob = probe_blob(kmers)
+    ix.run_programs(blob, 1)
+    ts = []
+    for _ in range(3):
+        t = time.perf_counter()
+        res = ix.run_programs(blob, 1)
+        ts.append(time.perf_counter() - t)
+    t_layout = min(ts)
+    want0 = ox.probe(kmers[:1])[0]
+    if not np.array_equal(res[0], want0):
+        raise SystemExit("layout-order stage: RESULT differs from the oracle's mask of the first k-mer")
+    info = ix.info
+    motifs = random_prosite_motifs(200, 3, wildcard=0.08, ranges=0.04, min_len=6, max_len=12)
+    timings = {}
+    masks = {}
+    for way in ("layout", "user"):
+        if way == "user":
+            os.environ["TXQ_HIBF_LAYOUT_ORDER"] = "0"
+        else:
+            os.environ.pop("TXQ_HIBF_LAYOUT_ORDER", None)
+        ix.query_masks(motifs[:20], False, 4)
+        best = None
+        for _ in range(3):
+            t = time.perf_counter()
+            m, status, stats = ix.query_masks(motifs, False, 4)
+            dt = time.perf_counter() - t
+            if best is None or dt < best[0]:
+                best = (dt, stats)
+        timings[way] = {"seconds": best[0], "queries_per_s": len(motifs) / best[0], **best[1]}
+        masks[way] = (m, list(status))
+    os.environ.pop("TXQ_HIBF_LAYOUT_ORDER", None)
+    same = np.array_equal(masks["layout"][0], masks["user"][0]) and masks["layout"][1] == masks["user"][1]
+    if not same:
+        raise SystemExit("layout-order and user-order query masks differ")
+    print(json.dumps({
+        "tree": "general HIBF, %d user bins, tmax %d: %d IBFs" % (user_bins, tmax, len(descs)), "kmers": n, "build_s": round(build_s, 1),
+        "tree_bytes": int(info.device_bytes), "mask_words_user_order": int(W),
+        "probe_user_order": {"what": "txq_probe_device (descent kernels, masks in user-bin order)", "seconds": t_user, "kmers_per_s": n / t_user,
+                             "mask_GBps": n * W * 8 / t_user / 1e9},
+        "probe_layout_order": {"what": "one session stage: k-mer table upload + layout-order rows of all k-mers + one op + result (txq_run_programs)",
+                               "seconds": t_layout, "kmers_per_s": n / t_layout},
+        "queries_layout_order": timings["layout"], "queries_user_order": timings["user"], "query_masks_identical": same}))
+
+
+if __name__ == "__main__":
+    main()
