@@ -109,13 +109,21 @@ def layout_hibf(O, seed, user_bins, tmax=64, h=2, n_values=20, value_bits=20, di
                 parts = 1 if j % 3 else int(rng.integers(2, 4))
                 for c in np.array_split(values[ub], parts):
                     entries.append((ub, 0, c))
-        if len(ubs) * 1.4 <= tmax:
-            direct_bins(ubs)
+        if len(ubs) <= tmax:  # a leaf: every user bin a technical bin, some split while there is room (the layout fills its IBFs)
+            room = tmax - len(ubs)
+            for j, ub in enumerate(ubs):
+                parts = 1
+                if j % 3 == 0 and room >= 2:
+                    parts = int(rng.integers(2, 4))
+                    room -= parts - 1
+                for c in np.array_split(values[ub], parts):
+                    entries.append((ub, 0, c))
         else:
             mine, rest = ubs[:direct], ubs[direct:]
             direct_bins(mine)
             room = tmax - len(entries)
-            for part in np.array_split(np.array(rest, dtype=np.int64), room):
+            n_parts = min(room, max(2, int(np.ceil(len(rest) / (tmax * 0.75)))))
+            for part in np.array_split(np.array(rest, dtype=np.int64), n_parts):
                 if len(part) == 0:
                     continue
                 part = [int(x) for x in part]

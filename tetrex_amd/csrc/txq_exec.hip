@@ -508,11 +508,12 @@ struct PathRows {
             for (int i = 1; i < H; ++i) gw &= l.g[a][i];
             if (a < depth) open = open && ((gw >> a_bit[a]) & 1ULL);
         }
+        const uint32_t stride = c_packed & 0xFFFFFu, shift = (c_packed >> 20) & 63u, hf = (c_packed >> 26) & 7u;
+        open = open && hf != 0;  // (the row's padding word belongs to no IBF)
         l.hit = open;
         if (!open) return;
         if constexpr (SRC) l.x[H] = L::load(l.src + (size_t)c * L::kWords);
         else l.x[H] = ~L::zero();
-        const uint32_t stride = c_packed & 0xFFFFFu, shift = (c_packed >> 20) & 63u, hf = (c_packed >> 26) & 7u;
         const bool single = (c_packed >> 29) & 1u;
 #pragma unroll
         for (int i = 0; i < H; ++i) {
@@ -1781,7 +1782,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         s.row_source = "regular tree, interleaved children, fused";
     const int tree_knob = s.kn.dense_tree;  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; -1 (default): best fit
     const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && tree_knob < 0;
-    const bool wide = W % 2 == 0 && (vspace || (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0));
+    const bool wide = W % 2 == 0 && (vspace ? ix.v_chunk_words == 2 : (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0));
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
@@ -2057,7 +2058,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 hipError_t e;
                 if (vspace) {  // (rows are whole 16-byte chunks: WIDE; two predecessors in flight — a lane keeps its ancestors' gates in registers)
                     auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                    e = launch_dense<true, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                    e = wide ? launch_dense<true, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                             : launch_dense<false, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 } else if (tree) {
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     // root of <= 64 merged bins and the suffix's lanes cover the mask: root words by lane (TXQ_DENSE_TREE=1: the general variant)
@@ -2096,7 +2098,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 hipError_t e;
                 if (vspace) {
                     auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                    e = launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                    e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                             : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
                 } else if (interleaved) {
                     auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)

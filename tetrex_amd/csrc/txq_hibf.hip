@@ -581,6 +581,10 @@ __global__ __launch_bounds__(256) void mask_alive_kernel(const uint64_t* __restr
 // registers, the k-mers stream past.  Per k-mer: the gate (the bit of the parent's row that leads to this IBF, written
 // by the previous level's launch), then — only where it is set — h row gathers, AND, and one coalesced store (a wave
 // covers 1 KiB of the row).  Chunks of IBFs that were not reached get zeros: every byte of the row is written once.
+// CW: words per chunk (2: 16-byte lanes; 1: 8-byte lanes, for trees of narrow IBFs whose rows would double in width if every
+// IBF were padded to 16 bytes).  H: the most hash functions of any IBF of the tree.  The lanes of a wave are shared out
+// between chunks and k-mers: a level with few chunks (the root: often one) takes as many k-mers per wave step instead.
+template <int CW, int H>
 __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __restrict__ chunks, const uint32_t* __restrict__ group_first,
                                                                 uint32_t n_groups, const uint64_t* __restrict__ kmers, size_t n,
                                                                 uint64_t* __restrict__ rows, uint32_t v_words, uint32_t n_tiles, uint32_t tile) {
@@ -588,46 +592,54 @@ __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __
     const uint32_t gsel = blockIdx.x % 8u, t = (blockIdx.x / 8u) % n_tiles, phase = blockIdx.x / (8u * n_tiles);
     const uint32_t g = phase * 8u + gsel;
     if (g >= n_groups) return;
-    const uint32_t c0 = group_first[g], c1 = group_first[g + 1];
+    const uint32_t c0 = group_first[g], c1 = group_first[g + 1], n_c = c1 - c0;
     const size_t k0 = (size_t)t * tile, k1 = k0 + tile < n ? k0 + tile : n;
-    for (uint32_t c = c0 + threadIdx.x; c < c1; c += blockDim.x) {
+    uint32_t cw = 1;  // chunk lanes per wave; the other lane bits take different k-mers
+    while (cw < 64u && cw < n_c) cw <<= 1;
+    const uint32_t kpw = 64u / cw, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t csub = lane % cw, ksub = lane / cw, k_step = (blockDim.x >> 6) * kpw;
+    for (uint32_t cb = 0; cb < n_c; cb += cw) {
+        const uint32_t c = c0 + cb + csub;
+        if (cb + csub >= n_c) continue;
         const VChunk rec = chunks[c];
         const uint64_t* words = (const uint64_t*)rec.words;
         const uint32_t stride = rec.packed & 0xFFFFFu, shift = (rec.packed >> 20) & 63u, hf = (rec.packed >> 26) & 7u;
-        const bool single = (rec.packed >> 29) & 1u;
-        for (size_t i0 = k0; i0 < k1; i0 += U) {
+        const bool single = CW == 2 && ((rec.packed >> 29) & 1u);
+        for (size_t i0 = k0 + wave * kpw + ksub; i0 < k1; i0 += (size_t)k_step * U) {
             uint64_t v[U];
             bool pass[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const size_t i = i0 + u < k1 ? i0 + u : k1 - 1;
-                v[u] = kmers[i];
-                pass[u] = i0 + u < k1;
+                const size_t i = i0 + (size_t)u * k_step;
+                pass[u] = i < k1;
+                v[u] = pass[u] ? kmers[i] : 0;
                 if (pass[u] && rec.gate_word != kNoGate) pass[u] = (gload(rows + i * v_words + rec.gate_word) >> rec.gate_bit) & 1ULL;
             }
-            ulonglong2 x[U][5];
+            ulonglong2 x[U][H];
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (uint32_t j = 0; j < 5; ++j) {
+                for (int j = 0; j < H; ++j) {
                     x[u][j] = ulonglong2{~0ULL, ~0ULL};
-                    if (j >= hf || !pass[u]) continue;
+                    if ((uint32_t)j >= hf || !pass[u]) continue;
                     const uint64_t r = hash_row_seeded32(v[u] * kSeeds[j], shift, rec.bin_size);
-                    if (single) x[u][j].x = gload(words + r);
+                    if (CW == 1 || single) x[u][j].x = gload(words + r * stride + rec.col);
                     else x[u][j] = gload2(words + r * stride + rec.col);
                 }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                if (i0 + u >= k1) break;
-                hu32x4 acc{0u, 0u, 0u, 0u};
-                if (pass[u]) {
-                    uint64_t a = ~0ULL, b = ~0ULL;
+                const size_t i = i0 + (size_t)u * k_step;
+                if (i >= k1) break;
+                uint64_t a = 0, b = 0;
+                if (pass[u] && hf) {
+                    a = b = ~0ULL;
 #pragma unroll
-                    for (uint32_t j = 0; j < 5; ++j) { a &= x[u][j].x; b &= x[u][j].y; }
+                    for (int j = 0; j < H; ++j) { a &= x[u][j].x; b &= x[u][j].y; }
                     if (single) b = 0;
-                    acc = hu32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
                 }
-                store_row16(reinterpret_cast<hu32x4*>(rows + (i0 + u) * v_words + (size_t)c * 2), acc, 0);
+                uint64_t* out = rows + i * v_words + (size_t)(c - 0) * CW;
+                if (CW == 1) __builtin_nontemporal_store(a, out);
+                else store_row16(reinterpret_cast<hu32x4*>(out), hu32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)}, 0);
             }
         }
     }
@@ -669,9 +681,16 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     for (uint64_t i = 0; i < n; ++i)
         for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
             if (tbu[off[i] + b] == TXQ_MERGED_BIN) { parent[next[off[i] + b]] = i; parent_tb[next[off[i] + b]] = b; }
+    // 16-byte chunks (every IBF padded to an even number of words) unless that widens the row by more than 30 % — trees of
+    // many one-word IBFs —: then 8-byte chunks
+    uint64_t exact = 0, padded2 = 0;
+    for (uint64_t i = 0; i < n; ++i) { exact += desc.ibf[i].bin_words; padded2 += (desc.ibf[i].bin_words + 1) & ~(uint64_t)1; }
+    const uint64_t cwords = padded2 * 10 > exact * 13 ? 1 : 2;
     uint64_t words = 0;
     for (auto& lv : by_level)
-        for (uint64_t i : lv) { seg[i] = words; words += (desc.ibf[i].bin_words + 1) & ~(uint64_t)1; }
+        for (uint64_t i : lv) { seg[i] = words; words += (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords; }
+    const bool pad_word = (words & 1) != 0;  // (slot masks of an even number of words: one word that belongs to no IBF)
+    if (pad_word) ++words;
     if (words >= (1u << 26)) return TXQ_OK;
     std::vector<VChunk> chunks;
     std::vector<VPath> paths(n);
@@ -689,8 +708,8 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
             const uint64_t bytes = f.bin_size * (uint64_t)f.stride * 8;
             if (L.group_first.empty() || group_bytes + bytes > ((uint64_t)2 << 20)) { L.group_first.push_back((uint32_t)chunks.size()); group_bytes = 0; }
             group_bytes += bytes;
-            const uint64_t padded = (desc.ibf[i].bin_words + 1) & ~(uint64_t)1;
-            for (uint64_t c = 0; c < padded; c += 2) {
+            const uint64_t padded = (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords;
+            for (uint64_t c = 0; c < padded; c += cwords) {
                 VChunk r{};
                 r.words = (uint64_t)(uintptr_t)f.words;
                 r.bin_size = (uint32_t)f.bin_size;
@@ -721,6 +740,14 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
                 slot.bit = (uint32_t)(parent_tb[child] & 63);
             }
         }
+        if (pad_word && &lv == &by_level.back()) {  // the padding word: a chunk without hash functions — always zero
+            VChunk r{};
+            r.words = (uint64_t)(uintptr_t)ix.ibf[0].words;
+            r.bin_size = 1;
+            r.packed = 1;  // stride 1, no hash function
+            r.gate_word = kNoGate;
+            chunks.push_back(r);
+        }
         L.n_chunks = (uint32_t)chunks.size() - L.first_chunk;
         L.group_first.push_back((uint32_t)chunks.size());
         ix.vlevels.push_back(L);
@@ -742,6 +769,7 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     TXQ_HIP(hipMemcpy(ix.d_vuser, vuser.data(), vuser.size() * 4, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_vgroups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
     ix.v_words = (uint32_t)words;
+    ix.v_chunk_words = (uint32_t)cwords;
     ix.n_vchunks = (uint32_t)chunks.size();
     ix.v_depth = ix.depth - 1;
     ix.tree_hash_max = 1;
@@ -759,7 +787,13 @@ int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers, size_t n, uint64
         const uint32_t at = L.group_first[0], ng = L.group_first[1];
         const uint32_t phases = (ng + 7) / 8;
         if ((uint64_t)phases * n_tiles * 8 >= ((uint64_t)1 << 31)) return fail(TXQ_ERR_ARG, "too many k-mers for one layout-order probe");
-        hibf_layout_level_kernel<<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile);
+#define TXQ_LEVEL(CW, H) hibf_layout_level_kernel<CW, H><<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile)
+        if (ix.v_chunk_words == 1) {
+            switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(1, 1); break; case 2: TXQ_LEVEL(1, 2); break; case 3: TXQ_LEVEL(1, 3); break; case 4: TXQ_LEVEL(1, 4); break; default: TXQ_LEVEL(1, 5); break; }
+        } else {
+            switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(2, 1); break; case 2: TXQ_LEVEL(2, 2); break; case 3: TXQ_LEVEL(2, 3); break; case 4: TXQ_LEVEL(2, 4); break; default: TXQ_LEVEL(2, 5); break; }
+        }
+#undef TXQ_LEVEL
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return fail_hip(e, "layout-order level kernel launch");
     }

@@ -75,7 +75,7 @@ static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
 // until the final masks are handed out: those are converted to user-bin order (split bins ORed) once per query.
 // Merged bins keep their bits in the rows (the next level reads them as its gates); they never reach a result because
 // the ONES slot of a layout-order session only has the bits of technical bins that ARE user bins.
-struct VChunk {          // one 16-byte chunk (two row words) of the layout-order row
+struct VChunk {          // one chunk of the layout-order row: two row words (16 bytes) of one IBF, or one (Index::v_chunk_words)
     uint64_t words;      // the IBF's rows
     uint32_t bin_size;   // rows (< 2^32)
     uint32_t packed;     // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | single-word rows (29)
@@ -139,7 +139,7 @@ struct Index {
     uint64_t* d_vleaf = nullptr;     // [v_words] bits of technical bins that are user bins (the ONES of a layout-order session)
     uint32_t* d_vuser = nullptr;     // [v_words * 64] user bin of a layout-order bit (kNoGate: none)
     uint32_t* d_vgroups = nullptr;   // per level its groups' first chunks, concatenated (+ end)
-    uint32_t v_words = 0, n_vchunks = 0, v_depth = 0;
+    uint32_t v_words = 0, n_vchunks = 0, v_depth = 0, v_chunk_words = 2;  // (chunks of 16 bytes, or of 8 for trees of narrow IBFs)
     std::vector<VLevel> vlevels;
     bool layout_order() const;       // sessions on this index work in layout order
     uint32_t depth = 1;              // levels of the tree
