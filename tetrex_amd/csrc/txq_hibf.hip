@@ -778,24 +778,32 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     return TXQ_OK;
 }
 
-int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_rows, hipStream_t s) {
+int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all, uint64_t* d_rows_all, hipStream_t s) {
     if (!ix.d_vchunks) return fail(TXQ_ERR_STATE, "the index has no layout order");
-    if (!n) return TXQ_OK;
+    if (!n_all) return TXQ_OK;
     const uint32_t tile = 2048;
-    const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
-    for (const VLevel& L : ix.vlevels) {
-        const uint32_t at = L.group_first[0], ng = L.group_first[1];
-        const uint32_t phases = (ng + 7) / 8;
-        if ((uint64_t)phases * n_tiles * 8 >= ((uint64_t)1 << 31)) return fail(TXQ_ERR_ARG, "too many k-mers for one layout-order probe");
+    // A level reads the gates the level above it wrote: the batch goes through the levels in pieces whose rows (about 100 MB)
+    // are still in the Infinity Cache when the next level asks for them
+    size_t piece = std::max<size_t>(tile, (((size_t)96 << 20) / ((size_t)ix.v_words * 8)) / tile * tile);
+    for (size_t off = 0; off < n_all; off += piece) {
+        const size_t n = std::min(piece, n_all - off);
+        const uint64_t* d_kmers = d_kmers_all + off;
+        uint64_t* d_rows = d_rows_all + off * ix.v_words;
+        const uint32_t n_tiles = (uint32_t)((n + tile - 1) / tile);
+        for (const VLevel& L : ix.vlevels) {
+            const uint32_t at = L.group_first[0], ng = L.group_first[1];
+            const uint32_t phases = (ng + 7) / 8;
+            if ((uint64_t)phases * n_tiles * 8 >= ((uint64_t)1 << 31)) return fail(TXQ_ERR_ARG, "too many k-mers for one layout-order probe");
 #define TXQ_LEVEL(CW, H) hibf_layout_level_kernel<CW, H><<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile)
-        if (ix.v_chunk_words == 1) {
-            switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(1, 1); break; case 2: TXQ_LEVEL(1, 2); break; case 3: TXQ_LEVEL(1, 3); break; case 4: TXQ_LEVEL(1, 4); break; default: TXQ_LEVEL(1, 5); break; }
-        } else {
-            switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(2, 1); break; case 2: TXQ_LEVEL(2, 2); break; case 3: TXQ_LEVEL(2, 3); break; case 4: TXQ_LEVEL(2, 4); break; default: TXQ_LEVEL(2, 5); break; }
-        }
+            if (ix.v_chunk_words == 1) {
+                switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(1, 1); break; case 2: TXQ_LEVEL(1, 2); break; case 3: TXQ_LEVEL(1, 3); break; case 4: TXQ_LEVEL(1, 4); break; default: TXQ_LEVEL(1, 5); break; }
+            } else {
+                switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(2, 1); break; case 2: TXQ_LEVEL(2, 2); break; case 3: TXQ_LEVEL(2, 3); break; case 4: TXQ_LEVEL(2, 4); break; default: TXQ_LEVEL(2, 5); break; }
+            }
 #undef TXQ_LEVEL
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return fail_hip(e, "layout-order level kernel launch");
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return fail_hip(e, "layout-order level kernel launch");
+        }
     }
     return TXQ_OK;
 }
