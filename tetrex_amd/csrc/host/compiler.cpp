@@ -722,6 +722,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         dense_seen_ = dense->size();
     }
     const bool go_dense = dense_ok_ && dense != nullptr;
+    if (evidence_asked_) wants_evidence_ = false;  // the pause lasted one stage: its answers are in (observe), or somebody else's are
     while (cursor_ < order_.size() && out.size() - start < op_budget) {
         if (verified_only) {
             // Expand only what the device has confirmed alive: an item whose input still holds a state

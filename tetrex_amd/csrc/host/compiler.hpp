@@ -41,8 +41,8 @@ namespace tetrex {
 // beyond it fails with a message; the reference would (slowly) answer, so the bound is generous.  One-shot
 // compilation (ProgramBatch: the whole program in one blob) bounds the totals instead.
 struct CompileLimits {
-    size_t max_ops = SIZE_MAX;                   // cumulative, per query
-    size_t max_states = SIZE_MAX;                // cumulative, per query
+    size_t max_ops = (size_t)1 << 33;            // cumulative, per query: generous (minutes of work) but finite (`tetrex query --max-ops`)
+    size_t max_states = (size_t)1 << 33;         // cumulative, per query
     size_t max_live_states = (size_t)96 << 20;   // waiting at the same time, per query (~2.3 GB)
     static CompileLimits one_shot() { return CompileLimits{(size_t)8 << 20, (size_t)8 << 20, (size_t)8 << 20}; }
 };

@@ -99,7 +99,7 @@ size_t popcount_mask(const uint64_t* m, uint64_t words) {
 int cmd_query(int argc, char** argv) {
     const std::vector<OptSpec> spec = {{'d', "draw", false}, {'v', "verbose", false}, {'f', "file", false}, {'c', "conj", false},
                                        {'a', "augment", false}, {'t', "threads", true}, {'o', "output", true}, {'g', "gibf", true},
-                                       {'D', "device", true}, {'S', "stats", false}, {'G', "gpus", true}, {'R', "shards", true}};
+                                       {'D', "device", true}, {'S', "stats", false}, {'G', "gpus", true}, {'R', "shards", true}, {'M', "max-ops", true}};
     Args a;
     try {
         a = parse(argc, argv, 2, spec);
@@ -147,6 +147,10 @@ int cmd_query(int argc, char** argv) {
     if (a.has("gibf")) dev.attach_dgram(read_dgram_index_file(a.get("gibf", "")));  // include/query.h:259-264
     StagedOptions sopt;
     sopt.gaps.augment = a.has("augment");
+    if (a.has("max-ops")) {  // -M / --max-ops (not in the reference): mask operations one query may expand to before it is given up (default 2^33)
+        const long long m = std::atoll(a.get("max-ops", "0").c_str());
+        if (m > 0) sopt.limits.max_ops = sopt.limits.max_states = (size_t)m;
+    }
     const KmerEncoder enc = dev.encoder();
     const uint64_t bins = dev.bins(), W = dev.result_words();
     const VerifyOptions vopt{threads};

@@ -550,7 +550,17 @@ int txq_session_stage(txq_session* s, const void* blob, size_t blob_bytes, const
     if (!s) return fail(TXQ_ERR_ARG, "null argument");
     if (int rc = bind_index(s->ix)) return rc;
     if ( !blob || (n_queries && (!query_program || !query_slot || !alive))) return fail(TXQ_ERR_ARG, "null argument");
-    return session_stage(*s, blob, blob_bytes, query_program, query_slot, n_queries, alive, nullptr);
+    if (s->failed) return fail(TXQ_ERR_STATE, "an earlier stage of this session failed: end the session");
+    const int rc = session_stage(*s, blob, blob_bytes, query_program, query_slot, n_queries, alive, nullptr);
+    if (rc != TXQ_OK) {
+        // Kernels of the stage may already be running (on either stream) and the stage's bookkeeping is half done: nothing of
+        // this session may be in flight when its buffers change hands, and no further stage may build on it
+        const std::string why = g_err;
+        (void)hipDeviceSynchronize();
+        s->failed = true;
+        g_err = why;
+    }
+    return rc;
 }
 
 int txq_session_end(txq_session* s, uint64_t* final_masks) {

@@ -214,6 +214,7 @@ struct Session {
     Knobs kn;              // the environment switches as they were when the session began
     size_t n_programs = 0;
     uint32_t W = 0;        // words of a slot mask: the shard's mask words, or (vspace) the words of a layout-order row
+    bool failed = false;   // a stage failed after it may have launched kernels: the device was drained, further stages are refused
     bool vspace = false;   // the index is a general HIBF: masks are rows in layout order, final masks are converted (Index::layout_order)
     std::vector<Index::ArenaChunk> chunks;  // arena chunks; bump allocation in chunks[cur]
     size_t cur = 0, chunk_used = 0, arena_words = 0;
