@@ -123,6 +123,11 @@ int txq_index_free(txq_index* ix);
  * (flat IBFs, regular two-level HIBFs) — such sessions also run TRACKED programs (sparse blocks with live lists). */
 int txq_index_supports_dense(const txq_index* ix);
 
+/* Device memory as a session on this index will find it: bytes free on the index's device, and bytes of slot storage the
+ * index keeps from earlier sessions (the next session reuses them before it allocates).  Host layers size their budgets
+ * for slot storage (dense blocks) by the sum instead of by a constant. */
+int txq_index_memory(const txq_index* ix, uint64_t* free_bytes, uint64_t* kept_bytes);
+
 /* One 64-bit value a host layer may keep with the index (0 after upload); libtetrex_query stores what its staged
  * expansion has learned about the index there. */
 int txq_index_set_tag(txq_index* ix, uint64_t tag);

@@ -20,7 +20,7 @@ TXQ_MERGED_BIN = 0xFFFFFFFFFFFFFFFF
 # every symbol include/txq.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
-    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_supports_dense", "txq_index_set_tag", "txq_index_get_tag", "txq_index_create_ibf",
+    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_supports_dense", "txq_index_memory", "txq_index_set_tag", "txq_index_get_tag", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
     "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_set_aux_index", "txq_session_stage", "txq_session_end",
     "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize", "txq_host_alloc", "txq_host_free",

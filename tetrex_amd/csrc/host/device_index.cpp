@@ -250,6 +250,11 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     opt.dense.tracked_ok = txq_index_supports_dense(ix) == 2;  // fused steps: the session keeps live lists (tracked programs)
     opt.dense.slot_bytes = info.shard_words * 8;
     opt.feedback_bins = std::min<uint64_t>(info.user_bins, info.shard_words * 64);
+    {   // dense blocks may take three quarters of what the device has left (and of what the index kept from earlier sessions),
+        // not a constant that ignores a 64 GB index next to them
+        uint64_t free_b = 0, kept_b = 0;
+        if (txq_index_memory(ix, &free_b, &kept_b) == TXQ_OK) opt.dense_pool_bytes = std::min<uint64_t>(opt.dense_pool_bytes, (free_b + kept_b) / 4 * 3);
+    }
     uint64_t tag = 0;
     (void)txq_index_get_tag(ix, &tag);
     if (opt.dense_evidence == DenseOptions::kUnknown) opt.dense_evidence = (int)(tag & 3);  // what earlier runs learned about the index

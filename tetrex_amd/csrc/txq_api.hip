@@ -373,6 +373,18 @@ int txq_index_free(txq_index* ix) {
     return TXQ_OK;
 }
 
+int txq_index_memory(const txq_index* ix, uint64_t* free_bytes, uint64_t* kept_bytes) {
+    if (!ix || !free_bytes || !kept_bytes) return fail(TXQ_ERR_ARG, "null argument");
+    if (int rc = bind_index(ix)) return rc;
+    size_t free_b = 0, total_b = 0;
+    TXQ_HIP(hipMemGetInfo(&free_b, &total_b));
+    uint64_t kept = 0;
+    for (const Index::ArenaChunk& c : ix->session_cache.chunks) kept += (uint64_t)c.cap * 8;
+    *free_bytes = free_b;
+    *kept_bytes = kept;
+    return TXQ_OK;
+}
+
 int txq_index_set_tag(txq_index* ix, uint64_t tag) {
     if (!ix) return fail(TXQ_ERR_ARG, "null argument");
     ix->user_tag = tag;
