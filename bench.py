@@ -540,8 +540,7 @@ def verified_end_to_end(args):
                 if best is None or whole["batch_seconds"] < best[0]["batch_seconds"]:
                     best = (whole, mask)
             whole, mask = best
-            hits = sum(1 for i in range(len(motifs)) if os.path.getsize(os.path.join(work, "M%03d.tsv" % i)) > 0) if all(
-                os.path.exists(os.path.join(work, "M%03d.tsv" % i)) for i in range(len(motifs))) else None
+            hits = sum(1 for i in range(len(motifs)) if os.path.exists(os.path.join(work, "M%03d.tsv" % i)) and os.path.getsize(os.path.join(work, "M%03d.tsv" % i)) > 0)
             runs["threads_%d" % threads] = {"queries_per_s": len(motifs) / whole["batch_seconds"], "seconds": whole["batch_seconds"],
                                             "mask_seconds": mask["mask_seconds"], "verify_seconds": whole["verify_seconds"],
                                             "refused_fraction": whole["refused"] / len(motifs), "motifs_with_verified_matches": hits}
