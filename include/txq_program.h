@@ -152,6 +152,13 @@ enum { TXQ_DENSE_ZERO = 0,   /* r_mask == 0: dst block := 0; r_mask != 0: only i
  * block of 4*20*20*2*1 entries, not 21^5.  Untracked blocks have the full geometry (every code at every position). */
 #define TXQ_PROGRAM_TRACKED_BIT 0x80000000u
 #define TXQ_DENSE_TRACKED 1u
+/* A tracked STEP with TXQ_DENSE_NOPROBE rolls its residues in WITHOUT a probe: dst[(x1 .. x_{k-2}, r)] |= src[(a, x1 .. x_{k-2})].
+ * That is the collector's update_path for states that have not seen k - 1 residues yet (reference
+ * include/otf_collector.h:247-259: the k-mer is still being filled, nothing is looked up): the lists behind the first
+ * residues of a motif — 20^4 states behind `C-x(4)` at k = 6 — are blocks too (their leading suffix positions hold the
+ * one code 0, as the k-mer value of such a state has zeros there; a list keeps states of different lengths in
+ * different blocks, the product never merges them). */
+#define TXQ_DENSE_NOPROBE 2u
 
 typedef struct {
     uint32_t kind;
@@ -160,7 +167,7 @@ typedef struct {
                          tracked ZERO: the block's capacity in entries                                            */
     uint32_t r_mask;  /* STEP: bit c set <=> residue code c is rolled in                                    */
     uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; /* per suffix position (oldest first): codes worth visiting    */
-    uint32_t reserved; /* bit 0: TXQ_DENSE_TRACKED */
+    uint32_t reserved; /* bit 0: TXQ_DENSE_TRACKED; bit 1: TXQ_DENSE_NOPROBE */
 } txq_dense_op; /* 64 bytes */
 
 typedef struct {

@@ -297,8 +297,12 @@ class SessionSimulator:
         B = self.blocks[p]
         self.dense_kinds[kind] += 1
         # every dense op of a tracked program says so, and only those (include/txq_program.h TXQ_DENSE_TRACKED)
-        assert int(row[15]) == (1 if self.tracked[p] else 0), "dense op and program disagree about tracking"
-        self.tracked_ops += int(row[15])
+        assert int(row[15]) & 1 == (1 if self.tracked[p] else 0), "dense op and program disagree about tracking"
+        assert not (int(row[15]) & 2) or (kind == 1 and self.tracked[p]), "TXQ_DENSE_NOPROBE on something that is no tracked STEP"
+        assert int(row[15]) < 4
+        self.tracked_ops += int(row[15]) & 1
+        noprobe = bool(int(row[15]) & 2)
+        self.noprobe_steps = getattr(self, "noprobe_steps", 0) + int(noprobe)
         shape = [self._codes(int(row[4 + j])) for j in range(pos)]
         assert all(c < A for cs in shape for c in cs)
 
@@ -383,7 +387,7 @@ class SessionSimulator:
                 val = self._canonical(fwd, k) if par["canonical"] else fwd
                 si = int(srk[0][ai]) * s_stride0 + smid
                 assert sblk["valid"][si].all(), "DENSE_STEP reads outside the zeroed shape of its source block"
-                acc |= sblk["arr"][si] & self.ox.probe(val)
+                acc |= sblk["arr"][si] if noprobe else sblk["arr"][si] & self.ox.probe(val)
             di = dmid * dn[pos - 1] + int(drk[pos - 1][r])
             assert dblk["valid"][di].all(), "DENSE_STEP accumulates outside the zeroed shape of its destination block"
             dblk["arr"][di] |= acc

@@ -17,6 +17,7 @@ int main(int argc, char** argv) {
     KmerEncoder enc(Molecule::Peptide, getenv("EB_K") ? (unsigned)atoi(getenv("EB_K")) : 4u, Alphabet::Base);
     StagedOptions opt; opt.threads = argc > 2 ? atoi(argv[2]) : 1;
     if (getenv("EB_DENSE")) { opt.dense.enabled = true; opt.dense.slot_bytes = 128; }
+    if (getenv("EB_TRACKED")) opt.dense.tracked_ok = true;  // the executor is assumed to keep live lists (tracked blocks)
     if (argc > 3) opt.ops_per_task = (size_t)atol(argv[3]);
     if (argc > 4) opt.ops_per_stage = (size_t)atol(argv[4]);
     for (int rep = 0; rep < 5; ++rep) {

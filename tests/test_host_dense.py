@@ -226,3 +226,16 @@ def test_sparse_evidence_turns_queries_to_tracked_blocks(host, oracle, monkeypat
     checked, without, sim2 = _run(host, ox, qs, False, 5, dict())
     assert checked == len(qs) and not any(sim2.tracked)
     assert with_lists["ops"] <= without["ops"]
+
+
+def test_tracked_programs_keep_the_states_of_their_first_residues_as_blocks_too(host, oracle):
+    """`C....C...` at k = 6: 20^4 states behind the four wildcards before the first k-mer is complete.  A tracked program keeps
+    such lists as blocks as well — one block per state length, rolled forward by TXQ_DENSE_NOPROBE steps (no k-mer to look
+    up yet) — instead of enumerating them on the host.  Masks = the oracle's; the host's state count collapses."""
+    ox = _index(oracle, bins=64, m=4099, h=2, k=6, dna=False, per_bin=500, seed=23)
+    qs = ["LM...KDE", "K.{2,3}C..[LIVM]", "L..M..K"]
+    checked, plain, sim0 = _run(host, ox, qs, False, 6, dict(min_states=32, sparse_below=4))
+    checked2, tracked, sim = _run(host, ox, qs, False, 6, dict(min_states=32, sparse_below=4, tracked=2))
+    assert checked == checked2 == len(qs)
+    assert sim.noprobe_steps >= 4 and getattr(sim0, "noprobe_steps", 0) == 0
+    assert tracked["states"] * 10 < plain["states"]

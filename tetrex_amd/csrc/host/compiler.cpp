@@ -283,12 +283,12 @@ void QueryExpansion::compute_static_shapes() {
 // the geometry of the blocks of the list at `item`: tracked programs lay a block out inside the list's static shape,
 // untracked ones over the whole alphabet (entry index = the suffix as a number in base A, as the step kernel of
 // untracked blocks computes it)
-QueryExpansion::Geometry QueryExpansion::geometry_of(int32_t item) const {
+QueryExpansion::Geometry QueryExpansion::geometry_of(int32_t item, unsigned phase) const {
     Geometry g{};
     if (tracked_) {
         g = static_shape_[item];
         for (unsigned j = 0; j < dense_pos_; ++j)
-            if (!g[j]) g[j] = 1u;  // a position nothing can reach yet: one (never used) code keeps the radix non-zero
+            if (!g[j] || j + phase < dense_pos_) g[j] = 1u;  // a position the states have not filled yet holds code 0, like their k-mer values
     } else
         for (unsigned j = 0; j < dense_pos_; ++j) g[j] = dense_a_ >= 32 ? 0xFFFFFFFFu : ((1u << dense_a_) - 1u);
     return g;
@@ -553,12 +553,13 @@ void QueryExpansion::emit_dense(OpVec& out, const txq_dense_op& d0) {
 }
 
 // the block this list accumulates into (created on first use; the caller has reserved it)
-QueryExpansion::DenseRef* QueryExpansion::owned_block(int32_t item, NodeStates& ns, OpVec& out) {
+QueryExpansion::DenseRef* QueryExpansion::owned_block(int32_t item, NodeStates& ns, OpVec& out, unsigned phase) {
     for (DenseRef& r : ns.dense)
-        if (r.owned) return &r;
+        if (r.owned && r.phase == phase) return &r;
     DenseRef r{};
-    r.block = new_block(out, geometry_of(item));
+    r.block = new_block(out, geometry_of(item, phase));
     r.owned = 1;
+    r.phase = phase;
     ns.dense.push_back(r);
     return &ns.dense.back();
 }
@@ -585,63 +586,66 @@ void QueryExpansion::densify(int32_t item, NodeStates& ns, OpVec& out, bool may_
     decide_tracking();
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     const uint64_t sym = enc_.symbol_mask();
-    size_t full = 0;
-    uint32_t shape[TXQ_DENSE_MAX_POSITIONS] = {};
-    for (const State& s : ns.items) {
-        if (s.gapped || s.shift < k - 1) continue;
-        ++full;
-        for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
-    }
-    if (full < dense_.min_states) return;
-    // the shape (the product of the per-position code sets) against the states it holds: shape_limit() — a tracked block
-    // costs what its living entries cost, whatever the shape
-    uint64_t product = 1;
-    for (unsigned j = 0; j < dense_pos_; ++j) product *= (uint64_t)__builtin_popcount(shape[j]);
-    if (!tracked_) {
-        const uint64_t limit = shape_limit();
-        if (limit == 0 || product > limit * full) return;
-    }
-    bool has_own = false;
-    for (const DenseRef& r : ns.dense) has_own |= r.owned != 0;
-    if (!has_own) {
-        caps_scratch_.assign(1, capacity_of(geometry_of(item)));
-        if (!can_take_blocks(caps_scratch_)) return;
-    }
-    DenseRef* own = owned_block(item, ns, out);
-    // States that all carry ONE mask and fill their shape exactly — the states behind a run of wildcards that have not been
-    // probed yet (they share ONES) — are spread by a single FILL.  (An append-only list may hold a key twice: no counting there.)
-    bool uniform = !may_hold_duplicates && product == full;
-    uint32_t the_slot = 0;
-    if (uniform) {
-        bool first = true;
+    // full-length states (k-1 residues and more) go to the list's ordinary block; a tracked program also makes blocks of the
+    // states that are still filling their first k-mer, one per length
+    for (unsigned phase = tracked_ ? 1 : k - 1; phase <= k - 1; ++phase) {
+        auto of_phase = [&](const State& s) { return !s.gapped && (phase == k - 1 ? s.shift >= k - 1 : s.shift == phase); };
+        size_t full = 0;
+        uint32_t shape[TXQ_DENSE_MAX_POSITIONS] = {};
         for (const State& s : ns.items) {
-            if (s.gapped || s.shift < k - 1) continue;
-            if (first) { the_slot = s.slot; first = false; }
-            else if (s.slot != the_slot) { uniform = false; break; }
+            if (!of_phase(s)) continue;
+            ++full;
+            for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
         }
-    }
-    for (unsigned j = 0; j < dense_pos_; ++j)
-        if (shape[j] & ~block_geom_[own->block][j]) throw std::logic_error("state list outside the geometry of its dense block");
-    if (uniform) {
-        txq_dense_op f{};
-        f.kind = TXQ_DENSE_FILL;
-        f.dst = dense_slot(own->block, 0);
-        f.src = the_slot;
-        for (unsigned j = 0; j < dense_pos_; ++j) f.shape[j] = shape[j];
-        emit_dense(out, f);
-    }
-    size_t kept = 0;
-    for (size_t i = 0; i < ns.items.size(); ++i) {
-        const State s = ns.items[i];
-        if (s.gapped || s.shift < k - 1) { ns.items[kept++] = s; continue; }
-        if (!uniform) {
-            const uint32_t e = dense_slot(own->block, dense_index(own->block, s.kmer));
-            emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
+        if (full < dense_.min_states) continue;
+        // the shape (the product of the per-position code sets) against the states it holds: shape_limit() — a tracked block
+        // costs what its living entries cost, whatever the shape
+        uint64_t product = 1;
+        for (unsigned j = 0; j < dense_pos_; ++j) product *= (uint64_t)__builtin_popcount(shape[j]);
+        if (!tracked_) {
+            const uint64_t limit = shape_limit();
+            if (limit == 0 || product > limit * full) continue;
         }
-        drop(s.slot);
+        if (!has_owned(ns, phase)) {
+            caps_scratch_.assign(1, capacity_of(geometry_of(item, phase)));
+            if (!can_take_blocks(caps_scratch_)) continue;
+        }
+        DenseRef* own = owned_block(item, ns, out, phase);
+        // States that all carry ONE mask and fill their shape exactly — the states behind a run of wildcards that have not been
+        // probed yet (they share ONES) — are spread by a single FILL.  (An append-only list may hold a key twice: no counting there.)
+        bool uniform = !may_hold_duplicates && product == full;
+        uint32_t the_slot = 0;
+        if (uniform) {
+            bool first = true;
+            for (const State& s : ns.items) {
+                if (!of_phase(s)) continue;
+                if (first) { the_slot = s.slot; first = false; }
+                else if (s.slot != the_slot) { uniform = false; break; }
+            }
+        }
+        for (unsigned j = 0; j < dense_pos_; ++j)
+            if (shape[j] & ~block_geom_[own->block][j]) throw std::logic_error("state list outside the geometry of its dense block");
+        if (uniform) {
+            txq_dense_op f{};
+            f.kind = TXQ_DENSE_FILL;
+            f.dst = dense_slot(own->block, 0);
+            f.src = the_slot;
+            for (unsigned j = 0; j < dense_pos_; ++j) f.shape[j] = shape[j];
+            emit_dense(out, f);
+        }
+        size_t kept = 0;
+        for (size_t i = 0; i < ns.items.size(); ++i) {
+            const State s = ns.items[i];
+            if (!of_phase(s)) { ns.items[kept++] = s; continue; }
+            if (!uniform) {
+                const uint32_t e = dense_slot(own->block, dense_index(own->block, s.kmer));
+                emit(out, TXQ_NO_KMER, e, e, s.slot);  // block[e] |= state (an append-only list may hold one key twice)
+            }
+            drop(s.slot);
+        }
+        for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= shape[j];
+        ns.items.resize(kept);
     }
-    for (unsigned j = 0; j < dense_pos_; ++j) own->shape[j] |= shape[j];
-    ns.items.resize(kept);
 }
 
 // blocks of `item` whose shape has shrunk to a few entries (or all of them, when no block can be had for
@@ -667,7 +671,7 @@ void QueryExpansion::materialise(int32_t item, OpVec& out, bool all) {
             const uint64_t idx = index_of_codes(r.block, code);
             const uint32_t d = fresh();
             emit(out, TXQ_NO_KMER, d, dense_slot(r.block, idx), TXQ_SLOT_ZERO);
-            arrive(item, State{kmer, d, (uint8_t)k, 0, 0, 0, 0}, out);
+            arrive(item, State{kmer, d, (uint8_t)(r.phase < dense_pos_ ? r.phase : k), 0, 0, 0, 0}, out);
             unsigned j = dense_pos_;
             for (;;) {
                 if (j == 0) { empty = true; break; }
@@ -685,9 +689,10 @@ void QueryExpansion::materialise(int32_t item, OpVec& out, bool all) {
 void QueryExpansion::dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out) {
     if (receiver == KGraph::kNone || !r_mask) return;
     NodeStates& rs = table_[receiver];
-    DenseRef* own = owned_block(receiver, rs, out);
+    DenseRef* own = owned_block(receiver, rs, out, std::min<unsigned>(src.phase + 1, dense_pos_));
     txq_dense_op d{};
     d.kind = TXQ_DENSE_STEP;
+    if (src.phase < dense_pos_) d.reserved = TXQ_DENSE_NOPROBE;  // the states are still filling their first k-mer: nothing to look up
     d.dst = dense_slot(own->block, 0);
     d.src = dense_slot(src.block, 0);
     d.r_mask = r_mask;
@@ -775,16 +780,27 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             }
             if (!cur.dense.empty() || may_densify) {
                 if (go_dense) decide_tracking();
+                // the lengths (phases) of the states this item will hold as blocks: those it holds already, and those densify() will make
+                uint32_t phases = 0, fresh_phases = 0;
+                for (const DenseRef& d : cur.dense) phases |= 1u << d.phase;
+                if (may_densify) {
+                    size_t count[TXQ_DENSE_MAX_POSITIONS + 1] = {};
+                    for (const State& s : cur.items)
+                        if (!s.gapped) ++count[s.shift < dense_pos_ ? s.shift : dense_pos_];
+                    for (unsigned p = tracked_ ? 1 : dense_pos_; p <= dense_pos_; ++p)
+                        if (count[p] >= dense_.min_states) { phases |= 1u << p; if (!has_owned(cur, p)) fresh_phases |= 1u << p; }
+                }
                 dense_receivers(next, receivers_scratch_);
                 caps_scratch_.clear();
-                for (int32_t r : receivers_scratch_) {
-                    bool has = false;
-                    for (const DenseRef& d : table_[r].dense) has |= d.owned != 0;
-                    if (!has) caps_scratch_.push_back(capacity_of(geometry_of(r)));
-                }
-                bool own = false;
-                for (const DenseRef& d : cur.dense) own |= d.owned != 0;
-                if (may_densify && !own) caps_scratch_.push_back(capacity_of(geometry_of(next)));
+                for (int32_t r : receivers_scratch_)
+                    for (unsigned p = 1; p <= dense_pos_; ++p) {
+                        if (!((phases >> p) & 1u)) continue;
+                        const unsigned q = std::min(p + 1, dense_pos_);
+                        if (p < dense_pos_ && q == dense_pos_ && ((phases >> dense_pos_) & 1u)) continue;  // (counted with phase k-1 itself)
+                        if (!has_owned(table_[r], q)) caps_scratch_.push_back(capacity_of(geometry_of(r, q)));
+                    }
+                for (unsigned p = 1; p <= dense_pos_; ++p)
+                    if ((fresh_phases >> p) & 1u) caps_scratch_.push_back(capacity_of(geometry_of(next, p)));
                 const bool ok = go_dense && can_take_blocks(caps_scratch_);
                 densify_here = ok && may_densify;
                 if (!ok && !cur.dense.empty()) materialise(next, out, true);

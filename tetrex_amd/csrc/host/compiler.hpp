@@ -202,7 +202,9 @@ class QueryExpansion {
     // its look-ups, growth and initialisation were a third of the expansion time there.
     // a block of the dense region as one list's (part of the) state set; shape[j] = codes that can occur at suffix
     // position j (0 = oldest): a superset, entries outside the real set are zero masks
-    struct DenseRef { uint32_t block; uint32_t owned; uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; };
+    // phase: how many residues the block's states have seen — k-1 for ordinary (full-length) states; tracked programs also
+    // keep the lists of SHORTER states as blocks (TXQ_DENSE_NOPROBE steps), one block per length
+    struct DenseRef { uint32_t block; uint32_t owned; uint32_t phase; uint32_t shape[TXQ_DENSE_MAX_POSITIONS]; };
     struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; std::vector<DenseRef> dense; };
     static constexpr uint32_t kMergeSample = 4096;  // lists shorter than this are not worth the question
     bool merging_pays(const StateVec& list);
@@ -272,7 +274,7 @@ class QueryExpansion {
     // superset, from one pass over the derived graph)
     std::vector<Geometry> static_shape_;
     void compute_static_shapes();
-    Geometry geometry_of(int32_t item) const;
+    Geometry geometry_of(int32_t item, unsigned phase) const;
     uint32_t capacity_of(const Geometry& g) const;
     DenseVec* dense_out_ = nullptr;
     static uint32_t dense_slot(uint32_t block, uint64_t index) { return TXQ_DENSE_SLOT_BIT | (block << TXQ_DENSE_BLOCK_SHIFT) | (uint32_t)index; }
@@ -284,7 +286,12 @@ class QueryExpansion {
     uint32_t new_block(OpVec& out, const Geometry& geom);
     void release_block(uint32_t block);
     void emit_dense(OpVec& out, const txq_dense_op& d);
-    DenseRef* owned_block(int32_t item, NodeStates& ns, OpVec& out);
+    DenseRef* owned_block(int32_t item, NodeStates& ns, OpVec& out, unsigned phase);
+    static bool has_owned(const NodeStates& ns, unsigned phase) {
+        for (const DenseRef& r : ns.dense)
+            if (r.owned && r.phase == phase) return true;
+        return false;
+    }
     void densify(int32_t item, NodeStates& ns, OpVec& out, bool may_hold_duplicates);
     void shape_zero(const DenseRef& r);
     uint64_t shape_limit() const;

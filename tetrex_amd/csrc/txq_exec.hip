@@ -932,6 +932,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W), dm = block_meta(q.dst, q.dst_cap, W);
         const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
         const uint32_t n_r = cnt[P.pos];
+        const bool noprobe = (d.reserved & TXQ_DENSE_NOPROBE) != 0;  // states that are still filling their first k-mer: the mask moves on as it is
         const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
         for (uint32_t it = 0; it < rounds; ++it) {
             const uint32_t e = first + it * ngrp + grp;
@@ -963,6 +964,15 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
                 }
                 if (!mine) continue;
                 uint32_t i = 0;
+                if (noprobe) {
+                    for (; i < n_r; ++i) {
+                        const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
+                        if (rk == 0xFFu) continue;
+                        atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, sv);
+                        hit |= 1u << i;
+                    }
+                    continue;
+                }
                 for (; i + UA <= n_r; i += UA) {
                     typename ROWS::Loads x[UA];
 #pragma unroll
@@ -1284,7 +1294,8 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
                     const txq_dense_op& x = dops[o[i].dst];
                     const uint32_t code_mask = v.dense.A >= 32 ? 0xFFFFFFFFu : ((1u << v.dense.A) - 1u);
                     bool ok = x.kind <= TXQ_DENSE_FILL;
-                    if (ok) ok = ((x.reserved & TXQ_DENSE_TRACKED) != 0) == (v.tracked[p] != 0) && (x.reserved & ~TXQ_DENSE_TRACKED) == 0;
+                    if (ok) ok = ((x.reserved & TXQ_DENSE_TRACKED) != 0) == (v.tracked[p] != 0) && (x.reserved & ~(TXQ_DENSE_TRACKED | TXQ_DENSE_NOPROBE)) == 0;
+                    if (ok && (x.reserved & TXQ_DENSE_NOPROBE)) ok = x.kind == TXQ_DENSE_STEP && v.tracked[p] != 0;  // (only the pushed steps of tracked programs)
                     if (ok && x.kind != TXQ_DENSE_REDUCE) ok = block_ok(x.dst);
                     if (ok && (x.kind == TXQ_DENSE_STEP || x.kind == TXQ_DENSE_REDUCE)) ok = block_ok(x.src);
                     if (ok && x.kind == TXQ_DENSE_FILL) ok = !(x.src & TXQ_DENSE_SLOT_BIT) && x.src < n_slots;
