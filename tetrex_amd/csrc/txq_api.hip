@@ -8,6 +8,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -16,6 +18,17 @@ namespace txq {
 
 static thread_local std::string g_err;
 static std::vector<int> g_devices;  // txq_init: shard r of an index lives on g_devices[r % size]
+
+static std::mutex g_spare_mutex;
+static std::map<int, std::vector<hipStream_t>> g_spare_streams;  // per device: streams created at txq_init for the first sessions
+hipStream_t take_spare_stream(int device) {
+    std::lock_guard<std::mutex> lk(g_spare_mutex);
+    auto it = g_spare_streams.find(device);
+    if (it == g_spare_streams.end() || it->second.empty()) return nullptr;
+    hipStream_t st = it->second.back();
+    it->second.pop_back();
+    return st;
+}
 
 static Knobs g_knobs;
 const Knobs& knobs() { return g_knobs; }
@@ -255,11 +268,14 @@ int txq_init(int n_devices, const int* device_ids) {
         preload_exec_kernels();
         preload_probe_kernels();
         preload_hibf_kernels();
-        // (the first non-default stream of a process costs what the runtime has put off until then — 17 ms with this library's
-        // kernels; a session creates two: have it happen here)
-        hipStream_t first = nullptr;
-        if (hipStreamCreateWithFlags(&first, hipStreamNonBlocking) == hipSuccess) (void)hipStreamDestroy(first);
-        (void)hipGetLastError();
+        // A non-blocking stream is a hardware queue of its own: 9 ms to create.  A session needs two; the first session of a
+        // process takes them from here instead of paying 18 ms inside its first query (later sessions on an index inherit its streams).
+        std::lock_guard<std::mutex> lk(g_spare_mutex);
+        while (g_spare_streams[devices[i]].size() < 2) {
+            hipStream_t st = nullptr;
+            if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); break; }
+            g_spare_streams[devices[i]].push_back(st);
+        }
     }
     g_devices = devices;
     return TXQ_OK;

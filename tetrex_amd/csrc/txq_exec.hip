@@ -1446,16 +1446,19 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
         c.in_use = true;
     }
     s->last_stage.assign(n_programs, 0);
+    const double t_streams = now_s();
     for (hipStream_t* st : {&s->upload, &s->side})
-        if (!*st) {
+        if (!*st && !(*st = take_spare_stream(ix.device))) {
             hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
             if (e != hipSuccess) { delete s; return fail_hip(e, "hipStreamCreate(session)"); }
         }
+    const double t_events = now_s();
     for (Index::StagingSet& t : s->set)
         if (!t.done) {
             hipError_t e = hipEventCreateWithFlags(&t.done, hipEventDisableTiming);
             if (e != hipSuccess) { delete s; return fail_hip(e, "hipEventCreate(session)"); }
         }
+    if (s->kn.trace) fprintf(stderr, "[txq] session begin: streams %.3f ms, events %.3f ms\n", (t_events - t_streams) * 1e3, (now_s() - t_events) * 1e3);
     *out = s;
     return TXQ_OK;
 }

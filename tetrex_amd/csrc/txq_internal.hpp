@@ -263,6 +263,8 @@ void preload_exec_kernels();
 void preload_probe_kernels();
 void preload_hibf_kernels();
 
+hipStream_t take_spare_stream(int device);  // a non-blocking stream made at txq_init, or null (txq_api.hip)
+
 int fail(int code, const char* fmt, ...);
 int fail_hip(hipError_t e, const char* what);
 int ensure(void** p, size_t* cap, size_t bytes);
