@@ -838,6 +838,10 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // of the op's shape (FILL) and, [pos], of its r_mask (STEP)
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     __shared__ GeomTables sg, dg;  // geometry of the block read / written
+    // destination entries a chunk's pushes have made live: collected here and appended to dst's list with ONE atomic on the
+    // block's count per chunk (one per wave and round, thousands on one address per launch, was what the big steps waited for)
+    __shared__ uint32_t fresh_list[kSparseChunk * 32];
+    __shared__ uint32_t fresh_n;
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
@@ -934,6 +938,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const uint32_t n_r = cnt[P.pos];
         const bool noprobe = (d.reserved & TXQ_DENSE_NOPROBE) != 0;  // states that are still filling their first k-mer: the mask moves on as it is
         const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
+        __syncthreads();  // (the previous chunk has copied its fresh entries out)
+        if (threadIdx.x == 0) fresh_n = 0;
+        __syncthreads();
         for (uint32_t it = 0; it < rounds; ++it) {
             const uint32_t e = first + it * ngrp + grp;
             bool live = e < end;
@@ -1008,14 +1015,19 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
                 }
             }
             for (uint32_t o = 1; o < G; o <<= 1) hit |= (uint32_t)__shfl_xor((int)hit, (int)o);
-            uint32_t fresh = 0;  // the entry's first lane lists the destinations that were empty until now
-            if (sub == 0)
+            if (sub == 0)  // the entry's first lane notes the destinations that were empty until now
                 for (uint32_t h = hit; h; h &= h - 1) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(h);
-                    if (mark_live(dm, dst0 + dg.rank[P.pos - 1][codes[P.pos][i]])) fresh |= 1u << i;
+                    const uint32_t i = (uint32_t)__builtin_ctz(h), entry = dst0 + dg.rank[P.pos - 1][codes[P.pos][i]];
+                    if (mark_live(dm, entry)) fresh_list[atomicAdd(&fresh_n, 1u)] = entry;
                 }
-            uint32_t at = reserve_live(dm, (uint32_t)__builtin_popcount(fresh));
-            for (uint32_t h = fresh; h; h &= h - 1) dm.list[at++] = dst0 + dg.rank[P.pos - 1][codes[P.pos][__builtin_ctz(h)]];
+        }
+        __syncthreads();
+        const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
+        if (n_fresh) {
+            __shared__ uint32_t fresh_at;
+            if (threadIdx.x == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
         }
     }
 }

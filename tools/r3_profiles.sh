@@ -10,7 +10,7 @@ timeout -k 10 600 python bench.py > $O/bench_default.json 2> $O/bench_default.er
 (cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_probe -o probe -- python3 $GRAFT_REPO_ROOT/bench.py --no-queries --no-hibf --no-cpu > $O/bench_probe_legs.json 2> /dev/null)
 (cd /tmp && K6_NO_CHECK=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_k6 -o k6 -- python3 $GRAFT_REPO_ROOT/tools/k6_profile.py > $O/k6_under_rocprof.json 2> /dev/null)
 python tools/trace_timeline.py $O/prof_k6/k6_kernel_trace.csv > $O/k6_timeline.txt 2>&1
-(cd /tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_e2e -o e2e -- python3 $GRAFT_REPO_ROOT/tools/e2e_profile.py > $O/e2e_1k.txt 2>&1)
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_e2e -o e2e -- python3 tools/e2e_profile.py > $O/e2e_1k.txt 2>&1
 python tools/trace_timeline.py $O/prof_e2e/e2e_kernel_trace.csv > $O/e2e_timeline.txt 2>&1
 rm -f $O/*/*_kernel_trace.csv $O/*/*.db
 timeout -k 10 500 python tools/pmc_sparse.py $O/pmc_sparse_kernel.json > /dev/null 2> $O/pmc_sparse.err
