@@ -937,75 +937,89 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const uint32_t sub = threadIdx.x % G, grp = threadIdx.x / G, ngrp = blockDim.x / G;
         const uint32_t n_r = cnt[P.pos];
         const bool noprobe = (d.reserved & TXQ_DENSE_NOPROBE) != 0;  // states that are still filling their first k-mer: the mask moves on as it is
-        // The work of a chunk is its (entry, residue) PAIRS, dealt to the lane groups UA at a time — a literal residue (one pair
-        // per entry) keeps as many loads in flight as a wildcard (twenty): UA x (1 predecessor chunk + H row gathers) per lane.
-        const uint32_t n_pairs = (end - first) * n_r;
-        const uint32_t rounds = (n_pairs + ngrp * UA - 1) / (ngrp * UA);
+        const uint32_t rounds = (end - first + ngrp - 1) / ngrp;
         __syncthreads();  // (the previous chunk has copied its fresh entries out)
         if (threadIdx.x == 0) fresh_n = 0;
         __syncthreads();
         for (uint32_t it = 0; it < rounds; ++it) {
-            uint32_t idx[UA], dst_e[UA];
-            uint64_t val[UA];
-            bool live[UA];
-#pragma unroll
-            for (int u = 0; u < UA; ++u) {
-                const uint32_t p = (it * UA + (uint32_t)u) * ngrp + grp;
-                live[u] = p < n_pairs;
-                const uint32_t e = first + (live[u] ? p / n_r : 0), ri = live[u] ? p % n_r : 0;
-                idx[u] = live[u] ? sm.list[e] : 0;
-                uint64_t high = 0;   // the k-mer without the residue rolled in
-                uint32_t dst0 = 0;   // the destination entry without that residue's rank
-                for (uint32_t jj = P.pos, rest = idx[u]; jj-- > 0;) {
-                    const uint32_t c = sg.code[jj][rest % sg.cnt[jj]];
-                    rest /= sg.cnt[jj];
-                    high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
-                    if (jj > 0) {
-                        const uint32_t rk = dg.rank[jj - 1][c];
-                        live[u] = live[u] && rk != 0xFFu;
-                        dst0 += rk * dg.stride[jj - 1];
-                    }
+            const uint32_t e = first + it * ngrp + grp;
+            bool live = e < end;
+            const uint32_t idx = live ? sm.list[e] : 0;
+            uint64_t high = 0;   // the k-mer without the residue rolled in
+            uint32_t dst0 = 0;   // the destination entry without that residue's rank
+            for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
+                const uint32_t c = sg.code[jj][rest % sg.cnt[jj]];
+                rest /= sg.cnt[jj];
+                high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
+                if (jj > 0) {
+                    const uint32_t rk = dg.rank[jj - 1][c];
+                    live = live && rk != 0xFFu;
+                    dst0 += rk * dg.stride[jj - 1];
                 }
-                const uint32_t code = codes[P.pos][ri], rk = dg.rank[P.pos - 1][code];
-                live[u] = live[u] && rk != 0xFFu && idx[u] < q.src_cap;
-                dst_e[u] = dst0 + (rk != 0xFFu ? rk : 0);
-                val[u] = (high << P.bits) | code;
-                if (P.canonical) val[u] = canonical_dna(val[u], P.k);
             }
-            uint32_t hit = 0;  // bit u: pair u left a bit in this lane's chunk(s)
+            high <<= P.bits;
+            live = live && idx < q.src_cap;
+            uint32_t hit = 0;  // bit i: residue codes[pos][i] left a bit in this lane's chunk
             for (uint32_t c0 = 0; c0 < chunks_w; c0 += G) {
                 const uint32_t c = c0 + sub;
-                const bool mine = c < chunks_w;
-                if (mine) rows.prepare(c);
-                T sv[UA];
-                typename ROWS::Loads x[UA];
-#pragma unroll
-                for (int u = 0; u < UA; ++u) {
-                    sv[u] = L::zero();
-                    if (!mine || !live[u]) continue;
-                    sv[u] = L::load(q.src + (size_t)idx[u] * W + (size_t)c * L::kWords);
-                    if (!noprobe) rows.template issue<false>(nullptr, val[u], x[u]);
+                bool mine = live && c < chunks_w;
+                T sv = L::zero();
+                if (mine) {
+                    rows.prepare(c);
+                    sv = L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords);
+                    mine = L::any(sv);
                 }
-                if (!noprobe) {
-#pragma unroll
-                    for (int u = 0; u < UA; ++u)
-                        if (mine && live[u]) rows.template issue_late<false>(x[u]);
+                if (!mine) continue;
+                uint32_t i = 0;
+                if (noprobe) {
+                    for (; i < n_r; ++i) {
+                        const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
+                        if (rk == 0xFFu) continue;
+                        atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, sv);
+                        hit |= 1u << i;
+                    }
+                    continue;
                 }
+                for (; i + UA <= n_r; i += UA) {
+                    typename ROWS::Loads x[UA];
 #pragma unroll
-                for (int u = 0; u < UA; ++u) {
-                    if (!mine || !live[u]) continue;
-                    const T y = noprobe ? sv[u] : sv[u] & rows.combine(x[u]);
-                    if (L::any(y)) {
-                        atomic_or_chunk<WIDE>(q.dst + (size_t)dst_e[u] * W + (size_t)c * L::kWords, y);
-                        hit |= 1u << u;
+                    for (int u = 0; u < UA; ++u) {
+                        uint64_t v = high | codes[P.pos][i + u];
+                        if (P.canonical) v = canonical_dna(v, P.k);
+                        rows.template issue<false>(nullptr, v, x[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) rows.template issue_late<false>(x[u]);
+#pragma unroll
+                    for (int u = 0; u < UA; ++u) {
+                        const T y = sv & rows.combine(x[u]);
+                        const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i + u]];
+                        if (L::any(y) && rk != 0xFFu) {
+                            atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
+                            hit |= 1u << (i + u);
+                        }
+                    }
+                }
+                for (; i < n_r; ++i) {
+                    typename ROWS::Loads x0;
+                    uint64_t v = high | codes[P.pos][i];
+                    if (P.canonical) v = canonical_dna(v, P.k);
+                    rows.template issue<false>(nullptr, v, x0);
+                    rows.template issue_late<false>(x0);
+                    const T y = sv & rows.combine(x0);
+                    const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
+                    if (L::any(y) && rk != 0xFFu) {
+                        atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
+                        hit |= 1u << i;
                     }
                 }
             }
             for (uint32_t o = 1; o < G; o <<= 1) hit |= (uint32_t)__shfl_xor((int)hit, (int)o);
-            if (sub == 0)  // the pair's first lane notes the destinations that were empty until now
-#pragma unroll
-                for (int u = 0; u < UA; ++u)
-                    if (((hit >> u) & 1u) && mark_live(dm, dst_e[u])) fresh_list[atomicAdd(&fresh_n, 1u)] = dst_e[u];
+            if (sub == 0)  // the entry's first lane notes the destinations that were empty until now
+                for (uint32_t h = hit; h; h &= h - 1) {
+                    const uint32_t i = (uint32_t)__builtin_ctz(h), entry = dst0 + dg.rank[P.pos - 1][codes[P.pos][i]];
+                    if (mark_live(dm, entry)) fresh_list[atomicAdd(&fresh_n, 1u)] = entry;
+                }
         }
         __syncthreads();
         const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
@@ -2141,14 +2155,6 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                              : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
                 }
                 if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
-                if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to
-                    const double t_l = now_s();
-                    (void)hipStreamSynchronize(st);
-                    uint32_t total_chunks = 0;
-                    (void)hipMemcpy(&total_chunks, prefix + ng, 4, hipMemcpyDeviceToHost);
-                    fprintf(stderr, "[txq]   sparse launch: level %zu, %u groups, %u chunks (bound %zu), grid %zu, %.1f us\n", l, ng, total_chunks, plan[l].sparse_chunks, grid,
-                            (now_s() - t_l) * 1e6);
-                }
                 ++s.n_sparse_launches;
                 s.n_sparse_groups += ng;
             }
