@@ -284,12 +284,24 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
         dist.barrier()
     t0 = time.perf_counter()
     masks = status = stats = None
+    repeats = []
     if err is None:
         try:
             masks, status, stats = ix.query_masks(motifs, False, k)
         except Exception as e:  # noqa: BLE001
             err = repr(e)
     t1 = time.perf_counter()
+    if err is None and world == 1:
+        # one GPU: the batch is timed three times and the best run counts, like the other legs (a single run is at the mercy of
+        # whatever else the host's sixteen CPUs were given to do in those 9 ms); all three are reported
+        repeats = [t1 - t0]
+        for _ in range(2):
+            ta = time.perf_counter()
+            m2, s2, st2 = ix.query_masks(motifs, False, k)
+            tb = time.perf_counter()
+            repeats.append(tb - ta)
+            if tb - ta < t1 - t0:
+                t0, t1, masks, status, stats = ta, tb, m2, s2, st2
     gather_s = 0.0
     total = t1 - t0
     if world > 1:
@@ -320,6 +332,7 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
                            "op": "all_gather of the final masks (%d x %d words per rank)" % (len(motifs), int(ix.shard_words))}} if world > 1 else {}),
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
                   "warmup": "one batch of the same size and mix from another seed", "first_batch_seconds": local["first_batch_s"],
+                  **({"timed_runs_seconds": repeats, "seconds_is": "the best of the timed runs"} if repeats else {}),
                   "k": k, "refused_fraction": float(sum(1 for s_ in status if s_)) / len(motifs), **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
         "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
                                "failed": int(sum(1 for s in plain_status if s)), **plain_stats},

@@ -769,6 +769,12 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     TXQ_HIP(hipMemcpy(ix.d_vuser, vuser.data(), vuser.size() * 4, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_vgroups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
     ix.v_words = (uint32_t)words;
+    ix.v_inner_words = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        bool inner = false;
+        for (uint64_t b = 0; b < desc.ibf[i].bins && !inner; ++b) inner = tbu[off[i] + b] == TXQ_MERGED_BIN;
+        if (inner) ix.v_inner_words += (uint32_t)((desc.ibf[i].bin_words + cwords - 1) / cwords * cwords);
+    }
     ix.v_chunk_words = (uint32_t)cwords;
     ix.n_vchunks = (uint32_t)chunks.size();
     ix.v_depth = ix.depth - 1;
@@ -782,9 +788,10 @@ int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all
     if (!ix.d_vchunks) return fail(TXQ_ERR_STATE, "the index has no layout order");
     if (!n_all) return TXQ_OK;
     const uint32_t tile = 2048;
-    // A level reads the gates the level above it wrote: the batch goes through the levels in pieces whose rows (about 100 MB)
-    // are still in the Infinity Cache when the next level asks for them
-    size_t piece = std::max<size_t>(tile, (((size_t)96 << 20) / ((size_t)ix.v_words * 8)) / tile * tile);
+    // A level reads the gates the level above it wrote (the words of the IBFs that have children: v_inner_words of a row):
+    // a very large batch goes through the levels in pieces whose gates (about 100 MB) are still in the Infinity Cache when
+    // the next level asks for them — but never in pieces so small that a level's launch could not fill the device
+    size_t piece = std::max<size_t>((size_t)128 << 10, (((size_t)96 << 20) / ((size_t)std::max(ix.v_inner_words, 1u) * 8)) / tile * tile);
     for (size_t off = 0; off < n_all; off += piece) {
         const size_t n = std::min(piece, n_all - off);
         const uint64_t* d_kmers = d_kmers_all + off;

@@ -139,6 +139,7 @@ struct Index {
     uint64_t* d_vleaf = nullptr;     // [v_words] bits of technical bins that are user bins (the ONES of a layout-order session)
     uint32_t* d_vuser = nullptr;     // [v_words * 64] user bin of a layout-order bit (kNoGate: none)
     uint32_t* d_vgroups = nullptr;   // per level its groups' first chunks, concatenated (+ end)
+    uint32_t v_inner_words = 0;  // of a row: the words of IBFs with merged bins (what the next level reads as gates)
     uint32_t v_words = 0, n_vchunks = 0, v_depth = 0, v_chunk_words = 2;  // (chunks of 16 bytes, or of 8 for trees of narrow IBFs)
     std::vector<VLevel> vlevels;
     bool layout_order() const;       // sessions on this index work in layout order
