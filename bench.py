@@ -496,7 +496,17 @@ def k6_end_to_end(capi, torch, args, check=True):
     cpu_dt = time.perf_counter() - t0
     ix.free()
     refused = int(sum(1 for x in best[3] if x))
-    return {"workload": "%d PROSITE-style motifs (5 %% wildcards, 2 %% x(m,n)) at k = 6 on a 1024-bin flat IBF of Swissprot-shaped bins "
+    roof = None
+    try:  # the kernel of this leg against the HBM roofline: from the committed rocprofv3 passes of this very workload (tools/pmc_sparse.py)
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_sparse_kernel.json")))
+        if files:
+            with open(files[-1]) as f:
+                roof = dict(json.load(f)["roofline"], source="profiles/" + os.path.basename(files[-1]) + " (separate rocprofv3 --stats / --pmc passes, not measured in this run)")
+    except Exception:  # noqa: BLE001
+        roof = None
+    return {**({"roofline": roof} if roof else {}),
+            "workload": "%d PROSITE-style motifs (5 %% wildcards, 2 %% x(m,n)) at k = 6 on a 1024-bin flat IBF of Swissprot-shaped bins "
                         "(6-mers of %d random residues per bin, h = 3, %d rows)" % (len(motifs), per_bin, m),
             "k": k, "queries_per_s": len(motifs) / best[0], "seconds": best[0], "refused": refused, "refused_fraction": refused / len(motifs),
             "mean_candidate_bins": float(np.unpackbits(best[2].view(np.uint8), axis=1).sum(axis=1).mean()), **best[1],

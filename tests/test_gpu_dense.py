@@ -543,3 +543,43 @@ def test_k6_motif_batch_tracked_blocks_equal_enumerated_states(capi, oracle, mon
         compared += 1
     assert compared > 30
     ix.free()
+
+
+@pytest.mark.parametrize("tree", ["16x64", "8x256-mixed", "4x64-bylane"])
+def test_tracked_blocks_on_regular_hibfs(capi, oracle, monkeypatch, tree):
+    """Tracked programs on regular two-level trees: the pushed steps take their rows from the tree (sparse_kernel with the
+    InterleavedRows / TreeRows policies, the shapes `tetrex index` writes: the README scenario runs exactly this).  Masks =
+    the oracle's collect() over membership_for."""
+    from helpers import regular_hibf
+    from tetrex_amd import host
+    monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    rng = np.random.default_rng(19)
+    aa = np.frombuffer(b"ACDEFGHIKLMNPQRSTVWY", dtype=np.uint8)
+    shape, _, variant = tree.partition("-")
+    children, per_child = (int(x) for x in shape.split("x"))
+    ub = children * per_child - (5 if variant == "mixed" else 0)
+    if variant == "bylane":
+        monkeypatch.setenv("TXQ_DENSE_TREE", "1")  # no interleaved children: TreeRows
+    seqs = [aa[rng.integers(0, 20, size=203)].tobytes() for _ in range(ub)]
+    ox, descs, values = regular_hibf(oracle, ub, children, 200, lambda b: host.record_values_array(seqs[b], 4, dna=False), h=2, mixed=variant == "mixed")
+    qs = ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "KRK[RK]{2,3}.DE", "LMA(E|Q)GLYN", "A.CD"]
+    for b in range(0, ub, max(1, ub // 10)):
+        w = [chr(c) for c in seqs[b][50:60]]
+        w[3] = "."
+        w[5] = "[" + "".join(sorted(set([w[5], "A", "K"]))) + "]"
+        w[7] = ".{0,2}"
+        qs.append("".join(w))
+    wants = [ox.query(q, with_stats=True) for q in qs]
+    ix = capi.Index.upload_hibf(ub, descs)
+    got, status, stats = ix.query_masks(qs, False, 4)
+    assert stats["tracked_queries"] >= 8 and stats["dense_ops"] > 20
+    hits = 0
+    for q, g, st, (want, ost) in zip(qs, got, status, wants):
+        assert st == 0, q
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+            hits += int(want.any())
+    assert hits >= 5
+    ix.free()
