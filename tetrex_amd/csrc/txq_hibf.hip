@@ -791,7 +791,9 @@ int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all
     // A level reads the gates the level above it wrote (the words of the IBFs that have children: v_inner_words of a row):
     // a very large batch goes through the levels in pieces whose gates (about 100 MB) are still in the Infinity Cache when
     // the next level asks for them — but never in pieces so small that a level's launch could not fill the device
-    size_t piece = std::max<size_t>((size_t)128 << 10, (((size_t)96 << 20) / ((size_t)std::max(ix.v_inner_words, 1u) * 8)) / tile * tile);
+    // (measured on the 65 536-bin trees of tests/perf_hibf_ragged.py: 1 M k-mers in one piece 28 ms, in pieces of 128 k 47 ms — the
+    // launches' tails cost more than the gates' cache misses; pieces are for batches of many millions)
+    size_t piece = std::max<size_t>((size_t)4 << 20, (((size_t)96 << 20) / ((size_t)std::max(ix.v_inner_words, 1u) * 8)) / tile * tile);
     for (size_t off = 0; off < n_all; off += piece) {
         const size_t n = std::min(piece, n_all - off);
         const uint64_t* d_kmers = d_kmers_all + off;
