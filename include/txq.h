@@ -44,7 +44,7 @@ extern "C" {
  * txq_session_begin, txq_run_programs* and txq_probe* — never while a stage runs — and a session keeps the values it began with.
  *   TXQ_TRACE, TXQ_TRACE_STAGES, TXQ_TRACE_SYNC      timers and per-stage notes on stderr
  *   TXQ_DENSE_TREE=0|1|2                              dense steps on a regular HIBF: generic descent | TreeRows | TreeRowsByLane
- *   TXQ_DENSE_UNROLL, TXQ_DENSE_SLICES, TXQ_DENSE_TILE_ROUNDS   shape of a dense step's tiles
+ *   TXQ_DENSE_UNROLL, TXQ_DENSE_SLICES, TXQ_DENSE_TILE_ROUNDS, TXQ_DENSE_NT   shape of a dense step's tiles, cache policy of its destination accesses
  *   TXQ_FUSE_UNITS=0, TXQ_ONE_STREAM                  one launch per kind and level; no second stream
  *   TXQ_HIBF_INTERLEAVE=0, TXQ_HIBF_INTERLEAVE_PROBE=0, TXQ_HIBF_LEVELS=1, TXQ_HIBF_STATIONARY=0, TXQ_HIBF_SMALL=0,
  *   TXQ_HIBF_LAYOUT_ORDER=0, TXQ_HIBF_LANE_HASH, TXQ_HIBF_STEPS_PER_GROUP, TXQ_HIBF_TILE, TXQ_HIBF_UNROLL, TXQ_HIBF_STORE_KIND, TXQ_HIBF_WAVES

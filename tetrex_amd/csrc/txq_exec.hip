@@ -213,7 +213,7 @@ struct DenseTile { uint32_t program, op, first, count; };
 // groups of one level back to back — and make_tiles_kernel writes them (one workgroup per group).
 struct TileGroup { uint32_t program, op, entries, per_tile; uint64_t first_tile; };
 static constexpr uint32_t kRootWordsLds = 4096;  // 32 KB of root verdicts per workgroup (TreeRowsByLane)
-struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; };
+struct DenseParams { uint32_t k, bits, A, canonical, pos; uint32_t pow_a[TXQ_DENSE_MAX_POSITIONS + 1]; uint32_t nt; };  // nt: A/B bits (TXQ_DENSE_NT): 1 destination stores, 2 destination loads
 // Where the blocks (and slots) of a stage's dense op live, resolved by the host side when it plans the stage:
 // dst = the block written (ZERO, STEP, FILL) or the slot accumulated into (REDUCE); src = the block read (STEP, REDUCE) or
 // the slot spread (FILL).  A tile reads this next to the op itself: no pointer chase through the program's tables.
@@ -235,6 +235,8 @@ template <> struct Lane<true> {
     static constexpr uint32_t kWords = 2;
     static __device__ __forceinline__ T load(const uint64_t* p) { return *reinterpret_cast<const T*>(p); }
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *reinterpret_cast<T*>(p) = v; }
+    static __device__ __forceinline__ void store_nt(uint64_t* p, T v) { __builtin_nontemporal_store(v, reinterpret_cast<T*>(p)); }
+    static __device__ __forceinline__ T load_nt(const uint64_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const T*>(p)); }
     static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
     static __device__ __forceinline__ bool any(T v) { return (v.x | v.y | v.z | v.w) != 0u; }
     static __device__ __forceinline__ T keep(T v, bool word0, bool word1) {  // zero the words that are not kept
@@ -251,6 +253,8 @@ template <> struct Lane<false> {
     static constexpr uint32_t kWords = 1;
     static __device__ __forceinline__ T load(const uint64_t* p) { return *p; }
     static __device__ __forceinline__ void store(uint64_t* p, T v) { *p = v; }
+    static __device__ __forceinline__ void store_nt(uint64_t* p, T v) { __builtin_nontemporal_store(v, p); }
+    static __device__ __forceinline__ T load_nt(const uint64_t* p) { return __builtin_nontemporal_load(p); }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool any(T v) { return v != 0; }
     static __device__ __forceinline__ T keep(T v, bool word0, bool) { return word0 ? v : 0; }
@@ -680,7 +684,8 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
                 for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
                 if (mine && slice == 0 && L::any(acc)) {
                     uint64_t* p = dst + (size_t)c * L::kWords;
-                    L::store(p, L::load(p) | acc);
+                    const T old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
+                    if (P.nt & 1u) L::store_nt(p, old | acc); else L::store(p, old | acc);
                 }
             }
         } else
@@ -718,7 +723,8 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
             for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
             if (mine && slice == 0 && L::any(acc)) {
                 uint64_t* p = dst + (size_t)c * L::kWords;
-                L::store(p, L::load(p) | acc);
+                const T old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
+                if (P.nt & 1u) L::store_nt(p, old | acc); else L::store(p, old | acc);
             }
         }
     }
@@ -1241,6 +1247,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             P.A > (1u << P.bits) || (P.canonical && P.bits != 2))
             return fail(TXQ_ERR_PROGRAM, "dense parameters out of range (k %u, %u bits, alphabet %u)", P.k, P.bits, P.A);
         P.pos = P.k - 1;
+        P.nt = (uint32_t)knobs().dense_nt;
         uint64_t n = 1;
         P.pow_a[0] = 1;
         for (uint32_t j = 1; j <= P.pos; ++j) {
@@ -2155,6 +2162,25 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                              : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
                 }
                 if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
+                if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to
+                    const double t_l = now_s();
+                    (void)hipStreamSynchronize(st);
+                    const double dt = now_s() - t_l;
+                    std::vector<uint32_t> cnts(ng);
+                    (void)hipMemcpy(cnts.data(), counts, (size_t)ng * 4, hipMemcpyDeviceToHost);
+                    const txq_dense_op* hd = (const txq_dense_op*)(blob + bv.dense_offset);
+                    uint64_t by_kind[5] = {0, 0, 0, 0, 0};  // entries: ZERO, STEP, REDUCE, FILL, STEP without probe
+                    uint64_t visits = 0;
+                    for (uint32_t gi = 0; gi < ng; ++gi) {
+                        const txq_dense_op& x = hd[sparse_groups[first_sparse + off + gi].op];
+                        const bool np_ = x.kind == TXQ_DENSE_STEP && (x.reserved & TXQ_DENSE_NOPROBE);
+                        by_kind[np_ ? 4 : x.kind] += cnts[gi];
+                        if (x.kind == TXQ_DENSE_STEP) visits += (uint64_t)cnts[gi] * (uint64_t)__builtin_popcount(x.r_mask);
+                    }
+                    fprintf(stderr, "[txq]   sparse launch: level %zu, %u groups, %.1f us; entries: zero %llu, step %llu (+ %llu without probe; %llu visits), reduce %llu, fill %llu\n", l, ng,
+                            dt * 1e6, (unsigned long long)by_kind[0], (unsigned long long)by_kind[1], (unsigned long long)by_kind[4], (unsigned long long)visits,
+                            (unsigned long long)by_kind[2], (unsigned long long)by_kind[3]);
+                }
                 ++s.n_sparse_launches;
                 s.n_sparse_groups += ng;
             }
