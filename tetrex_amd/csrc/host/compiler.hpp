@@ -352,8 +352,9 @@ struct StagedOptions {
     size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it quadruples with every further stage the query
                                              // needs (up to 16x), so a skewed batch is not held to many stages by its heaviest query
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
-    size_t wave_ops = 192u << 10;            // queries BEGIN in waves of about this many ops (growing with the ops already emitted), so that the
+    size_t wave_ops = 96u << 10;             // queries BEGIN in waves of about this many ops (growing with the ops already emitted), so that the
                                              // device runs wave n while the host expands wave n+1; 0: everybody begins in the first stage
+                                             // (profiles/r3_wave_size_ab.txt: 1000 motifs 7.4 / 7.1 / 6.9 / 8.9 ms at 192 k / 96 k / 64 k / 48 k)
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;
     DenseOptions dense;                      // run_staged fills `pool` itself

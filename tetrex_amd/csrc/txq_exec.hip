@@ -1394,6 +1394,7 @@ Session::~Session() {
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
         if (t.pending) { (void)hipEventSynchronize(t.done); t.pending = false; }
+    for (void* p : retired) (void)hipFree(p);
     if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
         size_t kept = 0;
@@ -1813,8 +1814,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
     std::vector<std::pair<uint64_t*, size_t>> to_clear;
+    const double t_begin = t0;
+    double t_mark[6] = {0, 0, 0, 0, 0, 0};  // (TXQ_TRACE_STAGES) where the host's time of this stage goes
     if (int rc = grow_slot_regions(s, bv, blob, &fresh, &moves, &to_clear)) return rc;
     s.t_grow += now_s() - t0;
+    t_mark[0] = now_s();
     for (size_t i = 0; i < n_q; ++i)
         if (!s.base[q_prog[i]]) return fail(TXQ_ERR_ARG, "feedback query %zu: program %u has not run an op yet", i, q_prog[i]);
 
@@ -1894,6 +1898,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // waits for THOSE copies only (pageable sources, some of them locals) — not for the kernels of the previous stage.
     s.t_plan += now_s() - t1;
     t1 = now_s();
+    t_mark[1] = t1;
     Index::StagingSet& S = s.set[(s.n_stages - 1) & 1];
     if (S.pending) {
         TXQ_HIP(hipEventSynchronize(S.done));
@@ -1901,6 +1906,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     }
     s.t_wait += now_s() - t1;
     t1 = now_s();
+    t_mark[2] = t1;
     size_t aux_bytes = 0;
     auto place = [&](size_t bytes) { const size_t at = aux_bytes; aux_bytes = (aux_bytes + bytes + 15) & ~(size_t)15; return at; };
     const size_t prog_bytes = s.n_programs * sizeof(DevProgram);
@@ -1918,21 +1924,35 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // rides behind the tables in `aux`
     const bool packed = aux_bytes + bytes <= ((size_t)256 << 10);
     const size_t at_blob = packed ? place(bytes) : 0;
+    // The set's buffers are idle (S.done was waited for), but hipFree drains the WHOLE device — the previous stage, which this
+    // stage may want to run beside: a buffer that has to grow (how the queries fall into waves depends on the host's timing, so
+    // stage sizes differ from batch to batch) is replaced generously and the old one freed with the session.
+    auto ensure_idle = [&](void** p, size_t* cap, size_t need) -> int {
+        if (*p && *cap >= need) return TXQ_OK;
+        if (*p) s.retired.push_back(*p);
+        *p = nullptr; *cap = 0;
+        const size_t want = std::max(need + need / 2, (size_t)1 << 20);
+        hipError_t e = hipMalloc(p, want);
+        if (e != hipSuccess) return fail_hip(e, "hipMalloc(staging set)");
+        *cap = want;
+        return TXQ_OK;
+    };
     if (!packed)
-        if (int rc = ensure((void**)&S.d_blob, &S.cap_blob, (bytes + 7) & ~(size_t)7)) return rc;
-    if (int rc = ensure((void**)&S.d_aux, &S.cap_aux, aux_bytes + 16)) return rc;
+        if (int rc = ensure_idle((void**)&S.d_blob, &S.cap_blob, (bytes + 7) & ~(size_t)7)) return rc;
+    if (int rc = ensure_idle((void**)&S.d_aux, &S.cap_aux, aux_bytes + 16)) return rc;
     const unsigned char* dblob = packed ? S.d_aux + at_blob : S.d_blob;
     for (size_t p = 0; p < s.n_programs; ++p)  // (the aux buffer has its final address now)
         s.base[s.n_programs + p] = s.blocks[p].empty() ? nullptr : reinterpret_cast<uint64_t*>(reinterpret_cast<uint64_t**>(S.d_aux + at_bt) + row_of[p]);
     const size_t nk = h->n_kmers;
-    // scratch the kernels in flight may still use: replacing it drains the device (ensure), so replace it generously
+    // scratch of the INDEX that kernels in flight may still use: replacing it drains the device (ensure), so replace it generously
     auto ensure_scratch = [&](uint64_t** p, size_t* cap, size_t need) -> int {
         if (*p && *cap >= need) return TXQ_OK;
         return ensure((void**)p, cap, std::max(need + need / 2, (size_t)64 << 20));
     };
-    if (int rc = ensure_scratch(&S.d_masks, &S.cap_masks, (nk ? nk : 1) * (size_t)W * 8)) return rc;
+    if (int rc = ensure_idle((void**)&S.d_masks, &S.cap_masks, std::max((nk ? nk : 1) * (size_t)W * 8, (size_t)16 << 20))) return rc;
     uint64_t* const d_masks = S.d_masks;
     s.t_alloc += now_s() - t1;
+    t_mark[3] = now_s();
     hipStream_t up = s.upload;
     if (packed) {
         s.host_aux.resize(aux_bytes);
@@ -1992,9 +2012,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (int rc = ensure_scratch(&ix.scratch_dense_kmers, &ix.cap_dense_kmers, most_pairs * 8)) return rc;
         if (int rc = ensure_scratch(&ix.scratch_dense_masks, &ix.cap_dense_masks, most_pairs * (size_t)W * 8)) return rc;
     }
+    t_mark[4] = now_s();
     TXQ_HIP(hipStreamSynchronize(up));
     s.t_upload += now_s() - t0;
     t0 = now_s();
+    t_mark[5] = t0;
 
     const bool one_stream = s.kn.one_stream;  // A/B knob
     const Index::StagingSet& prev = s.set[s.n_stages & 1];
@@ -2200,8 +2222,12 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     }
     TXQ_HIP(hipEventRecord(S.done, st));
     S.pending = true;
-    if (s.kn.trace_sync)  // charges the device time to the stage that caused it (void)hipStreamSynchronize(st);
+    if (s.kn.trace_sync) (void)hipStreamSynchronize(st);  // charges the device time to the stage that caused it
     s.t_device += now_s() - t0;
+    if (s.kn.trace_stages)
+        fprintf(stderr, "[txq] stage %zu: regions %.0f us, plan %.0f us, staging set %.0f us, buffers %.0f us, copies issued %.0f us, copies done %.0f us, launches %.0f us\n", s.n_stages,
+                (t_mark[0] - t_begin) * 1e6, (t_mark[1] - t_mark[0]) * 1e6, (t_mark[2] - t_mark[1]) * 1e6, (t_mark[3] - t_mark[2]) * 1e6, (t_mark[4] - t_mark[3]) * 1e6,
+                (t_mark[5] - t_mark[4]) * 1e6, (now_s() - t_mark[5]) * 1e6);
     return TXQ_OK;
 }
 

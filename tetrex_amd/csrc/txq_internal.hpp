@@ -243,6 +243,7 @@ struct Session {
     int stream_of_last = 0;            // 0: the caller's stream, 1: `side`
     uint64_t** d_base = nullptr;  // device copy of `base` as of the last stage (lives in that stage's staging set)
     bool owns_cache = false;      // buffers came from / go back to ix->session_cache
+    std::vector<void*> retired;   // staging buffers that were outgrown while another stage was running: freed with the session
     Index::StagingSet set[2];     // stage n uses set[n & 1]
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
     std::vector<unsigned char> host_aux;  // a small stage is packed here and sent as one copy

@@ -5,7 +5,8 @@ import csv, sys, collections
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
-        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:50]))
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].split("(")[0][:50],
+                     int(r.get("Grid_Size_X", 0) or 0) // max(int(r.get("Workgroup_Size_X", 1) or 1), 1), r.get("Queue_Id", "")))
 rows.sort()
 # the last batch = after the last gap longer than 20 ms... the script runs 4 repetitions back to back: split on gaps > 3 ms
 cuts = [0] + [i for i in range(1, len(rows)) if rows[i][0] - rows[i - 1][1] > 3_000_000] + [len(rows)]
@@ -13,7 +14,7 @@ seg = rows[cuts[-2]:cuts[-1]]
 span = (seg[-1][1] - seg[0][0]) / 1e3
 busy = collections.Counter(); n = collections.Counter()
 gap_hist = collections.Counter(); gaps = 0.0
-for i, (s, e, name) in enumerate(seg):
+for i, (s, e, name, *_) in enumerate(seg):
     busy[name] += (e - s) / 1e3; n[name] += 1
     if i:
         g = (s - seg[i - 1][1]) / 1e3
@@ -27,6 +28,12 @@ print("  gaps by size (us):", sorted(gap_hist.items()))
 # where the long gaps are: time since the batch's first launch, what ended before and what began after
 t0 = seg[0][0]
 for i in range(1, len(seg)):
-    g = (seg[i][0] - max(e for _, e, _ in seg[:i])) / 1e3
+    g = (seg[i][0] - max(r[1] for r in seg[:i])) / 1e3
     if g >= 100:
         print("  idle %.0f us at +%.0f us: after %s, before %s" % (g, (seg[i][0] - t0) / 1e3, seg[i - 1][2][:40], seg[i][2][:40]))
+
+# the dense / sparse launches one by one, when asked (argv[2] = "launches"): start, duration, workgroups, queue
+if len(sys.argv) > 2 and sys.argv[2] == "launches":
+    for s, e, name, wgs, q in seg:
+        if "dense_kernel" in name or "sparse_kernel" in name:
+            print("  +%8.1f us  %7.1f us  %7d workgroups  queue %s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, wgs, q, name[10:36]))
