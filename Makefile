@@ -7,7 +7,7 @@ HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-functi
 # `make EXPERIMENTS=1` (after `make clean`): timing experiments that deliberately compute WRONG masks (TXQ_HIBF_STORE bits 4/5,
 # tools/ab_hibf*.sh) are compiled in.  The product build does not contain them.
 ifdef EXPERIMENTS
-HIPFLAGS += -DTXQ_EXPERIMENTS
+HIPFLAGS += -DTXQ_EXPERIMENTS $(EXPERIMENT_FLAGS)
 endif
 HIP_SRCS := $(CSRC)/txq_api.hip $(CSRC)/txq_probe.hip $(CSRC)/txq_hibf.hip $(CSRC)/txq_exec.hip
 HIP_OBJS := $(HIP_SRCS:.hip=.o)

@@ -47,6 +47,7 @@ void read_knobs() {
     k.dense_nt = (int)num("TXQ_DENSE_NT", 0) & 3;
     k.fuse_units = !is("TXQ_FUSE_UNITS", '0');
     k.one_stream = flag("TXQ_ONE_STREAM");
+    k.kmer_table_mb = std::max(0LL, num("TXQ_KMER_TABLE_MB", 512));
     k.hibf_interleave = !is("TXQ_HIBF_INTERLEAVE", '0');
     k.hibf_interleave_probe = !is("TXQ_HIBF_INTERLEAVE_PROBE", '0');
     k.hibf_levels = is("TXQ_HIBF_LEVELS", '1');
@@ -205,8 +206,9 @@ void Index::release() {
     if (d_merged_off) (void)hipFree(d_merged_off);
     d_merged = d_merged_off = nullptr;
     for (void* p : {(void*)scratch_kmers, (void*)scratch_masks, (void*)frontier[0], (void*)frontier[1], (void*)d_counts,
-                    (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final, (void*)scratch_dense_kmers, (void*)scratch_dense_masks})
+                    (void*)scratch_blob, (void*)scratch_slots, (void*)scratch_final, (void*)scratch_dense_kmers, (void*)scratch_dense_masks, (void*)kmer_table})
         if (p) (void)hipFree(p);
+    kmer_table = nullptr; kmer_table_bits = 0;
     d_ibf = nullptr; d_next = d_tb_user = nullptr; d_map_off = nullptr;
     scratch_kmers = scratch_masks = nullptr; frontier[0] = frontier[1] = nullptr; d_counts = nullptr;
     scratch_blob = nullptr; scratch_slots = scratch_final = nullptr;

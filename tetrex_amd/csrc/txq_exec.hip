@@ -305,6 +305,32 @@ struct FlatRows {
     }
 };
 
+// The same index through its table of all k-mers' masks (Index::kmer_table, ensure_kmer_table below): M[k-mer] is ONE row, read
+// at the k-mer's packed value — what the reference's kmer_cache_ (include/otf_collector.h:247-262) is per query, here complete
+// and resident: a step moves two rows per predecessor instead of 1 + hash_funs, out of a table that is a fraction of the matrix
+// (every 4-mer of 1024 protein bins: 20 MB touched, against a 160 MB matrix).  H is not used (instantiated with 1).
+template <int H, bool WIDE>
+struct TableRows {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    struct Loads { T x[2]; };
+    static constexpr bool kRootByLane = false;
+    static constexpr int kPushUnroll = 3;
+    const uint64_t* table;
+    uint32_t stride;  // words per row (the session's mask width)
+    uint32_t c;
+    __device__ __forceinline__ void prepare(uint32_t chunk) { c = chunk; }
+    template <bool SRC = true>
+    __device__ __forceinline__ void issue(const uint64_t* src_slot, uint64_t value, Loads& l) const {
+        if constexpr (SRC) l.x[1] = L::load(src_slot + (size_t)c * L::kWords);
+        else l.x[1] = ~L::zero();
+        l.x[0] = L::load(table + value * stride + (size_t)c * L::kWords);
+    }
+    template <bool SRC = true>
+    __device__ __forceinline__ void issue_late(Loads&) const {}
+    __device__ __forceinline__ T combine(const Loads& l) const { return l.x[0] & l.x[1]; }
+};
+
 // Regular two-level HIBF (txq_internal.hpp ChildRec; membership_for(·, 1) of reference include/index_hibf.h:132-147 on
 // that shape): the lane's mask words are technical bins of ONE child, so M[k-mer] there = the child's rows ANDed,
 // if the k-mer is in the child's merged bin of the root (the root's rows ANDed, one bit of one word).  Two rounds of
@@ -656,6 +682,9 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
                 const uint32_t c = c0 + sub;
                 const bool mine = live && c < chunks;
                 T acc = L::zero();
+                T old = L::zero();  // (travels with the first trip of gathers, see below)
+                uint64_t* const p = dst + (size_t)c * L::kWords;
+                if (mine && slice == 0) old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
                 if (mine) {
                     rows.prepare(c);
                     uint32_t todo = 0;  // bit j: the root lets predecessor j of this suffix into my child
@@ -683,8 +712,6 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
                 }
                 for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
                 if (mine && slice == 0 && L::any(acc)) {
-                    uint64_t* p = dst + (size_t)c * L::kWords;
-                    const T old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
                     if (P.nt & 1u) L::store_nt(p, old | acc); else L::store(p, old | acc);
                 }
             }
@@ -693,37 +720,39 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
             const uint32_t c = c0 + sub;
             const bool mine = live && c < chunks;
             T acc = L::zero();
+            // what the destination holds (other steps of earlier levels OR into the same entries) travels with the first trip
+            // of gathers instead of being one more dependent trip behind the last
+            T old = L::zero();
+            uint64_t* const p = dst + (size_t)c * L::kWords;
+            if (mine && slice == 0) old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
             if (mine) {
                 rows.prepare(c);
-                uint32_t i = slice;
-                for (; i + (UA - 1) * SL < n_a; i += UA * SL) {  // UA predecessors at a time: UA * (H + 1) loads in flight
+                // UA predecessors per trip: UA * (H + 1) loads in flight per lane; the last trip is a partial one (its missing
+                // predecessors are skipped lane group by lane group), not a tail of single predecessors — n_a = 20 residues
+                // over two slices are 10 / UA trips, rounded up
+                for (uint32_t i = slice; i < n_a; i += UA * SL) {
                     typename ROWS::Loads x[UA];
+                    bool have[UA];
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
-                        const uint32_t a = codes[0][i + u * SL];
-                        uint64_t v = ((uint64_t)a << a_shift) | low;
-                        if (P.canonical) v = canonical_dna(v, P.k);
-                        rows.issue(srcm + (size_t)a * a_stride * W, v, x[u]);
+                        have[u] = i + u * SL < n_a;
+                        if (have[u]) {
+                            const uint32_t a = codes[0][i + u * SL];
+                            uint64_t v = ((uint64_t)a << a_shift) | low;
+                            if (P.canonical) v = canonical_dna(v, P.k);
+                            rows.issue(srcm + (size_t)a * a_stride * W, v, x[u]);
+                        }
                     }
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) rows.issue_late(x[u]);
+                    for (int u = 0; u < UA; ++u)
+                        if (have[u]) rows.issue_late(x[u]);
 #pragma unroll
-                    for (int u = 0; u < UA; ++u) acc |= rows.combine(x[u]);
-                }
-                for (; i < n_a; i += SL) {
-                    const uint32_t a0 = codes[0][i];
-                    uint64_t v0 = ((uint64_t)a0 << a_shift) | low;
-                    if (P.canonical) v0 = canonical_dna(v0, P.k);
-                    typename ROWS::Loads x0;
-                    rows.issue(srcm + (size_t)a0 * a_stride * W, v0, x0);
-                    rows.issue_late(x0);
-                    acc |= rows.combine(x0);
+                    for (int u = 0; u < UA; ++u)
+                        if (have[u]) acc |= rows.combine(x[u]);
                 }
             }
             for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
             if (mine && slice == 0 && L::any(acc)) {
-                uint64_t* p = dst + (size_t)c * L::kWords;
-                const T old = (P.nt & 2u) ? L::load_nt(p) : L::load(p);
                 if (P.nt & 1u) L::store_nt(p, old | acc); else L::store(p, old | acc);
             }
         }
@@ -1731,7 +1760,7 @@ static hipError_t launch_dense(int ua, uint32_t hash_funs, MAKE rows_of, const D
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        if (ua >= 6) dense_kernel<H, WIDE, 6, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
+        if (ua >= 5) dense_kernel<H, WIDE, 5, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
         else if (ua <= 2) dense_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
         else dense_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, tiles, dops, optr, base, n_programs, W, G, SL, P, U); \
     } while (0)
@@ -1768,6 +1797,43 @@ static hipError_t launch_sparse(uint32_t hash_funs, MAKE rows_of, const SparseGr
     }
 #undef TXQ_SPARSE
     return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uint64_t n) {
+    for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = i;
+}
+
+// The table of all k-mers' masks of a flat index (Index::kmer_table), built once per index when the first stage with dense steps
+// arrives: bulk_contains of every packed value below 2^(bits * k) — values with a residue code outside the alphabet included,
+// nobody reads their rows — with the probe kernel itself.  Returns whether the steps may read it.  (Synchronous: a later stage
+// on the other stream reads the table, too.)
+static bool ensure_kmer_table(Index& ix, const Knobs& kn, const DenseParams& P, uint32_t W, hipStream_t st) {
+    const uint32_t vb = P.bits * P.k;
+    if (ix.is_hibf || kn.kmer_table_mb <= 0 || vb == 0 || vb > 24) return false;
+    if (ix.kmer_table) return ix.kmer_table_bits == vb;  // (one encoder per index; a session with another k gathers rows)
+    const uint64_t n = 1ULL << vb, bytes = n * (uint64_t)W * 8;
+    if (ix.kmer_table_refused || bytes > ((uint64_t)kn.kmer_table_mb << 20)) return false;
+    const double t0 = now_s();
+    uint64_t *table = nullptr, *values = nullptr;
+    if (hipMalloc((void**)&table, bytes) != hipSuccess || hipMalloc((void**)&values, n * 8) != hipSuccess) {
+        (void)hipGetLastError();
+        if (table) (void)hipFree(table);
+        ix.kmer_table_refused = true;
+        return false;
+    }
+    iota_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, st>>>(values, n);
+    hipError_t e = launch_probe(ix.ibf[0], values, n, table, nullptr, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(values);
+    if (e != hipSuccess) {
+        (void)hipFree(table);
+        ix.kmer_table_refused = true;
+        return false;
+    }
+    ix.kmer_table = table;
+    ix.kmer_table_bits = vb;
+    if (kn.trace) fprintf(stderr, "[txq] table of all %llu k-mer masks (%u bits per k-mer): %.1f MB, built in %.2f ms\n", (unsigned long long)n, vb, bytes / 1e6, (now_s() - t0) * 1e3);
+    return true;
 }
 
 int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* q_prog, const uint32_t* q_slot, size_t n_q,
@@ -1828,7 +1894,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         s.row_source = "regular tree, interleaved children, fused";
     const int tree_knob = s.kn.dense_tree;  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; -1 (default): best fit
     const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && tree_knob < 0;
-    const bool wide = W % 2 == 0 && (vspace ? ix.v_chunk_words == 2 : (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0));
+    const bool table = any_dense && !ix.is_hibf && ensure_kmer_table(ix, s.kn, bv.dense, W, s.upload);
+    if (table) s.row_source = "flat IBF through its table of all k-mers' masks";
+    const bool wide = W % 2 == 0 && (vspace ? ix.v_chunk_words == 2 : (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && (table || ix.ibf[0].stride % 2 == 0)));
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
@@ -2144,6 +2212,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     else
                         e = wide ? launch_dense<true, TreeRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
                                  : launch_dense<false, TreeRows>(s.kn.dense_unroll, ix.tree_hash_max, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
+                } else if (table) {  // a flat index whose masks of all k-mers are tabulated: one row per k-mer
+                    auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
+                    e = wide ? launch_dense<true, TableRows>(s.kn.dense_unroll, 1, rows_tab, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
+                             : launch_dense<false, TableRows>(s.kn.dense_unroll, 1, rows_tab, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 } else {  // (an irregular HIBF only has ZERO / REDUCE tiles here: its steps are `hsteps`)
                     auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
                     e = wide ? launch_dense<true, FlatRows>(s.kn.dense_unroll, ix.ibf[0].hash_funs, rows_of, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
@@ -2178,6 +2250,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
                     e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
                              : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                } else if (table) {
+                    auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
+                    e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                             : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
                 } else {
                     auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
                     e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)

@@ -16,12 +16,13 @@ struct Knobs {
     bool trace = false, trace_stages = false, trace_sync = false;  // TXQ_TRACE, TXQ_TRACE_STAGES, TXQ_TRACE_SYNC
     // executor (txq_exec.hip)
     int dense_tree = -1;        // TXQ_DENSE_TREE: 0 generic HIBF steps, 1 TreeRows, 2 TreeRowsByLane where it applies; -1: best fit
-    int dense_unroll = 3;       // TXQ_DENSE_UNROLL: predecessors in flight per lane (2, 3, 6)
+    int dense_unroll = 3;       // TXQ_DENSE_UNROLL: predecessors in flight per lane (2, 3, 5)
     int dense_slices = 2;       // TXQ_DENSE_SLICES: lane groups sharing the predecessors of one suffix
     int dense_tile_rounds = 2;  // TXQ_DENSE_TILE_ROUNDS: destination suffixes per lane-group set and tile
     int dense_nt = 0;           // TXQ_DENSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads of a dense step's destination entries
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
+    long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most a flat index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
     // HIBF (txq_hibf.hip)
     bool hibf_interleave = true;        // TXQ_HIBF_INTERLEAVE=0: no interleaved copy of uniform children (at upload)
     bool hibf_interleave_probe = true;  // TXQ_HIBF_INTERLEAVE_PROBE=0: plain probes descend the tree
@@ -159,6 +160,10 @@ struct Index {
     uint64_t* scratch_final = nullptr; size_t cap_final = 0;
     uint64_t* scratch_dense_kmers = nullptr; size_t cap_dense_kmers = 0;  // dense steps on an HIBF: the pairs' k-mers ...
     uint64_t* scratch_dense_masks = nullptr; size_t cap_dense_masks = 0;  // ... and their descended masks
+    // A flat index's masks of ALL k-mers, M[v] at kmer_table + v * shard_words for every packed value v < 2^(bits * k) (txq_exec.hip
+    // ensure_kmer_table): where that fits TXQ_KMER_TABLE_MB, a dense step reads ONE row per k-mer instead of gathering hash_funs.
+    uint64_t* kmer_table = nullptr; uint32_t kmer_table_bits = 0;  // bits = bits per residue * k of the table that is built
+    bool kmer_table_refused = false;                               // (the allocation failed once: not tried again)
 
     // Device buffers of the last session, kept for the next one: a single query must not pay
     // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.

@@ -43,6 +43,16 @@ __device__ __forceinline__ uint64_t fastrange(uint64_t x, uint64_t n) {
     return (n >> 32) ? __umul64hi(x, n) : fastrange32(x, (uint32_t)n);
 }
 
+#if defined(TXQ_EXPERIMENTS) && defined(TXQ_CHEAP_HASH)
+// TIMING EXPERIMENT ONLY (wrong rows): three 32-bit multiplies instead of eleven — what do the kernels gain if hashing is free?
+__device__ __forceinline__ uint64_t hash_row_seeded(uint64_t v, uint32_t, uint64_t bin_size) {
+    return __umulhi(((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u, (uint32_t)bin_size);
+}
+__device__ __forceinline__ uint64_t hash_row_seeded32(uint64_t v, uint32_t, uint32_t bin_size) { return hash_row_seeded(v, 0, bin_size); }
+__device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t, uint64_t bin_size) {
+    return hash_row_seeded((uint64_t)(((uint32_t)v ^ ((uint32_t)(v >> 32) * 0x85EBCA6Bu)) * (uint32_t)seed), 0, bin_size);
+}
+#else
 // second half of hash_row for a value that is already multiplied by its seed
 __device__ __forceinline__ uint64_t hash_row_seeded(uint64_t v, uint32_t shift, uint64_t bin_size) {
     v ^= v >> shift;
@@ -61,5 +71,6 @@ __device__ __forceinline__ uint64_t hash_row_seeded32(uint64_t v, uint32_t shift
 __device__ __forceinline__ uint64_t hash_row(uint64_t v, uint64_t seed, uint32_t shift, uint64_t bin_size) {
     return hash_row_seeded(v * seed, shift, bin_size);
 }
+#endif
 
 }  // namespace txq
