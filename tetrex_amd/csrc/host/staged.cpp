@@ -233,7 +233,7 @@ class StagedRun {
         std::vector<uint32_t> program, slot;   // the questions: is slot `slot[a]` of program `program[a]` alive?
         std::vector<uint8_t> alive;            // the answers
         std::vector<uint32_t> run_on;          // unfinished queries that did not ask
-        std::vector<uint32_t> waiting;         // queries that have not begun (a later wave)
+        bool waiting = false;                  // there are queries that have not begun (a later wave)
     };
 
     void lap(const char* what) {
@@ -248,8 +248,10 @@ class StagedRun {
     void build_expansions() {
         for (size_t i = 0; i < n_; ++i) {
             if (bins_ <= 1) passthrough_[i] = 1;  // include/query.h:265-272
-            else unbuilt_[i] = 1;
+            else { unbuilt_[i] = 1; pending_.push_back((uint32_t)i); }
         }
+        // the longest first (a stage ends when its last task ends; nothing else is known about a query that has not been built)
+        std::stable_sort(pending_.begin(), pending_.end(), [&](uint32_t x, uint32_t y) { return regexes_[x].size() > regexes_[y].size(); });
     }
     void build_one(size_t i) {  // throws what the front-end throws
         const std::string postfix = preprocess_query(regexes_[i], enc_);
@@ -270,12 +272,16 @@ class StagedRun {
         why_[i] = e.what();
     }
 
-    // expands the queries of `set` (largest first) until each has used its budget; returns the ops emitted
-    size_t advance_set(std::vector<uint32_t>& set, size_t already, size_t feedback_budget) {
+    // Expands the queries under way (`active`, largest first) until each has used its budget, and lets queries that have not
+    // begun (`pending_`, longest first) begin while the wave and the dense pool have room; returns the ops emitted.  The
+    // workers stop taking pending queries at the first one that may not begin: a batch of 10 000 queries does not pay one
+    // contended counter increment per waiting query and stage (that, and sorting all of them, was a third of the host's time).
+    size_t advance_set(std::vector<uint32_t>& active, size_t already, size_t feedback_budget, std::vector<uint32_t>* begun_now = nullptr) {
         {
-            std::vector<uint64_t> w(n_, 0);
-            for (uint32_t i : set) w[i] = q_[i] ? q_[i]->weight() : (uint64_t)regexes_[i].size() * regexes_[i].size();  // not built yet: by length
-            std::stable_sort(set.begin(), set.end(), [&](uint32_t x, uint32_t y) { return w[x] > w[y]; });  // a stage ends when its last task ends
+            std::vector<std::pair<uint64_t, uint32_t>> w(active.size());
+            for (size_t j = 0; j < active.size(); ++j) w[j] = {q_[active[j]] ? q_[active[j]]->weight() : 0, active[j]};
+            std::stable_sort(w.begin(), w.end(), [](const auto& x, const auto& y) { return x.first > y.first; });  // a stage ends when its last task ends
+            for (size_t j = 0; j < active.size(); ++j) active[j] = w[j].second;
         }
         std::fill(busy_.begin(), busy_.end(), 0.0);
         std::atomic<size_t> total{already};
@@ -287,19 +293,19 @@ class StagedRun {
         // those under way finish, hand their blocks back (and the device recycles their regions) — instead of everybody
         // starting at once and the late ones falling back to enumerated states.  Somebody is always under way.
         size_t under_way = 0;
-        for (size_t i = 0; i < n_; ++i) under_way += q_[i] && started_[i] && !q_[i]->done();
+        for (uint32_t i : active) under_way += q_[i] && !q_[i]->done();
         std::atomic<size_t> begun{under_way};
-        pool_.run(set.size(), [&](size_t at, int t) {
-            const size_t i = set[at];
+        // returns false when query i has not begun and may not begin now
+        auto task = [&](size_t i, int t) -> bool {
             const double t0 = trace_ ? now_seconds() : 0.0;
-            if (total.load(std::memory_order_relaxed) >= opt_.ops_per_stage) return;  // waits for a later stage
+            if (total.load(std::memory_order_relaxed) >= opt_.ops_per_stage) return false;  // waits for a later stage
             if (!started_[i]) {
-                if (wave_limit && total.load(std::memory_order_relaxed) >= wave_limit && begun.load(std::memory_order_relaxed) > 0) return;
+                if (wave_limit && total.load(std::memory_order_relaxed) >= wave_limit && begun.load(std::memory_order_relaxed) > 0) return false;
                 // admission by an estimate of four blocks per query (what a chain of steps through x(m,n) gaps holds at a time)
                 if (dense_.enabled && admitted_.fetch_add(admit_bytes_, std::memory_order_relaxed) + admit_bytes_ > dense_total_ &&
                     begun.load(std::memory_order_relaxed) > 0) {
                     admitted_.fetch_sub(admit_bytes_, std::memory_order_relaxed);
-                    return;
+                    return false;
                 }
                 started_[i] = 1;
                 begun.fetch_add(1, std::memory_order_relaxed);
@@ -309,7 +315,7 @@ class StagedRun {
                         build_one(i);
                     } catch (const std::exception& e) {
                         fail(i, e);
-                        return;
+                        return true;
                     }
                 }
             }
@@ -323,7 +329,7 @@ class StagedRun {
                                asks && verified_levels_ && q_[i]->mostly_dying(), dense_.enabled ? &dense_ops_[i] : nullptr);
             } catch (const std::exception& e) {
                 fail(i, e);
-                return;
+                return true;
             }
             total.fetch_add(ops_[i].size(), std::memory_order_relaxed);
             slots_[i] = q_[i]->n_slots();
@@ -336,11 +342,29 @@ class StagedRun {
                 q_[i].reset();
             }
             if (trace_) busy_[t] += now_seconds() - t0;
+            return true;
+        };
+        const size_t head = pending_head_;
+        std::atomic<size_t> next_active{0}, next_pending{head};
+        std::atomic<bool> closed{false};  // a pending query could not begin: none behind it is tried in this call
+        pool_.run((size_t)threads_, [&](size_t, int t) {
+            for (size_t at; (at = next_active.fetch_add(1, std::memory_order_relaxed)) < active.size();) task(active[at], t);
+            while (!closed.load(std::memory_order_relaxed)) {
+                const size_t at = next_pending.fetch_add(1, std::memory_order_relaxed);
+                if (at >= pending_.size()) break;
+                if (!task(pending_[at], t)) closed.store(true, std::memory_order_relaxed);
+            }
         });
+        // the pending queries taken in this call: those that began leave the list (the others stay in front, in their order)
+        const size_t taken = std::min(next_pending.load(), pending_.size());
+        auto mid = std::stable_partition(pending_.begin() + head, pending_.begin() + taken, [&](uint32_t i) { return started_[i] != 0; });
+        if (begun_now) begun_now->assign(pending_.begin() + head, mid);
+        pending_head_ = (size_t)(mid - pending_.begin());
         if (trace_) {
             double sum = 0, mx = 0;
             for (double b : busy_) { sum += b; if (b > mx) mx = b; }
-            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu\n", sum * 1e3, mx * 1e3, total.load(), set.size());
+            std::fprintf(stderr, "[tetrex] busy sum %8.2f ms max %8.2f ms ops %zu queries %zu + %zu that began\n", sum * 1e3, mx * 1e3, total.load(), active.size(),
+                         pending_head_ - head);
         }
         return total.load() - already;
     }
@@ -371,17 +395,20 @@ class StagedRun {
                 unfinished += q_[i] && !q_[i]->done();
                 continue;
             }
-            if (unbuilt_[i] || (q_[i] && !q_[i]->done())) { act.push_back((uint32_t)i); ++unfinished; }
+            if (unbuilt_[i]) ++unfinished;  // (has not begun: advance_set takes it from pending_)
+            else if (q_[i] && !q_[i]->done()) { act.push_back((uint32_t)i); ++unfinished; }
         }
         // with few queries left, each gets a larger share of the stage (fewer, fuller stages)
         size_t feedback_budget = unfinished ? opt_.stage_target_ops / unfinished : opt_.ops_per_query_per_stage;
         if (feedback_budget < opt_.ops_per_query_per_stage) feedback_budget = opt_.ops_per_query_per_stage;
         if (feedback_budget > opt_.ops_per_task) feedback_budget = run_on_budget_;
         feedback_budget_ = feedback_budget;
-        const size_t total = carried_ + advance_set(act, carried_, feedback_budget);
+        std::vector<uint32_t> begun_now;
+        const size_t total = carried_ + advance_set(act, carried_, feedback_budget, &begun_now);
         carried_ = 0;
-        for (uint32_t i : act)
-            if (!ops_[i].empty() || !tables_[i].values().empty()) touched_.push_back(i);
+        for (const std::vector<uint32_t>* v : {&act, &begun_now})
+            for (uint32_t i : *v)
+                if (!ops_[i].empty() || !tables_[i].values().empty()) touched_.push_back(i);
         std::sort(touched_.begin(), touched_.end());
         lap("advance");
         return total;
@@ -484,7 +511,7 @@ class StagedRun {
     Frontier collect_frontier() {
         Frontier fr;
         for (size_t i = 0; i < n_; ++i) {
-            if (unbuilt_[i] || (q_[i] && !q_[i]->done() && !started_[i])) { fr.waiting.push_back((uint32_t)i); continue; }
+            if (unbuilt_[i]) { fr.waiting = true; continue; }
             if (!q_[i] || q_[i]->done()) continue;
             (q_[i]->wants_feedback() ? fr.queries : fr.run_on).push_back((uint32_t)i);
         }
@@ -509,18 +536,17 @@ class StagedRun {
     // queries begins (`ahead`; their ops are carried into the next stage).
     void execute(const Blob& blob, Frontier& fr) {
         const double start = now_seconds();
-        if (overlap_ && (!fr.run_on.empty() || !fr.waiting.empty())) {
+        if (overlap_ && (!fr.run_on.empty() || fr.waiting)) {
             std::future<void> running = std::async(std::launch::async, [&]() { exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive); });
-            std::vector<uint32_t> set = fr.run_on;
-            set.insert(set.end(), fr.waiting.begin(), fr.waiting.end());
+            std::vector<uint32_t> set = fr.run_on, begun_now;
             try {
-                carried_ = advance_set(set, 0, feedback_budget_);
+                carried_ = advance_set(set, 0, feedback_budget_, &begun_now);
             } catch (...) {
                 running.wait();
                 throw;
             }
-            for (uint32_t i : set)
-                if (started_[i]) ahead_[i] = 1;
+            for (uint32_t i : set) ahead_[i] = 1;
+            for (uint32_t i : begun_now) ahead_[i] = 1;
             const double ahead_s = now_seconds() - start;
             lap("ahead");
             running.get();
@@ -602,6 +628,8 @@ class StagedRun {
     std::vector<uint8_t> ahead_;                      // advanced while the previous stage executed
     std::vector<uint32_t> run_on_stages_;             // per query: stages it has run without asking for feedback
     std::vector<uint8_t> started_;                    // per query: its expansion has begun (waves, dense-memory admission)
+    std::vector<uint32_t> pending_;                   // the queries that have not begun are pending_[pending_head_ ..], longest first
+    size_t pending_head_ = 0;
     std::vector<uint8_t> unbuilt_;                    // per query: its k-graph is still to be built (when it begins)
     std::vector<uint8_t> flushed_, released_;         // finished and its last ops handed to the device / its blocks handed back
     std::vector<uint64_t> held_;                      // bytes of the dense pool a finished query still holds
