@@ -321,6 +321,22 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     if err is not None:
         return {"error": err}
     lat, plain_status, plain_stats, plain_s = local["lat"], local["plain_status"], local["plain_stats"], local["plain_s"]
+    big = None
+    if world == 1 and not args.no_big_batch:
+        # BASELINE configs[3]'s batch size: 10 000 motifs of the same mix in ONE call (one warm run, best of three timed)
+        try:
+            many = random_prosite_motifs(10 * args.motifs, 6)
+            ix.query_masks(many, False, k)
+            runs = []
+            for _ in range(3):
+                ta = time.perf_counter()
+                _, st_many, stats_many = ix.query_masks(many, False, k)
+                runs.append((time.perf_counter() - ta, stats_many, st_many))
+            best = min(runs, key=lambda r: r[0])
+            big = {"motifs": len(many), "k": k, "seconds": best[0], "queries_per_s": len(many) / best[0], "timed_runs_seconds": [r[0] for r in runs],
+                   "refused_fraction": float(sum(1 for s_ in best[2] if s_)) / len(many), **best[1]}
+        except Exception as e:  # noqa: BLE001
+            big = {"error": repr(e)}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_query_baseline(ix, args.m_rows, args.hash, args.bins_per_gpu, k, motifs, masks, args.cpu_query_seconds)
@@ -334,6 +350,7 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
                   "warmup": "one batch of the same size and mix from another seed", "first_batch_seconds": local["first_batch_s"],
                   **({"timed_runs_seconds": repeats, "seconds_is": "the best of the timed runs"} if repeats else {}),
                   "k": k, "refused_fraction": float(sum(1 for s_ in status if s_)) / len(motifs), **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
+        **({"batch_10x": big} if big else {}),
         "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
                                "failed": int(sum(1 for s in plain_status if s)), **plain_stats},
         "single_query": {"motif": single, "median_latency_ms": float(np.median(lat)) * 1e3,
@@ -737,6 +754,7 @@ def main():
     ap.add_argument("--motifs", type=int, default=1000, help="PROSITE-style motifs in the end-to-end batch")
     ap.add_argument("--no-hibf", action="store_true", help="skip the HIBF descent leg")
     ap.add_argument("--no-k6", action="store_true", help="skip the k = 6 end-to-end leg (end_to_end.k6_batch)")
+    ap.add_argument("--no-big-batch", action="store_true", help="skip the 10x batch of the end-to-end leg (end_to_end.batch_10x)")
     ap.add_argument("--no-verification", action="store_true", help="skip the end-to-end leg that includes verification (end_to_end.with_verification)")
     ap.add_argument("--hibf-kmers", type=int, default=1 << 20)
     ap.add_argument("--hibf-per-bin", type=int, default=300)
