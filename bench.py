@@ -360,11 +360,13 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
 
 def hibf_end_to_end(capi, torch, args):
     """BASELINE configs[2]: the end-to-end batch (1000 PROSITE-style motifs, k = 4) on a 1024-user-bin peptide HIBF — 16
-    children of 64 bins, h = 3, 20 000 values per bin, every IBF filled on the device with the real hash.  The tree is
-    regular with uniform children, so its dense steps run fused on the interleaved children (csrc/txq_exec.hip
-    InterleavedRows).  Check inside this run: the same batch once more with the steps sent through the generic HIBF
-    descent (TXQ_DENSE_TREE=0: k-mers written out, hibf_probe, combine — the path the parity tests pin to the oracle);
-    all masks must be identical.  N = 1 only; does not touch `value`."""
+    children of 64 bins, h = 3, 20 000 values per bin, every IBF filled on the device with the real hash.  Its dense steps
+    read the index's table of all 4-mers' masks (csrc/txq_exec.hip ensure_kmer_table / TableRows: membership_for of every
+    packed value, built with the tree's descent when the first batch arrives); `interleaved_rows_seconds` is the same batch
+    with the table off (TXQ_KMER_TABLE_MB=0: steps fused on the tree's interleaved children, InterleavedRows).  Check inside
+    this run: the same batch once more with the steps sent through the generic HIBF descent (TXQ_DENSE_TREE=0: k-mers
+    written out, hibf_probe, combine — the path the parity tests pin to the oracle); all masks must be identical.  N = 1 only;
+    does not touch `value`."""
     from motifs import random_prosite_motifs
     user_bins, children, per_bin, h = 1024, 16, 20000, 3
     per_child = user_bins // children
@@ -403,6 +405,22 @@ def hibf_end_to_end(capi, torch, args):
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, stats, masks, status)
+    knob = os.environ.get("TXQ_KMER_TABLE_MB")
+    os.environ["TXQ_KMER_TABLE_MB"] = "0"
+    try:
+        rows_dt = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            rows_masks, _, _ = ix.query_masks(motifs, False, 4)
+            dt = time.perf_counter() - t0
+            rows_dt = dt if rows_dt is None else min(rows_dt, dt)
+    finally:
+        if knob is None:
+            del os.environ["TXQ_KMER_TABLE_MB"]
+        else:
+            os.environ["TXQ_KMER_TABLE_MB"] = knob
+    if not np.array_equal(best[2], rows_masks):
+        raise SystemExit("bench: the HIBF batch gives other masks through the table of all k-mers' masks than with rows gathered from the tree")
     knob = os.environ.get("TXQ_DENSE_TREE")
     os.environ["TXQ_DENSE_TREE"] = "0"
     try:
@@ -437,7 +455,8 @@ def hibf_end_to_end(capi, torch, args):
             "k": 4, "oracle_masks_compared": compared, "refused_fraction": float(sum(1 for x in best[3] if x)) / len(motifs),
             "queries_per_s": len(motifs) / best[0], "seconds": best[0], "failed": int(sum(1 for x in best[3] if x)),
             "mean_candidate_bins": float(np.unpackbits(best[2].view(np.uint8), axis=1).sum(axis=1).mean()), **best[1],
-            "checked_against": "the same batch with its dense steps through the generic HIBF descent (TXQ_DENSE_TREE=0)",
+            "interleaved_rows_seconds": rows_dt,
+            "checked_against": "the same batch with its dense steps through the generic HIBF descent (TXQ_DENSE_TREE=0), and with rows gathered from the tree (TXQ_KMER_TABLE_MB=0)",
             "masks_identical": bool(np.array_equal(best[2], ref_masks) and list(best[3]) == list(ref_status)),
             "generic_descent_seconds": ref_dt}
 

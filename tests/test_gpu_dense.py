@@ -225,7 +225,9 @@ def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
     for rank in range(n_shards):
         ix = capi.Index.upload_hibf(ub, descs, shard_rank=rank, n_shards=n_shards)
         lo, nw = int(ix.info.shard_word0), ix.shard_words
-        for knobs in (("2", "2"), ("1", "0"), None):
+        # the tree's own step kernels first (the index's table of all k-mers' masks off), then, last, the steps through that table
+        for knobs in (("2", "2"), ("1", "0"), None, ("2", "2", "table")):
+            monkeypatch.setenv("TXQ_KMER_TABLE_MB", "512" if knobs and len(knobs) == 3 else "0")
             if knobs:
                 monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
                 monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
@@ -352,7 +354,9 @@ def test_every_way_of_running_a_batch_gives_the_same_masks(capi, oracle, monkeyp
             {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_WAVE_OPS": "800", "TETREX_TASK_OPS": "200", "TXQ_FUSE_UNITS": "0"},
             {"TETREX_DENSE_EVIDENCE": "sparse", "TETREX_WAVE_OPS": "3000"},
             {"TETREX_DENSE_EVIDENCE": "ask", "TETREX_WAVE_OPS": "5000"},
-            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_DENSE_MIN": "4", "TETREX_DENSE_SPARSE_BELOW": "2", "TETREX_WAVE_OPS": "2000"}]
+            {"TETREX_DENSE_EVIDENCE": "dense", "TETREX_DENSE_MIN": "4", "TETREX_DENSE_SPARSE_BELOW": "2", "TETREX_WAVE_OPS": "2000"},
+            {"TETREX_DENSE_EVIDENCE": "dense", "TXQ_KMER_TABLE_MB": "0"},  # rows gathered (the other ways read the table of all k-mers' masks)
+            {"TETREX_DENSE_EVIDENCE": "dense", "TXQ_KMER_TABLE_MB": "0", "TETREX_WAVE_OPS": "3000", "TXQ_DENSE_UNROLL": "5"}]
     if index != "flat":
         ways += [{"TETREX_DENSE_EVIDENCE": "dense", "TXQ_DENSE_TREE": t, "TETREX_WAVE_OPS": "3000"} for t in ("0", "1", "2")]
         ways += [{"TETREX_DENSE_EVIDENCE": "dense", "TXQ_HIBF_INTERLEAVE_PROBE": "0", "TETREX_WAVE_OPS": "3000"}]
@@ -573,13 +577,15 @@ def test_tracked_blocks_on_regular_hibfs(capi, oracle, monkeypatch, tree):
         qs.append("".join(w))
     wants = [ox.query(q, with_stats=True) for q in qs]
     ix = capi.Index.upload_hibf(ub, descs)
-    got, status, stats = ix.query_masks(qs, False, 4)
-    assert stats["tracked_queries"] >= 8 and stats["dense_ops"] > 20
-    hits = 0
-    for q, g, st, (want, ost) in zip(qs, got, status, wants):
-        assert st == 0, q
-        if not ost["quirk_merges"]:
-            assert np.array_equal(g, want), q
-            hits += int(want.any())
+    for table_mb in ("0", "512"):  # the tree's rows; then the same steps through the index's table of all k-mers' masks
+        monkeypatch.setenv("TXQ_KMER_TABLE_MB", table_mb)
+        got, status, stats = ix.query_masks(qs, False, 4)
+        assert stats["tracked_queries"] >= 8 and stats["dense_ops"] > 20
+        hits = 0
+        for q, g, st, (want, ost) in zip(qs, got, status, wants):
+            assert st == 0, q
+            if not ost["quirk_merges"]:
+                assert np.array_equal(g, want), (q, table_mb)
+                hits += int(want.any())
     assert hits >= 5
     ix.free()

@@ -1803,13 +1803,14 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uin
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = i;
 }
 
-// The table of all k-mers' masks of a flat index (Index::kmer_table), built once per index when the first stage with dense steps
+// The table of all k-mers' masks of an index (Index::kmer_table), built once per index when the first stage with dense steps
 // arrives: bulk_contains of every packed value below 2^(bits * k) — values with a residue code outside the alphabet included,
-// nobody reads their rows — with the probe kernel itself.  Returns whether the steps may read it.  (Synchronous: a later stage
-// on the other stream reads the table, too.)
+// nobody reads their rows — with the probe kernel itself; for an HIBF the descent's user-bin masks, so that dense steps on ANY
+// tree whose table fits read one row per k-mer like a flat index's.  Returns whether the steps may read it.  (Synchronous: a
+// later stage on the other stream reads the table, too.)
 static bool ensure_kmer_table(Index& ix, const Knobs& kn, const DenseParams& P, uint32_t W, hipStream_t st) {
     const uint32_t vb = P.bits * P.k;
-    if (ix.is_hibf || kn.kmer_table_mb <= 0 || vb == 0 || vb > 24) return false;
+    if (kn.kmer_table_mb <= 0 || vb == 0 || vb > 24 || W != ix.shard_words) return false;
     if (ix.kmer_table) return ix.kmer_table_bits == vb;  // (one encoder per index; a session with another k gathers rows)
     const uint64_t n = 1ULL << vb, bytes = n * (uint64_t)W * 8;
     if (ix.kmer_table_refused || bytes > ((uint64_t)kn.kmer_table_mb << 20)) return false;
@@ -1822,7 +1823,10 @@ static bool ensure_kmer_table(Index& ix, const Knobs& kn, const DenseParams& P, 
         return false;
     }
     iota_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, st>>>(values, n);
-    hipError_t e = launch_probe(ix.ibf[0], values, n, table, nullptr, st);
+    hipError_t e = hipSuccess;
+    if (ix.is_hibf) {  // membership_for(., 1) of every value, in user-bin order: any tree, whatever its shape
+        if (hibf_probe(ix, values, n, table, nullptr, st) != TXQ_OK) e = hipErrorUnknown;
+    } else e = launch_probe(ix.ibf[0], values, n, table, nullptr, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(values);
     if (e != hipSuccess) {
@@ -1848,6 +1852,20 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     ++s.n_stages;
     s.bytes_uploaded += bytes;
     const BlobView* h = &bv;
+    bool any_dense = false;
+    for (uint8_t d : bv.has_dense) any_dense |= d != 0;
+    // Dense steps through the index's table of all k-mers' masks, where it fits (TXQ_DENSE_TREE set: the tree paths are asked for).
+    // A session on a general HIBF that would keep its masks in layout order goes back to user-bin order for it — in its first
+    // stage, before anything has been laid out.
+    bool table = false;
+    if (any_dense && (!ix.is_hibf || s.kn.dense_tree < 0)) {
+        if (!s.vspace) table = ensure_kmer_table(ix, s.kn, bv.dense, s.W, s.upload);
+        else if (s.n_stages == 1 && !s.aux && ensure_kmer_table(ix, s.kn, bv.dense, (uint32_t)ix.shard_words, s.upload)) {
+            s.vspace = false;
+            s.W = (uint32_t)ix.shard_words;
+            table = true;
+        }
+    }
     const uint32_t W = s.W;
     for (size_t i = 0; i < n_q; ++i) {
         if (q_prog[i] >= s.n_programs) return fail(TXQ_ERR_ARG, "feedback query %zu: program out of range", i);
@@ -1857,8 +1875,6 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         for (size_t i = 0; i < n_q; ++i) alive[i] = 0;
         return TXQ_OK;
     }
-    bool any_dense = false;
-    for (uint8_t d : bv.has_dense) any_dense |= d != 0;
     if (any_dense && !ix.is_hibf && (ix.ibf[0].bin_size >> 32))
         return fail(TXQ_ERR_PROGRAM, "dense ops need fewer than 2^32 rows");
     // Does this stage continue anything the previous stage — possibly still running — works on?  Programs with ops in both,
@@ -1871,11 +1887,11 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             s.last_stage[p] = (uint32_t)s.n_stages;
         }
     // dense steps on a regular two-level HIBF run fused, too (TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
-    const bool tree = index_fuses_tree_steps(ix);
+    const bool tree = !table && index_fuses_tree_steps(ix);
     bool any_tracked = false;
     for (size_t p = 0; p < s.n_programs; ++p) any_tracked |= bv.tracked[p] != 0 && bv.has_dense[p] != 0;
     const bool vspace = s.vspace;
-    if (any_tracked && ix.is_hibf && !tree && !vspace)
+    if (any_tracked && ix.is_hibf && !tree && !vspace && !table)
         return fail(TXQ_ERR_PROGRAM, "tracked blocks need an index whose dense steps run fused (txq_index_supports_dense() == 2)");
     std::vector<uint32_t> fresh;  // programs that got their first region: ZERO/ONES/RESULT need initialising
     std::vector<RegionMove> moves;
@@ -1894,9 +1910,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         s.row_source = "regular tree, interleaved children, fused";
     const int tree_knob = s.kn.dense_tree;  // 0: generic HIBF steps, 1: TreeRows, 2: TreeRowsByLane where it applies; -1 (default): best fit
     const bool interleaved = tree && ix.interleaved.words && ix.interleaved.shard_words == W && ix.root_node.bins <= 64 && tree_knob < 0;
-    const bool table = any_dense && !ix.is_hibf && ensure_kmer_table(ix, s.kn, bv.dense, W, s.upload);
-    if (table) s.row_source = "flat IBF through its table of all k-mers' masks";
-    const bool wide = W % 2 == 0 && (vspace ? ix.v_chunk_words == 2 : (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && (table || ix.ibf[0].stride % 2 == 0)));
+    if (table) s.row_source = ix.is_hibf ? "HIBF through its table of all k-mers' masks" : "flat IBF through its table of all k-mers' masks";
+    const bool wide = W % 2 == 0 && (vspace ? ix.v_chunk_words == 2 : table ? true : (interleaved ? ix.interleaved.stride % 2 == 0 : tree ? ix.child_row_words >= 2 : !ix.is_hibf && ix.ibf[0].stride % 2 == 0));
     uint32_t g_dense = 1;
     while (g_dense < 64 && g_dense < (wide ? W / 2 : W)) g_dense <<= 1;
     // ... and two such lane groups share the predecessors of one suffix (TXQ_DENSE_SLICES: A/B knob; on the bench batch
@@ -1914,7 +1929,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<SparseGroup> sparse_groups;
     std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
+    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
     size_t n_sparse_launches = 0;
@@ -2170,8 +2185,8 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             ++s.n_levels;
             // a flat index runs the level's units inside its dense launch (below), or its sparse launch when it has no tiles;
             // otherwise they are a launch of their own
-            const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree || vspace);
-            const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree || vspace);
+            const bool ride = fuse_units && cnt && plan[l].tiles && (!ix.is_hibf || tree || vspace || table);
+            const bool ride_sparse = fuse_units && cnt && !ride && plan[l].sparse && (!ix.is_hibf || tree || vspace || table);
             if (cnt && !ride && !ride_sparse) {
                 ++s.n_unit_launches;
                 exec_units_kernel<<<(unsigned)cnt, 256, 0, st>>>(d_units + first, d_ops, s.d_base, np, d_masks, W, g_units_log2);
