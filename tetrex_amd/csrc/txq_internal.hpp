@@ -22,7 +22,7 @@ struct Knobs {
     int dense_nt = 0;           // TXQ_DENSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads of a dense step's destination entries
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
-    long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most a flat index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
+    long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most an index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
     // HIBF (txq_hibf.hip)
     bool hibf_interleave = true;        // TXQ_HIBF_INTERLEAVE=0: no interleaved copy of uniform children (at upload)
     bool hibf_interleave_probe = true;  // TXQ_HIBF_INTERLEAVE_PROBE=0: plain probes descend the tree
