@@ -228,6 +228,7 @@ def test_dense_steps_on_hibf_indexes(capi, oracle, monkeypatch, tree):
         # the tree's own step kernels first (the index's table of all k-mers' masks off), then, last, the steps through that table
         for knobs in (("2", "2"), ("1", "0"), None, ("2", "2", "table")):
             monkeypatch.setenv("TXQ_KMER_TABLE_MB", "512" if knobs and len(knobs) == 3 else "0")
+            monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
             if knobs:
                 monkeypatch.setenv("TETREX_DENSE_MIN", knobs[0])
                 monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", knobs[1])
@@ -579,6 +580,7 @@ def test_tracked_blocks_on_regular_hibfs(capi, oracle, monkeypatch, tree):
     ix = capi.Index.upload_hibf(ub, descs)
     for table_mb in ("0", "512"):  # the tree's rows; then the same steps through the index's table of all k-mers' masks
         monkeypatch.setenv("TXQ_KMER_TABLE_MB", table_mb)
+        monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
         got, status, stats = ix.query_masks(qs, False, 4)
         assert stats["tracked_queries"] >= 8 and stats["dense_ops"] > 20
         hits = 0

@@ -13,7 +13,9 @@ KNOBS = [
     {}, {"TXQ_TRACE_SYNC": "1"}, {"TXQ_DENSE_TREE": "0"}, {"TXQ_DENSE_TREE": "1"}, {"TXQ_DENSE_TREE": "2"},
     {"TXQ_DENSE_UNROLL": "2"}, {"TXQ_DENSE_UNROLL": "6"}, {"TXQ_DENSE_SLICES": "1"}, {"TXQ_DENSE_SLICES": "4"},
     {"TXQ_DENSE_TILE_ROUNDS": "1"}, {"TXQ_DENSE_TILE_ROUNDS": "5"}, {"TXQ_FUSE_UNITS": "0"}, {"TXQ_ONE_STREAM": "1"},
-    {"TXQ_KMER_TABLE_MB": "0"}, {"TXQ_KMER_TABLE_MB": "0", "TXQ_DENSE_UNROLL": "6"}, {"TXQ_KMER_TABLE_MB": "64"},  # (the 1024-bin table is 128 MB)
+    # (five queries: no table of all k-mers' masks by default — TXQ_KMER_TABLE_MIN=1 builds it; the 1024-bin table is 128 MB)
+    {"TXQ_KMER_TABLE_MIN": "1"}, {"TXQ_KMER_TABLE_MIN": "1", "TXQ_DENSE_UNROLL": "5"}, {"TXQ_KMER_TABLE_MIN": "1", "TXQ_KMER_TABLE_MB": "64"},
+    {"TXQ_KMER_TABLE_MIN": "1", "TXQ_KMER_TABLE_MB": "0"}, {"TXQ_KMER_TABLE_MIN": "1", "TXQ_DENSE_SLICES": "1", "TXQ_FUSE_UNITS": "0"},
     {"TXQ_HIBF_INTERLEAVE": "0"}, {"TXQ_HIBF_INTERLEAVE_PROBE": "0"}, {"TXQ_HIBF_LEVELS": "1"}, {"TXQ_HIBF_STATIONARY": "0"},
     {"TXQ_HIBF_SMALL": "0"}, {"TXQ_HIBF_LANE_HASH": "1"}, {"TXQ_HIBF_STEPS_PER_GROUP": "1"}, {"TXQ_HIBF_TILE": "256"},
     {"TXQ_HIBF_UNROLL": "2"}, {"TXQ_HIBF_UNROLL": "4"}, {"TXQ_HIBF_STORE_KIND": "1"}, {"TXQ_HIBF_STORE_KIND": "2"}, {"TXQ_HIBF_STORE_KIND": "3"},

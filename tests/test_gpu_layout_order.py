@@ -58,6 +58,7 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
     # switched off for the ways that name a path, and gets a way of its own, last: once built it stays with the index)
     for way in ("layout", "layout-blocks", "layout-tracked", "user-order", "table", "table-tracked"):
         monkeypatch.setenv("TXQ_KMER_TABLE_MB", "512" if way.startswith("table") else "0")
+        monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
         monkeypatch.delenv("TETREX_DENSE_MIN", raising=False)
         monkeypatch.delenv("TETREX_DENSE_SPARSE_BELOW", raising=False)
         monkeypatch.delenv("TETREX_DENSE_TRACKED", raising=False)

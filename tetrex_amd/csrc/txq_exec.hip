@@ -1857,8 +1857,9 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // Dense steps through the index's table of all k-mers' masks, where it fits (TXQ_DENSE_TREE set: the tree paths are asked for).
     // A session on a general HIBF that would keep its masks in layout order goes back to user-bin order for it — in its first
     // stage, before anything has been laid out.
+    // A session of a few queries does not build it (0.4-1 ms: more than a single query's steps cost); it uses one that is there.
     bool table = false;
-    if (any_dense && (!ix.is_hibf || s.kn.dense_tree < 0)) {
+    if (any_dense && (!ix.is_hibf || s.kn.dense_tree < 0) && (ix.kmer_table || (long long)s.n_programs >= s.kn.kmer_table_min)) {
         if (!s.vspace) table = ensure_kmer_table(ix, s.kn, bv.dense, s.W, s.upload);
         else if (s.n_stages == 1 && !s.aux && ensure_kmer_table(ix, s.kn, bv.dense, (uint32_t)ix.shard_words, s.upload)) {
             s.vspace = false;

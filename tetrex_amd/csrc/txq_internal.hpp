@@ -23,6 +23,7 @@ struct Knobs {
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
     long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most an index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
+    long long kmer_table_min = 16;  // TXQ_KMER_TABLE_MIN: the session of fewest programs that builds the table (a single query does not pay for it; once built it is used)
     // HIBF (txq_hibf.hip)
     bool hibf_interleave = true;        // TXQ_HIBF_INTERLEAVE=0: no interleaved copy of uniform children (at upload)
     bool hibf_interleave_probe = true;  // TXQ_HIBF_INTERLEAVE_PROBE=0: plain probes descend the tree
