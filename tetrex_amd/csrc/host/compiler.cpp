@@ -582,7 +582,8 @@ uint64_t QueryExpansion::shape_limit() const {
 // a list with many full-length states becomes (part of) a block: one scatter op per state now instead of
 // one op per state and residue at every later step
 void QueryExpansion::densify(int32_t item, NodeStates& ns, OpVec& out, bool may_hold_duplicates) {
-    if (!dense_ok_ || ns.items.size() < dense_.min_states) return;
+    const uint32_t min_states = min_states_now();
+    if (!dense_ok_ || ns.items.size() < min_states) return;
     decide_tracking();
     const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     const uint64_t sym = enc_.symbol_mask();
@@ -597,7 +598,7 @@ void QueryExpansion::densify(int32_t item, NodeStates& ns, OpVec& out, bool may_
             ++full;
             for (unsigned j = 0; j < dense_pos_; ++j) shape[j] |= 1u << ((s.kmer >> (bits * (dense_pos_ - 1 - j))) & sym);
         }
-        if (full < dense_.min_states) continue;
+        if (full < min_states) continue;
         // the shape (the product of the per-position code sets) against the states it holds: shape_limit() — a tracked block
         // costs what its living entries cost, whatever the shape
         uint64_t product = 1;
@@ -760,7 +761,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             for (const DenseRef& d : cur.dense)
                 if (d.owned) shape_zero(d);
             if (!cur.dense.empty()) materialise(next, out, !go_dense);
-            bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= dense_.min_states;
+            bool may_densify = go_dense && input_of_[next] == KGraph::kNone && cur.items.size() >= min_states_now();
             if (may_densify && dense_.evidence) {
                 const int ev = dense_.evidence->load(std::memory_order_relaxed);
                 if (ev != DenseOptions::kUnknown) wants_evidence_ = false;
@@ -788,7 +789,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     for (const State& s : cur.items)
                         if (!s.gapped) ++count[s.shift < dense_pos_ ? s.shift : dense_pos_];
                     for (unsigned p = tracked_ ? 1 : dense_pos_; p <= dense_pos_; ++p)
-                        if (count[p] >= dense_.min_states) { phases |= 1u << p; if (!has_owned(cur, p)) fresh_phases |= 1u << p; }
+                        if (count[p] >= min_states_now()) { phases |= 1u << p; if (!has_owned(cur, p)) fresh_phases |= 1u << p; }
                 }
                 dense_receivers(next, receivers_scratch_);
                 caps_scratch_.clear();

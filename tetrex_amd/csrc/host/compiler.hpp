@@ -65,9 +65,16 @@ void dgram_record_values(std::string_view seq, uint64_t min_gap, uint64_t max_ga
 // block of A^(k-1) device slots and emits one op per residue set instead of one per state and residue.
 struct DenseOptions {
     bool enabled = false;          // the executor runs dense ops (a flat-IBF device session)
-    // (bench batch, 1000 motifs at k = 4: min_states / sparse_below 128 / 24: 30 ms; 64 / 24: 23 ms; 32 / 16: 18 ms; 24 / 12: 19 ms)
-    uint32_t min_states = 32;      // a list with at least this many full-length states becomes a block
-    uint32_t sparse_below = 16;    // a block whose shape holds at most this many entries is enumerated again
+    // (round 2, device-bound bench batch of 1000 motifs at k = 4: min_states / sparse_below 128 / 24: 30 ms; 64 / 24: 23 ms; 32 / 16: 18 ms;
+    // round 3, the batches bound by the host's expansion — profiles/r3_dense_thresholds_ab.txt: 32 / 16, 16 / 8, 8 / 4, 4 / 2 give
+    // 6.6 / 6.6 / 6.2 / 6.5 ms at 1000 motifs and 44.9 / 33.7 / 33.8 / 33.1 ms at 10 000; every other workload gains or stays)
+    uint32_t min_states = 8;       // a list with at least this many full-length states becomes a block
+    uint32_t sparse_below = 4;     // a block whose shape holds at most this many entries is enumerated again
+    // ... while the run's pool of block memory is roomy (at least half of it left, and 256 full blocks or more to begin with);
+    // when it is short the blocks go to the lists that need them most (a wildcard's thousands of states, not a residue
+    // class's dozen): the thresholds of round 2
+    uint32_t short_min_states = 32, short_sparse_below = 16;
+    int64_t pool_total = 0;        // what `pool` started with (0: unknown — never short)
     uint32_t cool_down = 1;        // released blocks kept out of circulation while new ones can be had (see can_take_blocks)
     uint32_t max_shape_per_state = 64;  // a list becomes a block only if its shape holds at most this many suffixes per state (fewer for wide masks: QueryExpansion::shape_limit)
     double host_ns_per_op = 12.0;       // what an enumerated state and residue costs the batch (wall time, all expansion threads)
@@ -299,7 +306,14 @@ class QueryExpansion {
     void dense_receivers(int32_t item, std::vector<int32_t>& out) const;
     std::vector<int32_t> receivers_scratch_;
     void dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out);
-    bool small_enough(const DenseRef& r) const { return shape_entries(r) <= dense_.sparse_below; }
+    // the run's pool of block memory is short: less than half of it left, or never more than 256 full blocks to begin with
+    bool pool_short() const {
+        if (!dense_.pool || dense_.pool_total <= 0) return false;
+        const int64_t block = (int64_t)(dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128));
+        return dense_.pool->load(std::memory_order_relaxed) * 2 < dense_.pool_total || dense_.pool_total < 256 * block;
+    }
+    uint32_t min_states_now() const { return pool_short() ? std::max(dense_.min_states, dense_.short_min_states) : dense_.min_states; }
+    bool small_enough(const DenseRef& r) const { return shape_entries(r) <= (pool_short() ? std::max(dense_.sparse_below, dense_.short_sparse_below) : dense_.sparse_below); }
 
     uint32_t fresh();
     void share(uint32_t s);

@@ -182,6 +182,7 @@ class StagedRun {
         // does need more takes it from the pool like everybody else)
         admit_bytes_ = (int64_t)std::min<uint64_t>(4 * dense_block_slots(enc, dense_) * (dense_.slot_bytes ? dense_.slot_bytes : 128), (uint64_t)256 << 20);
         dense_.pool = &dense_pool_;
+        dense_.pool_total = dense_total_;
         evidence_.store(opt.dense_evidence);
         if (const char* e = std::getenv("TETREX_DENSE_EVIDENCE"))  // A/B knob and tests: dense / sparse / ask
             evidence_.store(e[0] == 'd' ? DenseOptions::kDense : e[0] == 's' ? DenseOptions::kSparse : e[0] == 't' ? DenseOptions::kThin : DenseOptions::kUnknown);
