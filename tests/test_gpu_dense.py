@@ -415,7 +415,7 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
     monkeypatch.delenv("TXQ_ONE_STREAM")
     rng = np.random.default_rng(5)
     for it in range(16):
-        monkeypatch.setenv("TETREX_WAVE_OPS", str(int(rng.integers(200, 20000))))
+        monkeypatch.setenv("TETREX_WAVE_OPS", str(int(rng.integers(200, 4000))))  # (the batch is some 15 000 ops)
         if rng.random() < 0.5:
             monkeypatch.setenv("TETREX_TASK_OPS", str(int(rng.integers(100, 3000))))
         else:

@@ -70,7 +70,7 @@ struct DenseOptions {
     // 6.6 / 6.6 / 6.2 / 6.5 ms at 1000 motifs and 44.9 / 33.7 / 33.8 / 33.1 ms at 10 000; every other workload gains or stays)
     uint32_t min_states = 8;       // a list with at least this many full-length states becomes a block
     uint32_t sparse_below = 4;     // a block whose shape holds at most this many entries is enumerated again
-    // ... while the run's pool of block memory is roomy (at least half of it left, and 256 full blocks or more to begin with);
+    // ... while the run's pool of block memory is roomy (at least half of it left, and 256 blocks or more to begin with);
     // when it is short the blocks go to the lists that need them most (a wildcard's thousands of states, not a residue
     // class's dozen): the thresholds of round 2
     uint32_t short_min_states = 32, short_sparse_below = 16;
@@ -306,10 +306,11 @@ class QueryExpansion {
     void dense_receivers(int32_t item, std::vector<int32_t>& out) const;
     std::vector<int32_t> receivers_scratch_;
     void dense_step(const DenseRef& src, uint32_t r_mask, int32_t receiver, OpVec& out);
-    // the run's pool of block memory is short: less than half of it left, or never more than 256 full blocks to begin with
+    // the run's pool of block memory is short: less than half of it left, or never more than 256 blocks to begin with (full
+    // blocks of A^(k-1) entries, or 16 MB where those are larger: at k = 6 blocks are tracked and laid out inside their geometry)
     bool pool_short() const {
         if (!dense_.pool || dense_.pool_total <= 0) return false;
-        const int64_t block = (int64_t)(dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128));
+        const int64_t block = std::min<int64_t>((int64_t)(dense_n_ * (dense_.slot_bytes ? dense_.slot_bytes : 128)), (int64_t)16 << 20);
         return dense_.pool->load(std::memory_order_relaxed) * 2 < dense_.pool_total || dense_.pool_total < 256 * block;
     }
     uint32_t min_states_now() const { return pool_short() ? std::max(dense_.min_states, dense_.short_min_states) : dense_.min_states; }
