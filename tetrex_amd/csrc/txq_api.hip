@@ -43,7 +43,7 @@ void read_knobs() {
     k.dense_tree = (int)num("TXQ_DENSE_TREE", -1);
     k.dense_unroll = (int)num("TXQ_DENSE_UNROLL", 3);
     k.dense_slices = (int)std::max(1LL, num("TXQ_DENSE_SLICES", 2));
-    k.dense_tile_rounds = (int)std::max(1LL, num("TXQ_DENSE_TILE_ROUNDS", 2));
+    k.dense_tile_rounds = (int)std::max(1LL, num("TXQ_DENSE_TILE_ROUNDS", 4));
     k.dense_nt = (int)num("TXQ_DENSE_NT", 0) & 3;
     k.fuse_units = !is("TXQ_FUSE_UNITS", '0');
     k.one_stream = flag("TXQ_ONE_STREAM");

@@ -18,7 +18,7 @@ struct Knobs {
     int dense_tree = -1;        // TXQ_DENSE_TREE: 0 generic HIBF steps, 1 TreeRows, 2 TreeRowsByLane where it applies; -1: best fit
     int dense_unroll = 3;       // TXQ_DENSE_UNROLL: predecessors in flight per lane (2, 3, 5)
     int dense_slices = 2;       // TXQ_DENSE_SLICES: lane groups sharing the predecessors of one suffix
-    int dense_tile_rounds = 2;  // TXQ_DENSE_TILE_ROUNDS: destination suffixes per lane-group set and tile
+    int dense_tile_rounds = 4;  // TXQ_DENSE_TILE_ROUNDS: destination suffixes per lane-group set and tile (profiles/r3_dense_tile_shapes_ab.txt)
     int dense_nt = 0;           // TXQ_DENSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads of a dense step's destination entries
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
