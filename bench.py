@@ -321,6 +321,25 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
     if err is not None:
         return {"error": err}
     lat, plain_status, plain_stats, plain_s = local["lat"], local["plain_status"], local["plain_stats"], local["plain_s"]
+    enumerated = None
+    if world == 1:
+        # ALL masks of the timed batch against the same batch with every state enumerated (TETREX_DENSE=0: no blocks, no table of
+        # k-mer masks — ordinary ops on probed masks only); the CPU oracle below covers as many motifs as its 10 s allow
+        knob = os.environ.get("TETREX_DENSE")
+        os.environ["TETREX_DENSE"] = "0"
+        try:
+            ta = time.perf_counter()
+            ref_masks, ref_status, ref_stats = ix.query_masks(motifs, False, k)
+            ref_dt = time.perf_counter() - ta
+        finally:
+            if knob is None:
+                del os.environ["TETREX_DENSE"]
+            else:
+                os.environ["TETREX_DENSE"] = knob
+        if not (np.array_equal(masks, ref_masks) and list(status) == list(ref_status)):
+            raise SystemExit("bench: the end-to-end batch gives other masks with dense blocks than with enumerated states")
+        enumerated = {"what": "the same batch with TETREX_DENSE=0 (no blocks: states enumerated and pruned through host feedback)",
+                      "seconds": ref_dt, "ops": ref_stats["ops"], "masks_identical": True}
     big = None
     if world == 1 and not args.no_big_batch:
         # BASELINE configs[3]'s batch size: 10 000 motifs of the same mix in ONE call (one warm run, best of three timed)
@@ -330,10 +349,13 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
             runs = []
             for _ in range(3):
                 ta = time.perf_counter()
-                _, st_many, stats_many = ix.query_masks(many, False, k)
-                runs.append((time.perf_counter() - ta, stats_many, st_many))
+                masks_many, st_many, stats_many = ix.query_masks(many, False, k)
+                runs.append((time.perf_counter() - ta, stats_many, st_many, masks_many))
             best = min(runs, key=lambda r: r[0])
+            if many[:len(motifs)] == motifs and not np.array_equal(best[3][:len(motifs)], masks):  # (its first motifs are the batch above)
+                raise SystemExit("bench: the first motifs of the 10x batch give other masks than the same motifs as a batch of their own")
             big = {"motifs": len(many), "k": k, "seconds": best[0], "queries_per_s": len(many) / best[0], "timed_runs_seconds": [r[0] for r in runs],
+                   "first_masks_equal_the_batch_above": bool(many[:len(motifs)] == motifs),
                    "refused_fraction": float(sum(1 for s_ in best[2] if s_)) / len(many), **best[1]}
         except Exception as e:  # noqa: BLE001
             big = {"error": repr(e)}
@@ -349,7 +371,8 @@ def end_to_end_queries(ix, torch, dist, world, rank, args):
         "batch": {"motifs": len(motifs), "seconds": total, "gather_seconds": gather_s, "failed": int(sum(1 for s in status if s)),
                   "warmup": "one batch of the same size and mix from another seed", "first_batch_seconds": local["first_batch_s"],
                   **({"timed_runs_seconds": repeats, "seconds_is": "the best of the timed runs"} if repeats else {}),
-                  "k": k, "refused_fraction": float(sum(1 for s_ in status if s_)) / len(motifs), **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean())},
+                  "k": k, "refused_fraction": float(sum(1 for s_ in status if s_)) / len(motifs), **stats, "mean_candidate_bins": float(np.unpackbits(masks.view(np.uint8), axis=1).sum(axis=1).mean()),
+                  **({"enumerated_states": enumerated} if enumerated else {})},
         **({"batch_10x": big} if big else {}),
         "batch_no_wildcards": {"motifs": len(plain), "seconds": plain_s, "queries_per_s": len(plain) / plain_s,
                                "failed": int(sum(1 for s in plain_status if s)), **plain_stats},
