@@ -367,9 +367,10 @@ struct StagedOptions {
     size_t ops_per_task = 256u << 10;        // a feedback-free query's first budget; it quadruples with every further stage the query
                                              // needs (up to 16x), so a skewed batch is not held to many stages by its heaviest query
     size_t stage_target_ops = 4u << 20;      // with few queries left, each gets a larger share of this
-    size_t wave_ops = 96u << 10;             // queries BEGIN in waves of about this many ops (growing with the ops already emitted), so that the
-                                             // device runs wave n while the host expands wave n+1; 0: everybody begins in the first stage
-                                             // (profiles/r3_wave_size_ab.txt: 1000 motifs 7.4 / 7.1 / 6.9 / 8.9 ms at 192 k / 96 k / 64 k / 48 k)
+    size_t wave_ops = 40000;                 // queries BEGIN in waves of about this many ops — a wave is at least as large as everything emitted before
+                                             // it, so a large batch does not become many small stages —, so that the device runs wave n while the host
+                                             // expands wave n+1; 0: everybody begins in the first stage (profiles/r3_wave_size_ab.txt, last part:
+                                             // 1000 / 10 000 motifs 6.4 / 31 ms with one wave of 96 k growing by halves, 5.4 / 30.5 ms with 40 k doubling)
     bool verified_levels = true;             // queries that still ask for feedback only expand states confirmed alive
     CompileLimits limits;
     DenseOptions dense;                      // run_staged fills `pool` itself

@@ -189,6 +189,7 @@ class StagedRun {
         dense_.evidence = &evidence_;
         wave_ops_ = opt.wave_ops;
         if (const char* e = std::getenv("TETREX_WAVE_OPS")) wave_ops_ = (size_t)std::max(0LL, std::atoll(e));  // A/B knob; 0 = one wave
+        if (const char* e = std::getenv("TETREX_WAVE_GROWTH")) wave_growth_percent_ = (size_t)std::max(0LL, std::atoll(e));  // A/B knob: a wave is at least this share (%) of all ops emitted before it
         if (const char* e = std::getenv("TETREX_TASK_OPS")) run_on_budget_ = std::max<size_t>((size_t)std::atoll(e), 1);  // A/B knob
     }
 
@@ -289,7 +290,7 @@ class StagedRun {
         // Queries begin in waves: the first stage goes to the device after about wave_ops_ ops, and the later waves are
         // expanded while it executes (execute()); the waves grow with what has been emitted, so a large batch does not
         // turn into many small stages.
-        const size_t wave_limit = wave_ops_ ? std::max<size_t>(wave_ops_, (size_t)(st_.ops / 2)) : 0;
+        const size_t wave_limit = wave_ops_ ? std::max<size_t>(wave_ops_, (size_t)(st_.ops * wave_growth_percent_ / 100)) : 0;
         // Dense blocks are device memory: when the run's pool runs low, queries that have not begun wait for a later stage —
         // those under way finish, hand their blocks back (and the device recycles their regions) — instead of everybody
         // starting at once and the late ones falling back to enumerated states.  Somebody is always under way.
@@ -641,7 +642,7 @@ class StagedRun {
     BlobStore& blob_store_;                           // (kept with the thread pool from run to run)
     StagedStats st_;
     size_t run_on_budget_ = 0, feedback_budget_ = 0;  // the latter: what a query that asks gets per stage (advance_stage sets it)
-    size_t wave_ops_ = 0;
+    size_t wave_ops_ = 0, wave_growth_percent_ = 100;
     bool trace_ = false, verified_levels_ = true, overlap_ = true;
     double lap_at_ = 0;
 };
