@@ -113,6 +113,36 @@ def test_dna_and_reduced_alphabets_dense(capi, oracle, monkeypatch):
         assert checked >= 3 and dense_ops > 5
 
 
+@pytest.mark.parametrize("tracked", [False, True], ids=["blocks", "tracked"])
+def test_steps_through_the_table_of_all_kmer_masks(capi, oracle, monkeypatch, tracked):
+    """Index::kmer_table (csrc/txq_exec.hip ensure_kmer_table, TableRows): dense steps read bulk_contains of every packed
+    k-mer value from a table built once per index instead of gathering rows — DNA (canonical k-mers: the steps look the
+    canonical value up), reduced alphabets (4-bit codes), peptide k = 4 on column shards, full and tracked blocks.  Masks
+    against the oracle, table on (built by a session of any size here: TXQ_KMER_TABLE_MIN=1) and off."""
+    monkeypatch.setenv("TETREX_DENSE_MIN", "1")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "0")
+    monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
+    if tracked:
+        monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
+    cases = []
+    for bins, m, k, per_bin, h in ((70, 257, 3, 8, 3), (300, 4099, 5, 300, 2), (128, 8191, 7, 900, 4)):
+        cases.append((_oracle_index(oracle, bins=bins, m=m, h=h, k=k, dna=True, per_bin=per_bin, seed=bins),
+                      DNA_QUERIES + ["ACG..T.GA", "A.{2,4}CGT.A", "AC[GT]..[AC]CGT"], True, k, 0, (1,)))
+    for red in (1, 2):
+        cases.append((_oracle_index(oracle, bins=256, m=8191, h=2, k=5, dna=False, per_bin=1500, seed=red, reduction=red),
+                      ["LMA(E|Q)GLYN", "LMAEGLYNK", "W[LIVM]D.FYLK", "LMAE(GL|YN)K.DE", "KRDEG..NLMA"], False, 5, red, (1,)))
+    cases.append((_oracle_index(oracle, bins=700, m=8191, h=3, k=4, dna=False, per_bin=2500, seed=9),
+                  ["LMK.{1,3}A[DE]..GK", "WKL..[LIVM]D.[FY]", "LMKA.C.E.GH", "CLM.{2,4}C...[LIVMFYWC]", "A.CD", "K[RK]DE"], False, 4, 0, (1, 2)))
+    for ox, qs, dna, k, red, shards in cases:
+        wants = _wants(ox, qs)
+        for table_mb in ("512", "0"):
+            monkeypatch.setenv("TXQ_KMER_TABLE_MB", table_mb)
+            checked, dense_ops = _check(capi, ox, qs, dna, k, red, shards=shards, wants=wants)
+            assert checked >= 3 and dense_ops > 5, (dna, k, red, table_mb)
+            if tracked:
+                assert TRACKED[0] > 0
+
+
 def test_dense_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
     """Tiny per-query stage budgets: blocks are written in one stage and read in the next; regions grow while they
     hold live blocks (device-to-device copy) and blocks are recycled."""
