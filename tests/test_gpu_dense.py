@@ -161,6 +161,7 @@ def test_waves_of_queries_on_a_session_that_is_never_waited_for(capi, oracle, mo
     staging set, upload stream) while the kernels of stage n run; with a small task budget the queries also CONTINUE
     across those stages (regions grow and move, blocks live from one stage to the next).  Masks equal the oracle's."""
     monkeypatch.setenv("TETREX_WAVE_OPS", "500")
+    monkeypatch.setenv("TETREX_WAVE_GROWTH", "0")  # (waves of 500 ops throughout; by default a wave is at least as large as all before it)
     if task_ops:
         monkeypatch.setenv("TETREX_TASK_OPS", task_ops)
     ox = _oracle_index(oracle, bins=1000, m=30011, h=3, k=4, dna=False, per_bin=3000, seed=21)
@@ -446,6 +447,7 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
     rng = np.random.default_rng(5)
     for it in range(16):
         monkeypatch.setenv("TETREX_WAVE_OPS", str(int(rng.integers(200, 4000))))  # (the batch is some 15 000 ops)
+        monkeypatch.setenv("TETREX_WAVE_GROWTH", str(int(rng.choice([0, 50, 100]))))
         if rng.random() < 0.5:
             monkeypatch.setenv("TETREX_TASK_OPS", str(int(rng.integers(100, 3000))))
         else:

@@ -41,7 +41,9 @@ def _run(host, ox, queries, dna, k, per_query, per_stage=0):
 
 
 @pytest.mark.parametrize("per_query", [0, 1, 7, 64, 4096, 1 << 30])  # 0 = the product's default policy
-def test_every_stage_budget_gives_the_oracle_masks(host, oracle, per_query):
+def test_every_stage_budget_gives_the_oracle_masks(host, oracle, monkeypatch, per_query):
+    if per_query == 1 << 30:
+        monkeypatch.setenv("TETREX_WAVE_OPS", "0")  # (one stage: everybody begins at once, nobody pauses)
     ox = _index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=1)
     qs = [q for q in PEPTIDE_QUERIES if "{2,4}C" not in q] + random_prosite_motifs(25, 3, wildcard=0.05, ranges=0.0)
     checked, stats, sim = _run(host, ox, qs, False, 4, per_query)
@@ -111,6 +113,7 @@ def test_waves_of_queries_give_the_same_masks(host, oracle, monkeypatch, wave_op
     qs = random_prosite_motifs(24, 5, wildcard=0.05, ranges=0.03)
     qs.insert(7, "AC(DE")  # syntax error in the middle of a wave
     monkeypatch.setenv("TETREX_WAVE_OPS", wave_ops)
+    monkeypatch.setenv("TETREX_WAVE_GROWTH", "0")  # (waves of that size throughout; by default a wave is at least as large as all before it)
     checked, stats, sim = _run(host, ox, qs, False, 4, 0)
     assert checked >= len(qs) - 6
     if wave_ops == "0":
