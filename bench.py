@@ -978,6 +978,18 @@ def main():
         except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
             out.setdefault("hibf", {"error": repr(e)})
             out.setdefault("hibf_1024", {"error": repr(e)})
+        if world == 1 and rank == 0:
+            # ... and a GENERAL tree as seqan::hibf's layout shapes the reference's index (include/index_hibf.h:114-129): 65 536 user
+            # bins scattered over IBFs of at most 256 technical bins, split bins, user bins next to merged bins (tests/helpers.py
+            # layout_hibf).  Plain probes (user-bin order: descent kernels) and a 200-motif batch (session in layout order, against
+            # the same batch in user-bin order: masks identical; 2048 probed masks against the CPU oracle).  tests/perf_hibf_ragged.py
+            try:
+                from perf_hibf_ragged import measure as hibf_irregular
+                out["hibf_irregular"] = hibf_irregular(capi, torch, 1 << 20, 256, 65536)
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
+                out["hibf_irregular"] = {"error": repr(e)}
     if world > 1 and not strong and not args.no_queries and not args.rehearse_single_device:
         # both deployments of the sharded index are measured at first contact with a multi-GPU node: after the one-process-
         # per-GPU legs above, rank 0 alone drives all N devices; everybody else waits (a failure must not cost the line)

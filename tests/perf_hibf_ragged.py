@@ -31,16 +31,11 @@ def probe_blob(kmers):
     return head + kmers.tobytes() + struct.pack("<6I", 0, 1, 3, 0, 1, 0) + struct.pack("<4I", 0, 2, 1, 2) + struct.pack("<2I", 1, 0)
 
 
-def main():
-    import torch
+def measure(capi, torch, n=1 << 20, tmax=64, user_bins=65536):
+    """the measurement (bench.py's `hibf_irregular` leg calls it with its own capi / torch); returns the dict that main() prints"""
     import oracle as O
     from helpers import layout_hibf
     from motifs import random_prosite_motifs
-    from tetrex_amd import capi
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
-    tmax = int(sys.argv[2]) if len(sys.argv) > 2 else 64
-    user_bins = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
-    capi.init(0)
     t0 = time.perf_counter()
     ox, descs, values = layout_hibf(O, 9, user_bins=user_bins, tmax=tmax, n_values=12)
     build_s = time.perf_counter() - t0
@@ -100,14 +95,25 @@ def main():
     same = np.array_equal(masks["layout"][0], masks["user"][0]) and masks["layout"][1] == masks["user"][1]
     if not same:
         raise SystemExit("layout-order and user-order query masks differ")
-    print(json.dumps({
+    ix.free()
+    return {
         "tree": "general HIBF, %d user bins, tmax %d: %d IBFs" % (user_bins, tmax, len(descs)), "kmers": n, "build_s": round(build_s, 1),
         "tree_bytes": int(info.device_bytes), "mask_words_user_order": int(W),
         "probe_user_order": {"what": "txq_probe_device (descent kernels, masks in user-bin order)", "seconds": t_user, "kmers_per_s": n / t_user,
                              "mask_GBps": n * W * 8 / t_user / 1e9},
         "probe_layout_order": {"what": "one session stage: k-mer table upload + layout-order rows of all k-mers + one op + result (txq_run_programs)",
                                "seconds": t_layout, "kmers_per_s": n / t_layout},
-        "queries_layout_order": timings["layout"], "queries_user_order": timings["user"], "query_masks_identical": same}))
+        "queries_layout_order": timings["layout"], "queries_user_order": timings["user"], "query_masks_identical": same}
+
+
+def main():
+    import torch
+    from tetrex_amd import capi
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    tmax = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    user_bins = int(sys.argv[3]) if len(sys.argv) > 3 else 65536
+    capi.init(0)
+    print(json.dumps(measure(capi, torch, n, tmax, user_bins)))
 
 
 if __name__ == "__main__":
