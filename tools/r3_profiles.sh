@@ -22,3 +22,6 @@ timeout -k 10 300 python tests/perf_config5_queries.py > $O/config5.json 2> /dev
 timeout -k 10 100 python tools/single_query_latency.py > $O/single_query_latency.txt 2> /dev/null
 tail -c 500 $O/bench_default.json; echo; cat $O/k6_timeline.txt | head -12; cat $O/e2e_timeline.txt | head -8; grep "^rep" $O/e2e_1k.txt | tail -2; grep -E "^rep" $O/e2e_10k.txt | tail -2 | cut -c1-300; cut -c1-400 $O/config5.json; cat $O/single_query_latency.txt; python -c "
 import json; d=json.load(open('$O/pmc_sparse_kernel.json')); print(json.dumps(d.get('roofline')))"
+(cd /tmp && PERF_HIBF_NO_CHECK=1 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_ragged -o ragged -- python3 $GRAFT_REPO_ROOT/tests/perf_hibf_ragged.py 1048576 256 > $O/hibf_ragged_under_rocprof.json 2> /dev/null)
+rm -f $O/prof_ragged/*_kernel_trace.csv $O/prof_ragged/*.db
+head -12 $O/prof_ragged/ragged_kernel_stats.csv | cut -c1-160
