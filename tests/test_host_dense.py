@@ -170,6 +170,22 @@ def test_queries_begin_in_waves_when_block_memory_is_short(host, oracle):
     assert tight["stages"] > free["stages"] and tight["ops"] < 3 * roomy32["ops"]
 
 
+def test_a_block_that_waits_for_the_answer_is_cleared_whole(host, oracle, monkeypatch):
+    """Found by tests/test_fuzz_parity.py with the thresholds of round 3 (`D?[AC]+.?`, k = 4): a list that already owns a block
+    pauses to ask how states fare on the index (TETREX_DENSE_EVIDENCE=ask) AFTER its block's ZERO has been cut down to the shape
+    seen so far; in the next stage the list's own states join the block with a residue that shape does not have, and the ZERO —
+    shipped with the first stage — had not cleared those entries.  The pause now widens the ZERO to the whole block again."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "ask")
+    rng = np.random.default_rng(7)
+    ox = oracle.Index.ibf(130, 2053, 3, dna=False, k=4)
+    for b in range(130):
+        ox.emplace(rng.integers(0, 1 << 20, size=900, dtype=np.uint64), b)
+    qs = ["D?[AC]+.?", "E?[KR]+.?", "D?[ACD]+..?", "[DE]?[AC]+.?G"]
+    for dense in (dict(), dict(min_states=8, sparse_below=5), dict(min_states=4, sparse_below=3)):
+        checked, stats, sim = _run(host, ox, qs, False, 4, dense)
+        assert checked == len(qs) and sim.dense_steps > 0
+
+
 @pytest.mark.parametrize("kind", ["saturated", "sparse"])
 def test_the_expansion_asks_before_its_first_block(host, oracle, monkeypatch, kind):
     """Nothing known about the index (TETREX_DENSE_EVIDENCE=ask, the product's default for a fresh index): a query pauses

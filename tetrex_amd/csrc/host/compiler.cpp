@@ -525,6 +525,15 @@ void QueryExpansion::shape_zero(const DenseRef& r) {
     z.r_mask = 1;  // "the shape is given"
 }
 
+// the block will receive more states in a later stage, when its ZERO is out of reach: the ZERO clears the whole block again
+void QueryExpansion::shape_unzero(const DenseRef& r) {
+    if (tracked_) return;
+    if (!dense_out_ || r.block >= zero_at_.size() || zero_epoch_[r.block] != dense_epoch_ || zero_at_[r.block] >= dense_out_->size()) return;
+    txq_dense_op& z = (*dense_out_)[zero_at_[r.block]];
+    if (z.kind != TXQ_DENSE_ZERO || z.dst != dense_slot(r.block, 0)) return;
+    z.r_mask = 0;  // "everything"
+}
+
 void QueryExpansion::release_block(uint32_t block) {
     if (--block_refs_[block] == 0) parked_blocks_.push_back(block);  // reusable once the current item is finished
 }
@@ -774,6 +783,10 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     for (const State& s : cur.items) probed += !s.gapped && s.shift >= k;
                     if (probed >= 16) {
                         evidence_asked_ = wants_evidence_ = true;
+                        // (the item waits for the next stage, where its own states may still join its block — with residues its
+                        // block's ZERO, shaped a few lines up and shipped with this stage, would not have cleared)
+                        for (const DenseRef& d : cur.dense)
+                            if (d.owned) shape_unzero(d);
                         break;
                     }
                 }

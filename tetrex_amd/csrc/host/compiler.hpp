@@ -301,6 +301,7 @@ class QueryExpansion {
     }
     void densify(int32_t item, NodeStates& ns, OpVec& out, bool may_hold_duplicates);
     void shape_zero(const DenseRef& r);
+    void shape_unzero(const DenseRef& r);
     uint64_t shape_limit() const;
     void materialise(int32_t item, OpVec& out, bool all);
     void dense_receivers(int32_t item, std::vector<int32_t>& out) const;
