@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Random regexes (the grammar of tests/test_fuzz_parity.py, drawn with hypothesis' generators from a seed) through the GPU path
+in batches, every mask against the CPU oracle: the device reads whatever the arena holds where a ZERO has not cleared, which the
+numpy simulator of the CPU tests only sees as a poisoned entry.  Peptide k = 4 on 130 bins and DNA k = 3 on 70 bins (the fuzz
+tests' indexes), product defaults (a fresh index asks how states fare on it), then TETREX_DENSE_EVIDENCE=dense / thin.
+Usage on the GPU box: tools/gpu_regex_fuzz.py [regexes per index] [seed]"""
+import os, sys, warnings
+import numpy as np
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+warnings.filterwarnings("ignore")
+import hypothesis
+from hypothesis import strategies as st
+import oracle as O
+from tetrex_amd import capi
+from test_fuzz_parity import regex_strategy, AA
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 600
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+capi.init(0)
+
+
+def draw(strategy, count, seed):
+    out = []
+
+    @hypothesis.seed(seed)
+    @hypothesis.settings(max_examples=count, database=None, deadline=None, suppress_health_check=list(hypothesis.HealthCheck), phases=[hypothesis.Phase.generate])
+    @hypothesis.given(strategy)
+    def collect(rx):
+        out.append(rx)
+    collect()
+    return list(dict.fromkeys(out))
+
+
+rng = np.random.default_rng(7)
+pep = O.Index.ibf(130, 2053, 3, dna=False, k=4)
+for b in range(130):
+    pep.emplace(rng.integers(0, 1 << 20, size=900, dtype=np.uint64), b)
+dna = O.Index.ibf(70, 257, 2, dna=True, k=3)
+for b in range(70):
+    dna.emplace(rng.integers(0, 1 << 6, size=10, dtype=np.uint64), b)
+bad = 0
+for name, ox, is_dna, k, alphabet, leaves in (("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8)):
+    qs = draw(regex_strategy(alphabet, max_leaves=leaves), n, seed)
+    wants = []
+    for q in qs:
+        try:
+            wants.append(ox.expected_mask(q)[0])
+        except Exception:  # noqa: BLE001 - a regex the reference path cannot search either
+            wants.append(None)
+    sh = ox.shape()
+    for ev in (None, "dense", "thin"):
+        if ev:
+            os.environ["TETREX_DENSE_EVIDENCE"] = ev
+        else:
+            os.environ.pop("TETREX_DENSE_EVIDENCE", None)
+        for chunk in (len(qs), 40, 7):  # one batch, and batches small enough to leave the table of all k-mers' masks alone
+            ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())  # a fresh index: it is asked
+            checked = 0
+            for at in range(0, len(qs), chunk):
+                part = qs[at:at + chunk]
+                got, status, stats = ix.query_masks(part, is_dna, k)
+                for q, g, w, s_ in zip(part, got, wants[at:at + chunk], status):
+                    if w is None:
+                        if s_ == 0:
+                            print("MISMATCH: %r runs here, the oracle refuses it" % q); bad += 1
+                        continue
+                    if s_ != 0 or not np.array_equal(g, w):
+                        print("MISMATCH %s evidence %s batch %d: %r status %d" % (name, ev, chunk, q, s_)); bad += 1
+                    checked += 1
+            ix.free()
+            print("%s, evidence %s, batches of %d: %d of %d regexes compared with the oracle" % (name, ev or "asked", chunk, checked, len(qs)), flush=True)
+print("regex fuzz on the GPU: %d mismatches" % bad)
+sys.exit(1 if bad else 0)
