@@ -2,7 +2,7 @@
 """Random regexes (the grammar of tests/test_fuzz_parity.py, drawn with hypothesis' generators from a seed) through the GPU path
 in batches, every mask against the CPU oracle: the device reads whatever the arena holds where a ZERO has not cleared, which the
 numpy simulator of the CPU tests only sees as a poisoned entry.  Peptide k = 4 on 130 bins and DNA k = 3 on 70 bins (the fuzz
-tests' indexes), product defaults (a fresh index asks how states fare on it), then TETREX_DENSE_EVIDENCE=dense / thin.
+tests' indexes) and peptide k = 4 on 1024 bins (16-byte lanes), product defaults (a fresh index asks how states fare on it), then TETREX_DENSE_EVIDENCE=dense / thin.
 Usage on the GPU box: tools/gpu_regex_fuzz.py [regexes per index] [seed]"""
 import os, sys, warnings
 import numpy as np
@@ -38,8 +38,11 @@ for b in range(130):
 dna = O.Index.ibf(70, 257, 2, dna=True, k=3)
 for b in range(70):
     dna.emplace(rng.integers(0, 1 << 6, size=10, dtype=np.uint64), b)
+wide = O.Index.ibf(1024, 8191, 3, dna=False, k=4)  # 16-word masks: the 16-byte lanes of the step kernels
+for b in range(1024):
+    wide.emplace(rng.integers(0, 1 << 20, size=2500, dtype=np.uint64), b)
 bad = 0
-for name, ox, is_dna, k, alphabet, leaves in (("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8)):
+for name, ox, is_dna, k, alphabet, leaves in (("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)):
     qs = draw(regex_strategy(alphabet, max_leaves=leaves), n, seed)
     wants = []
     for q in qs:
