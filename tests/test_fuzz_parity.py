@@ -66,14 +66,28 @@ def test_translate_and_kgraph_agree_with_the_oracle(host, oracle, rx):
         assert got["labels"] == want["labels"] and got["succ"] == [tuple(s) for s in want["succ"]]
 
 
-DENSE = [dict(), dict(min_states=2, sparse_below=3), dict(min_states=1, sparse_below=1)]  # the product's defaults, and nearly / really everything dense
+# the product's defaults, nearly / really everything dense, and the same on an executor that keeps live lists (tracked blocks)
+DENSE = [dict(), dict(min_states=2, sparse_below=3), dict(min_states=1, sparse_below=1), dict(tracked=2), dict(tracked=2, min_states=2, sparse_below=3)]
+EVIDENCE = [None, None, "dense", "thin"]  # what the run knows about the index: nothing (it asks: the product on a fresh index), lists saturate, states die out
 
 
-def _check_masks(host, oracle, ox, rx, dna, k, budget, dense=0):
+def _check_masks(host, oracle, ox, rx, dna, k, budget, dense=0, evidence=None):
     """Dense DP steps are on, as in the product on a flat IBF: a generated regex such as ((.*)*)* saturates every list of
     its (large) k-graph, which enumerated state by state is millions of ops — nothing a Python test double can run."""
+    import os
     sim = SessionSimulator(ox, 1)
-    status, _ = host.run_staged([rx], dna, k, 0, ox.bins, sim.stage, budget, dense=DENSE[dense])
+    before = os.environ.get("TETREX_DENSE_EVIDENCE")
+    if evidence:
+        os.environ["TETREX_DENSE_EVIDENCE"] = evidence
+    else:
+        os.environ.pop("TETREX_DENSE_EVIDENCE", None)
+    try:
+        status, _ = host.run_staged([rx], dna, k, 0, ox.bins, sim.stage, budget, dense=DENSE[dense])
+    finally:
+        if before is None:
+            os.environ.pop("TETREX_DENSE_EVIDENCE", None)
+        else:
+            os.environ["TETREX_DENSE_EVIDENCE"] = before
     try:
         want, quirks = ox.expected_mask(rx)
     except oracle.OracleError:
@@ -84,12 +98,12 @@ def _check_masks(host, oracle, ox, rx, dna, k, budget, dense=0):
 
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(rx=regex_strategy(AA, max_leaves=6), budget=st.sampled_from([0, 1, 5]), dense=st.sampled_from([0, 0, 1, 2]))
-def test_peptide_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense):
-    _check_masks(host, oracle, indexes["pep"], rx, False, 4, budget, dense)
+@given(rx=regex_strategy(AA, max_leaves=6), budget=st.sampled_from([0, 1, 5]), dense=st.sampled_from([0, 0, 1, 2, 3, 4]), evidence=st.sampled_from(EVIDENCE))
+def test_peptide_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense, evidence):
+    _check_masks(host, oracle, indexes["pep"], rx, False, 4, budget, dense, evidence)
 
 
 @settings(max_examples=200, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
-@given(rx=regex_strategy("ACGT", max_leaves=8), budget=st.sampled_from([0, 2]), dense=st.sampled_from([0, 1, 2]))
-def test_dna_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense):
-    _check_masks(host, oracle, indexes["dna"], rx, True, 3, budget, dense)
+@given(rx=regex_strategy("ACGT", max_leaves=8), budget=st.sampled_from([0, 2]), dense=st.sampled_from([0, 1, 2, 3, 4]), evidence=st.sampled_from(EVIDENCE))
+def test_dna_masks_equal_the_oracle(host, oracle, indexes, rx, budget, dense, evidence):
+    _check_masks(host, oracle, indexes["dna"], rx, True, 3, budget, dense, evidence)
