@@ -41,8 +41,19 @@ for b in range(70):
 wide = O.Index.ibf(1024, 8191, 3, dna=False, k=4)  # 16-word masks: the 16-byte lanes of the step kernels
 for b in range(1024):
     wide.emplace(rng.integers(0, 1 << 20, size=2500, dtype=np.uint64), b)
+# HIBFs: a random irregular 3-level tree, a tree as a layout algorithm shapes it, a regular 16 x 64 tree (tests/helpers.py)
+from helpers import layout_hibf, random_hibf, regular_hibf
+trees = {}
+ox_t, descs, _ = random_hibf(O, 21, user_bins=300, levels=3, n_values=60)
+trees["hibf-irregular-300"] = (ox_t, descs, 300)
+ox_t, descs, _ = layout_hibf(O, 5, user_bins=900, tmax=32, n_values=30)
+trees["hibf-layout-900"] = (ox_t, descs, 900)
+ox_t, descs, _ = regular_hibf(O, 1024, 16, 200, lambda b: np.random.default_rng(b).integers(0, 1 << 20, size=200, dtype=np.uint64), h=2)
+trees["hibf-regular-16x64"] = (ox_t, descs, 1024)
 bad = 0
-for name, ox, is_dna, k, alphabet, leaves in (("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)):
+cases = [("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)]
+cases += [(name, t[0], False, 4, AA, 6) for name, t in trees.items()]
+for name, ox, is_dna, k, alphabet, leaves in cases:
     qs = draw(regex_strategy(alphabet, max_leaves=leaves), n, seed)
     wants = []
     for q in qs:
@@ -50,14 +61,17 @@ for name, ox, is_dna, k, alphabet, leaves in (("peptide", pep, False, 4, AA, 6),
             wants.append(ox.expected_mask(q)[0])
         except Exception:  # noqa: BLE001 - a regex the reference path cannot search either
             wants.append(None)
-    sh = ox.shape()
+    sh = ox.shape() if name not in trees else None
     for ev in (None, "dense", "thin"):
         if ev:
             os.environ["TETREX_DENSE_EVIDENCE"] = ev
         else:
             os.environ.pop("TETREX_DENSE_EVIDENCE", None)
         for chunk in (len(qs), 40, 7):  # one batch, and batches small enough to leave the table of all k-mers' masks alone
-            ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())  # a fresh index: it is asked
+            if name in trees:
+                ix = capi.Index.upload_hibf(trees[name][2], trees[name][1])
+            else:
+                ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())  # a fresh index: it is asked
             checked = 0
             for at in range(0, len(qs), chunk):
                 part = qs[at:at + chunk]
