@@ -53,8 +53,12 @@ trees["hibf-regular-16x64"] = (ox_t, descs, 1024)
 bad = 0
 cases = [("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)]
 cases += [(name, t[0], False, 4, AA, 6) for name, t in trees.items()]
+more = int(os.environ.get("FUZZ_MORE_LEAVES", "0"))  # larger regexes (the oracle enumerates every state: keep the count down)
+only = os.environ.get("FUZZ_ONLY")                    # a comma-separated choice of the cases above
 for name, ox, is_dna, k, alphabet, leaves in cases:
-    qs = draw(regex_strategy(alphabet, max_leaves=leaves), n, seed)
+    if only and name not in only.split(","):
+        continue
+    qs = draw(regex_strategy(alphabet, max_leaves=leaves + more), n, seed)
     wants = []
     for q in qs:
         try:
