@@ -66,6 +66,21 @@ def usable_cpus():
     return cpus
 
 
+def self_launch(n_gpus):
+    """Run this very command under `python -m torch.distributed.run --nproc-per-node N` (one rank per GPU, rendezvous on
+    127.0.0.1 at a free port) as a child process; stdout / stderr pass through, the child's exit code is returned."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.run(cmd, env=env).returncode
+
+
 def splitmix64(seed, n, start=0):
     with np.errstate(over="ignore"):
         x = np.uint64(seed) + (np.arange(1, n + 1, dtype=np.uint64) + np.uint64(start)) * np.uint64(0x9E3779B97F4A7C15)
@@ -658,49 +673,237 @@ def verified_end_to_end(args):
     return out
 
 
-def one_process_n_devices(capi, torch, args, world, bins_total, m, h, value_bits, motifs_k):
+def one_process_n_devices(capi, torch, n_devices, world, build_shard, motifs, warm, dna, k, what):
     """The C++ product deployment of the sharded index: ONE process drives all N devices — txq_init(N, ids),
     shard r on device r, one frontier expansion feeding every shard's session (ShardedStageExecutor, host/device_index.cpp),
     the shards' masks joined on the host (txe_query_masks_sharded; the seam of run_collection / run_multiple_queries,
     reference include/query.h:250-290,329-346).  Runs on rank 0 alone after the distributed legs, while the other ranks
-    wait at a barrier; the index is the weak-scaling index of this run (bins_total bins), rebuilt shard by shard on the
-    devices.  Reports the batch time and what the shards' stages took."""
-    from motifs import random_prosite_motifs
-    capi.init_devices(list(range(world)))
+    wait on the HOST (a gloo group: no barrier kernel spins on the devices rank 0 is measuring); build_shard(r) builds
+    shard r of the leg's index on the current device.  Reports the batch time and what the shards' stages took."""
+    capi.init_devices(list(range(n_devices)))
     shards = []
     t0 = time.perf_counter()
     try:
-        bins_local = bins_total // world
         for r in range(world):
-            torch.cuda.set_device(r)
-            shards.append(build_index(capi, torch, bins_total, bins_local, m, h, r, world, args.per_bin, value_bits))
+            torch.cuda.set_device(r % n_devices)
+            shards.append(build_shard(r))
         build_s = time.perf_counter() - t0
         devices = [int(s.info.device) for s in shards]
-        motifs = random_prosite_motifs(args.motifs, 6)
-        capi.query_masks_sharded(shards, random_prosite_motifs(args.motifs, 8), False, motifs_k)  # warm, like the other legs
+        capi.query_masks_sharded(shards, warm, dna, k)  # warm, like the other legs
         best = None
         for _ in range(2):
             t1 = time.perf_counter()
-            masks, status, stats = capi.query_masks_sharded(shards, motifs, False, motifs_k)
+            masks, status, stats = capi.query_masks_sharded(shards, motifs, dna, k)
             dt = time.perf_counter() - t1
             if best is None or dt < best[0]:
                 best = (dt, stats, masks, status)
         # the same batch on shard 0 alone must give shard 0's columns of the joined masks
-        part, _, _ = shards[0].query_masks(motifs, False, motifs_k)
+        part, _, _ = shards[0].query_masks(motifs, dna, k)
         w0, nw = int(shards[0].info.shard_word0), shards[0].shard_words
         if not np.array_equal(part, best[2][:, w0:w0 + nw]):
             raise RuntimeError("joined masks differ from shard 0's own run in its columns")
-        return {"what": "one process, %d devices: txe_query_masks_sharded (one expansion, %d shard sessions, host-side join)" % (world, world),
-                "devices": devices, "queries_per_s": len(motifs) / best[0], "seconds": best[0], "k": motifs_k,
+        return {"what": "one process, %d device(s): txe_query_masks_sharded (one expansion, %d shard sessions, host-side join) — %s" % (n_devices, world, what),
+                "devices": devices, "motifs": len(motifs), "queries_per_s": len(motifs) / best[0], "seconds": best[0], "k": k,
                 "refused_fraction": float(sum(1 for x in best[3] if x)) / len(motifs), **best[1], "index_build_s": round(build_s, 1),
-                "mask_words": int(best[2].shape[1])}
+                "mask_words": int(best[2].shape[1])}, best[2]
     finally:
         for s in shards:
             s.free()
         torch.cuda.set_device(0)
 
 
-def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
+def rank0_alone(torch, dist, host_group, rank, fn):
+    """fn() on rank 0 while every other rank waits on the host (gloo monitored_barrier with a long timeout; their devices
+    idle and their caches emptied).  A failure of fn is returned as {"error": ...}: it must not cost the contract line."""
+    import datetime
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    dist.monitored_barrier(group=host_group, timeout=datetime.timedelta(minutes=30))
+    res = None
+    if rank == 0:
+        try:
+            res = fn()
+        except Exception as e:  # noqa: BLE001
+            res = {"error": repr(e)}
+    dist.monitored_barrier(group=host_group, timeout=datetime.timedelta(minutes=30))
+    return res
+
+
+DNA_LETTERS = np.frombuffer(b"ACTG", dtype=np.uint8)  # the reference's 2-bit code (include/nucleotide_decomposer.h): (c >> 1) & 3
+
+
+def dna_group_codes(torch, group, seq_len):
+    """The 2-bit codes of the 64 sequences of bin group `group` (bins 64*group .. 64*group+63), generated on the device from a
+    seed that depends on the group only — every rank of every N sees the same sequences."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(0x5EED0000 + group)
+    return torch.randint(0, 4, (64, seq_len), generator=g, device="cuda", dtype=torch.int64)
+
+
+def dna_canonical_kmers(torch, codes, k):
+    """Canonical k-mer values (min of forward and reverse complement, complement = code ^ 2) of every window of every row."""
+    n = codes.shape[1] - k + 1
+    fwd = torch.zeros((codes.shape[0], n), dtype=torch.int64, device=codes.device)
+    rc = torch.zeros_like(fwd)
+    for j in range(k):
+        w = codes[:, j:j + n]
+        fwd |= w << (2 * (k - 1 - j))
+        rc |= (w ^ 2) << (2 * j)
+    return torch.minimum(fwd, rc)
+
+
+def dna_build_shard(capi, torch, bins_total, rows, h, k, seq_len, r, R):
+    """Column shard r of R of the DNA index on the current device: bin b holds the canonical k-mers of sequence b."""
+    ix = capi.Index.create_ibf(bins_total, rows, h, shard_rank=r, n_shards=R)
+    w0, nw = int(ix.info.shard_word0), ix.shard_words
+    stream = torch.cuda.current_stream().cuda_stream
+    for g in range(w0, w0 + nw):
+        codes = dna_group_codes(torch, g, seq_len)
+        vals = dna_canonical_kmers(torch, codes, k).reshape(-1)
+        bins_of = (g * 64 + torch.arange(64, device="cuda", dtype=torch.int32)).repeat_interleave(seq_len - k + 1)
+        ix.emplace_device(vals.data_ptr(), bins_of.data_ptr(), vals.numel(), stream)
+        torch.cuda.synchronize()
+    return ix
+
+
+def dna_motifs(rng, windows, n_motifs):
+    """The motif generator of tests/perf_config4_queries.py: 24-32 nt windows of the indexed sequences with up to two positions
+    turned into a wildcard, a class or an optional residue.  windows: uint8 letters [n_motifs, 32]."""
+    motifs = []
+    for i in range(n_motifs):
+        L = int(rng.integers(24, 33))
+        w = list(windows[i, :L].tobytes().decode())
+        for p in rng.choice(np.arange(4, L - 4), size=int(rng.integers(0, 3)), replace=False):
+            p = int(p)
+            r = rng.random()
+            if r < 0.4:
+                w[p] = "."
+            elif r < 0.8:
+                w[p] = "[" + "".join(sorted(set(w[p] + "ACGT"[int(rng.integers(0, 4))]))) + "]"
+            else:
+                w[p] = w[p] + "?"
+        motifs.append("".join(w))
+    return motifs
+
+
+def dna_batch_8192(capi, torch, dist, args, rank, world):
+    """BASELINE configs[3]: the 8192-bin DNA IBF (62.5 M rows, h = 3: 64 GB) cut into N column shards, k = 16, and a batch of
+    10 000 motifs in ONE call per rank (every rank expands the batch; the path's only exchange is the all-gather of the final
+    masks over RCCL — tetrex_amd/dist.py; shards are disjoint columns, so the gather IS the OR-reduce).  Every bin holds the
+    canonical 16-mers of a random 100 kb sequence (generated and inserted on the device); a motif is a window of one bin's
+    sequence (its home) with a few degenerate positions, so it must be found there (checked on all motifs), and the masks of a
+    64-bin column are compared with the CPU oracle, whose matrix is built on the host from the same sequences by the oracle's
+    own encoder.  This leg is strong-scaled whatever --scaling says (the index is fixed).  Reference seam:
+    include/query.h:250-290,329-346 (run_collection / run_multiple_queries)."""
+    from tetrex_amd.dist import gather_final_masks
+    bins_total, h, k, seq_len = 8192, 3, 16, args.dna_seq_len
+    rows, n_motifs = args.dna_rows, args.dna_motifs
+    if 128 % world:
+        return {"skipped": "%d ranks do not divide the 128 mask words" % world}, None
+    t0 = time.perf_counter()
+    rng = np.random.default_rng(4)
+    home = rng.integers(0, bins_total, size=n_motifs)
+    at = rng.integers(0, seq_len - 32, size=n_motifs)
+    windows = np.zeros((n_motifs, 32), dtype=np.uint8)
+    check_word = 77  # the mask column the CPU oracle rebuilds (at N > 1 it is not rank 0's: the comparison crosses the gather)
+    check_codes = None
+    for g in range(bins_total // 64):  # the motifs' windows: every rank regenerates every group's sequences (milliseconds on the device)
+        sel = np.nonzero(home // 64 == g)[0]
+        if sel.size or (g == check_word and rank == 0):
+            codes = dna_group_codes(torch, g, seq_len)
+            if sel.size:
+                idx = torch.from_numpy(at[sel]).cuda()[:, None] + torch.arange(32, device="cuda")[None, :]
+                windows[sel] = DNA_LETTERS[codes[torch.from_numpy(home[sel] % 64).cuda()[:, None], idx].cpu().numpy()]
+            if g == check_word and rank == 0:
+                check_codes = codes.cpu().numpy()
+    ix = dna_build_shard(capi, torch, bins_total, rows, h, k, seq_len, rank, world)
+    w0, nw = int(ix.info.shard_word0), ix.shard_words
+    build_s = time.perf_counter() - t0
+    motifs = dna_motifs(rng, windows, n_motifs)
+    err = None
+    masks = status = stats = None
+    runs = []
+    try:
+        ix.query_masks(motifs[:200], True, k)  # warm: arena, staging sets
+        if world > 1:
+            dist.barrier()
+        for _ in range(3 if world == 1 else 1):
+            ta = time.perf_counter()
+            m_, s_, st_ = ix.query_masks(motifs, True, k)
+            runs.append(time.perf_counter() - ta)
+            if masks is None or runs[-1] <= min(runs):
+                masks, status, stats = m_, s_, st_
+    except Exception as e:  # noqa: BLE001 - reported in the line
+        err = repr(e)
+        if world == 1:
+            ix.free()
+            return {"error": err}, None
+    local_s = min(runs) if runs else 0.0
+    total, gather_s, full = local_s, 0.0, masks
+    if world > 1:
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=args.coll_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            ix.free()
+            return {"error": err or "another rank failed"}, None
+        tg = time.perf_counter()
+        loc = torch.from_numpy(masks.view(np.int64)).to(args.coll_device)
+        full = gather_final_masks(loc, 128)
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg
+        t = torch.tensor([local_s + gather_s], dtype=torch.float64, device=args.coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+        full = full.cpu().numpy().view(np.uint64)
+    device_bytes = int(ix.info.device_bytes)
+    ix.free()
+    out = {"workload": "BASELINE configs[3]: %d DNA motifs (k = %d) in one call on the 8192-bin x %d-row IBF (h = %d), %d column shard(s)"
+                       % (n_motifs, k, rows, h, world),
+           "k": k, "motifs": n_motifs, "seconds": total, "queries_per_s": n_motifs / total, "gather_seconds": gather_s,
+           "timed_runs_seconds": runs, "failed": int(sum(1 for x in status if x)), "refused_fraction": float(sum(1 for x in status if x)) / n_motifs,
+           **stats, "index_build_s": round(build_s, 1), "matrix_bytes_per_gpu": device_bytes, "scaling": "strong (fixed index)",
+           **({"collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                              "op": "all_gather of the final masks (%d x %d words per rank)" % (n_motifs, nw)}} if world > 1 else {})}
+    if rank == 0:
+        ok_q = np.array([s == 0 for s in status])
+        found = (full[np.arange(n_motifs), home >> 6] >> (home & 63).astype(np.uint64)) & np.uint64(1)
+        if not bool(found[ok_q].all()):
+            raise SystemExit("bench: a DNA motif lost the bin it was cut from")
+        out["motifs_found_in_their_home_bin"] = int(ok_q.sum())
+        out["mean_candidate_bins"] = float(np.unpackbits(full.view(np.uint8), axis=1).sum(axis=1).mean())
+        if not args.no_cpu:
+            out["cpu_oracle"] = dna_column_check(check_codes, check_word, rows, h, k, motifs, home, status, full, args.cpu_query_seconds)
+    return out, {"motifs": motifs, "full": full, "shape": (bins_total, rows, h, k, seq_len)}
+
+
+def dna_column_check(codes, word, rows, h, k, motifs, home, status, full, budget_s):
+    """Word `word` of the gathered masks against the CPU oracle on that 64-bin column: the oracle's own 64-bin IBF of the same
+    rows (bin b of it = bin 64*word + b of the index), filled by the oracle's encoder from the sequences' letters.  All motifs
+    cut from those bins first, then others until the budget is spent."""
+    import oracle as O
+    ox = O.Index.ibf(64, rows, h, dna=True, k=k)
+    for b in range(64):
+        ox.emplace(O.decompose(DNA_LETTERS[codes[b]].tobytes().decode(), k, dna=True), b)
+    order = [i for i in range(len(motifs)) if home[i] >> 6 == word] + [i for i in range(len(motifs)) if home[i] >> 6 != word]
+    own_total = sum(1 for i in order if home[i] >> 6 == word and not status[i])
+    compared, own, t0 = 0, 0, time.perf_counter()
+    for i in order:
+        if status[i]:
+            continue
+        want = ox.expected_mask(motifs[i])[0]
+        if int(want[0]) != int(full[i, word]):
+            raise SystemExit("bench: mask column %d of DNA motif %r differs from the CPU oracle" % (word, motifs[i]))
+        compared += 1
+        own += int(home[i] >> 6 == word)
+        if time.perf_counter() - t0 > budget_s / 2 and own >= own_total:
+            break
+    dt = time.perf_counter() - t0
+    return {"masks_compared": compared, "of_which_cut_from_the_column": own, "column_word": word, "seconds": dt,
+            "queries_per_s_on_a_64_bin_column": compared / dt if dt > 0 else None,
+            "sample": "mask word %d (64 of the 8192 bins) of the gathered masks; oracle matrix rebuilt on the host from the sequences" % word}
+
+
+def hibf_descent(capi, torch, dist, args, rank, world, user_bins=65536, children=256, queries=False):
     """Third figure (BASELINE configs[4] shape, SURVEY.md §8d S-HIBF-65536): k-mers/s of the HIBF
     descent — root IBF of 256 merged bins over 256 child IBFs of 256 user bins each, h = 2, sizes from
     compute_bitcount at fpr 0.05, values from a 10-letter k = 5 universe (10^5 k-mers).  Every IBF is
@@ -777,7 +980,81 @@ def hibf_descent(capi, torch, args, rank, world, user_bins=65536, children=256):
            "kmers": n, "kmers_per_s_per_gpu": n / dt, "seconds_per_batch": dt, "mask_bytes_per_kmer": W * 8,
            "mask_write_GBps": n * W * 8 / dt / 1e9, "column_shards": world, "tree_bytes": int(ix.info.device_bytes),
            "index_build_s": round(build_s, 1), "checked_present_values": int(mine.sum())}
+    if queries and not args.no_queries:
+        try:
+            out["query_batch"] = hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 - reported in the line; the ranks stay in step (see hibf_query_batch)
+            out["query_batch"] = {"error": repr(e)}
     ix.free()
+    return out
+
+
+def hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world):
+    """BASELINE configs[4]: whole queries on the 65536-user-bin HIBF — Murphy-reduced alphabet, k = 5, 8 KiB masks — the tree
+    replicated, its user-bin columns sharded over the ranks (every rank descends only into sub-trees of its own columns), the
+    final masks all-gathered.  200 PROSITE-style motifs (the batch of tests/perf_config5_queries.py); a sample of the gathered
+    masks is compared with the CPU oracle's HIBF (membership_for restated, oracle/txo_ibf.hpp) built from the same IBFs."""
+    from motifs import random_prosite_motifs
+    from tetrex_amd.dist import gather_final_masks
+    k, reduction = 5, 1
+    motifs = random_prosite_motifs(200, 6)
+    err, masks, status, stats, runs = None, None, None, None, []
+    try:
+        ix.query_masks(motifs[:5], False, k, reduction)
+        if world > 1:
+            dist.barrier()
+        for _ in range(3 if world == 1 else 1):
+            t0 = time.perf_counter()
+            m_, s_, st_ = ix.query_masks(motifs, False, k, reduction)
+            runs.append(time.perf_counter() - t0)
+            if masks is None or runs[-1] <= min(runs):
+                masks, status, stats = m_, s_, st_
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+        if world == 1:
+            return {"error": err}
+    total, gather_s, full = (min(runs) if runs else 0.0), 0.0, masks
+    if world > 1:
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=args.coll_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            return {"error": err or "another rank failed"}
+        tg = time.perf_counter()
+        full = gather_final_masks(torch.from_numpy(masks.view(np.int64)).to(args.coll_device), int(ix.info.mask_words))
+        torch.cuda.synchronize()
+        gather_s = time.perf_counter() - tg
+        t = torch.tensor([total + gather_s], dtype=torch.float64, device=args.coll_device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        total = float(t.item())
+        full = full.cpu().numpy().view(np.uint64)
+    out = {"workload": "BASELINE configs[4]: %d PROSITE-style motifs, Murphy alphabet, k = %d, on S-HIBF-%d (%d column shard(s))" % (len(motifs), k, user_bins, world),
+           "k": k, "motifs": len(motifs), "seconds": total, "queries_per_s": len(motifs) / total, "gather_seconds": gather_s, "timed_runs_seconds": runs,
+           "refused_fraction": float(sum(1 for x in status if x)) / len(motifs), **stats,
+           **({"collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                              "op": "all_gather of the final masks (%d x %d words per rank)" % (len(motifs), ix.shard_words)}} if world > 1 else {})}
+    if rank == 0:
+        out["mean_candidate_bins"] = float(np.unpackbits(full.view(np.uint8), axis=1).sum(axis=1).mean())
+        if not args.no_cpu:
+            import oracle as O
+            ox = O.Index.hibf(user_bins, dna=False, k=k, reduction=reduction)
+            for d in descs:
+                ox.add_ibf(d["bins"], d["bin_size"], d["hash_funs"], d["next_ibf_id"], d["tb_to_user"], words=d["words"])
+            compared, t0 = 0, time.perf_counter()
+            for i, rx in enumerate(motifs):
+                if status[i]:
+                    continue
+                try:
+                    want = ox.expected_mask(rx)[0]
+                except Exception:  # noqa: BLE001 - a motif the reference path cannot search either
+                    continue
+                if not np.array_equal(want, full[i]):
+                    raise SystemExit("bench: the candidate-bin mask of %r on S-HIBF-%d differs from the CPU oracle" % (rx, user_bins))
+                compared += 1
+                if time.perf_counter() - t0 > args.cpu_query_seconds / 2:
+                    break
+            out["cpu_oracle"] = {"masks_compared": compared, "seconds": time.perf_counter() - t0}
     return out
 
 
@@ -807,10 +1084,20 @@ def main():
                     help="weak: 1024 bins per GPU (index of 1024*N bins), value in shard-probes/s; strong: the fixed 8192-bin x 62.5 M-row "
                          "index cut into N column shards, value in whole-index probes/s")
     ap.add_argument("--no-hbm-leg", action="store_true", help="skip the out-of-cache roofline_hbm leg (8 GB matrix)")
+    ap.add_argument("--no-dna-batch", action="store_true", help="skip end_to_end.dna_batch_8192 (BASELINE configs[3]: 10 000 DNA motifs on the 8192-bin index)")
+    ap.add_argument("--dna-rows", type=int, default=62500000, help="rows of the 8192-bin DNA index (62.5 M = 64 GB over all shards)")
+    ap.add_argument("--dna-motifs", type=int, default=10000)
+    ap.add_argument("--dna-seq-len", type=int, default=100000, help="length of the sequence every bin of the DNA index holds")
+    ap.add_argument("--rehearse-one-process", action="store_true", help="with --rehearse-single-device: also rehearse the one-process legs (all shards on cuda:0)")
     ap.add_argument("--rehearse-single-device", action="store_true",
                     help="N>1 rehearsal on a one-GPU box: every rank uses cuda:0 and the collectives run over gloo on host "
                          "tensors (RCCL refuses two ranks on one device); numbers from such a run are not bench results")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves, as a CHILD process (never an exec: nothing
+        # here may replace a process), before anything in this one touches a GPU; relay its output and its exit code
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.distributed as dist
@@ -819,8 +1106,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (one rank per GPU: launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher at all)" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.rehearse_single_device:
@@ -830,12 +1117,14 @@ def main():
     if world > 1:
         # the ranks of a node share its CPUs: each rank's expansion threads = its share (at most 16, at least 2)
         cpus = usable_cpus()
-        os.environ.setdefault("TETREX_THREADS", str(max(2, min(16, cpus // world))))
+        os.environ.setdefault("TETREX_THREADS", str(max(2, min(64, cpus // world))))
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse_single_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        import datetime
+        host_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(minutes=30))  # host-only waits (rank0_alone)
 
     from tetrex_amd import capi
 
@@ -970,15 +1259,29 @@ def main():
                 out["roofline_hbm"] = leg
         except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
             out["roofline_hbm"] = {"error": repr(e)}
-    if not args.no_hibf and not strong:
+    e2e = out.setdefault("end_to_end", {}) if not args.no_queries else {}
+    dna_ctx = None
+    if not args.no_queries and not args.no_dna_batch:
+        # BASELINE configs[3] in its own shape, at every N and in both scaling modes: 10 000 DNA motifs on the fixed 8192-bin index
         try:
-            out["hibf"] = hibf_descent(capi, torch, args, rank, world)
-            # the Swissprot-HIBF shape (BASELINE configs[2]): 1024 user bins, 16 children of 64 bins
-            out["hibf_1024"] = hibf_descent(capi, torch, args, rank, world, user_bins=1024, children=16)
+            e2e["dna_batch_8192"], dna_ctx = dna_batch_8192(capi, torch, dist, args, rank, world)
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line (a failure BEFORE the leg's collectives
+            e2e["dna_batch_8192"] = {"error": repr(e)}  # would leave the other ranks waiting: the leg catches what can fail there itself)
+    if not args.no_hibf:
+        try:
+            # BASELINE configs[4]: descent rate and (queries=True) the motif batch with its gather, at every N and in both modes
+            out["hibf"] = hibf_descent(capi, torch, dist, args, rank, world, queries=True)
+            if not strong:  # the Swissprot-HIBF shape (BASELINE configs[2]): 1024 user bins, 16 children of 64 bins
+                out["hibf_1024"] = hibf_descent(capi, torch, dist, args, rank, world, user_bins=1024, children=16)
+        except SystemExit:
+            raise
         except Exception as e:  # noqa: BLE001 - an extra leg must not cost the contract line
             out.setdefault("hibf", {"error": repr(e)})
-            out.setdefault("hibf_1024", {"error": repr(e)})
-        if world == 1 and rank == 0:
+            if not strong:
+                out.setdefault("hibf_1024", {"error": repr(e)})
+        if world == 1 and rank == 0 and not strong:
             # ... and a GENERAL tree as seqan::hibf's layout shapes the reference's index (include/index_hibf.h:114-129): 65 536 user
             # bins scattered over IBFs of at most 256 technical bins, split bins, user bins next to merged bins (tests/helpers.py
             # layout_hibf).  Plain probes (user-bin order: descent kernels) and a 200-motif batch (session in layout order, against
@@ -990,17 +1293,34 @@ def main():
                 raise
             except Exception as e:  # noqa: BLE001
                 out["hibf_irregular"] = {"error": repr(e)}
-    if world > 1 and not strong and not args.no_queries and not args.rehearse_single_device:
+    if world > 1 and not args.no_queries and (not args.rehearse_single_device or args.rehearse_one_process):
         # both deployments of the sharded index are measured at first contact with a multi-GPU node: after the one-process-
-        # per-GPU legs above, rank 0 alone drives all N devices; everybody else waits (a failure must not cost the line)
-        dist.barrier()
-        if rank == 0:
-            try:
-                out.setdefault("end_to_end", {})["one_process_n_devices"] = one_process_n_devices(
-                    capi, torch, args, world, bins_total, m, h, value_bits, max(2, args.kmer_bits // 5))
-            except Exception as e:  # noqa: BLE001
-                out.setdefault("end_to_end", {})["one_process_n_devices"] = {"error": repr(e)}
-        dist.barrier()
+        # per-GPU legs above, rank 0 alone drives all N devices; everybody else waits on the host (a failure must not cost the line)
+        from motifs import random_prosite_motifs
+        devs = 1 if args.rehearse_single_device else world  # (rehearsal: txq_init with one device deals every shard onto it)
+        kq = max(2, args.kmer_bits // 5)
+        if not strong:
+            def weak_leg():
+                res, _ = one_process_n_devices(capi, torch, devs, world, lambda r: build_index(capi, torch, bins_total, bins_local, m, h, r, world, args.per_bin, value_bits),
+                                               random_prosite_motifs(args.motifs, 6), random_prosite_motifs(args.motifs, 8), False, kq,
+                                               "the %d-bin index of this run, %d PROSITE-style motifs" % (bins_total, args.motifs))
+                return res
+            res = rank0_alone(torch, dist, host_group, rank, weak_leg)
+            if rank == 0:
+                e2e["one_process_n_devices"] = res
+        if not args.no_dna_batch:
+            def dna_leg():
+                bt, rows_, h_, k_, sl = dna_ctx["shape"]
+                res, joined = one_process_n_devices(capi, torch, devs, world, lambda r: dna_build_shard(capi, torch, bt, rows_, h_, k_, sl, r, world),
+                                                    dna_ctx["motifs"], dna_ctx["motifs"][:200], True, k_,
+                                                    "BASELINE configs[3]: %d DNA motifs on the 8192-bin index" % len(dna_ctx["motifs"]))
+                if not np.array_equal(joined, dna_ctx["full"]):
+                    raise RuntimeError("the host-side join gives other masks than the all-gather of the one-process-per-GPU run")
+                res["masks_equal_the_gathered_run"] = True
+                return res
+            res = rank0_alone(torch, dist, host_group, rank, dna_leg if dna_ctx is not None else (lambda: {"skipped": "the DNA leg failed"}))
+            if rank == 0 and isinstance(e2e.get("dna_batch_8192"), dict):
+                e2e["dna_batch_8192"]["one_process_n_devices"] = res
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:

@@ -623,3 +623,35 @@ def test_tracked_blocks_on_regular_hibfs(capi, oracle, monkeypatch, tree):
                 hits += int(want.any())
     assert hits >= 5
     ix.free()
+
+
+def test_emplace_after_a_dense_batch_drops_the_table_of_kmer_masks(capi, oracle, monkeypatch):
+    """ADVICE r3: the index caches bulk_contains of every packed k-mer value (Index::kmer_table, built by the first dense
+    batch); txq_emplace_device changes the bits under it.  Half the values, a wildcard batch (table built), the other half, the
+    batch again: both runs must equal the oracle on the bits of their time."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
+    bins, m, h, k = 200, 4001, 3, 4
+    rng = np.random.default_rng(17)
+    values = rng.integers(0, 1 << 20, size=60000, dtype=np.uint64)
+    bins_of = rng.integers(0, bins, size=values.size, dtype=np.uint32)
+    qs = ["L..A", "A.C.E", "W..[LIVM]D", "K[RK].DE", "C..C.", "[ST].[RK].A", "LM.{1,3}A[DE]", "A.C.E.GH"] * 3
+    ox = oracle.Index.ibf(bins, m, h, dna=False, k=k)
+    ix = capi.Index.create_ibf(bins, m, h)
+    half = values.size // 2
+    for lo, hi in ((0, half), (half, values.size)):
+        ox.emplace_pairs(values[lo:hi], bins_of[lo:hi])
+        dv, db = capi.DeviceBuffer.from_numpy(values[lo:hi]), capi.DeviceBuffer.from_numpy(bins_of[lo:hi])
+        ix.emplace_device(dv.ptr, db.ptr, hi - lo)
+        capi.synchronize()
+        got, status, stats = ix.query_masks(qs, False, k)
+        assert stats["dense_ops"] > 0
+        informative = 0
+        for q, g, st in zip(qs, got, status):
+            assert st == 0
+            want, _ = ox.expected_mask(q)
+            assert np.array_equal(g, want), (q, lo)
+            informative += int(want.any())
+        assert informative >= 9
+        assert np.array_equal(ix.download_words_rows(m), ox.words())
+    ix.free()

@@ -73,21 +73,28 @@ def test_two_shards_on_one_gpu_gather_to_the_oracle_masks():
     assert res == [(0, True), (1, True)]
 
 
-def test_bench_two_rank_rehearsal_prints_one_contract_line():
-    """bench.py's N>1 path (shard build per rank, barriers, max-over-ranks timing, final-mask
-    all-gather) rehearsed with two ranks on the one GPU of this box (gloo collectives; RCCL needs one
-    device per rank).  Checks the JSON contract, not the numbers."""
+SMALL_DNA = ["--dna-rows", "200003", "--dna-motifs", "300", "--dna-seq-len", "3000"]
+
+
+def _contract_line(res):
     import json
-    import subprocess
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--kmers", str(1 << 18), "--per-bin", "2000", "--motifs", "40", "--hibf-kmers", str(1 << 16), "--rehearse-single-device"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert res.returncode == 0, res.stderr[-2000:]
+    assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_bench_two_rank_rehearsal_prints_one_contract_line():
+    """bench.py's N>1 path (shard build per rank, barriers, max-over-ranks timing, final-mask all-gathers of the protein,
+    DNA (BASELINE configs[3]) and HIBF (configs[4]) query legs, and the one-process legs) rehearsed with two ranks on the one
+    GPU of this box (gloo collectives; RCCL needs one device per rank) — started WITHOUT a launcher: `python bench.py --gpus 2`
+    starts its ranks itself as a child process.  Checks the JSON contract, not the numbers."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--kmers", str(1 << 18), "--per-bin", "2000", "--motifs", "40", "--hibf-kmers", str(1 << 16), "--cpu-query-seconds", "2",
+           "--rehearse-single-device", "--rehearse-one-process"] + SMALL_DNA
+    out = _contract_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
                 "dtype", "data", "config", "roofline"):
         assert key in out, key
@@ -95,32 +102,56 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     # weak mode counts probes of ONE 1024-bin shard; the whole-index rate is spelled out beside it
     assert out["unit"] == "shard-probes/s" and abs(out["value"] - 2 * out["config"]["whole_index_probes_per_s"]) < 1e-6 * out["value"]
     assert out["collective"]["ranks"] == 2 and out["collective"]["backend"] == "gloo"
-    assert "error" not in out["end_to_end"], out["end_to_end"]
-    assert out["end_to_end"]["batch"]["failed"] == 0 and out["end_to_end"]["collective"]["ranks"] == 2
-    assert out["end_to_end"]["batch"]["gather_seconds"] > 0
+    e2e = out["end_to_end"]
+    assert "error" not in e2e, e2e
+    assert e2e["batch"]["failed"] == 0 and e2e["collective"]["ranks"] == 2
+    assert e2e["batch"]["gather_seconds"] > 0
     assert "error" not in out["hibf"], out["hibf"]
     assert out["hibf"]["column_shards"] == 2 and out["hibf"]["mask_bytes_per_kmer"] == 4096
+    _check_wide_legs(out, 2)
+    one = e2e["one_process_n_devices"]
+    assert "error" not in one and one["mask_words"] == 32 and one["queries_per_s"] > 0, one
+
+
+def _check_wide_legs(out, ranks):
+    dna = out["end_to_end"]["dna_batch_8192"]  # BASELINE configs[3]: DNA motifs on the fixed 8192-bin index, masks gathered
+    assert "error" not in dna and "skipped" not in dna, dna
+    assert dna["collective"]["ranks"] == ranks and dna["gather_seconds"] > 0 and dna["failed"] == 0 and dna["k"] == 16
+    assert dna["motifs_found_in_their_home_bin"] == dna["motifs"] == 300
+    assert dna["cpu_oracle"]["masks_compared"] >= dna["cpu_oracle"]["of_which_cut_from_the_column"] > 0
+    one = dna["one_process_n_devices"]
+    assert "error" not in one and one["masks_equal_the_gathered_run"] is True and one["mask_words"] == 128, one
+    hq = out["hibf"]["query_batch"]  # BASELINE configs[4]: Murphy k = 5 motifs on S-HIBF-65536, masks gathered
+    assert "error" not in hq, hq
+    assert hq["collective"]["ranks"] == ranks and hq["gather_seconds"] > 0 and hq["k"] == 5 and hq["cpu_oracle"]["masks_compared"] > 0
 
 
 def test_bench_strong_scaling_rehearsal():
     """--scaling strong: the fixed 8192-bin index cut into N column shards (here N = 2 on one GPU, with fewer rows than
     the real 62.5 M so that the rehearsal builds in seconds): value counts probes of the WHOLE index, bytes_per_probe is
-    the per-GPU share."""
-    import json
+    the per-GPU share; the line carries the configs[3] DNA batch and the configs[4] HIBF batch with their gathers.  Started
+    through the external launcher, as the driver does."""
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--scaling", "strong", "--rows", "2000003", "--per-bin", "500", "--kmers", str(1 << 18), "--rehearse-single-device"]
-    res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
-    assert res.returncode == 0, res.stderr[-2000:]
-    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][0])
+           "--scaling", "strong", "--rows", "2000003", "--per-bin", "500", "--kmers", str(1 << 18), "--hibf-kmers", str(1 << 16),
+           "--cpu-query-seconds", "2", "--rehearse-single-device", "--rehearse-one-process"] + SMALL_DNA
+    out = _contract_line(subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT))
     assert out["scaling"] == "strong" and out["unit"] == "probes/s" and out["n_gpus"] == 2
     cfg = out["config"]
     assert cfg["bins_total"] == 8192 and cfg["bins_per_gpu"] == 4096 and cfg["mask_words"] == 64 and cfg["workload"] == "S-IBF-8192"
     assert out["roofline"]["bytes_per_probe"] == 3 * 64 * 8 + 64 * 8 + 8
     assert abs(out["value"] - cfg["whole_index_probes_per_s"]) < 1e-6 * out["value"]
-    assert "end_to_end" not in out and "hibf" not in out
+    assert "batch" not in out["end_to_end"] and "hibf_1024" not in out
+    _check_wide_legs(out, 2)
+
+
+def test_bench_refuses_a_rank_count_that_is_not_gpus():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert res.returncode != 0 and "WORLD_SIZE=3" in res.stderr
 
 
 def test_bench_single_gpu_contract_line_with_all_legs():
@@ -129,7 +160,7 @@ def test_bench_single_gpu_contract_line_with_all_legs():
     import json
     import subprocess
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--kmers", str(1 << 18), "--per-bin", "2000",
-           "--motifs", "40", "--hibf-kmers", str(1 << 16), "--cpu-query-seconds", "1"]
+           "--motifs", "40", "--hibf-kmers", str(1 << 16), "--cpu-query-seconds", "1"] + SMALL_DNA
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
@@ -151,3 +182,6 @@ def test_bench_single_gpu_contract_line_with_all_legs():
     assert "error" not in hb and hb["masks_identical"] is True and hb["failed"] == 0 and hb["queries_per_s"] > 0
     assert "error" not in out["hibf"] and out["hibf"]["checked_present_values"] > 0
     assert "error" not in out["hibf_1024"] and out["hibf_1024"]["user_bins"] == 1024
+    dna = e2e["dna_batch_8192"]
+    assert "error" not in dna and dna["failed"] == 0 and dna["motifs_found_in_their_home_bin"] == 300 and dna["cpu_oracle"]["masks_compared"] > 0
+    assert "error" not in out["hibf"]["query_batch"] and out["hibf"]["query_batch"]["cpu_oracle"]["masks_compared"] > 0

@@ -69,17 +69,27 @@ def test_hibf_trees_are_validated(capi):
 
 def test_session_feedback_queries_are_bounds_checked(capi):
     ix = capi.Index.upload_ibf(64, 8, 2, np.zeros(8, dtype=np.uint64))
-    sess = ix.session(2)
     blob = make_blob(np.zeros(0, dtype=np.uint64), [(4, [(0xFFFFFFFF, 3, 1, 0)]), (3, [])])
-    assert list(sess.stage(blob, [0, 0], [3, 1])) == [True, True]
-    for qp, qs in (([2], [0]), ([0], [4]), ([1], [3])):
+    empty = make_blob(np.zeros(0, dtype=np.uint64), [(4, []), (3, [])])
+    for qp, qs, bad in (([2], [0], empty), ([0], [4], empty), ([1], [3], empty),
+                        ([], [], make_blob(np.zeros(0, dtype=np.uint64), [(3, [])]))):  # (the last: wrong program count for this session)
+        sess = ix.session(2)
+        assert list(sess.stage(blob, [0, 0], [3, 1])) == [True, True]
         with pytest.raises(capi.TxqError):
-            sess.stage(make_blob(np.zeros(0, dtype=np.uint64), [(4, []), (3, [])]), qp, qs)
-    with pytest.raises(capi.TxqError):  # wrong program count for this session
-        sess.stage(make_blob(np.zeros(0, dtype=np.uint64), [(3, [])]))
+            sess.stage(bad, qp, qs)
+        # a session with a failed stage takes no further stage and hands out no masks (half-executed state must
+        # not come back as plausible masks with TXQ_OK)
+        with pytest.raises(capi.TxqError) as e:
+            sess.stage(empty)
+        assert e.value.code == -4
+        with pytest.raises(capi.TxqError) as e:
+            sess.end()
+        assert e.value.code == -4
+    sess = ix.session(2)
+    assert list(sess.stage(blob, [0, 0], [3, 1])) == [True, True]
     out = sess.end()
     assert out.shape == (2, 1) and not out.any()
-    ix.free()
+    ix.free()  # (every failed session was closed by its end(): the index has no session left)
 
 
 def test_emplace_and_download_guards(capi):
@@ -92,6 +102,17 @@ def test_emplace_and_download_guards(capi):
     ix.emplace_device(vals.ptr, bins.ptr, 10)
     capi.synchronize()
     assert not ix.download_words_rows(50).any()
+    ix.free()
+    # the bits of an index cannot change under an open session
+    ix = capi.Index.create_ibf(100, 50, 3)
+    sess = ix.session(1)
+    with pytest.raises(capi.TxqError) as e:
+        ix.emplace_device(vals.ptr, bins.ptr, 10)
+    assert e.value.code == -4
+    capi.check(capi.lib().txq_session_end(sess._h, None))
+    sess._h = None
+    ix.emplace_device(vals.ptr, bins.ptr, 10)
+    capi.synchronize()
     ix.free()
     hx = capi.Index.upload_hibf(4, [dict(bins=4, bin_size=16, hash_funs=2, words=random_words(4, 16, 0.5, 2),
                                           next_ibf_id=np.zeros(4, dtype=np.uint64), tb_to_user=np.arange(4, dtype=np.uint64))])

@@ -8,7 +8,7 @@ kernels, the path the earlier rounds pinned)."""
 import numpy as np
 import pytest
 
-from helpers import layout_hibf, random_hibf
+from helpers import layout_hibf, random_hibf, MERGED
 
 pytestmark = pytest.mark.gpu
 
@@ -112,4 +112,28 @@ def test_a_65536_bin_three_level_tree(capi, oracle, monkeypatch):
             assert np.array_equal(g, want), q
             hits += int(want.any())
     assert hits >= 10
+    ix.free()
+
+
+def test_a_five_level_tree_is_not_taken_in_layout_order(capi, oracle, monkeypatch):
+    """The fused layout-order steps follow at most three ancestors (txq_internal.hpp kMaxVDepth): a deeper tree must not get a
+    layout order at upload — its sessions run in user-bin order through the descent, and still equal the oracle."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    monkeypatch.setenv("TXQ_KMER_TABLE_MB", "0")
+    ox, descs, values = random_hibf(oracle, 77, user_bins=300, levels=5, n_values=40)
+    depth = {0: 1}
+    for i, d in enumerate(descs):  # (parents come before their children in random_hibf's numbering)
+        for nxt, ub in zip(d["next_ibf_id"], d["tb_to_user"]):
+            if int(ub) == MERGED:
+                depth[int(nxt)] = depth[i] + 1
+    assert max(depth.values()) == 5
+    ix = capi.Index.upload_hibf(300, descs)
+    assert ix.supports_dense() != 2
+    qs = _queries(values)
+    got, status, stats = ix.query_masks(qs, False, 4)
+    for q, g, st in zip(qs, got, status):
+        assert st == 0, q
+        want, ost = ox.query(q, with_stats=True)
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
     ix.free()

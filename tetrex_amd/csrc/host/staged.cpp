@@ -70,8 +70,11 @@ int usable_cpus() {
     return n < 1 ? 1 : n;
 }
 
-// default: the CPUs this process may use, but at most 16 — one GPU's CPU share on a multi-GPU node
-// (override with StagedOptions::threads or the TETREX_THREADS environment variable)
+// default: this process's share of the CPUs it may use — all of them when it is alone on the node (the one-process
+// deployment drives every GPU itself), 1 / LOCAL_WORLD_SIZE of them when a launcher started one rank per GPU beside it
+// (torch.distributed.run and mpirun export the count) — at most 64: the expansion of 10 000 motifs stops gaining there
+// (profiles/r3_host_scaling_10k_motifs.txt: 16 threads 21 ms, 32 threads 14 ms).
+// Override with StagedOptions::threads or the TETREX_THREADS environment variable.
 int expansion_threads(const StagedOptions& opt, size_t n_queries) {
     int threads = opt.threads;
     if (threads <= 0) {
@@ -79,7 +82,11 @@ int expansion_threads(const StagedOptions& opt, size_t n_queries) {
     }
     if (threads <= 0) {
         threads = usable_cpus();
-        if (threads > 16) threads = 16;
+        int ranks = 1;
+        for (const char* name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS"})
+            if (const char* env = std::getenv(name)) { ranks = std::atoi(env); break; }
+        if (ranks > 1) threads = std::max(2, threads / ranks);
+        if (threads > 64) threads = 64;
     }
     if (threads < 1) threads = 1;
     if ((size_t)threads > n_queries) threads = n_queries ? (int)n_queries : 1;

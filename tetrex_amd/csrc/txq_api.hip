@@ -31,7 +31,11 @@ hipStream_t take_spare_stream(int device) {
 }
 
 static Knobs g_knobs;
-const Knobs& knobs() { return g_knobs; }
+static std::mutex g_knobs_mutex;
+Knobs knobs() {
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
+    return g_knobs;
+}
 void read_knobs() {
     auto flag = [](const char* name) { return std::getenv(name) != nullptr; };
     auto is = [](const char* name, char c) { const char* e = std::getenv(name); return e && e[0] == c; };
@@ -69,6 +73,7 @@ void read_knobs() {
     k.probe_blocks_per_cu = (int)std::max(1LL, num("TXQ_PROBE_BLOCKS_PER_CU", 256));
     k.probe_unroll = (int)num("TXQ_PROBE_UNROLL", 2);
     k.probe_nt = flag("TXQ_PROBE_NT");
+    std::lock_guard<std::mutex> lock(g_knobs_mutex);
     g_knobs = k;
 }
 
@@ -380,7 +385,7 @@ int txq_index_supports_dense(const txq_index* ix) {
     read_knobs();
     if (!ix || ix->ibf.empty() || ix->shard_words == 0) return 0;
     if (!ix->is_hibf) return (ix->ibf[0].bin_size >> 32) == 0 ? 2 : 0;
-    return index_fuses_tree_steps(*ix) || ix->layout_order() ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
+    return index_fuses_tree_steps(*ix, knobs()) || ix->layout_order(knobs()) ? 2 : 1;  // other HIBFs: steps run as k-mer batches through the descent
 }
 
 int txq_index_free(txq_index* ix) {
@@ -436,7 +441,7 @@ int txq_probe_device(txq_index* ix, const uint64_t* d_kmers, size_t n, uint64_t*
     if (!ix || (n && (!d_kmers || !d_masks))) return fail(TXQ_ERR_ARG, "null argument");
     if (n >> 32) return fail(TXQ_ERR_ARG, "at most 2^32-1 k-mers per call");
     hipStream_t s = (hipStream_t)stream;
-    if (ix->is_hibf) return hibf_probe(*ix, d_kmers, n, d_masks, d_alive, s);
+    if (ix->is_hibf) return hibf_probe(*ix, knobs(), d_kmers, n, d_masks, d_alive, s);
     hipError_t e = launch_probe(ix->ibf[0], d_kmers, n, d_masks, d_alive, s);
     if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
     return TXQ_OK;
@@ -521,6 +526,19 @@ int txq_emplace_device(txq_index* ix, const uint64_t* d_values, const uint32_t* 
     if (int rc = bind_index(ix)) return rc;
     if (!ix || (n && (!d_values || !d_bins_of))) return fail(TXQ_ERR_ARG, "null argument");
     if (ix->is_hibf) return fail(TXQ_ERR_ARG, "emplace is for flat IBFs");
+    if (ix->open_sessions > 0)
+        return fail(TXQ_ERR_STATE, "the index has %d open session(s): its bits cannot change under them (txq_session_end first)", ix->open_sessions);
+    {   // what was derived from the old bits goes: the table of all k-mers' masks (dense steps would read stale rows), the host's
+        // verdict on how states fare on the index (tag) stays — it is advisory
+        std::lock_guard<std::mutex> lock(ix->table_mutex);
+        if (ix->kmer_table) {
+            TXQ_HIP(hipDeviceSynchronize());  // (kernels of ended sessions may still be reading it)
+            (void)hipFree(ix->kmer_table);
+            ix->kmer_table = nullptr;
+            ix->kmer_table_bits = 0;
+        }
+        ix->kmer_table_refused = false;
+    }
     hipError_t e = launch_emplace(ix->ibf[0], d_values, d_bins_of, n, (hipStream_t)stream);
     if (e != hipSuccess) return fail_hip(e, "emplace kernel launch");
     return TXQ_OK;
@@ -599,7 +617,10 @@ int txq_session_end(txq_session* s, uint64_t* final_masks) {
     if (!s) return TXQ_OK;
     int rc = bind_index(s->ix);  // the calling thread may never have selected the device
     if (rc != TXQ_OK) { delete static_cast<Session*>(s); return rc; }
-    if (final_masks && s->n_programs && s->W) {
+    if (final_masks && s->failed) {
+        // a stage of this session failed: its slots hold half-executed state, there are no final masks to hand out
+        rc = fail(TXQ_ERR_STATE, "a stage of this session failed: it has no final masks");
+    } else if (final_masks && s->n_programs && s->W) {
         Index& ix = *s->ix;
         const size_t bytes = s->n_programs * (size_t)ix.shard_words * 8;  // (a layout-order session hands out user-bin masks too)
         rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);

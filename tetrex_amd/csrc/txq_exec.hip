@@ -1232,7 +1232,7 @@ struct BlobView {
     std::vector<uint8_t> tracked;    // TXQ_PROGRAM_TRACKED_BIT
 };
 
-static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, BlobView* out) {
+static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_programs, const Knobs& kn, BlobView* out) {
     if (bytes < sizeof(txq_blob_header)) return fail(TXQ_ERR_PROGRAM, "blob shorter than its header");
     if ((uintptr_t)blob % 8) return fail(TXQ_ERR_PROGRAM, "blob must be 8-byte aligned");
     const txq_blob_header* h1 = (const txq_blob_header*)blob;
@@ -1276,7 +1276,7 @@ static int validate_blob(const unsigned char* blob, size_t bytes, size_t n_progr
             P.A > (1u << P.bits) || (P.canonical && P.bits != 2))
             return fail(TXQ_ERR_PROGRAM, "dense parameters out of range (k %u, %u bits, alphabet %u)", P.k, P.bits, P.A);
         P.pos = P.k - 1;
-        P.nt = (uint32_t)knobs().dense_nt;
+        P.nt = (uint32_t)kn.dense_nt;
         uint64_t n = 1;
         P.pow_a[0] = 1;
         for (uint32_t j = 1; j <= P.pos; ++j) {
@@ -1475,7 +1475,7 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
     s->kn = knobs();
     ++ix.open_sessions;
     s->n_programs = n_programs;
-    s->vspace = ix.layout_order();  // a general HIBF: the session's masks are rows in layout order (txq_internal.hpp VChunk)
+    s->vspace = ix.layout_order(s->kn);  // a general HIBF: the session's masks are rows in layout order (txq_internal.hpp VChunk)
     s->W = s->vspace ? ix.v_words : (uint32_t)ix.shard_words;
     s->base.assign(2 * n_programs, nullptr);
     s->cap.assign(n_programs, 0);
@@ -1811,6 +1811,7 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uin
 static bool ensure_kmer_table(Index& ix, const Knobs& kn, const DenseParams& P, uint32_t W, hipStream_t st) {
     const uint32_t vb = P.bits * P.k;
     if (kn.kmer_table_mb <= 0 || vb == 0 || vb > 24 || W != ix.shard_words) return false;
+    std::lock_guard<std::mutex> lock(ix.table_mutex);  // two sessions of one index may arrive here at once: one builds, the other finds it
     if (ix.kmer_table) return ix.kmer_table_bits == vb;  // (one encoder per index; a session with another k gathers rows)
     const uint64_t n = 1ULL << vb, bytes = n * (uint64_t)W * 8;
     if (ix.kmer_table_refused || bytes > ((uint64_t)kn.kmer_table_mb << 20)) return false;
@@ -1825,7 +1826,10 @@ static bool ensure_kmer_table(Index& ix, const Knobs& kn, const DenseParams& P, 
     iota_kernel<<<(unsigned)std::min<uint64_t>((n + 255) / 256, 4096), 256, 0, st>>>(values, n);
     hipError_t e = hipSuccess;
     if (ix.is_hibf) {  // membership_for(., 1) of every value, in user-bin order: any tree, whatever its shape
-        if (hibf_probe(ix, values, n, table, nullptr, st) != TXQ_OK) e = hipErrorUnknown;
+        // the descent keeps its frontiers in the INDEX's scratch: a stage of this or another session that is still descending
+        // (hibf_probe on another stream) must have finished before this descent overwrites them — once per index
+        e = hipDeviceSynchronize();
+        if (e == hipSuccess && hibf_probe(ix, kn, values, n, table, nullptr, st) != TXQ_OK) e = hipErrorUnknown;
     } else e = launch_probe(ix.ibf[0], values, n, table, nullptr, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(values);
@@ -1846,7 +1850,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     const unsigned char* blob = (const unsigned char*)blob_v;
     BlobView bv;
     double t0 = now_s();
-    if (int rc = validate_blob(blob, bytes, s.n_programs, &bv)) return rc;
+    if (int rc = validate_blob(blob, bytes, s.n_programs, s.kn, &bv)) return rc;
     s.t_validate += now_s() - t0;
     t0 = now_s();
     ++s.n_stages;
@@ -1881,14 +1885,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     // Does this stage continue anything the previous stage — possibly still running — works on?  Programs with ops in both,
     // feedback questions, grown regions (moves), an HIBF that is descended or a d-gram index (scratch of the index) tie it
     // to the previous stage's stream; a stage of other programs only (the next wave of queries) runs beside it.
-    bool continues = n_q != 0 || (ix.is_hibf && !ix.probes_interleaved() && !s.vspace) || s.aux != nullptr;
+    bool continues = n_q != 0 || (ix.is_hibf && !ix.probes_interleaved(s.kn) && !s.vspace) || s.aux != nullptr;
     for (size_t p = 0; p < s.n_programs; ++p)
         if (bv.programs[p].n_ops) {
             continues = continues || s.last_stage[p] + 1 == s.n_stages;
             s.last_stage[p] = (uint32_t)s.n_stages;
         }
     // dense steps on a regular two-level HIBF run fused, too (TreeRows; TXQ_DENSE_TREE=0 sends them through the generic HIBF path)
-    const bool tree = !table && index_fuses_tree_steps(ix);
+    const bool tree = !table && index_fuses_tree_steps(ix, s.kn);
     bool any_tracked = false;
     for (size_t p = 0; p < s.n_programs; ++p) any_tracked |= bv.tracked[p] != 0 && bv.has_dense[p] != 0;
     const bool vspace = s.vspace;
@@ -2137,7 +2141,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
         if (vspace) {
             if (int rc = hibf_probe_layout_order(ix, d_kmers, n_main, d_masks, st)) return rc;
         } else if (ix.is_hibf) {
-            if (int rc = hibf_probe(ix, d_kmers, n_main, d_masks, nullptr, st)) return rc;
+            if (int rc = hibf_probe(ix, s.kn, d_kmers, n_main, d_masks, nullptr, st)) return rc;
         } else {
             hipError_t e = launch_probe(ix.ibf[0], d_kmers, n_main, d_masks, nullptr, st);
             if (e != hipSuccess) return fail_hip(e, "probe kernel launch");
@@ -2200,7 +2204,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 if (pairs) {
                     dense_hibf_kmers_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, bv.dense, ix.scratch_dense_kmers);
                     TXQ_HIP(hipGetLastError());
-                    if (int rc = hibf_probe(ix, ix.scratch_dense_kmers, pairs, ix.scratch_dense_masks, nullptr, st)) return rc;
+                    if (int rc = hibf_probe(ix, s.kn, ix.scratch_dense_kmers, pairs, ix.scratch_dense_masks, nullptr, st)) return rc;
                     dense_hibf_combine_kernel<<<(unsigned)(c1 - c0), 256, 0, st>>>(d_hsteps + c0, d_pair_base + c0, d_dops, d_optr, W, bv.dense, ix.scratch_dense_masks);
                     TXQ_HIP(hipGetLastError());
                 }

@@ -1060,13 +1060,12 @@ static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes
 
 // fused descent (hibf_fused_kernel) when a k-mer's row and IBF stack fit the LDS; returns false if not
 // (TXQ_HIBF_LEVELS=1 forces the level-synchronous path, for A/B runs and for testing both)
-static bool hibf_probe_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s, int* rc) {
+static bool hibf_probe_fused(Index& ix, const Knobs& kn, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s, int* rc) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     const uint32_t stack_cap = (uint32_t)ix.ibf.size();
     const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2;
     const size_t wave_bytes = wave_words * 8;
     const size_t lds_budget = 64u << 10;
-    const Knobs& kn = knobs();
     if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || kn.hibf_levels) return false;
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
@@ -1185,10 +1184,10 @@ void preload_hibf_kernels() {
     (void)hipGetLastError();
 }
 
-int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s) {
+int hibf_probe(Index& ix, const Knobs& kn, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     if (n == 0) return TXQ_OK;
-    if (ix.probes_interleaved()) {
+    if (ix.probes_interleaved(kn)) {
         // a small regular tree of uniform children: its interleaved children are probed like a flat IBF (one row segment per
         // hash function), the root's word clears the words of the children the k-mer cannot be in (txq_probe.hip TreeRoot)
         uint32_t wpr_log2 = 0;
@@ -1199,7 +1198,7 @@ int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, 
     }
     {
         int rc = TXQ_OK;
-        if (hibf_probe_fused(ix, d_kmers, n, d_masks, d_alive, s, &rc)) return rc;
+        if (hibf_probe_fused(ix, kn, d_kmers, n, d_masks, d_alive, s, &rc)) return rc;
     }
     if (w_out) TXQ_HIP(hipMemsetAsync(d_masks, 0, n * w_out * 8, s));
     // Frontier bound: a (k-mer, IBF) pair occurs at most once, so level l holds at most

@@ -4,6 +4,7 @@
 #include "../../include/txq.h"
 #include <cstdlib>
 #include <map>
+#include <mutex>
 #include <vector>
 
 namespace txq {
@@ -38,8 +39,8 @@ struct Knobs {
     int probe_blocks_per_cu = 256, probe_unroll = 2;  // TXQ_PROBE_BLOCKS_PER_CU, TXQ_PROBE_UNROLL
     bool probe_nt = false;                            // TXQ_PROBE_NT
 };
-const Knobs& knobs();  // the snapshot taken at the last entry point
-void read_knobs();     // take it (txq_api.hip)
+Knobs knobs();      // a copy of the snapshot taken at the last entry point (published under a lock: entry points run on several threads)
+void read_knobs();  // take it (txq_api.hip)
 
 // Everything about one IBF of an HIBF tree in one 32-byte record (txq_hibf.hip: nodes[e] = the child behind merged
 // technical bin e; the dense steps on a regular tree take the root as a kernel argument).
@@ -126,9 +127,9 @@ struct Index {
     // so that a dense step gathers one row segment per hash function instead of one cache line per child.
     IbfDev interleaved{};
     // plain k-mer probes go to the interleaved children too (TXQ_HIBF_INTERLEAVE_PROBE=0: the tree descent kernels; A/B and tests)
-    bool probes_interleaved() const {
+    bool probes_interleaved(const Knobs& kn) const {
         return is_hibf && interleaved.words && interleaved.stride >= 2 && !(interleaved.stride & 1) && interleaved.shard_words == shard_words &&
-               root_node.bins <= 64 && knobs().hibf_interleave_probe;
+               root_node.bins <= 64 && kn.hibf_interleave_probe;
     }
     HibfNode root_node{};            // host copy of the root's record
     uint32_t tree_hash_max = 0;      // most hash functions of any IBF of the regular tree
@@ -145,7 +146,7 @@ struct Index {
     uint32_t v_inner_words = 0;  // of a row: the words of IBFs with merged bins (what the next level reads as gates)
     uint32_t v_words = 0, n_vchunks = 0, v_depth = 0, v_chunk_words = 2;  // (chunks of 16 bytes, or of 8 for trees of narrow IBFs)
     std::vector<VLevel> vlevels;
-    bool layout_order() const;       // sessions on this index work in layout order
+    bool layout_order(const Knobs& kn) const;  // sessions on this index work in layout order
     uint32_t depth = 1;              // levels of the tree
     uint64_t hibf_total_tbs = 0;     // technical bins over all IBFs of the tree
     uint64_t max_level_width = 1;    // max number of IBFs on one level (bounds the frontier)
@@ -165,6 +166,7 @@ struct Index {
     // ensure_kmer_table): where that fits TXQ_KMER_TABLE_MB, a dense step reads ONE row per k-mer instead of gathering hash_funs.
     uint64_t* kmer_table = nullptr; uint32_t kmer_table_bits = 0;  // bits = bits per residue * k of the table that is built
     bool kmer_table_refused = false;                               // (the allocation failed once: not tried again)
+    std::mutex table_mutex;                                        // building / dropping the table (sessions of one index may run on several threads)
 
     // Device buffers of the last session, kept for the next one: a single query must not pay
     // hipMalloc/hipFree (they cost more than its kernels).  One session at a time may hold them.
@@ -204,11 +206,11 @@ struct Index {
 // Does a session on this index run dense steps fused on the tree (txq_exec.hip TreeRows / InterleavedRows)?  A regular
 // two-level HIBF whose children tile this shard's mask columns.  TXQ_DENSE_TREE=0 (A/B and tests) sends steps through
 // the generic HIBF path instead.
-inline bool Index::layout_order() const {
-    return is_hibf && d_vchunks && v_words && knobs().hibf_layout_order && shard_words == mask_words && shard_word0 == 0;
+inline bool Index::layout_order(const Knobs& kn) const {
+    return is_hibf && d_vchunks && v_words && kn.hibf_layout_order && shard_words == mask_words && shard_word0 == 0;
 }
-inline bool index_fuses_tree_steps(const Index& ix) {
-    return ix.is_hibf && ix.d_children && ix.n_children && knobs().dense_tree != 0 && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
+inline bool index_fuses_tree_steps(const Index& ix, const Knobs& kn) {
+    return ix.is_hibf && ix.d_children && ix.n_children && kn.dense_tree != 0 && ix.tree_hash_max >= 1 && ix.tree_hash_max <= 5 &&
            (uint64_t)ix.n_children * ix.child_row_words == ix.shard_words;
 }
 
@@ -287,7 +289,7 @@ hipError_t launch_emplace(const IbfDev& f, const uint64_t* values, const uint32_
 
 // txq_hibf.hip
 int hibf_upload(Index& ix, const txq_index_desc& desc);
-int hibf_probe(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s);
+int hibf_probe(Index& ix, const Knobs& kn, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s);
 // layout-order rows of n k-mers: d_rows[n][v_words]
 int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_rows, hipStream_t s);
 // final masks of a layout-order session -> user-bin order: d_out[n][shard_words] (zeroed here)
