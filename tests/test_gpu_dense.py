@@ -461,7 +461,16 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
 
 # ---- tracked (sparse) blocks: steps pushed from the live lists (csrc/txq_exec.hip sparse_kernel) ----------------------
 
-def test_tracked_blocks_vs_oracle(capi, oracle, monkeypatch):
+@pytest.fixture(params=["compacted", "lane-groups"])
+def step_kernel(request, monkeypatch):
+    """Pushed steps on a flat index run compacted (sparse_step_kernel: items queued in LDS, one per lane) or, with
+    TXQ_SPARSE_STEPS=0, in sparse_kernel with a lane group per entry like the trees' — both must give the oracle's masks."""
+    if request.param == "lane-groups":
+        monkeypatch.setenv("TXQ_SPARSE_STEPS", "0")
+    return request.param
+
+
+def test_tracked_blocks_vs_oracle(capi, oracle, monkeypatch, step_kernel):
     """TETREX_DENSE_TRACKED=1: every query keeps its blocks with live lists; STEP / REDUCE / ZERO / FILL follow the lists
     (sparse_plan_kernel + sparse_kernel).  Same masks as the oracle and as the run without dense blocks, on a flat index, on
     column shards, with nearly every list a block."""
@@ -479,7 +488,7 @@ def test_tracked_blocks_vs_oracle(capi, oracle, monkeypatch):
     assert checked > 60 and dense_ops > 20
 
 
-def test_tracked_blocks_on_odd_and_wide_masks_dna_and_reduced_alphabets(capi, oracle, monkeypatch):
+def test_tracked_blocks_on_odd_and_wide_masks_dna_and_reduced_alphabets(capi, oracle, monkeypatch, step_kernel):
     monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
     monkeypatch.setenv("TETREX_DENSE_MIN", "2")
     monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
@@ -500,7 +509,7 @@ def test_tracked_blocks_on_odd_and_wide_masks_dna_and_reduced_alphabets(capi, or
         assert checked >= 3 and dense_ops > 5 and TRACKED[0] >= 2
 
 
-def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
+def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch, step_kernel):
     """Tiny stage budgets with tracked blocks: a block's list is written in one stage and read in the next; finished
     programs hand their blocks to later ones (cleared before they are used again)."""
     monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
@@ -514,7 +523,7 @@ def test_tracked_blocks_across_stages_and_recycling(capi, oracle, monkeypatch):
         assert checked == len(qs) and dense_ops > 30 and TRACKED[0] >= 20
 
 
-def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
+def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch, step_kernel):
     """The reference's default k (include/arg_parse.h:12) on the Base alphabet: 21^5 suffixes per block, of which a sparse
     index keeps a few alive.  With the run told that states thin out (what it learns by asking) wildcard motifs become
     tracked blocks — a handful of ops instead of one per state and residue — and give the oracle's masks, identical to the
@@ -549,7 +558,7 @@ def test_k6_wildcard_motifs_run_as_tracked_blocks(capi, oracle, monkeypatch):
     ix.free()
 
 
-def test_k6_motif_batch_tracked_blocks_equal_enumerated_states(capi, oracle, monkeypatch):
+def test_k6_motif_batch_tracked_blocks_equal_enumerated_states(capi, oracle, monkeypatch, step_kernel):
     """A batch of PROSITE-style motifs with wildcards and x(m,n) gaps at k = 6 on 1024 bins of random sequences (the shape
     of tests/perf_cli_swissprot_shape.py, smaller): nothing is told about the index — the run asks, learns that states thin
     out, and keeps wildcard lists as tracked blocks.  Masks identical to the run without dense blocks (every state
@@ -654,4 +663,33 @@ def test_emplace_after_a_dense_batch_drops_the_table_of_kmer_masks(capi, oracle,
             informative += int(want.any())
         assert informative >= 9
         assert np.array_equal(ix.download_words_rows(m), ox.words())
+    ix.free()
+
+
+def test_blocks_are_pooled_with_the_index_from_batch_to_batch(capi, oracle, monkeypatch):
+    """All blocks of a session go back into a pool kept with the index (csrc/txq_internal.hpp SessionCache::blocks); the next
+    batch takes its blocks from there, and a block that a tracked program left behind — all zero outside its live list — is
+    taken over by a tracked program WITHOUT being cleared: the ZERO that creates the block clears what is listed.  Batches of
+    different motifs, tracked and untracked in turn, on one index: every batch must give the oracle's masks."""
+    monkeypatch.setenv("TETREX_DENSE_MIN", "2")
+    monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
+    ox = _oracle_index(oracle, bins=1024, m=4099, h=3, k=4, dna=False, per_bin=1500, seed=21)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    batches = [random_prosite_motifs(40, seed, wildcard=0.12, ranges=0.06) for seed in (31, 32, 33)]
+    wants = [_wants(ox, b) for b in batches]
+    order = [(0, "1"), (1, "1"), (0, "1"), (2, None), (1, "1"), (0, None), (2, "1"), (2, "1")]
+    for which, tracked in order:
+        if tracked:
+            monkeypatch.setenv("TETREX_DENSE_TRACKED", tracked)
+        else:
+            monkeypatch.delenv("TETREX_DENSE_TRACKED", raising=False)
+        got, status, stats = ix.query_masks(batches[which], False, 4)
+        assert stats["dense_ops"] > 20
+        assert (stats["tracked_queries"] > 10) == bool(tracked)
+        for q, g, w, st in zip(batches[which], got, wants[which], status):
+            if w is False:
+                assert st != 0, q
+            elif w is not None:
+                assert st == 0 and np.array_equal(g, w), (q, which, tracked)
     ix.free()

@@ -51,6 +51,7 @@ void read_knobs() {
     k.dense_nt = (int)num("TXQ_DENSE_NT", 0) & 3;
     k.fuse_units = !is("TXQ_FUSE_UNITS", '0');
     k.one_stream = flag("TXQ_ONE_STREAM");
+    k.sparse_steps = !is("TXQ_SPARSE_STEPS", '0');
     k.kmer_table_mb = std::max(0LL, num("TXQ_KMER_TABLE_MB", 512));
     k.kmer_table_min = std::max(1LL, num("TXQ_KMER_TABLE_MIN", 16));
     k.hibf_interleave = !is("TXQ_HIBF_INTERLEAVE", '0');
@@ -184,6 +185,7 @@ void Index::release() {
     }
     host_pipe = HostPipe{};
     for (const ArenaChunk& c : session_cache.chunks) (void)hipFree(c.p);
+    for (const ArenaChunk& c : session_cache.block_chunks) (void)hipFree(c.p);
     for (StagingSet& t : session_cache.set)
         if (t.done) (void)hipEventDestroy(t.done);
     if (session_cache.upload) (void)hipStreamDestroy(session_cache.upload);
@@ -405,6 +407,7 @@ int txq_index_memory(const txq_index* ix, uint64_t* free_bytes, uint64_t* kept_b
     TXQ_HIP(hipMemGetInfo(&free_b, &total_b));
     uint64_t kept = 0;
     for (const Index::ArenaChunk& c : ix->session_cache.chunks) kept += (uint64_t)c.cap * 8;
+    for (const Index::ArenaChunk& c : ix->session_cache.block_chunks) kept += (uint64_t)c.cap * 8;
     *free_bytes = free_b;
     *kept_bytes = kept;
     return TXQ_OK;

@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     }
     if (threadIdx.x <= P.pos) {
         const uint32_t j = threadIdx.x;
-        const uint32_t mask = j < P.pos ? d.shape[j] : d.r_mask;
+        const uint32_t mask = j < P.pos ? dops[t.op].shape[j] : d.r_mask;  // (read where it lies: indexing the copy would put it in scratch)
         uint32_t n = 0;
         for (uint32_t c = 0; c < 32; ++c)
             if ((mask >> c) & 1u) codes[j][n++] = (uint8_t)c;
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
     }
 }
 
-__device__ __forceinline__ void dense_codes(const txq_dense_op& d, const DenseParams& P, uint8_t (*codes)[32], uint32_t* cnt);
+__device__ __forceinline__ void dense_codes(const txq_dense_op* __restrict__ d, uint32_t pos, uint8_t (*codes)[32], uint32_t* cnt);
 
 // ---- tracked (sparse) blocks: dense ops whose work follows the live list --------------------------
 // The dense ops of tracked programs (include/txq_program.h) are not cut into tiles by the host — how many entries a
@@ -861,7 +861,9 @@ __device__ __forceinline__ void load_geometry(GeomTables& g, const uint32_t* __r
     __syncthreads();
 }
 
-template <int H, bool WIDE, class ROWS>
+// WITH_STEP = false: the launch holds no STEP group (flat indexes and tables of k-mer masks send those to sparse_step_kernel
+// below) — the STEP code, its tables and its registers are compiled out (ROWS is not used then).
+template <int H, bool WIDE, class ROWS, bool WITH_STEP = true>
 __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                      const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
                                                      const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     __shared__ GeomTables sg, dg;  // geometry of the block read / written
     // destination entries a chunk's pushes have made live: collected here and appended to dst's list with ONE atomic on the
     // block's count per chunk (one per wave and round, thousands on one address per launch, was what the big steps waited for)
-    __shared__ uint32_t fresh_list[kSparseChunk * 32];
+    __shared__ uint32_t fresh_list[WITH_STEP ? kSparseChunk * 32 : 1];
     __shared__ uint32_t fresh_n;
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
@@ -904,9 +906,10 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         const DenseOpPtr q = optr[sgr.op];
         if (loaded != g && (d.kind == TXQ_DENSE_STEP || d.kind == TXQ_DENSE_FILL)) {
             __syncthreads();  // the previous chunk has read its tables
-            dense_codes(d, P, codes, cnt);
+            dense_codes(dops + sgr.op, P.pos, codes, cnt);
             load_geometry(dg, block_meta(q.dst, q.dst_cap, W).geom, P.pos);
-            if (d.kind == TXQ_DENSE_STEP) load_geometry(sg, block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W).geom, P.pos);
+            if constexpr (WITH_STEP)
+                if (d.kind == TXQ_DENSE_STEP) load_geometry(sg, block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W).geom, P.pos);
             loaded = g;
         }
         if (d.kind == TXQ_DENSE_ZERO) {  // the listed entries := 0, their bits in the bitmap cleared (the plan kernel has reset the count)
@@ -964,6 +967,8 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             }
             continue;
         }
+        if constexpr (!WITH_STEP) continue;  // (no such group in this launch)
+        else {
         // STEP, pushed: every listed entry (a, x1 .. x_{k-2}) of src is rolled forward by the residues of r_mask —
         // dst[(x1 .. x_{k-2}, r)] |= src[entry] & M[k-mer(entry, r)] — G lanes per entry, UA residues in flight.  A product
         // that is empty is not written (the collector's path_.none() pruning, include/otf_collector.h:383); a destination entry
@@ -1064,6 +1069,256 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
         }
+        }
+    }
+}
+
+// ---- pushed steps of a flat index / a table of all k-mers' masks: compacted -----------------------------------------
+// The STEP groups of a level (sparse_kernel above does the same work with G lanes per entry: of the 8 lanes of a 1024-bin
+// mask one or two hold a bit once states have thinned out — the others idle through the row gathers, and every round of 32
+// entries is a chain of dependent trips).  Here a workgroup turns its entries into ITEMS first — an item = one 16-byte chunk
+// of one live entry that holds a bit, with what its pushes need (the chunk, the k-mer without the residue rolled in, the
+// destination entry without that residue's rank) — queued in LDS, and whenever 256 items wait every lane takes ONE and rolls
+// it forward by all residues of the step, UA residues (UA x H row gathers) in flight: all 64 lanes of a wave gather.
+//   fill:     one thread per entry decodes it (list -> entry number -> codes -> k-mer prefix, destination entry); then the
+//             workgroup loads the entries' chunks coalesced (8 lanes x 16 B = one 128-byte mask), two rounds in flight, and
+//             the lanes whose chunk holds a bit append an item (wave ballot: one LDS atomic per wave)
+//   process:  item per lane; a non-empty product is ORed atomically into the destination entry's chunk, an entry that gets
+//             its first bit joins dst's list (collected in LDS, appended with one atomic on the block's count per flush)
+// Items of one group (op) accumulate over the group's chunks; the queue is drained when the group changes.
+static constexpr uint32_t kStepQueue = 768;   // items: fewer than 256 that wait + two fill rounds of 256
+static constexpr uint32_t kStepFresh = 2048;  // fresh destination entries collected per flush (more: appended one by one)
+static constexpr uint32_t kStepFillRounds = 2;
+template <class T> struct alignas(16) StepItem { T sv; uint64_t high; uint32_t dst0, c; };
+struct StepParams { uint32_t k, bits, pos, canonical; };
+
+// one trip of an item: N residues' rows in flight, the non-empty products ORed into the destination entries; bit u of the
+// result: residue code[u] left a bit
+template <int N, bool WIDE, class ROWS>
+__device__ __forceinline__ uint32_t step_trip(ROWS& rows, uint64_t high, typename Lane<WIDE>::T sv, const uint8_t* code, const uint8_t* rank, uint64_t* dchunk,
+                                              uint32_t dst0, uint32_t W, const StepParams& P) {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    typename ROWS::Loads x[N];
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        uint64_t v = high | code[u];
+        if (P.canonical) v = canonical_dna(v, P.k);
+        rows.template issue<false>(nullptr, v, x[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < N; ++u) rows.template issue_late<false>(x[u]);
+    uint32_t hit = 0;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+        const T y = sv & rows.combine(x[u]);
+        const uint32_t rk = rank[u];
+        if (L::any(y) && rk != 0xFFu) {
+            atomic_or_chunk<WIDE>(dchunk + (size_t)(dst0 + rk) * W, y);
+            hit |= 1u << u;
+        }
+    }
+    return hit;
+}
+
+template <int H, bool WIDE, class ROWS>
+__global__ __launch_bounds__(256) void sparse_step_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
+                                                          const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
+                                                          const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                          uint32_t W, StepParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
+    using L = Lane<WIDE>;
+    using T = typename L::T;
+    constexpr int UA = ROWS::kPushUnroll;
+    __shared__ uint32_t pre[kMaxSparseGroups + 1];
+    __shared__ uint8_t rcode[32], rrank[32];  // the step's residues: code, and rank in the last position of dst's geometry (0xFF: not in it)
+    __shared__ GeomTables sg, dg;
+    __shared__ StepItem<T> queue[kStepQueue];
+    __shared__ uint32_t q_head, q_tail, fresh_n, fresh_at, n_hits;
+    __shared__ uint32_t fresh_list[kStepFresh];
+    __shared__ uint32_t e_idx[kSparseChunk], e_dst0[kSparseChunk];
+    __shared__ uint64_t e_high[kSparseChunk];
+    if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
+        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
+        return;
+    }
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    for (uint32_t i = tid; i <= n_groups; i += blockDim.x) pre[i] = prefix[i];
+    if (tid == 0) { q_head = 0; q_tail = 0; fresh_n = 0; n_hits = 0; }
+    __syncthreads();
+    const uint32_t total = pre[n_groups];
+    const uint32_t j = blockIdx.x - U.n_units, J = gridDim.x - U.n_units;
+    const uint32_t lo = (uint32_t)((uint64_t)total * j / J), hi = (uint32_t)((uint64_t)total * (j + 1) / J);
+    if (lo >= hi) return;
+    uint32_t g = 0;  // the group of chunk lo: the last one that starts at or before it
+    for (uint32_t b = n_groups; b - g > 1;) {
+        const uint32_t m = (g + b) / 2;
+        if (pre[m] <= lo) g = m; else b = m;
+    }
+    const uint32_t chunks_w = (W + L::kWords - 1) / L::kWords;
+    const bool cw_pow2 = (chunks_w & (chunks_w - 1)) == 0;
+    const uint32_t cw_shift = 31u - (uint32_t)__builtin_clz(chunks_w);
+    unsigned long long c_entries = 0, c_units = 0;  // (thread 0: what this workgroup did, for TXQ_TRACE)
+    // One loop, one copy of every phase; what it does next follows from values every thread sees alike (shared counters read
+    // behind a barrier, the chunk cursor).  The group whose items are queued:
+    uint32_t loaded = 0xFFFFFFFFu, n_r = 0;
+    bool noprobe = false;
+    DenseOpPtr q{};
+    BlockMeta dm{};
+    const uint32_t* src_list = nullptr;
+    // the chunk being filled from
+    uint32_t t = lo, base = 0, pairs = 0;
+    bool decoded = false, switch_group = false;
+    for (;;) {
+        const uint32_t waiting = q_tail - q_head;
+        const bool input_done = t >= hi, force = input_done || switch_group;
+        if (waiting >= 256u || (force && waiting)) {
+            // ---- process: up to 256 waiting items, one per lane, rolled forward by every residue of the step
+            const uint32_t n = waiting < 256u ? waiting : 256u;
+            if (tid < n) {
+                const StepItem<T> it = queue[(q_head + tid) % kStepQueue];
+                const T sv = it.sv;
+                const uint32_t c = it.c;
+                rows.prepare(c);
+                uint64_t* const dchunk = q.dst + (size_t)c * L::kWords;
+                uint32_t hit = 0;  // bit i: residue rcode[i] left a bit in this chunk
+                if (noprobe) {  // states that are still filling their first k-mer: the mask moves on as it is
+                    for (uint32_t i = 0; i < n_r; ++i) {
+                        const uint32_t rk = rrank[i];
+                        if (rk == 0xFFu) continue;
+                        atomic_or_chunk<WIDE>(dchunk + (size_t)(it.dst0 + rk) * W, sv);
+                        hit |= 1u << i;
+                    }
+                } else {
+                    uint32_t i = 0;
+                    for (; i + UA <= n_r; i += UA)
+                        hit |= step_trip<UA, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i;
+                    // the last, partial trip: its residues in flight together (n_r is the same in every lane)
+                    if constexpr (UA > 2) { if (n_r - i == 2) { hit |= step_trip<2, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; i += 2; } }
+                    if constexpr (UA > 1) { if (n_r - i == 1) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
+                    if constexpr (UA > 3) { for (; i < n_r; ++i) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
+                }
+                if (ctr && hit) atomicAdd(&n_hits, (uint32_t)__builtin_popcount(hit));
+                for (uint32_t h = hit; h; h &= h - 1) {  // destinations that were empty until now join dst's list
+                    const uint32_t entry = it.dst0 + rrank[__builtin_ctz(h)];
+                    if (mark_live(dm, entry)) {
+                        const uint32_t at = atomicAdd(&fresh_n, 1u);
+                        if (at < kStepFresh) fresh_list[at] = entry;
+                        else append_live(dm, entry);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) { q_head += n; c_units += (unsigned long long)n * n_r; }
+            __syncthreads();
+            if (fresh_n < kStepFresh / 2) continue;
+        }
+        if (force || fresh_n >= kStepFresh / 2) {
+            // ---- flush: the fresh destination entries join dst's list with one atomic on the block's count
+            const uint32_t n_fresh = fresh_n < kStepFresh ? fresh_n : kStepFresh;
+            if (n_fresh) {
+                if (tid == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                for (uint32_t i = tid; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
+                __syncthreads();
+                if (tid == 0) fresh_n = 0;
+                __syncthreads();
+            }
+            if (!force || q_tail != q_head) continue;  // (a flush in the middle, or items are still waiting)
+            if (input_done) break;
+            // ---- the queue is empty: the tables of the next chunk's group
+            const uint32_t op = groups[g].op;
+            q = optr[op];
+            dm = block_meta(q.dst, q.dst_cap, W);
+            const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W);
+            src_list = sm.list;
+            noprobe = (dops[op].reserved & TXQ_DENSE_NOPROBE) != 0;
+            load_geometry(dg, dm.geom, P.pos);
+            load_geometry(sg, sm.geom, P.pos);
+            const uint32_t r_mask = dops[op].r_mask;
+            if (tid == 0) {
+                uint32_t m = 0;
+                for (uint32_t c = 0; c < 32; ++c)
+                    if ((r_mask >> c) & 1u) { rcode[m] = (uint8_t)c; rrank[m] = dg.rank[P.pos - 1][c]; ++m; }
+            }
+            n_r = (uint32_t)__builtin_popcount(r_mask);
+            __syncthreads();
+            loaded = g;
+            switch_group = false;
+            continue;
+        }
+        if (!decoded) {
+            // ---- decode the next chunk's entries, one thread each
+            while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
+            if (loaded != g) { switch_group = true; continue; }  // its items may not mix with the queued ones: drain first
+            const uint32_t first = (t - pre[g]) * kSparseChunk;
+            const uint32_t n = counts[g];
+            const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
+            const uint32_t n_e = end > first ? end - first : 0u;
+            if (tid < n_e) {
+                const uint32_t idx = src_list[first + tid];
+                bool live = idx < q.src_cap;
+                uint64_t high = 0;   // the k-mer without the residue rolled in
+                uint32_t dst0 = 0;   // the destination entry without that residue's rank
+                for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
+                    const uint32_t cn = sg.cnt[jj];
+                    const uint32_t c = sg.code[jj][rest % cn];
+                    rest /= cn;
+                    high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
+                    if (jj > 0) {
+                        const uint32_t rk = dg.rank[jj - 1][c];
+                        live = live && rk != 0xFFu;
+                        dst0 += rk * dg.stride[jj - 1];
+                    }
+                }
+                e_idx[tid] = live ? idx : 0xFFFFFFFFu;
+                e_high[tid] = high << P.bits;
+                e_dst0[tid] = dst0;
+            }
+            __syncthreads();
+            if (tid == 0) c_entries += n_e;
+            pairs = n_e * chunks_w;
+            base = 0;
+            decoded = pairs != 0;
+            if (!decoded) ++t;
+            continue;
+        }
+        // ---- fill: the chunks of the decoded entries, coalesced, two rounds in flight; a chunk that holds a bit becomes an item
+        {
+            T sv[kStepFillRounds];
+            uint32_t el[kStepFillRounds], cc[kStepFillRounds];
+#pragma unroll
+            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
+                const uint32_t f = base + r * 256u + tid;
+                el[r] = cw_pow2 ? f >> cw_shift : f / chunks_w;
+                cc[r] = cw_pow2 ? f & (chunks_w - 1) : f % chunks_w;
+                sv[r] = L::zero();
+                if (f < pairs) {
+                    const uint32_t idx = e_idx[el[r]];
+                    if (idx != 0xFFFFFFFFu) sv[r] = L::load(q.src + (size_t)idx * W + (size_t)cc[r] * L::kWords);
+                }
+            }
+#pragma unroll
+            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
+                const bool push = L::any(sv[r]);
+                const unsigned long long votes = __ballot(push);
+                uint32_t at = 0;
+                if (lane == 0 && votes) at = atomicAdd(&q_tail, (uint32_t)__popcll(votes));
+                at = (uint32_t)__shfl((int)at, 0);
+                if (push) {
+                    const uint32_t slot = (at + (uint32_t)__popcll(votes & ((1ULL << lane) - 1ULL))) % kStepQueue;
+                    queue[slot] = StepItem<T>{sv[r], e_high[el[r]], e_dst0[el[r]], cc[r]};
+                }
+            }
+            base += 256u * kStepFillRounds;
+            if (base >= pairs) { decoded = false; ++t; }
+            __syncthreads();  // (the items are visible; the entries' table may be overwritten by the next decode)
+        }
+    }
+    if (ctr && tid == 0) {
+        atomicAdd(ctr + 0, c_entries);
+        atomicAdd(ctr + 1, (unsigned long long)q_tail);
+        atomicAdd(ctr + 2, c_units);
+        atomicAdd(ctr + 3, (unsigned long long)n_hits);
     }
 }
 
@@ -1073,10 +1328,11 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
 // (pair p of a tile = suffix first + p / n_a, predecessor p % n_a), descended in one hibf_probe batch, and the
 // combine kernel ANDs each mask with its predecessor's slot and ORs the result into the destination suffix.
 // pair_base[tile] = index of the tile's first pair in the chunk's k-mer / mask arrays.
-__device__ __forceinline__ void dense_codes(const txq_dense_op& d, const DenseParams& P, uint8_t (*codes)[32], uint32_t* cnt) {
-    if (threadIdx.x <= P.pos) {
+// (the op is read where it lies: a by-value copy indexed by threadIdx.x would live in scratch memory)
+__device__ __forceinline__ void dense_codes(const txq_dense_op* __restrict__ d, uint32_t pos, uint8_t (*codes)[32], uint32_t* cnt) {
+    if (threadIdx.x <= pos) {
         const uint32_t j = threadIdx.x;
-        const uint32_t mask = j < P.pos ? d.shape[j] : d.r_mask;
+        const uint32_t mask = j < pos ? d->shape[j] : d->r_mask;
         uint32_t n = 0;
         for (uint32_t c = 0; c < 32; ++c)
             if ((mask >> c) & 1u) codes[j][n++] = (uint8_t)c;
@@ -1107,8 +1363,7 @@ __global__ __launch_bounds__(256) void dense_hibf_kmers_kernel(const DenseTile* 
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     const DenseTile t = tiles[blockIdx.x];
-    const txq_dense_op d = dops[t.op];
-    dense_codes(d, P, codes, cnt);
+    dense_codes(dops + t.op, P.pos, codes, cnt);
     const uint32_t n_a = cnt[0];
     uint64_t* out = kmers + pair_base[blockIdx.x];
     for (uint32_t p = threadIdx.x; p < t.count * n_a; p += blockDim.x) {
@@ -1127,8 +1382,7 @@ __global__ __launch_bounds__(256) void dense_hibf_combine_kernel(const DenseTile
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
     const DenseTile t = tiles[blockIdx.x];
-    const txq_dense_op d = dops[t.op];
-    dense_codes(d, P, codes, cnt);
+    dense_codes(dops + t.op, P.pos, codes, cnt);
     const uint64_t* src = optr[t.op].src;
     uint64_t* dstb = optr[t.op].dst;
     const uint64_t* M = masks + (size_t)pair_base[blockIdx.x] * W;
@@ -1416,13 +1670,29 @@ Session::~Session() {
         fprintf(stderr, "[txq]   dense work: %llu predecessor visits for %llu destination suffixes, %llu slots zeroed, %llu entries reduced; mask %u words\n",
                 (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
     if (kn.trace && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
-    if (kn.trace && n_blocks_made + n_block_memsets)
-        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all), %zu cleared for tracked programs; %zu sparse launches (%zu groups)\n", n_blocks_made,
-                block_bytes_made / 1e6, n_block_memsets, n_sparse_launches, n_sparse_groups);
+    if (kn.trace && n_blocks_made + n_block_memsets + n_blocks_relisted)
+        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all), %zu cleared for tracked programs, %zu taken over as a tracked program left them; %zu sparse launches (%zu groups)\n",
+                n_blocks_made, block_bytes_made / 1e6, n_block_memsets, n_blocks_relisted, n_sparse_launches, n_sparse_groups);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
         if (t.pending) { (void)hipEventSynchronize(t.done); t.pending = false; }
+    if (d_step_ctr) {
+        unsigned long long c[4] = {0, 0, 0, 0};
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(c, d_step_ctr, sizeof c, hipMemcpyDeviceToHost);
+        (void)hipFree(d_step_ctr);
+        if (c[0] && ix) {
+            // algorithmic bytes of the pushed steps: per live entry its list index and its mask, per item and
+            // residue the rows' 16-byte (8-byte) pieces, per non-empty product a 16-byte read-modify-write of the destination
+            const uint64_t piece = W % 2 == 0 ? 16 : 8;
+            const uint64_t rows_per_unit = ix->kmer_table && !ix->is_hibf ? 1 : (ix->is_hibf ? 1 : ix->ibf[0].hash_funs);
+            const double bytes = (double)c[0] * (4 + 8.0 * W) + (double)c[2] * rows_per_unit * piece + (double)c[3] * 2 * piece;
+            fprintf(stderr, "[txq]   sparse steps: %llu live entries, %llu items (chunks that hold a bit), %llu item-residue units, %llu non-empty products; "
+                            "algorithmic bytes %.0f (%llu row pieces of %llu B per unit)\n", c[0], c[1], c[2], c[3], bytes,
+                    (unsigned long long)rows_per_unit, (unsigned long long)piece);
+        }
+    }
     for (void* p : retired) (void)hipFree(p);
     if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
@@ -1431,6 +1701,24 @@ Session::~Session() {
             if (kept + k.cap * 8 <= Index::kArenaKeepBytes) { c.chunks.push_back(k); kept += k.cap * 8; }
             else (void)hipFree(k.p);
         }
+        // the blocks: every one this session holds goes into the index's pool (a tracked program's are all zero outside their
+        // lists), unless a stage failed (their state is unknown) or slots and blocks together outgrow what an index keeps
+        size_t block_bytes = 0;
+        for (const Index::ArenaChunk& k : block_chunks) block_bytes += k.cap * 8;
+        if (!failed && kept + block_bytes <= Index::kArenaKeepBytes) {
+            c.block_chunks.swap(block_chunks);
+            c.block_cur = bcur;
+            c.block_used = bused;
+            c.blocks_W = W;
+            c.blocks.swap(pool);
+            for (size_t p = 0; p < blocks.size(); ++p)
+                for (const DenseBlock& b : blocks[p])
+                    if (b.p) c.blocks.emplace(b.cap, DenseBlock{b.p, b.cap, (uint8_t)(tracked[p] ? kListed : kGarbage)});
+            for (const auto& kv : free_blocks) c.blocks.emplace(kv.first, kv.second);
+            for (const std::vector<DenseBlock>& v : given_back)
+                for (const DenseBlock& b : v) c.blocks.emplace(b.cap, b);
+        } else
+            for (const Index::ArenaChunk& k : block_chunks) (void)hipFree(k.p);
         c.set[0] = set[0];
         c.set[1] = set[1];
         c.upload = upload;
@@ -1439,6 +1727,7 @@ Session::~Session() {
         return;
     }
     for (const Index::ArenaChunk& k : chunks) (void)hipFree(k.p);
+    for (const Index::ArenaChunk& k : block_chunks) (void)hipFree(k.p);
     for (Index::StagingSet& t : set) {
         if (t.done) (void)hipEventDestroy(t.done);
         for (void* p : {(void*)t.d_blob, (void*)t.d_aux, (void*)t.d_masks}) if (p) (void)hipFree(p);
@@ -1487,6 +1776,13 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
         s->owns_cache = true;
         s->chunks.swap(c.chunks);
         for (const Index::ArenaChunk& k : s->chunks) s->arena_words += k.cap;
+        s->block_chunks.swap(c.block_chunks);
+        for (const Index::ArenaChunk& k : s->block_chunks) s->block_arena_words += k.cap;
+        if (c.blocks_W == s->W) {  // the pooled blocks fit this session's masks: take them over, go on allocating behind them
+            s->pool.swap(c.blocks);
+            s->bcur = c.block_cur;
+            s->bused = c.block_used;
+        }  // (else: another mask width — the chunks are reused from their beginning)
         s->set[0] = c.set[0];
         s->set[1] = c.set[1];
         s->upload = c.upload;
@@ -1495,6 +1791,9 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
         c.in_use = true;
     }
     s->last_stage.assign(n_programs, 0);
+    if (s->kn.trace && hipMalloc((void**)&s->d_step_ctr, 4 * sizeof(unsigned long long)) == hipSuccess)
+        (void)hipMemset(s->d_step_ctr, 0, 4 * sizeof(unsigned long long));
+    else { (void)hipGetLastError(); s->d_step_ctr = nullptr; }
     const double t_streams = now_s();
     for (hipStream_t* st : {&s->upload, &s->side})
         if (!*st && !(*st = take_spare_stream(ix.device))) {
@@ -1520,15 +1819,35 @@ int session_begin(Index& ix, size_t n_programs, Session** out) {
 // must be all zero first (the caller memsets them on the stage's stream).
 static size_t block_alloc_words(uint32_t cap, uint32_t W) { return ((size_t)cap * W + block_meta_words(cap) + 1) & ~(size_t)1; }
 
+// the blocks' own arena (kept with the index between sessions together with the pool of blocks inside it)
+static int block_arena_alloc(Session& s, size_t words, uint64_t** out) {
+    while (s.bcur < s.block_chunks.size() && s.bused + words > s.block_chunks[s.bcur].cap) { ++s.bcur; s.bused = 0; }
+    if (s.bcur >= s.block_chunks.size()) {
+        size_t cap = std::max((size_t)8 << 20, s.block_arena_words);  // 64 MiB first, then as much again as there is
+        if (words > cap) cap = words;
+        uint64_t* c = nullptr;
+        TXQ_HIP(hipMalloc((void**)&c, cap * 8));
+        s.block_chunks.push_back(Index::ArenaChunk{c, cap});
+        s.block_arena_words += cap;
+        s.bcur = s.block_chunks.size() - 1;
+        s.bused = 0;
+    }
+    *out = s.block_chunks[s.bcur].p + s.bused;
+    s.bused += words;
+    return TXQ_OK;
+}
+
 static int take_block(Session& s, uint32_t cap, Session::DenseBlock* out) {
-    auto it = s.free_blocks.find(cap);
-    if (it != s.free_blocks.end()) {
-        *out = it->second;
-        s.free_blocks.erase(it);
-        return TXQ_OK;
+    for (auto* from : {&s.free_blocks, &s.pool}) {  // given back in this session; left by earlier sessions on this index
+        auto it = from->find(cap);
+        if (it != from->end()) {
+            *out = it->second;
+            from->erase(it);
+            return TXQ_OK;
+        }
     }
     Session::DenseBlock b{nullptr, cap, Session::kGarbage};
-    if (int rc = arena_alloc(s, block_alloc_words(cap, s.W), &b.p)) return rc;
+    if (int rc = block_arena_alloc(s, block_alloc_words(cap, s.W), &b.p)) return rc;
     ++s.n_blocks_made;
     s.block_bytes_made += block_alloc_words(cap, s.W) * 8;
     *out = b;
@@ -1602,8 +1921,11 @@ static int grow_slot_regions(Session& s, const BlobView& bv, const unsigned char
             }
             if (int rc = take_block(s, z.src, &b)) return rc;
             ++s.n_blocks_live;
-            // (a kListed block could be cleared through its list instead of whole)
-            to_clear->emplace_back(b.p, block_alloc_words(b.cap, s.W) * 8);
+            // a block a tracked program left behind is all zero outside its list, and the ZERO that creates the block here
+            // clears what is listed (sparse_plan_kernel resets the count, the chunks clear entries and bitmap bits): as it is
+            if (b.state == Session::kListed) ++s.n_blocks_relisted;
+            else to_clear->emplace_back(b.p, block_alloc_words(b.cap, s.W) * 8);
+            b.state = Session::kGarbage;  // (what it is while its program runs; tracked[p] decides what it is given back as)
         }
     }
     return TXQ_OK;
@@ -1613,12 +1935,17 @@ static int grow_slot_regions(Session& s, const BlobView& bv, const unsigned char
 // their ops are cut into units per dependency level (units of level l, all programs, are contiguous in `units`),
 // their dense ops into tiles, and every level becomes one launch of each kind over the whole GPU.
 // Returns the number of programs left to exec_kernel.
-struct LevelPlan { size_t units = 0, tiles = 0, hsteps = 0, sparse = 0, sparse_chunks = 0; };
+struct LevelPlan {
+    size_t units = 0, tiles = 0, hsteps = 0, sparse = 0, sparse_chunks = 0;
+    // split_steps (flat indexes, tables of k-mer masks): the level's sparse groups are ordered [others | STEPs]; the first
+    // sparse_misc go to sparse_kernel, the STEPs to sparse_step_kernel (sparse_chunks counts the others' chunks then)
+    size_t sparse_misc = 0, step_chunks = 0;
+};
 // hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
 // HIBF a step is three launches (dense_hibf_*), not a tile of dense_kernel.
 // The dense ops of tracked programs become sparse groups (one per op; sparse_kernel), and every dense op's blocks are
 // resolved to pointers here (`optr`, indexed like the stage's dense table).
-static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, std::vector<ExecUnit>* units,
+static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* blob, uint32_t W, uint32_t G_dense, bool hibf, bool split_steps, std::vector<ExecUnit>* units,
                          std::vector<TileGroup>* groups, size_t* n_tiles, uint64_t (*work)[4], std::vector<DenseTile>* hsteps, std::vector<uint32_t>* hstep_na,
                          std::vector<SparseGroup>* sparse, std::vector<DenseOpPtr>* optr, std::vector<LevelPlan>* plan) {
     const uint32_t per_unit = unit_ops(W);
@@ -1629,8 +1956,8 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
     std::vector<std::vector<ExecUnit>> per_level;
     std::vector<std::vector<TileGroup>> groups_level;
     std::vector<std::vector<DenseTile>> hsteps_level;
-    std::vector<std::vector<SparseGroup>> sparse_level;
-    std::vector<size_t> sparse_chunks;
+    std::vector<std::vector<SparseGroup>> sparse_level, step_level;  // (step_level: the STEP groups when split_steps)
+    std::vector<size_t> sparse_chunks, step_chunks;
     // entries per tile: every lane-group set of the workgroup gets two destination suffixes of a step (TXQ_DENSE_TILE_ROUNDS)
     const uint32_t step_tile = (uint32_t)s.kn.dense_tile_rounds * (256 / (G_dense ? G_dense : 1));
     size_t n_small = 0;
@@ -1643,6 +1970,7 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
         if (per_level.size() < d.n_levels) {
             per_level.resize(d.n_levels); groups_level.resize(d.n_levels); hsteps_level.resize(d.n_levels);
             sparse_level.resize(d.n_levels); sparse_chunks.resize(d.n_levels, 0);
+            step_level.resize(d.n_levels); step_chunks.resize(d.n_levels, 0);
         }
         // (validate_blob has checked that block operands name existing block ids; grow_slot_regions has given the program its
         // blocks — a tracked block exists once a ZERO has created it: an op on one that was never created is refused here)
@@ -1689,10 +2017,11 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
                     if (x.reserved & TXQ_DENSE_TRACKED) {  // work follows the block's live list (FILL: its shape)
                         const bool fixed = x.kind == TXQ_DENSE_FILL;
                         if (fixed && !shape_entries) continue;
-                        sparse_level[l].push_back(SparseGroup{o.dst, fixed ? (uint32_t)shape_entries : kNotFixed});
+                        const bool to_steps = split_steps && x.kind == TXQ_DENSE_STEP;
+                        (to_steps ? step_level : sparse_level)[l].push_back(SparseGroup{o.dst, fixed ? (uint32_t)shape_entries : kNotFixed});
                         // most chunks this group can turn out to have: a list never outgrows its block
                         const uint64_t most = fixed ? shape_entries : x.kind == TXQ_DENSE_ZERO ? q.dst_cap : q.src_cap;
-                        sparse_chunks[l] += (size_t)((most + kSparseChunk - 1) / kSparseChunk);
+                        (to_steps ? step_chunks : sparse_chunks)[l] += (size_t)((most + kSparseChunk - 1) / kSparseChunk);
                         continue;
                     }
                     uint64_t entries = 1, per_tile = step_tile;
@@ -1738,9 +2067,12 @@ static size_t plan_units(const Session& s, BlobView& bv, const unsigned char* bl
         *n_tiles += level_tiles;
         groups->insert(groups->end(), groups_level[l].begin(), groups_level[l].end());
         (*plan)[l].hsteps = hsteps_level[l].size();
-        (*plan)[l].sparse = sparse_level[l].size();
+        (*plan)[l].sparse = sparse_level[l].size() + step_level[l].size();
+        (*plan)[l].sparse_misc = sparse_level[l].size();
         (*plan)[l].sparse_chunks = sparse_chunks[l];
+        (*plan)[l].step_chunks = step_chunks[l];
         sparse->insert(sparse->end(), sparse_level[l].begin(), sparse_level[l].end());
+        sparse->insert(sparse->end(), step_level[l].begin(), step_level[l].end());
         units->insert(units->end(), per_level[l].begin(), per_level[l].end());
         for (const DenseTile& t : hsteps_level[l]) {
             hsteps->push_back(t);
@@ -1801,6 +2133,29 @@ static hipError_t launch_sparse(uint32_t hash_funs, MAKE rows_of, const SparseGr
 
 __global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uint64_t n) {
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = i;
+}
+
+// the STEP groups of a level on a flat index / through the table of k-mer masks (sparse_step_kernel)
+template <bool WIDE, template <int, bool> class ROWS, class MAKE>
+static hipError_t launch_sparse_steps(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
+                                      size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W,
+                                      const StepParams& P, const LevelUnits& U, unsigned long long* ctr, hipStream_t st) {
+#define TXQ_STEPS(H) \
+    do { \
+        ROWS<H, WIDE> rows{}; \
+        rows_of(rows); \
+        sparse_step_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, P, U, ctr); \
+    } while (0)
+    switch (hash_funs) {
+        case 1: TXQ_STEPS(1); break;
+        case 2: TXQ_STEPS(2); break;
+        case 3: TXQ_STEPS(3); break;
+        case 4: TXQ_STEPS(4); break;
+        case 5: TXQ_STEPS(5); break;
+        default: return hipErrorInvalidValue;
+    }
+#undef TXQ_STEPS
+    return hipGetLastError();
 }
 
 // The table of all k-mers' masks of an index (Index::kmer_table), built once per index when the first stage with dense steps
@@ -1934,11 +2289,15 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<SparseGroup> sparse_groups;
     std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
+    // pushed steps of tracked blocks on a flat index or through the table of k-mer masks run compacted (sparse_step_kernel);
+    // TXQ_SPARSE_STEPS=0: in sparse_kernel like the trees' (A/B and tests)
+    const bool split_steps = s.kn.sparse_steps && !vspace && !tree && (table || !ix.is_hibf);
+    const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, split_steps, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
     size_t n_sparse_launches = 0;
-    for (const LevelPlan& lp : plan) n_sparse_launches += (lp.sparse + kMaxSparseGroups - 1) / kMaxSparseGroups;
+    for (const LevelPlan& lp : plan)
+        n_sparse_launches += (lp.sparse_misc + kMaxSparseGroups - 1) / kMaxSparseGroups + (lp.sparse - lp.sparse_misc + kMaxSparseGroups - 1) / kMaxSparseGroups;
     // the stage's block table: per program with blocks a row [flags | block 0 | its capacity | block 1 | ..] (DenseRow)
     std::vector<uint64_t*> block_table;
     std::vector<size_t> row_of(s.n_programs, 0);
@@ -2246,61 +2605,87 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 s.n_dense_tiles += plan[l].tiles;
                 ++s.n_dense_launches;
             }
-            // the level's sparse groups (dense ops of tracked programs): plan (counts -> chunks), then the chunks
-            for (size_t off = 0; off < plan[l].sparse; off += kMaxSparseGroups, ++sparse_launch) {
-                const uint32_t ng = (uint32_t)std::min<size_t>(kMaxSparseGroups, plan[l].sparse - off);
-                const SparseGroup* gr = d_sgroups + first_sparse + off;
-                uint32_t* counts = d_scounts + first_sparse + off;
-                uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
-                sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, counts, prefix);
-                TXQ_HIP(hipGetLastError());
-                const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && off == 0 ? (uint32_t)cnt : 0u, g_units_log2};
-                // as many workgroups as the chunks could be at most, within what the device holds at a time
-                const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(plan[l].sparse_chunks, 2048));
-                hipError_t e;
-                if (vspace) {
-                    auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                    e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                             : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
-                } else if (interleaved) {
-                    auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                    e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                             : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
-                } else if (tree) {
-                    auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                    e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                             : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
-                } else if (table) {
-                    auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
-                    e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                             : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
-                } else {
-                    auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                    e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                             : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
-                }
-                if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
-                if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to
-                    const double t_l = now_s();
-                    (void)hipStreamSynchronize(st);
-                    const double dt = now_s() - t_l;
-                    std::vector<uint32_t> cnts(ng);
-                    (void)hipMemcpy(cnts.data(), counts, (size_t)ng * 4, hipMemcpyDeviceToHost);
-                    const txq_dense_op* hd = (const txq_dense_op*)(blob + bv.dense_offset);
-                    uint64_t by_kind[5] = {0, 0, 0, 0, 0};  // entries: ZERO, STEP, REDUCE, FILL, STEP without probe
-                    uint64_t visits = 0;
-                    for (uint32_t gi = 0; gi < ng; ++gi) {
-                        const txq_dense_op& x = hd[sparse_groups[first_sparse + off + gi].op];
-                        const bool np_ = x.kind == TXQ_DENSE_STEP && (x.reserved & TXQ_DENSE_NOPROBE);
-                        by_kind[np_ ? 4 : x.kind] += cnts[gi];
-                        if (x.kind == TXQ_DENSE_STEP) visits += (uint64_t)cnts[gi] * (uint64_t)__builtin_popcount(x.r_mask);
+            // the level's sparse groups (dense ops of tracked programs): plan (counts -> chunks), then the chunks.  split_steps: the
+            // groups are ordered [others | STEPs] and the STEPs go to the compacted step kernel (two ranges, each in segments of
+            // at most kMaxSparseGroups groups); otherwise sparse_kernel takes all of them
+            const size_t n_misc = split_steps ? plan[l].sparse_misc : plan[l].sparse;
+            bool rode = false;  // the level's ordinary ops ride in its first sparse launch
+            for (int range = 0; range < 2; ++range) {
+                const size_t r_lo = range == 0 ? 0 : n_misc, r_hi = range == 0 ? n_misc : plan[l].sparse;
+                const bool steps = range == 1;
+                const size_t range_chunks = steps ? plan[l].step_chunks : plan[l].sparse_chunks;
+                for (size_t off = r_lo; off < r_hi; off += kMaxSparseGroups, ++sparse_launch) {
+                    const uint32_t ng = (uint32_t)std::min<size_t>(kMaxSparseGroups, r_hi - off);
+                    const SparseGroup* gr = d_sgroups + first_sparse + off;
+                    uint32_t* counts = d_scounts + first_sparse + off;
+                    uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
+                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, counts, prefix);
+                    TXQ_HIP(hipGetLastError());
+                    const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && !rode ? (uint32_t)cnt : 0u, g_units_log2};
+                    rode = true;
+                    // as many workgroups as the chunks could be at most, within what the device holds at a time
+                    const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(range_chunks, 2048));
+                    hipError_t e;
+                    if (steps) {
+                        const StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical};
+                        if (table) {
+                            auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
+                            e = wide ? launch_sparse_steps<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st)
+                                     : launch_sparse_steps<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st);
+                        } else {
+                            auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
+                            e = wide ? launch_sparse_steps<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st)
+                                     : launch_sparse_steps<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st);
+                        }
+                    } else if (split_steps) {  // ZERO / REDUCE / FILL only: the variant without the step code (its row source is not used)
+                        FlatRows<1, true> none{};
+                        if (wide) sparse_kernel<1, true, FlatRows<1, true>, false><<<(unsigned)grid, 256, 0, st>>>(none, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu);
+                        else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu); }
+                        e = hipGetLastError();
+                    } else if (vspace) {
+                        auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
+                        e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                                 : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                    } else if (interleaved) {
+                        auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                        e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                                 : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                    } else if (tree) {
+                        auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
+                        e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                                 : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                    } else if (table) {
+                        auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
+                        e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                                 : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                    } else {
+                        auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
+                        e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
+                                 : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
                     }
-                    fprintf(stderr, "[txq]   sparse launch: level %zu, %u groups, %.1f us; entries: zero %llu, step %llu (+ %llu without probe; %llu visits), reduce %llu, fill %llu\n", l, ng,
-                            dt * 1e6, (unsigned long long)by_kind[0], (unsigned long long)by_kind[1], (unsigned long long)by_kind[4], (unsigned long long)visits,
-                            (unsigned long long)by_kind[2], (unsigned long long)by_kind[3]);
+                    if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
+                    if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to
+                        const double t_l = now_s();
+                        (void)hipStreamSynchronize(st);
+                        const double dt = now_s() - t_l;
+                        std::vector<uint32_t> cnts(ng);
+                        (void)hipMemcpy(cnts.data(), counts, (size_t)ng * 4, hipMemcpyDeviceToHost);
+                        const txq_dense_op* hd = (const txq_dense_op*)(blob + bv.dense_offset);
+                        uint64_t by_kind[5] = {0, 0, 0, 0, 0};  // entries: ZERO, STEP, REDUCE, FILL, STEP without probe
+                        uint64_t visits = 0;
+                        for (uint32_t gi = 0; gi < ng; ++gi) {
+                            const txq_dense_op& x = hd[sparse_groups[first_sparse + off + gi].op];
+                            const bool np_ = x.kind == TXQ_DENSE_STEP && (x.reserved & TXQ_DENSE_NOPROBE);
+                            by_kind[np_ ? 4 : x.kind] += cnts[gi];
+                            if (x.kind == TXQ_DENSE_STEP) visits += (uint64_t)cnts[gi] * (uint64_t)__builtin_popcount(x.r_mask);
+                        }
+                        fprintf(stderr, "[txq]   sparse launch%s: level %zu, %u groups, %.1f us; entries: zero %llu, step %llu (+ %llu without probe; %llu visits), reduce %llu, fill %llu\n",
+                                steps ? " (steps)" : "", l, ng, dt * 1e6, (unsigned long long)by_kind[0], (unsigned long long)by_kind[1], (unsigned long long)by_kind[4],
+                                (unsigned long long)visits, (unsigned long long)by_kind[2], (unsigned long long)by_kind[3]);
+                    }
+                    ++s.n_sparse_launches;
+                    s.n_sparse_groups += ng;
                 }
-                ++s.n_sparse_launches;
-                s.n_sparse_groups += ng;
             }
             first_sparse += plan[l].sparse;
             first += cnt;

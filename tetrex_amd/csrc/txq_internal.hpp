@@ -23,6 +23,7 @@ struct Knobs {
     int dense_nt = 0;           // TXQ_DENSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads of a dense step's destination entries
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
+    bool sparse_steps = true;   // TXQ_SPARSE_STEPS=0: pushed steps of tracked blocks on a flat index / table run in sparse_kernel (G lanes per entry), not compacted
     long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most an index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
     long long kmer_table_min = 16;  // TXQ_KMER_TABLE_MIN: the session of fewest programs that builds the table (a single query does not pay for it; once built it is used)
     // HIBF (txq_hibf.hip)
@@ -181,8 +182,19 @@ struct Index {
         hipEvent_t done = nullptr;
         bool pending = false;
     };
+    // A dense block as it is handed on: [cap][W] mask words, then its live list.  state: kGarbage (fresh memory, or left by an
+    // untracked program), kListed (left by a tracked program: all zero except the entries in its list, which is intact — the
+    // ZERO that re-creates it for a tracked program clears exactly those, so such a block needs no clearing at all).
+    struct DenseBlock { uint64_t* p; uint32_t cap; uint8_t state; };
     struct SessionCache {
         std::vector<ArenaChunk> chunks;  // slot-arena chunks, at most kArenaKeepBytes in all
+        // dense blocks live in chunks of their own, and ALL blocks of a session go back into a pool by capacity when it ends:
+        // the next batch on this index takes its blocks from there — no allocation, and for tracked programs no clearing
+        // (5.3 GB of memset per 200-motif batch at k = 6 before)
+        std::vector<ArenaChunk> block_chunks;
+        size_t block_cur = 0, block_used = 0;
+        std::multimap<uint32_t, DenseBlock> blocks;
+        uint32_t blocks_W = 0;  // the mask width the pooled blocks were laid out for
         StagingSet set[2];
         hipStream_t upload = nullptr, side = nullptr;
         bool in_use = false;
@@ -236,8 +248,11 @@ struct Session {
     // block table (ordinary ops on dense slots) or through the per-op pointers the host side resolves (DenseOpPtr).
     // What a block holds when it is handed on: kGarbage (fresh arena memory, or left by an untracked program),
     // kListed (left by a tracked program: all zero except the entries in its list, which is intact).
-    struct DenseBlock { uint64_t* p; uint32_t cap; uint8_t state; };  // cap: entries ([cap][W] mask words, then the live list)
+    using DenseBlock = Index::DenseBlock;  // cap: entries ([cap][W] mask words, then the live list)
     enum : uint8_t { kGarbage = 0, kListed = 1 };
+    std::vector<Index::ArenaChunk> block_chunks;  // the blocks' own arena (bump allocation in block_chunks[bcur]); kept with the index
+    size_t bcur = 0, bused = 0, block_arena_words = 0;
+    std::multimap<uint32_t, DenseBlock> pool;     // blocks earlier sessions on this index left behind, by capacity
     std::vector<std::vector<DenseBlock>> blocks;  // per program, by block id (p == nullptr: a tracked block no ZERO has created yet)
     std::vector<uint8_t> tracked;                 // per program: TXQ_PROGRAM_TRACKED_BIT (fixed with its first block)
     std::multimap<uint32_t, DenseBlock> free_blocks;  // blocks of finished programs by capacity, reusable ...
@@ -245,7 +260,7 @@ struct Session {
     std::vector<DenseBlock> given_back[2];
     uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet): the capacity of untracked blocks
     size_t block_bytes_made = 0;
-    size_t n_blocks_live = 0, n_blocks_made = 0, n_block_memsets = 0, n_sparse_launches = 0, n_sparse_groups = 0;
+    size_t n_blocks_live = 0, n_blocks_made = 0, n_block_memsets = 0, n_blocks_relisted = 0, n_sparse_launches = 0, n_sparse_groups = 0;
     std::vector<uint32_t> last_stage;  // per program: the last stage (1-based) that had ops for it
     hipStream_t side = nullptr;        // a stage that continues nothing of the stage in flight runs beside it, on the other stream
     int stream_of_last = 0;            // 0: the caller's stream, 1: `side`
@@ -254,6 +269,7 @@ struct Session {
     std::vector<void*> retired;   // staging buffers that were outgrown while another stage was running: freed with the session
     Index::StagingSet set[2];     // stage n uses set[n & 1]
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
+    unsigned long long* d_step_ctr = nullptr;  // TXQ_TRACE: what sparse_step_kernel did (entries, items, item x residue units, non-empty products)
     std::vector<unsigned char> host_aux;  // a small stage is packed here and sent as one copy
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;
