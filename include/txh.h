@@ -106,6 +106,9 @@ uint64_t txe_last_tracked_queries(void);
  * posix != 0: leftmost-longest (RE2::POSIX, peptides); 0: leftmost-first (RE2 default, DNA).  out receives (start, length)
  * pairs; returns the number of matches (may exceed cap / 2 pairs; nothing written past cap), <0 on a syntax error. */
 int64_t txh_regex_find_all(const char* pattern, int posix, const char* text, size_t len, uint64_t* out, size_t cap);
+/* The matcher's prefilter: the longest run of plain bytes that every match of the pattern contains (memmem in front of the
+ * automata; may be empty).  Writes at most `cap` bytes, returns the literal's length, < 0 on a syntax error. */
+int64_t txh_regex_required_literal(const char* pattern, int posix, char* out, size_t cap);
 
 /* values inserted for one record; returns the count (may exceed cap; nothing written past cap) */
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,

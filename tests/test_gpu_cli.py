@@ -202,3 +202,52 @@ def test_hibf_written_by_tetrex_index_takes_the_fused_tree_steps(tmp_path):
                 fused += 1
         assert out["flat"] == out["tree"] and len(out["flat"]) >= 5, q
     assert fused >= 2
+
+
+@pytest.mark.parametrize("dna", [False, True], ids=["peptides", "dna"])
+def test_motif_batches_are_verified_bin_major_with_the_same_files(tmp_path, dna):
+    """`tetrex query -f`: the candidate bins of ALL motifs are read once each and every motif that selected a bin runs over its
+    records (host/verify.cpp verify_batch) — the reference verifies motif by motif (include/query.h:329-346 over :126-138).
+    The result files, the reverse-strand rows on stdout and the per-motif log lines must be what the motif-by-motif run
+    (TETREX_VERIFY_PER_MOTIF=1) writes, byte for byte, with one thread and with several."""
+    rng = np.random.default_rng(5)
+    letters = list("ACGT") if dna else list("ACDEFGHIKLMNPQRSTVWY")
+    planted = ["ACGTTGCAAC", "GGATCCAT", "TTGACAGCTAGC"] if dna else ["LMAEGLYN", "WKLPDSFY", "CAAHKCLLMH"]
+    files = []
+    for b in range(48):
+        seqs = ["".join(rng.choice(letters, size=300)) for _ in range(6)]
+        for j, w in enumerate(planted):
+            if (b + j) % 7 == 0:
+                seqs[j] = seqs[j][:40 + b] + w + seqs[j][40 + b + len(w):]
+        p = tmp_path / ("bin%02d.fa" % b)
+        p.write_text("".join(">r%d_%d\n%s\n" % (b, i, s_) for i, s_ in enumerate(seqs)))
+        files.append(str(p))
+    k = "6" if dna else "4"
+    rc, so, se = run("index", *(["-n"] if dna else []), "-k", k, "-i", str(tmp_path / "ix"), *files)
+    assert rc == 0, se
+    if dna:
+        motifs = ["ACGTTGCAAC", "GGAT.CAT", "TTGACA[GC]CTAGC", "ACG(T|A)TGCA", "GTTGCAACGT", "AAAAAAAAAAAA", "AC+GT", "GGATC{1,2}AT"]
+    else:
+        motifs = ["LMA(E|Q)GLYN", "WKLPD.FY", "CAAHKC[LI]LMH", "LMAEG", "W.LPDSF", "KCLLMH", "QQQQQQQQ", "LM.EGLY", "AAH.{0,2}CLLM"]
+    (tmp_path / "motifs.tsv").write_text("".join("M%d\t%s\n" % (i, m) for i, m in enumerate(motifs)))
+    results = {}
+    for mode, threads in (("per-motif", "1"), ("bin-major", "1"), ("bin-major", "5")):
+        out = tmp_path / (mode + threads)
+        out.mkdir()
+        env = dict(os.environ)
+        if mode == "per-motif":
+            env["TETREX_VERIFY_PER_MOTIF"] = "1"
+        r = subprocess.run([TETREX, "query", "-f", "-t", threads, str(tmp_path / "ix.ibf"), str(tmp_path / "motifs.tsv")], capture_output=True, text=True,
+                           cwd=str(out), env=env, timeout=300)
+        assert r.returncode == 0, r.stderr
+        files_out = {os.path.basename(p): open(p, "rb").read() for p in sorted(glob.glob(str(out / "*.tsv")))}
+        log = [l.split("Query Time")[0] for l in r.stderr.splitlines() if l.startswith("M")]
+        results[(mode, threads)] = (files_out, r.stdout, log)
+    base = results[("per-motif", "1")]
+    assert sum(1 for v in base[0].values() if v) >= 4 and len(base[2]) == len(motifs)
+    if dna:
+        assert "REVERSE STRAND HIT" in base[1]
+    for key, got in results.items():
+        assert got[0] == base[0], key
+        assert got[1] == base[1], key
+        assert got[2] == base[2], key

@@ -91,3 +91,27 @@ def test_megabyte_records_with_quantifier_motifs_take_linear_time(host):
     assert host.regex_find_all("((A+)+C)", run, posix=True) == [(0, 2_000_001)]
     assert host.regex_find_all("((A|AA)+C)", run, posix=False) == [(0, 2_000_001)]
     assert time.perf_counter() - t0 < 20
+
+
+def test_the_required_literal_is_contained_in_every_match(host):
+    """The prefilter in front of the automata (Matcher::may_match): the longest run of plain bytes on the pattern's spine.  It must
+    be a string EVERY match contains — checked against Python's re on random texts — and the known cases come out as expected."""
+    known = {"(LMA(E|Q)GLYN)": "GLYN", "(C.{2,4}C.{3}[LIVMFYWC].{8}H.{3,5}H)": "C", "(AB|CD)": "", "(A(BC)+DE)": "BC", "((AB)*CDE)": "CDE",
+             "(N[^P][ST][^P])": "N", "(LMA{3}E)": "LM", "(K[RK]{2,3}DE)": "DE", "(^MAEG$)": "MAEG", "(L(MA)*EG)": "EG", "(AC?GT)": "GT", "(.*LMAE.+)": "LMAE",
+             "(W..[LIVM]D)": "W", "(A{2,4}C)": "A"}
+    for rx, lit in known.items():
+        assert host.regex_required_literal(rx) == lit, rx
+    rng = np.random.default_rng(3)
+    alphabet = list("ACDE")
+    pieces = ["A", "C", "D", "E", ".", "[AC]", "[^D]", "(A|CD)", "(DE)+", "C?", "A*", "E{2}", "D{1,2}", "(AC)?", "(C|D)+"]
+    for _ in range(300):
+        rx = "(" + "".join(rng.choice(pieces, size=int(rng.integers(2, 7)))) + ")"
+        lit = host.regex_required_literal(rx)
+        pat = re.compile(rx)
+        for _ in range(20):
+            text = "".join(rng.choice(alphabet, size=40))
+            for m in pat.finditer(text):
+                assert lit in m.group(0), (rx, lit, m.group(0))
+            # and find_all is unchanged by the prefilter: the same matches as Python's leftmost-first search loop
+            want = _consume_loop(lambda t, pos: (lambda m: m.span() if m else None)(pat.search(t, pos)), text)
+            assert host.regex_find_all(rx, text, posix=False) == want, (rx, text)

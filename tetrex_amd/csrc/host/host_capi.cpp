@@ -211,6 +211,15 @@ int64_t txh_regex_find_all(const char* pattern, int posix, const char* text, siz
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int64_t txh_regex_required_literal(const char* pattern, int posix, char* out, size_t cap) {
+    try {
+        const Matcher m(pattern, posix ? Matcher::Semantics::LeftmostLongest : Matcher::Semantics::LeftmostFirst);
+        const std::string& lit = m.required_literal();
+        for (size_t i = 0; i < lit.size() && i < cap; ++i) out[i] = lit[i];
+        return (int64_t)lit.size();
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int64_t txh_record_values(int dna, unsigned k, unsigned reduction, const char* seq, size_t len, int wraparound,
                           uint64_t* out, size_t cap) {
     KmerEncoder enc = encoder(dna, k, reduction);

@@ -205,6 +205,23 @@ int cmd_query(int argc, char** argv) {
         const double batch = (now() - t0) / std::max<size_t>(1, motifs.size());
         const double t_verify = now();
         int failed = 0;
+        // The batch is verified BIN-MAJOR (verify_batch): every candidate bin is read once and all the motifs that selected it run
+        // over its records; the reference — and TETREX_VERIFY_PER_MOTIF=1 here, for comparison — verifies motif by motif
+        // (include/query.h:329-346), re-reading a bin once per motif.  Files and rows are the same either way.
+        std::vector<std::string> fwd, rev;
+        bool bin_major = !std::getenv("TETREX_VERIFY_PER_MOTIF");
+        if (bin_major) {
+            std::vector<const uint64_t*> mptr(motifs.size(), nullptr);
+            for (size_t i = 0; i < motifs.size(); ++i)
+                if (!status[i]) mptr[i] = masks.data() + i * W;
+            try {
+                verify_batch(mptr, bins, image.bin_paths, motifs, enc, &fwd, &rev, vopt);
+            } catch (const std::exception& e) {  // (a bin that cannot be read: motif by motif, so that the others still get their results)
+                std::cerr << e.what() << '\n';
+                bin_major = false;
+            }
+        }
+        const double per_motif = bin_major ? (now() - t_verify) / std::max<size_t>(1, motifs.size()) : 0.0;
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
             if (status[i]) {  // its mask is incomplete: verifying the bins it happens to hold would silently lose matches
@@ -212,7 +229,16 @@ int cmd_query(int argc, char** argv) {
                 ++failed;
                 continue;
             }
-            run_one(motifs[i], masks.data() + i * W, ids[i] + ".tsv", true, now() - batch);
+            if (!bin_major) { run_one(motifs[i], masks.data() + i * W, ids[i] + ".tsv", true, now() - batch); continue; }
+            const size_t narrowed = popcount_mask(masks.data() + i * W, W);
+            std::cerr << "Bin Count: " << narrowed << "\t";
+            if (narrowed) {
+                std::ofstream f(ids[i] + ".tsv");
+                if (!f) std::cerr << "Failed to open output file: " << ids[i] << ".tsv" << '\n';
+                else f << fwd[i];
+                std::cout << rev[i];
+            }
+            std::cerr << "Query Time: " << (batch + per_motif) << std::endl;  // (the batch's time, shared out evenly)
         }
         // -S: the whole batch as the reference times a query — from after the index is loaded to the last output byte
         // (include/query.h:256,287-289): candidate masks + verification of the candidate bins

@@ -192,6 +192,42 @@ Matcher::Matcher(const std::string& pattern, Semantics semantics) : semantics_(s
     build(false, fwd_);
     build(true, rev_);
     for (const Inst& in : fwd_.inst) has_begin_ = has_begin_ || in.op == kBegin;
+    // The longest run of single-byte factors on the pattern's spine — the factors every match goes through in order: the
+    // concatenation at the top, and what sits inside `+` / {m,..} with m >= 1 (at least one round) — is a string every
+    // match contains.  Alternations, optional parts and byte sets end a run and contribute nothing.
+    {
+        std::string run;
+        auto single = [&](const Node& n, unsigned char* byte) {
+            const std::array<uint64_t, 4>& st = sets_[n.set];
+            int bits = 0;
+            for (int w = 0; w < 4; ++w) bits += __builtin_popcountll(st[w]);
+            if (bits != 1) return false;
+            for (int w = 0; w < 4; ++w) if (st[w]) *byte = (unsigned char)(w * 64 + __builtin_ctzll(st[w]));
+            return true;
+        };
+        std::function<void(int)> walk = [&](int id) {
+            const Node n = ps.nodes[id];
+            unsigned char b = 0;
+            switch (n.type) {
+                case nCat: walk(n.a); walk(n.b); return;
+                case nSet:
+                    if (single(n, &b)) { run.push_back((char)b); if (run.size() > literal_.size()) literal_ = run; }
+                    else run.clear();
+                    return;
+                case nPlus: run.clear(); walk(n.a); run.clear(); return;
+                case nRepeat: run.clear(); if (n.lo >= 1) walk(n.a); run.clear(); return;
+                case nEmpty: return;
+                default: run.clear(); return;  // nAlt, nStar, nQuest, anchors
+            }
+        };
+        walk(root);
+    }
+}
+
+bool Matcher::may_match(std::string_view text) const {
+    if (literal_.empty()) return true;
+    if (literal_.size() == 1) return std::memchr(text.data(), (unsigned char)literal_[0], text.size()) != nullptr;
+    return memmem(text.data(), text.size(), literal_.data(), literal_.size()) != nullptr;
 }
 
 // epsilon closure of `seeds` in priority order: the Char and Match instructions reachable without consuming a byte
@@ -357,6 +393,7 @@ size_t Matcher::pike_end(std::string_view text, size_t start, Cache& c, bool at_
 }
 
 bool Matcher::contains(std::string_view text, Cache& c) const {
+    if (!may_match(text)) return false;
     Cache::Dfa& d = c.fwd_un;
     if (d.sets.size() > 20000) d = Cache::Dfa{};
     if (!d.ready) dfa_init(fwd_, true, d, c);

@@ -57,6 +57,7 @@ class Matcher {
     // the record's beginning only; where the pattern has a `^`, the position a match ended at is tried under that rule first.
     template <class Fn>
     void find_all(std::string_view text, Cache& cache, Fn&& fn) const {
+        if (!may_match(text)) return;  // a string every match contains is not in the text (memmem: far cheaper than the automata)
         match_starts(text, cache);
         size_t pos = 0;
         bool fresh_begin = false;  // `pos` is where a non-empty match ended: the beginning of what FindAndConsume searches next
@@ -81,6 +82,10 @@ class Matcher {
     }
     // does the pattern match anywhere in the text?
     bool contains(std::string_view text, Cache& cache) const;
+    // The prefilter in front of the automata: false = the text lacks a string that every match of the pattern contains
+    // (required_literal(): the longest run of plain bytes on the pattern's spine; empty when there is none).
+    bool may_match(std::string_view text) const;
+    const std::string& required_literal() const { return literal_; }
 
   private:
     struct Inst { uint8_t op; uint32_t x, y; };  // Char: x = set index, y unused; Split: x preferred over y; Jmp: x
@@ -93,6 +98,7 @@ class Matcher {
     };
     Semantics semantics_;
     bool has_begin_ = false;                     // the pattern has a `^`
+    std::string literal_;                        // a string every match contains (may be empty)
     std::vector<std::array<uint64_t, 4>> sets_;  // byte sets of the pattern
     std::array<uint8_t, 256> class_of_{};        // byte -> equivalence class
     std::vector<std::vector<uint8_t>> set_has_class_;  // [set][class]

@@ -4,6 +4,7 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 
@@ -69,6 +70,103 @@ size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::str
     for (size_t i = 0; i < bins.size(); ++i) {
         out << fwd[i];
         reverse_out << rev[i];
+        total += found[i];
+    }
+    return total;
+}
+
+size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, const std::vector<std::string>& bin_paths,
+                    const std::vector<std::string>& regexes, const KmerEncoder& enc, std::vector<std::string>* forward,
+                    std::vector<std::string>* reverse, const VerifyOptions& opt) {
+    const bool dna = enc.molecule() == Molecule::DNA;
+    const bool reduced = !dna && enc.alphabet() != Alphabet::Base;
+    const size_t nq = regexes.size();
+    forward->assign(nq, std::string());
+    reverse->assign(nq, std::string());
+    std::vector<std::unique_ptr<Matcher>> rx(nq);
+    for (size_t q = 0; q < nq; ++q) {
+        if (!masks[q]) continue;
+        std::string pattern = regexes[q];
+        if (reduced) pattern = reduce_query_alphabet(pattern, enc.reduce_table());
+        rx[q] = std::make_unique<Matcher>("(" + pattern + ")", dna ? Matcher::Semantics::LeftmostFirst : Matcher::Semantics::LeftmostLongest);
+    }
+    // bin -> the queries that selected it (ascending), for the bins anybody selected
+    std::vector<std::vector<uint32_t>> wanted(bins);
+    for (size_t q = 0; q < nq; ++q) {
+        if (!masks[q]) continue;
+        for (uint64_t w = 0; w * 64 < bins; ++w)
+            for (uint64_t x = masks[q][w]; x; x &= x - 1) {
+                const uint64_t b = w * 64 + (uint64_t)__builtin_ctzll(x);
+                if (b < bins) wanted[b].push_back((uint32_t)q);
+            }
+    }
+    std::vector<uint64_t> todo;
+    for (uint64_t b = 0; b < bins; ++b)
+        if (!wanted[b].empty()) todo.push_back(b);
+    // per bin: the rows of each of its queries (bins are joined per query in ascending order afterwards)
+    struct Rows { std::string fwd, rev; };
+    std::vector<std::vector<Rows>> rows(todo.size());
+    std::vector<size_t> found(todo.size(), 0);
+    std::string error;
+#pragma omp parallel num_threads(opt.threads > 0 ? opt.threads : 1)
+    {
+        std::vector<std::unique_ptr<Matcher::Cache>> caches(nq);  // this thread's automata, built on first use, kept from bin to bin
+        std::string seq, rc;
+#pragma omp for schedule(dynamic)
+        for (size_t i = 0; i < todo.size(); ++i) {
+            try {
+                const std::string& path = bin_paths.at(todo[i]);
+                const std::vector<uint32_t>& qs = wanted[todo[i]];
+                std::vector<Rows>& mine = rows[i];
+                mine.resize(qs.size());
+                for_each_record(path, [&](const FastaRecord& rec) {
+                    const std::string* text = &rec.seq;
+                    if (reduced) {
+                        seq = rec.seq;
+                        for (char& c : seq) c = enc.reduce((unsigned char)c);
+                        text = &seq;
+                    }
+                    bool have_rc = false;
+                    for (size_t j = 0; j < qs.size(); ++j) {
+                        const uint32_t q = qs[j];
+                        const Matcher& m = *rx[q];
+                        if (!caches[q]) caches[q] = std::make_unique<Matcher::Cache>();
+                        if (m.may_match(*text))
+                            m.find_all(*text, *caches[q], [&](size_t s, size_t n) {
+                                std::string& o = mine[j].fwd;
+                                o += path; o += "\t>"; o += rec.name; o += '\t'; o.append(*text, s, n); o += '\t';
+                                o += std::to_string(s); o += ','; o += std::to_string(s + n); o += '\n';
+                                ++found[i];
+                            });
+                        if (dna) {
+                            if (!have_rc) {
+                                rc.assign(text->rbegin(), text->rend());
+                                for (char& c : rc) c = complement(c);
+                                have_rc = true;
+                            }
+                            if (m.may_match(rc))
+                                m.find_all(rc, *caches[q], [&](size_t s, size_t n) {
+                                    std::string& o = mine[j].rev;
+                                    o += path; o += "\t>"; o += rec.name; o += '\t'; o.append(rc, s, n); o += "\tREVERSE STRAND HIT\n";
+                                    ++found[i];
+                                });
+                        }
+                    }
+                });
+            } catch (const std::exception& e) {
+#pragma omp critical
+                error = e.what();
+            }
+        }
+    }
+    if (!error.empty()) throw std::runtime_error(error);
+    size_t total = 0;
+    for (size_t i = 0; i < todo.size(); ++i) {
+        const std::vector<uint32_t>& qs = wanted[todo[i]];
+        for (size_t j = 0; j < qs.size(); ++j) {
+            (*forward)[qs[j]] += rows[i][j].fwd;
+            (*reverse)[qs[j]] += rows[i][j].rev;
+        }
         total += found[i];
     }
     return total;

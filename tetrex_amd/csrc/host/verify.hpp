@@ -25,6 +25,17 @@ struct VerifyOptions {
 size_t verify_bins(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths, const std::string& regex,
                    const KmerEncoder& enc, std::ostream& out, std::ostream& reverse_out, const VerifyOptions& opt);
 
+// A batch of queries (-f), verified BIN-MAJOR: the reference verifies motif by motif (include/query.h:329-346 over
+// :126-138), so a batch re-opens, re-inflates and re-parses a FASTA bin once per motif that selected it.  Here every
+// candidate bin is read ONCE and all the motifs that selected it run over its records (OpenMP over the bins, like the
+// reference's loop over one motif's bins); a thread keeps its lazily built automata from bin to bin.  masks[q] = the
+// candidate-bin mask of query q (mask_words words; nullptr: the query is skipped).  forward[q] / reverse[q] receive exactly
+// the rows verify_bins(set_bins(masks[q]), ...) writes to `out` / `reverse_out` — same bytes, same order.
+// Returns the matches found.
+size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, const std::vector<std::string>& bin_paths,
+                    const std::vector<std::string>& regexes, const KmerEncoder& enc, std::vector<std::string>* forward,
+                    std::vector<std::string>* reverse, const VerifyOptions& opt);
+
 // -c: records that match EVERY query
 size_t verify_conjunction(const std::vector<uint64_t>& bins, const std::vector<std::string>& bin_paths,
                           const std::vector<std::string>& queries, std::ostream& out, const VerifyOptions& opt);

@@ -770,6 +770,7 @@ __device__ __forceinline__ void dense_codes(const txq_dense_op* __restrict__ d, 
 struct SparseGroup { uint32_t op; uint32_t fixed; };  // fixed != kNotFixed: the host knows the entries (FILL: its shape)
 static constexpr uint32_t kNotFixed = 0xFFFFFFFFu;
 static constexpr uint32_t kSparseChunk = 64;
+static constexpr uint32_t kUnitStepWords = 32;  // masks up to this wide (2048 bins) step by units (sparse_kernel, narrow masks)
 static constexpr uint32_t kMaxSparseGroups = 1024;  // per launch (the chunk totals sit in LDS)
 
 __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __restrict__ groups, uint32_t n_groups, const txq_dense_op* __restrict__ dops,
@@ -861,16 +862,17 @@ __device__ __forceinline__ void load_geometry(GeomTables& g, const uint32_t* __r
     __syncthreads();
 }
 
-// WITH_STEP = false: the launch holds no STEP group (flat indexes and tables of k-mer masks send those to sparse_step_kernel
-// below) — the STEP code, its tables and its registers are compiled out (ROWS is not used then).
+// WITH_STEP = false: the launch holds no STEP group (on flat indexes and tables of k-mer masks a level's STEP groups get a
+// launch of their own) — the STEP code, its tables and its registers are compiled out (ROWS is not used then).
 template <int H, bool WIDE, class ROWS, bool WITH_STEP = true>
 __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                      const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
                                                      const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                     uint32_t W, uint32_t G, DenseParams P, LevelUnits U) {
+                                                     uint32_t W, uint32_t G, DenseParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
     using L = Lane<WIDE>;
     using T = typename L::T;
     constexpr int UA = ROWS::kPushUnroll;  // residues in flight per lane: UA * H row gathers
+    (void)ctr;
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // of the op's shape (FILL) and, [pos], of its r_mask (STEP)
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
@@ -878,7 +880,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     // destination entries a chunk's pushes have made live: collected here and appended to dst's list with ONE atomic on the
     // block's count per chunk (one per wave and round, thousands on one address per launch, was what the big steps waited for)
     __shared__ uint32_t fresh_list[WITH_STEP ? kSparseChunk * 32 : 1];
-    __shared__ uint32_t fresh_n;
+    __shared__ uint32_t fresh_n, fresh_at;
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
@@ -1064,7 +1066,6 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
         __syncthreads();
         const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
         if (n_fresh) {
-            __shared__ uint32_t fresh_at;
             if (threadIdx.x == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
             for (uint32_t i = threadIdx.x; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
@@ -1073,77 +1074,37 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     }
 }
 
-// ---- pushed steps of a flat index / a table of all k-mers' masks: compacted -----------------------------------------
-// The STEP groups of a level (sparse_kernel above does the same work with G lanes per entry: of the 8 lanes of a 1024-bin
-// mask one or two hold a bit once states have thinned out — the others idle through the row gathers, and every round of 32
-// entries is a chain of dependent trips).  Here a workgroup turns its entries into ITEMS first — an item = one 16-byte chunk
-// of one live entry that holds a bit, with what its pushes need (the chunk, the k-mer without the residue rolled in, the
-// destination entry without that residue's rank) — queued in LDS, and whenever 256 items wait every lane takes ONE and rolls
-// it forward by all residues of the step, UA residues (UA x H row gathers) in flight: all 64 lanes of a wave gather.
-//   fill:     one thread per entry decodes it (list -> entry number -> codes -> k-mer prefix, destination entry); then the
-//             workgroup loads the entries' chunks coalesced (8 lanes x 16 B = one 128-byte mask), two rounds in flight, and
-//             the lanes whose chunk holds a bit append an item (wave ballot: one LDS atomic per wave)
-//   process:  item per lane; a non-empty product is ORed atomically into the destination entry's chunk, an entry that gets
-//             its first bit joins dst's list (collected in LDS, appended with one atomic on the block's count per flush)
-// Items of one group (op) accumulate over the group's chunks; the queue is drained when the group changes.
-static constexpr uint32_t kStepQueue = 768;   // items: fewer than 256 that wait + two fill rounds of 256
-static constexpr uint32_t kStepFresh = 2048;  // fresh destination entries collected per flush (more: appended one by one)
-static constexpr uint32_t kStepFillRounds = 2;
-template <class T> struct alignas(16) StepItem { T sv; uint64_t high; uint32_t dst0, c; };
 struct StepParams { uint32_t k, bits, pos, canonical; };
 
-// one trip of an item: N residues' rows in flight, the non-empty products ORed into the destination entries; bit u of the
-// result: residue code[u] left a bit
-template <int N, bool WIDE, class ROWS>
-__device__ __forceinline__ uint32_t step_trip(ROWS& rows, uint64_t high, typename Lane<WIDE>::T sv, const uint8_t* code, const uint8_t* rank, uint64_t* dchunk,
-                                              uint32_t dst0, uint32_t W, const StepParams& P) {
+// ---- pushed steps on narrow masks: by units -------------------------------------------------------------------------
+// The STEP groups of a level when a mask is a cache line or two (W <= kUnitStepWords: up to 2048 bins per shard), where every
+// lane group touches the same lines whichever of its lanes hold bits.  sparse_kernel above walks a chunk of 64 entries in
+// rounds of one entry per lane group — list -> mask chunk -> rows -> listing, twice per chunk, with one k-mer in flight per
+// group for a literal residue.  Here the chunk's entries are decoded by one thread each, and the lane groups then share out
+// the chunk's UNITS — (entry, residue) pairs — UA at a time: a unit's loads are the entry's mask chunk and the h rows of its
+// k-mer, all in ONE trip, and UA units are in flight per group whatever the step's number of residues.  Whether a
+// destination entry was empty is asked with a returning atomic on dst's bitmap; the answer is looked at a trip later, behind
+// the next trip's loads.  A chunk is: list (coalesced) -> its units' trips -> one append of the fresh entries.
+template <int H, bool WIDE, int UA, class ROWS>
+__global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
+                                                           const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
+                                                           uint32_t W, uint32_t G, StepParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
     using L = Lane<WIDE>;
     using T = typename L::T;
-    typename ROWS::Loads x[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        uint64_t v = high | code[u];
-        if (P.canonical) v = canonical_dna(v, P.k);
-        rows.template issue<false>(nullptr, v, x[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < N; ++u) rows.template issue_late<false>(x[u]);
-    uint32_t hit = 0;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        const T y = sv & rows.combine(x[u]);
-        const uint32_t rk = rank[u];
-        if (L::any(y) && rk != 0xFFu) {
-            atomic_or_chunk<WIDE>(dchunk + (size_t)(dst0 + rk) * W, y);
-            hit |= 1u << u;
-        }
-    }
-    return hit;
-}
-
-template <int H, bool WIDE, class ROWS>
-__global__ __launch_bounds__(256) void sparse_step_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
-                                                          const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                          uint32_t W, StepParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
-    using L = Lane<WIDE>;
-    using T = typename L::T;
-    constexpr int UA = ROWS::kPushUnroll;
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
     __shared__ uint8_t rcode[32], rrank[32];  // the step's residues: code, and rank in the last position of dst's geometry (0xFF: not in it)
     __shared__ GeomTables sg, dg;
-    __shared__ StepItem<T> queue[kStepQueue];
-    __shared__ uint32_t q_head, q_tail, fresh_n, fresh_at, n_hits;
-    __shared__ uint32_t fresh_list[kStepFresh];
-    __shared__ uint32_t e_idx[kSparseChunk], e_dst0[kSparseChunk];
+    __shared__ uint32_t fresh_list[kSparseChunk * 32];
+    __shared__ uint32_t fresh_n, fresh_at;
+    __shared__ uint32_t e_idx[kSparseChunk], e_dst0[kSparseChunk];  // the chunk's entries, decoded
     __shared__ uint64_t e_high[kSparseChunk];
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
     }
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x;
     for (uint32_t i = tid; i <= n_groups; i += blockDim.x) pre[i] = prefix[i];
-    if (tid == 0) { q_head = 0; q_tail = 0; fresh_n = 0; n_hits = 0; }
     __syncthreads();
     const uint32_t total = pre[n_groups];
     const uint32_t j = blockIdx.x - U.n_units, J = gridDim.x - U.n_units;
@@ -1155,83 +1116,31 @@ __global__ __launch_bounds__(256) void sparse_step_kernel(ROWS rows, const Spars
         if (pre[m] <= lo) g = m; else b = m;
     }
     const uint32_t chunks_w = (W + L::kWords - 1) / L::kWords;
-    const bool cw_pow2 = (chunks_w & (chunks_w - 1)) == 0;
-    const uint32_t cw_shift = 31u - (uint32_t)__builtin_clz(chunks_w);
-    unsigned long long c_entries = 0, c_units = 0;  // (thread 0: what this workgroup did, for TXQ_TRACE)
-    // One loop, one copy of every phase; what it does next follows from values every thread sees alike (shared counters read
-    // behind a barrier, the chunk cursor).  The group whose items are queued:
+    const uint32_t sub = tid % G, grp = tid / G, ngrp = blockDim.x / G;
+    const bool lane_on = sub < chunks_w;
+    if (lane_on) rows.prepare(sub);
+    const unsigned long long group_lanes = (G >= 64u ? ~0ULL : ((1ULL << G) - 1ULL)) << ((tid & 63u) & ~(G - 1u));
     uint32_t loaded = 0xFFFFFFFFu, n_r = 0;
     bool noprobe = false;
     DenseOpPtr q{};
     BlockMeta dm{};
     const uint32_t* src_list = nullptr;
-    // the chunk being filled from
-    uint32_t t = lo, base = 0, pairs = 0;
-    bool decoded = false, switch_group = false;
-    for (;;) {
-        const uint32_t waiting = q_tail - q_head;
-        const bool input_done = t >= hi, force = input_done || switch_group;
-        if (waiting >= 256u || (force && waiting)) {
-            // ---- process: up to 256 waiting items, one per lane, rolled forward by every residue of the step
-            const uint32_t n = waiting < 256u ? waiting : 256u;
-            if (tid < n) {
-                const StepItem<T> it = queue[(q_head + tid) % kStepQueue];
-                const T sv = it.sv;
-                const uint32_t c = it.c;
-                rows.prepare(c);
-                uint64_t* const dchunk = q.dst + (size_t)c * L::kWords;
-                uint32_t hit = 0;  // bit i: residue rcode[i] left a bit in this chunk
-                if (noprobe) {  // states that are still filling their first k-mer: the mask moves on as it is
-                    for (uint32_t i = 0; i < n_r; ++i) {
-                        const uint32_t rk = rrank[i];
-                        if (rk == 0xFFu) continue;
-                        atomic_or_chunk<WIDE>(dchunk + (size_t)(it.dst0 + rk) * W, sv);
-                        hit |= 1u << i;
-                    }
-                } else {
-                    uint32_t i = 0;
-                    for (; i + UA <= n_r; i += UA)
-                        hit |= step_trip<UA, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i;
-                    // the last, partial trip: its residues in flight together (n_r is the same in every lane)
-                    if constexpr (UA > 2) { if (n_r - i == 2) { hit |= step_trip<2, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; i += 2; } }
-                    if constexpr (UA > 1) { if (n_r - i == 1) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
-                    if constexpr (UA > 3) { for (; i < n_r; ++i) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
-                }
-                if (ctr && hit) atomicAdd(&n_hits, (uint32_t)__builtin_popcount(hit));
-                for (uint32_t h = hit; h; h &= h - 1) {  // destinations that were empty until now join dst's list
-                    const uint32_t entry = it.dst0 + rrank[__builtin_ctz(h)];
-                    if (mark_live(dm, entry)) {
-                        const uint32_t at = atomicAdd(&fresh_n, 1u);
-                        if (at < kStepFresh) fresh_list[at] = entry;
-                        else append_live(dm, entry);
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) { q_head += n; c_units += (unsigned long long)n * n_r; }
-            __syncthreads();
-            if (fresh_n < kStepFresh / 2) continue;
-        }
-        if (force || fresh_n >= kStepFresh / 2) {
-            // ---- flush: the fresh destination entries join dst's list with one atomic on the block's count
-            const uint32_t n_fresh = fresh_n < kStepFresh ? fresh_n : kStepFresh;
-            if (n_fresh) {
-                if (tid == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                for (uint32_t i = tid; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
-                __syncthreads();
-                if (tid == 0) fresh_n = 0;
-                __syncthreads();
-            }
-            if (!force || q_tail != q_head) continue;  // (a flush in the middle, or items are still waiting)
-            if (input_done) break;
-            // ---- the queue is empty: the tables of the next chunk's group
+    unsigned long long c_entries = 0, c_units = 0;  // (TXQ_TRACE; thread 0)
+    uint32_t c_products = 0, c_hits = 0;            // this lane's non-empty products; this group's units that left a bit
+    for (uint32_t t = lo; t < hi; ++t) {
+        while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
+        const uint32_t first = (t - pre[g]) * kSparseChunk;
+        const uint32_t n = counts[g];
+        const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
+        __syncthreads();  // the previous chunk has copied its fresh entries out and is done with the tables
+        if (tid == 0) fresh_n = 0;
+        if (loaded != g) {
             const uint32_t op = groups[g].op;
             q = optr[op];
             dm = block_meta(q.dst, q.dst_cap, W);
             const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W);
             src_list = sm.list;
-            noprobe = (dops[op].reserved & TXQ_DENSE_NOPROBE) != 0;
+            noprobe = (dops[op].reserved & TXQ_DENSE_NOPROBE) != 0;  // states that are still filling their first k-mer: the mask moves on as it is
             load_geometry(dg, dm.geom, P.pos);
             load_geometry(sg, sm.geom, P.pos);
             const uint32_t r_mask = dops[op].r_mask;
@@ -1241,84 +1150,103 @@ __global__ __launch_bounds__(256) void sparse_step_kernel(ROWS rows, const Spars
                     if ((r_mask >> c) & 1u) { rcode[m] = (uint8_t)c; rrank[m] = dg.rank[P.pos - 1][c]; ++m; }
             }
             n_r = (uint32_t)__builtin_popcount(r_mask);
-            __syncthreads();
             loaded = g;
-            switch_group = false;
-            continue;
         }
-        if (!decoded) {
-            // ---- decode the next chunk's entries, one thread each
-            while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
-            if (loaded != g) { switch_group = true; continue; }  // its items may not mix with the queued ones: drain first
-            const uint32_t first = (t - pre[g]) * kSparseChunk;
-            const uint32_t n = counts[g];
-            const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
-            const uint32_t n_e = end > first ? end - first : 0u;
-            if (tid < n_e) {
-                const uint32_t idx = src_list[first + tid];
-                bool live = idx < q.src_cap;
-                uint64_t high = 0;   // the k-mer without the residue rolled in
-                uint32_t dst0 = 0;   // the destination entry without that residue's rank
-                for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
-                    const uint32_t cn = sg.cnt[jj];
-                    const uint32_t c = sg.code[jj][rest % cn];
-                    rest /= cn;
-                    high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
-                    if (jj > 0) {
-                        const uint32_t rk = dg.rank[jj - 1][c];
-                        live = live && rk != 0xFFu;
-                        dst0 += rk * dg.stride[jj - 1];
+        const uint32_t n_e = end > first ? end - first : 0u;
+        if (tid < n_e) {  // decode: one thread per entry
+            const uint32_t idx = src_list[first + tid];
+            bool live = idx < q.src_cap;
+            uint64_t high = 0;   // the k-mer without the residue rolled in
+            uint32_t dst0 = 0;   // the destination entry without that residue's rank
+            for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
+                const uint32_t cn = sg.cnt[jj];
+                const uint32_t c = sg.code[jj][rest % cn];
+                rest /= cn;
+                high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
+                if (jj > 0) {
+                    const uint32_t rk = dg.rank[jj - 1][c];
+                    live = live && rk != 0xFFu;
+                    dst0 += rk * dg.stride[jj - 1];
+                }
+            }
+            e_idx[tid] = live ? idx : 0xFFFFFFFFu;
+            e_high[tid] = high << P.bits;
+            e_dst0[tid] = dst0;
+        }
+        __syncthreads();
+        const uint32_t units = n_e * n_r;
+        if (tid == 0) { c_entries += n_e; c_units += units; }
+        // destination entries whose bitmap word was asked for in the previous trip (the group's first lane keeps them)
+        uint64_t asked_old[UA];
+        uint32_t asked_entry[UA];
+        uint32_t asked = 0;  // bit u: asked_*[u] is waiting
+        for (uint32_t u0 = grp * UA; u0 < units; u0 += ngrp * UA) {
+            typename ROWS::Loads x[UA];
+            uint32_t dent[UA];  // the unit's destination entry, or none
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                const uint32_t unit = u0 + u;
+                dent[u] = 0xFFFFFFFFu;
+                if (unit < units) {
+                    const uint32_t el = unit / n_r, ri = unit - el * n_r;
+                    const uint32_t idx = e_idx[el], rk = rrank[ri];
+                    if (idx != 0xFFFFFFFFu && rk != 0xFFu) {
+                        dent[u] = e_dst0[el] + rk;
+                        if (lane_on) {
+                            const uint64_t* src_slot = q.src + (size_t)idx * W;
+                            if (noprobe) x[u].x[0] = L::load(src_slot + (size_t)sub * L::kWords);
+                            else {
+                                uint64_t v = e_high[el] | rcode[ri];
+                                if (P.canonical) v = canonical_dna(v, P.k);
+                                rows.template issue<true>(src_slot, v, x[u]);
+                            }
+                        }
                     }
                 }
-                e_idx[tid] = live ? idx : 0xFFFFFFFFu;
-                e_high[tid] = high << P.bits;
-                e_dst0[tid] = dst0;
             }
-            __syncthreads();
-            if (tid == 0) c_entries += n_e;
-            pairs = n_e * chunks_w;
-            base = 0;
-            decoded = pairs != 0;
-            if (!decoded) ++t;
-            continue;
+            if (!noprobe) {
+#pragma unroll
+                for (int u = 0; u < UA; ++u)
+                    if (dent[u] != 0xFFFFFFFFu && lane_on) rows.template issue_late<true>(x[u]);
+            }
+            // the previous trip's answers (they have arrived behind this trip's loads)
+#pragma unroll
+            for (int u = 0; u < UA; ++u)
+                if (((asked >> u) & 1u) && !((asked_old[u] >> (asked_entry[u] & 63u)) & 1ULL)) fresh_list[atomicAdd(&fresh_n, 1u)] = asked_entry[u];
+            asked = 0;
+#pragma unroll
+            for (int u = 0; u < UA; ++u) {
+                bool nz = false;
+                if (dent[u] != 0xFFFFFFFFu && lane_on) {
+                    const T y = noprobe ? x[u].x[0] : rows.combine(x[u]);
+                    nz = L::any(y);
+                    if (nz) atomic_or_chunk<WIDE>(q.dst + (size_t)dent[u] * W + (size_t)sub * L::kWords, y);
+                    c_products += nz;
+                }
+                const bool group_hit = (__ballot(nz) & group_lanes) != 0ULL;
+                if (group_hit && sub == 0) {  // a product of this unit is not empty: its destination entry is (now) live
+                    ++c_hits;
+                    asked_entry[u] = dent[u];
+                    asked_old[u] = __hip_atomic_fetch_or(dm.bitmap + (dent[u] >> 6), 1ULL << (dent[u] & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asked |= 1u << u;
+                }
+            }
         }
-        // ---- fill: the chunks of the decoded entries, coalesced, two rounds in flight; a chunk that holds a bit becomes an item
-        {
-            T sv[kStepFillRounds];
-            uint32_t el[kStepFillRounds], cc[kStepFillRounds];
 #pragma unroll
-            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
-                const uint32_t f = base + r * 256u + tid;
-                el[r] = cw_pow2 ? f >> cw_shift : f / chunks_w;
-                cc[r] = cw_pow2 ? f & (chunks_w - 1) : f % chunks_w;
-                sv[r] = L::zero();
-                if (f < pairs) {
-                    const uint32_t idx = e_idx[el[r]];
-                    if (idx != 0xFFFFFFFFu) sv[r] = L::load(q.src + (size_t)idx * W + (size_t)cc[r] * L::kWords);
-                }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
-                const bool push = L::any(sv[r]);
-                const unsigned long long votes = __ballot(push);
-                uint32_t at = 0;
-                if (lane == 0 && votes) at = atomicAdd(&q_tail, (uint32_t)__popcll(votes));
-                at = (uint32_t)__shfl((int)at, 0);
-                if (push) {
-                    const uint32_t slot = (at + (uint32_t)__popcll(votes & ((1ULL << lane) - 1ULL))) % kStepQueue;
-                    queue[slot] = StepItem<T>{sv[r], e_high[el[r]], e_dst0[el[r]], cc[r]};
-                }
-            }
-            base += 256u * kStepFillRounds;
-            if (base >= pairs) { decoded = false; ++t; }
-            __syncthreads();  // (the items are visible; the entries' table may be overwritten by the next decode)
+        for (int u = 0; u < UA; ++u)
+            if (((asked >> u) & 1u) && !((asked_old[u] >> (asked_entry[u] & 63u)) & 1ULL)) fresh_list[atomicAdd(&fresh_n, 1u)] = asked_entry[u];
+        __syncthreads();
+        const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
+        if (n_fresh) {
+            if (tid == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            for (uint32_t i = tid; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
         }
     }
-    if (ctr && tid == 0) {
-        atomicAdd(ctr + 0, c_entries);
-        atomicAdd(ctr + 1, (unsigned long long)q_tail);
-        atomicAdd(ctr + 2, c_units);
-        atomicAdd(ctr + 3, (unsigned long long)n_hits);
+    if (ctr) {  // what the pushed steps amount to (TXQ_TRACE; DESIGN.md section 3: the algorithmic bytes of this kernel)
+        if (tid == 0) { atomicAdd(ctr + 0, c_entries); atomicAdd(ctr + 1, c_units); }
+        if (c_products) atomicAdd(ctr + 2, (unsigned long long)c_products);
+        if (c_hits) atomicAdd(ctr + 3, (unsigned long long)c_hits);
     }
 }
 
@@ -1686,11 +1614,11 @@ Session::~Session() {
             // algorithmic bytes of the pushed steps: per live entry its list index and its mask, per item and
             // residue the rows' 16-byte (8-byte) pieces, per non-empty product a 16-byte read-modify-write of the destination
             const uint64_t piece = W % 2 == 0 ? 16 : 8;
-            const uint64_t rows_per_unit = ix->kmer_table && !ix->is_hibf ? 1 : (ix->is_hibf ? 1 : ix->ibf[0].hash_funs);
-            const double bytes = (double)c[0] * (4 + 8.0 * W) + (double)c[2] * rows_per_unit * piece + (double)c[3] * 2 * piece;
-            fprintf(stderr, "[txq]   sparse steps: %llu live entries, %llu items (chunks that hold a bit), %llu item-residue units, %llu non-empty products; "
-                            "algorithmic bytes %.0f (%llu row pieces of %llu B per unit)\n", c[0], c[1], c[2], c[3], bytes,
-                    (unsigned long long)rows_per_unit, (unsigned long long)piece);
+            const uint64_t rows_per_unit = ix->kmer_table ? 1 : (ix->is_hibf ? ix->tree_hash_max : ix->ibf[0].hash_funs);
+            const double bytes = (double)c[0] * (4 + 8.0 * W) + (double)c[1] * rows_per_unit * 8.0 * W + (double)c[2] * 2 * piece + (double)c[3] * 8;
+            fprintf(stderr, "[txq]   sparse steps: %llu live entries, %llu units (entry x residue), %llu non-empty %llu-byte products, %llu units that left a bit; "
+                            "algorithmic bytes %.0f (per entry its list index and mask, per unit %llu row segment(s) of %u B, per product a read-modify-write, "
+                            "per unit with a bit one bitmap word)\n", c[0], c[1], c[2], (unsigned long long)piece, c[3], bytes, (unsigned long long)rows_per_unit, W * 8);
         }
     }
     for (void* p : retired) (void)hipFree(p);
@@ -1938,7 +1866,7 @@ static int grow_slot_regions(Session& s, const BlobView& bv, const unsigned char
 struct LevelPlan {
     size_t units = 0, tiles = 0, hsteps = 0, sparse = 0, sparse_chunks = 0;
     // split_steps (flat indexes, tables of k-mer masks): the level's sparse groups are ordered [others | STEPs]; the first
-    // sparse_misc go to sparse_kernel, the STEPs to sparse_step_kernel (sparse_chunks counts the others' chunks then)
+    // sparse_misc go to the sparse_kernel without step code, the STEPs to the one with it (sparse_chunks counts the others' chunks then)
     size_t sparse_misc = 0, step_chunks = 0;
 };
 // hibf: STEP tiles go to their own list (`hsteps`, with the number of predecessors per suffix in `hstep_na`): on an
@@ -2112,12 +2040,12 @@ static hipError_t launch_dense(int ua, uint32_t hash_funs, MAKE rows_of, const D
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
 static hipError_t launch_sparse(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
                                 size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G,
-                                const DenseParams& P, const LevelUnits& U, hipStream_t st) {
+                                const DenseParams& P, const LevelUnits& U, unsigned long long* ctr, hipStream_t st) {
 #define TXQ_SPARSE(H) \
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        sparse_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U); \
+        sparse_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
     } while (0)
     switch (hash_funs) {
         case 1: TXQ_SPARSE(1); break;
@@ -2135,26 +2063,28 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uin
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = i;
 }
 
-// the STEP groups of a level on a flat index / through the table of k-mer masks (sparse_step_kernel)
+// the STEP groups of a level on narrow masks (sparse_units_kernel)
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
-static hipError_t launch_sparse_steps(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
-                                      size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W,
-                                      const StepParams& P, const LevelUnits& U, unsigned long long* ctr, hipStream_t st) {
-#define TXQ_STEPS(H) \
+static hipError_t launch_sparse_units(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
+                                      size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G,
+                                      const StepParams& P, const LevelUnits& U, unsigned long long* ctr, int ua, hipStream_t st) {
+    // ua: units in flight per lane group (TXQ_SPARSE_UNROLL: A/B knob; 3 = 149 VGPRs at h = 3, 2 = a wave more per SIMD)
+#define TXQ_UNITS(H) \
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        sparse_step_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, P, U, ctr); \
+        if (ua <= 2) sparse_units_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
+        else sparse_units_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
     } while (0)
     switch (hash_funs) {
-        case 1: TXQ_STEPS(1); break;
-        case 2: TXQ_STEPS(2); break;
-        case 3: TXQ_STEPS(3); break;
-        case 4: TXQ_STEPS(4); break;
-        case 5: TXQ_STEPS(5); break;
+        case 1: TXQ_UNITS(1); break;
+        case 2: TXQ_UNITS(2); break;
+        case 3: TXQ_UNITS(3); break;
+        case 4: TXQ_UNITS(4); break;
+        case 5: TXQ_UNITS(5); break;
         default: return hipErrorInvalidValue;
     }
-#undef TXQ_STEPS
+#undef TXQ_UNITS
     return hipGetLastError();
 }
 
@@ -2289,9 +2219,12 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<SparseGroup> sparse_groups;
     std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    // pushed steps of tracked blocks on a flat index or through the table of k-mer masks run compacted (sparse_step_kernel);
-    // TXQ_SPARSE_STEPS=0: in sparse_kernel like the trees' (A/B and tests)
-    const bool split_steps = s.kn.sparse_steps && !vspace && !tree && (table || !ix.is_hibf);
+    // on a flat index / through the table of k-mer masks a level's STEP groups get a launch of their own: the ZERO / REDUCE / FILL
+    // groups then run in the sparse_kernel variant without step code (66 VGPRs instead of 110)
+    const bool split_steps = !vspace && !tree && (table || !ix.is_hibf);
+    // ... and where a mask is a cache line or two, that launch shares the steps out by units (sparse_units_kernel; TXQ_SPARSE_STEPS=0:
+    // sparse_kernel's rounds of entries, A/B and tests)
+    const bool by_units = split_steps && s.kn.sparse_steps && W <= kUnitStepWords;
     const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, split_steps, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
@@ -2626,42 +2559,42 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     // as many workgroups as the chunks could be at most, within what the device holds at a time
                     const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(range_chunks, 2048));
                     hipError_t e;
-                    if (steps) {
+                    if (steps && by_units) {
                         const StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical};
                         if (table) {
                             auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
-                            e = wide ? launch_sparse_steps<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st)
-                                     : launch_sparse_steps<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st);
+                            e = wide ? launch_sparse_units<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st)
+                                     : launch_sparse_units<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st);
                         } else {
                             auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                            e = wide ? launch_sparse_steps<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st)
-                                     : launch_sparse_steps<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, s.d_step_ctr, st);
+                            e = wide ? launch_sparse_units<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st)
+                                     : launch_sparse_units<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st);
                         }
-                    } else if (split_steps) {  // ZERO / REDUCE / FILL only: the variant without the step code (its row source is not used)
+                    } else if (split_steps && !steps) {  // ZERO / REDUCE / FILL only: the variant without the step code (its row source is not used)
                         FlatRows<1, true> none{};
-                        if (wide) sparse_kernel<1, true, FlatRows<1, true>, false><<<(unsigned)grid, 256, 0, st>>>(none, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu);
-                        else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu); }
+                        if (wide) sparse_kernel<1, true, FlatRows<1, true>, false><<<(unsigned)grid, 256, 0, st>>>(none, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, nullptr);
+                        else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, nullptr); }
                         e = hipGetLastError();
                     } else if (vspace) {
                         auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                        e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                                 : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                        e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
+                                 : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
                     } else if (interleaved) {
                         auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                                 : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                        e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
+                                 : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
                     } else if (tree) {
                         auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                                 : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                        e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
+                                 : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
                     } else if (table) {
                         auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
-                        e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                                 : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                        e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
+                                 : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
                     } else {
                         auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                        e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st)
-                                 : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, st);
+                        e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
+                                 : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
                     }
                     if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
                     if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to

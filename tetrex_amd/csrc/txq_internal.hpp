@@ -23,7 +23,8 @@ struct Knobs {
     int dense_nt = 0;           // TXQ_DENSE_NT: bit 0 non-temporal stores, bit 1 non-temporal loads of a dense step's destination entries
     bool fuse_units = true;     // TXQ_FUSE_UNITS=0: a level's ordinary ops get a launch of their own
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
-    bool sparse_steps = true;   // TXQ_SPARSE_STEPS=0: pushed steps of tracked blocks on a flat index / table run in sparse_kernel (G lanes per entry), not compacted
+    int sparse_unroll = 3;      // TXQ_SPARSE_UNROLL: units in flight per lane group in sparse_units_kernel (2 or 3)
+    bool sparse_steps = true;   // TXQ_SPARSE_STEPS=0: pushed steps on narrow masks run in sparse_kernel (rounds of one entry per lane group), not by units (sparse_units_kernel)
     long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most an index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
     long long kmer_table_min = 16;  // TXQ_KMER_TABLE_MIN: the session of fewest programs that builds the table (a single query does not pay for it; once built it is used)
     // HIBF (txq_hibf.hip)
@@ -269,7 +270,7 @@ struct Session {
     std::vector<void*> retired;   // staging buffers that were outgrown while another stage was running: freed with the session
     Index::StagingSet set[2];     // stage n uses set[n & 1]
     hipStream_t upload = nullptr; // the uploads' stream (non-blocking: independent of the stream the kernels run on)
-    unsigned long long* d_step_ctr = nullptr;  // TXQ_TRACE: what sparse_step_kernel did (entries, items, item x residue units, non-empty products)
+    unsigned long long* d_step_ctr = nullptr;  // TXQ_TRACE: what sparse_units_kernel did (entries, units, non-empty products, units that left a bit)
     std::vector<unsigned char> host_aux;  // a small stage is packed here and sent as one copy
     // where a stage's wall time goes (reported on stderr at session end when TXQ_TRACE is set)
     double t_validate = 0, t_upload = 0, t_device = 0;

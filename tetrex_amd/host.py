@@ -196,6 +196,18 @@ def regex_find_all(pattern, text, posix):
     return [(int(out[2 * i]), int(out[2 * i + 1])) for i in range(n)]
 
 
+def regex_required_literal(pattern, posix=True):
+    """The matcher's prefilter string for `pattern` (host/matcher.hpp required_literal)."""
+    L = lib()
+    L.txh_regex_required_literal.restype = C.c_int64
+    L.txh_regex_required_literal.argtypes = [C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+    buf = C.create_string_buffer(4096)
+    n = L.txh_regex_required_literal(pattern.encode(), int(posix), buf, 4096)
+    if n < 0:
+        raise _err()
+    return buf.raw[:n].decode()
+
+
 def record_values(seq, k, dna=True, reduction=0, wraparound=False):
     s = seq.encode() if isinstance(seq, str) else seq
     cap = len(s) + 2
