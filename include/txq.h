@@ -102,6 +102,12 @@ typedef struct {
     uint64_t device_bytes; /* HBM held by the index                                   */
     int      is_hibf;
     int      device;       /* HIP device ordinal                                      */
+    int      join_or;      /* 0: this shard owns the mask-word columns [shard_word0, shard_word0 + shard_words);
+                              1: a SUB-TREE shard (txq_index_upload_subtrees): it emits full-width masks (shard_word0 = 0,
+                              shard_words = mask_words) that hold only the user bins of its sub-trees — the shards' masks are ORed */
+    int      shard_rank;   /* which shard of ... */
+    int      n_shards;     /* ... how many this index was uploaded as                 */
+    int      reserved;
 } txq_index_info;
 
 /* Bind this process to n_devices GPUs (device_ids == NULL: devices 0 .. n_devices-1).  One process per GPU
@@ -118,6 +124,15 @@ int txq_device_count(void); /* >= 0, or a negative txq_status */
  * mask-word columns of shard `shard_rank` are kept (flat IBF: words [W*r/R, W*(r+1)/R) of every row, re-laid out
  * contiguously; HIBF: the whole tree is kept and only the user-bin mask columns are sharded). */
 int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out);
+/* The same for an HIBF, sharded by SUB-TREES where the tree is a general one (as seqan::hibf's layout shapes it: reference
+ * include/index_hibf.h:114-129): the root is replicated, its merged bins — the level-1 sub-trees — are dealt over the shards
+ * by the row words under them (largest first, to the shard that holds least), the user bins that sit in the root itself go to
+ * shard 0, and a shard keeps only its own sub-trees (in its copy of the root the technical bins of the others are cleared, so
+ * nothing is ever descended into or reported for them).  Such a shard emits FULL-WIDTH masks (info.join_or = 1) with the user
+ * bins of its sub-trees only; a split bin may straddle shards: the join is an OR.  Its sessions work in layout order like an
+ * unsharded general tree's.  A regular two-level tree (what `tetrex index` writes) and a flat IBF are sharded by mask
+ * columns exactly as txq_index_upload does (info.join_or = 0). */
+int txq_index_upload_subtrees(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out);
 int txq_index_get_info(const txq_index* ix, txq_index_info* info);
 int txq_index_free(txq_index* ix);
 

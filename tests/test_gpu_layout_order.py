@@ -137,3 +137,67 @@ def test_a_five_level_tree_is_not_taken_in_layout_order(capi, oracle, monkeypatc
         if not ost["quirk_merges"]:
             assert np.array_equal(g, want), q
     ix.free()
+
+
+@pytest.mark.parametrize("tree,R", [("random-3", 2), ("random-4", 3), ("layout-64", 8), ("layout-16-deep", 3), ("layout-64", 5)])
+def test_general_trees_shard_by_sub_trees(capi, oracle, monkeypatch, tree, R):
+    """txq_index_upload_subtrees (BASELINE configs[4] on several GPUs for a tree as seqan::hibf lays it out, reference
+    include/index_hibf.h:114-147): the root is replicated, its sub-trees are dealt over the shards, every shard works in layout
+    order on its own part of the tree and emits full-width masks that are ORed (info.join_or; split bins may straddle shards).
+    Here all shards share the one GPU of the box.  The joined masks of whole queries (one expansion driving all shards:
+    txe_query_masks_sharded) and the ORed plain probes must equal the oracle's and the unsharded index's."""
+    monkeypatch.setenv("TETREX_DENSE_EVIDENCE", "dense")
+    monkeypatch.setenv("TXQ_KMER_TABLE_MB", "0")
+    kind, _, arg = tree.partition("-")
+    if kind == "random":
+        ox, descs, values = random_hibf(oracle, 50 + int(arg), user_bins=420, levels=int(arg), n_values=60)
+        ub = 420
+    elif arg == "64":
+        ox, descs, values = layout_hibf(oracle, 5, user_bins=3000, tmax=64, n_values=30)
+        ub = 3000
+    else:
+        ox, descs, values = layout_hibf(oracle, 6, user_bins=900, tmax=16, n_values=30, direct=3)
+        ub = 900
+    qs = _queries(values)
+    one = capi.Index.upload_hibf(ub, descs)
+    ref, status_ref, _ = one.query_masks(qs, False, 4)
+    shards = [capi.Index.upload_hibf(ub, descs, shard_rank=r, n_shards=R, subtrees=True) for r in range(R)]
+    W = (ub + 63) // 64
+    for s_ in shards:
+        assert s_.info.join_or == 1 and int(s_.info.shard_word0) == 0 and s_.shard_words == W and s_.info.n_shards == R
+    assert sum(int(s_.info.n_ibf) - 1 for s_ in shards) == len(descs) - 1  # every sub-tree IBF lives in exactly one shard
+    for way in ("layout", "user-order"):
+        if way == "user-order":
+            monkeypatch.setenv("TXQ_HIBF_LAYOUT_ORDER", "0")
+        full, status, stats = capi.query_masks_sharded(shards, qs, False, 4)
+        assert list(status) == list(status_ref) and np.array_equal(full, ref), way
+    hits = 0
+    for q, g, st in zip(qs, ref, status_ref):
+        assert st == 0, q
+        want, ost = ox.query(q, with_stats=True)
+        if not ost["quirk_merges"]:
+            assert np.array_equal(g, want), q
+            hits += int(want.any())
+    assert hits >= 10
+    # plain probes: every shard reports the user bins of its own sub-trees, the OR is membership_for of the whole tree
+    kmers = np.concatenate([v[:1] for v in values[:400]] + [np.random.default_rng(2).integers(0, 1 << 20, size=300, dtype=np.uint64)])
+    got = np.zeros((kmers.size, W), dtype=np.uint64)
+    for s_ in shards:
+        got |= s_.probe(kmers)
+    assert np.array_equal(got, ox.probe(kmers))
+    for s_ in shards + [one]:
+        s_.free()
+
+
+def test_a_regular_tree_keeps_its_column_shards(capi, oracle):
+    """txq_index_upload_subtrees on the layout `tetrex index` writes (regular two-level tree): mask columns, as txq_index_upload."""
+    from helpers import regular_hibf
+    rng = np.random.default_rng(4)
+    ox, descs, values = regular_hibf(oracle, 1024, 16, 40, lambda b: rng.integers(0, 1 << 20, size=40, dtype=np.uint64), h=2)
+    shards = [capi.Index.upload_hibf(1024, descs, shard_rank=r, n_shards=2, subtrees=True) for r in range(2)]
+    assert [int(s_.info.join_or) for s_ in shards] == [0, 0] and [s_.shard_words for s_ in shards] == [8, 8]
+    kmers = np.concatenate([v[:1] for v in values[:200]])
+    want = ox.probe(kmers)
+    assert np.array_equal(np.concatenate([s_.probe(kmers) for s_ in shards], axis=1), want)
+    for s_ in shards:
+        s_.free()

@@ -20,7 +20,7 @@ TXQ_MERGED_BIN = 0xFFFFFFFFFFFFFFFF
 # every symbol include/txq.h declares (checked by tests/test_capi_symbols.py)
 SYMBOLS = [
     "txq_init", "txq_shutdown", "txq_last_error", "txq_device_count",
-    "txq_index_upload", "txq_index_get_info", "txq_index_free", "txq_index_supports_dense", "txq_index_memory", "txq_index_set_tag", "txq_index_get_tag", "txq_index_create_ibf",
+    "txq_index_upload", "txq_index_upload_subtrees", "txq_index_get_info", "txq_index_free", "txq_index_supports_dense", "txq_index_memory", "txq_index_set_tag", "txq_index_get_tag", "txq_index_create_ibf",
     "txq_index_download_words", "txq_probe", "txq_probe_device", "txq_emplace_device",
     "txq_run_programs", "txq_run_programs_device", "txq_session_begin", "txq_session_set_aux_index", "txq_session_stage", "txq_session_end",
     "txq_malloc", "txq_free", "txq_memcpy_h2d", "txq_memcpy_d2h", "txq_synchronize", "txq_host_alloc", "txq_host_free",
@@ -48,7 +48,8 @@ class IndexDesc(C.Structure):
 class IndexInfo(C.Structure):
     _fields_ = [("user_bins", C.c_uint64), ("mask_words", C.c_uint64), ("shard_word0", C.c_uint64),
                 ("shard_words", C.c_uint64), ("n_ibf", C.c_uint64), ("device_bytes", C.c_uint64),
-                ("is_hibf", C.c_int), ("device", C.c_int)]
+                ("is_hibf", C.c_int), ("device", C.c_int), ("join_or", C.c_int), ("shard_rank", C.c_int), ("n_shards", C.c_int),
+                ("reserved", C.c_int)]
 
 
 _LIB = None
@@ -65,6 +66,7 @@ def lib():
         L.txq_last_error.restype = C.c_char_p
         L.txq_init.argtypes = [C.c_int, C.POINTER(C.c_int)]
         L.txq_index_upload.argtypes = [C.POINTER(IndexDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.txq_index_upload_subtrees.argtypes = [C.POINTER(IndexDesc), C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.txq_index_get_info.argtypes = [C.c_void_p, C.POINTER(IndexInfo)]
         L.txq_index_free.argtypes = [C.c_void_p]
         L.txq_index_create_ibf.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
@@ -229,8 +231,9 @@ class Index:
         return cls(h.value)
 
     @classmethod
-    def upload_hibf(cls, user_bins, ibfs, shard_rank=0, n_shards=1):
-        """ibfs: list of dicts {bins, bin_size, hash_funs, words, next_ibf_id, tb_to_user}."""
+    def upload_hibf(cls, user_bins, ibfs, shard_rank=0, n_shards=1, subtrees=False):
+        """ibfs: list of dicts {bins, bin_size, hash_funs, words, next_ibf_id, tb_to_user}.  subtrees: txq_index_upload_subtrees
+        (a general tree is sharded by sub-trees: full-width masks that are ORed, info.join_or == 1)."""
         n = len(ibfs)
         keep = []
         descs = (IbfDesc * n)()
@@ -246,7 +249,7 @@ class Index:
             tbu[i] = b.ctypes.data_as(u64p)
         desc = IndexDesc(n, descs, nxt, tbu, user_bins)
         h = C.c_void_p()
-        check(lib().txq_index_upload(C.byref(desc), shard_rank, n_shards, C.byref(h)))
+        check((lib().txq_index_upload_subtrees if subtrees else lib().txq_index_upload)(C.byref(desc), shard_rank, n_shards, C.byref(h)))
         return cls(h.value)
 
     @classmethod

@@ -70,7 +70,8 @@ txq_index* DeviceIndex::upload_one(const IndexImage& image, int shard_rank, int 
             tb.push_back(h.tb_to_user_bin[i].data());
         }
         txq_index_desc desc{ds.size(), ds.data(), nx.data(), tb.data(), h.user_bins};
-        txq_check(txq_index_upload(&desc, shard_rank, n_shards, &ix), "txq_index_upload");
+        // (a general tree is sharded by sub-trees — full-width masks, ORed —, a regular two-level one by mask columns: the library decides)
+        txq_check(txq_index_upload_subtrees(&desc, shard_rank, n_shards, &ix), "txq_index_upload_subtrees");
     }
     return ix;
 }
@@ -197,6 +198,15 @@ std::vector<uint64_t> ShardedStageExecutor::finish() {
         ptr[r] = part[r].data();
     }
     if (!error.empty()) throw std::runtime_error(error);
+    if (info_[0].join_or) {  // sub-tree shards of a general HIBF: full-width masks, ORed (a split bin may straddle shards)
+        const uint64_t mw = info_[0].mask_words;
+        std::vector<uint64_t> full(n_programs_ * mw, 0);
+        for (size_t r = 0; r < R; ++r) {
+            if (!info_[r].join_or || info_[r].shard_words != mw) throw std::runtime_error("shards of different kinds in one join");
+            for (size_t i = 0; i < n_programs_ * mw; ++i) full[i] |= part[r][i];
+        }
+        return full;
+    }
     return join_shard_masks(n_programs_, info_[0].mask_words, word0, words, ptr);
 }
 

@@ -298,9 +298,7 @@ int txq_shutdown(void) {
     return TXQ_OK;
 }
 
-int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out) {
-    read_knobs();
-    if (int rc = require_init()) return rc;
+static int check_desc(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out, bool* hibf_out) {
     if (!desc || !out || !desc->ibf || desc->n_ibf == 0) return fail(TXQ_ERR_ARG, "null descriptor");
     if (n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) return fail(TXQ_ERR_ARG, "bad shard %d/%d", shard_rank, n_shards);
     const bool hibf = desc->next_ibf_id != nullptr || desc->tb_to_user_bin != nullptr || desc->n_ibf > 1;
@@ -309,14 +307,22 @@ int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, t
         if (int rc = validate_ibf(desc->ibf[i], true)) return rc;
     if (!hibf && desc->user_bins != desc->ibf[0].bins) return fail(TXQ_ERR_ARG, "flat IBF: user_bins must equal ibf[0].bins");
     if (desc->user_bins == 0) return fail(TXQ_ERR_ARG, "user_bins == 0");
+    *hibf_out = hibf;
+    return TXQ_OK;
+}
 
+// the upload itself: the index goes to the device of `device_rank`; it keeps mask columns `range_rank` of `range_shards`
+static int upload_impl(const txq_index_desc* desc, bool hibf, int device_rank, int range_rank, int range_shards, txq_index** out) {
+    const int shard_rank = range_rank, n_shards = range_shards;
     txq_index* ix = new (std::nothrow) txq_index();
     if (!ix) return fail(TXQ_ERR_NOMEM, "out of host memory");
-    ix->device = g_devices[(size_t)shard_rank % g_devices.size()];  // shards go round-robin over the devices of txq_init
+    ix->device = g_devices[(size_t)device_rank % g_devices.size()];  // shards go round-robin over the devices of txq_init
     if (int rc = bind_device(ix->device)) { delete ix; return rc; }
     ix->is_hibf = hibf;
     ix->user_bins = desc->user_bins;
     ix->mask_words = (desc->user_bins + 63) / 64;
+    ix->shard_rank = device_rank;
+    ix->n_shards = range_shards;
     uint64_t lo, hi;
     shard_range(ix->mask_words, shard_rank, n_shards, &lo, &hi);
     ix->shard_word0 = lo;
@@ -339,6 +345,124 @@ int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, t
     return TXQ_OK;
 }
 
+int txq_index_upload(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out) {
+    read_knobs();
+    if (int rc = require_init()) return rc;
+    bool hibf = false;
+    if (int rc = check_desc(desc, shard_rank, n_shards, out, &hibf)) return rc;
+    return upload_impl(desc, hibf, shard_rank, shard_rank, n_shards, out);
+}
+
+// Is the tree what hibf_upload recognises as a regular two-level one (root of merged bins only over leaf IBFs that each map an
+// aligned run of user bins, all of one power-of-two row width, tiling the mask)?  Those shard by mask columns.
+static bool regular_two_level(const txq_index_desc& d) {
+    const uint64_t n = d.n_ibf;
+    if (n < 2 || d.ibf[0].bins != n - 1) return false;
+    const uint64_t wpr = d.ibf[1].bin_words;
+    if (wpr < 1 || (wpr & (wpr - 1)) || wpr > 128 || (d.user_bins + 63) / 64 != wpr * (n - 1)) return false;
+    std::vector<uint8_t> seen(n, 0), column(n - 1, 0);
+    for (uint64_t b = 0; b < d.ibf[0].bins; ++b) {
+        if (d.tb_to_user_bin[0][b] != TXQ_MERGED_BIN) return false;
+        const uint64_t c = d.next_ibf_id[0][b];
+        if (c == 0 || c >= n || seen[c]) return false;
+        seen[c] = 1;
+    }
+    for (uint64_t i = 1; i < n; ++i) {
+        if (d.ibf[i].bin_words != wpr) return false;
+        const uint64_t base = d.tb_to_user_bin[i][0];
+        if (base == TXQ_MERGED_BIN || base % (wpr * 64)) return false;
+        for (uint64_t b = 0; b < d.ibf[i].bins; ++b)
+            if (d.tb_to_user_bin[i][b] != base + b) return false;
+        const uint64_t col = base / (wpr * 64);
+        if (col >= n - 1 || column[col]) return false;
+        column[col] = 1;
+    }
+    return true;
+}
+
+int txq_index_upload_subtrees(const txq_index_desc* desc, int shard_rank, int n_shards, txq_index** out) {
+    read_knobs();
+    if (int rc = require_init()) return rc;
+    bool hibf = false;
+    if (int rc = check_desc(desc, shard_rank, n_shards, out, &hibf)) return rc;
+    if (!hibf || n_shards == 1) return upload_impl(desc, hibf, shard_rank, shard_rank, n_shards, out);
+    const uint64_t n = desc->n_ibf;
+    for (uint64_t i = 0; i < n; ++i)
+        if (!desc->next_ibf_id[i] || !desc->tb_to_user_bin[i]) return fail(TXQ_ERR_ARG, "HIBF map %llu is null", (unsigned long long)i);
+    if (regular_two_level(*desc)) return upload_impl(desc, hibf, shard_rank, shard_rank, n_shards, out);
+    // the sub-trees under the root's merged bins and the row words under each (the whole tree is checked by hibf_upload below;
+    // here only what the walk itself needs: children in range, no IBF reached twice)
+    std::vector<int> owner_of_ibf(n, -1);  // which root bin's sub-tree an IBF belongs to (-1: the root)
+    std::vector<uint64_t> weight(desc->ibf[0].bins, 0);
+    std::vector<uint8_t> reached(n, 0);
+    reached[0] = 1;
+    for (uint64_t b = 0; b < desc->ibf[0].bins; ++b) {
+        if (desc->tb_to_user_bin[0][b] != TXQ_MERGED_BIN) continue;
+        std::vector<uint64_t> stack{desc->next_ibf_id[0][b]};
+        while (!stack.empty()) {
+            const uint64_t i = stack.back();
+            stack.pop_back();
+            if (i >= n || reached[i]) return fail(TXQ_ERR_ARG, "HIBF: bad child %llu (out of range or reached twice)", (unsigned long long)i);
+            reached[i] = 1;
+            owner_of_ibf[i] = (int)b;
+            weight[b] += desc->ibf[i].bin_words;
+            for (uint64_t c = 0; c < desc->ibf[i].bins; ++c)
+                if (desc->tb_to_user_bin[i][c] == TXQ_MERGED_BIN) stack.push_back(desc->next_ibf_id[i][c]);
+        }
+    }
+    for (uint64_t i = 0; i < n; ++i)
+        if (!reached[i]) return fail(TXQ_ERR_ARG, "IBF %llu is unreachable from the root", (unsigned long long)i);
+    // largest sub-tree first, to the shard that holds least (ties: the lower shard) — the same deal on every rank
+    std::vector<uint64_t> order;
+    for (uint64_t b = 0; b < desc->ibf[0].bins; ++b)
+        if (desc->tb_to_user_bin[0][b] == TXQ_MERGED_BIN) order.push_back(b);
+    std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return weight[a] > weight[b]; });
+    std::vector<uint64_t> load(n_shards, 0);
+    std::vector<int> shard_of_bin(desc->ibf[0].bins, 0);  // (the root's own user bins: shard 0)
+    for (uint64_t b : order) {
+        int best = 0;
+        for (int r = 1; r < n_shards; ++r)
+            if (load[r] < load[best]) best = r;
+        shard_of_bin[b] = best;
+        load[best] += weight[b];
+    }
+    // this shard's tree: the root and its own sub-trees, renumbered in the original order; in its copy of the root the columns of
+    // everybody else's technical bins are cleared and those bins become plain technical bins that never fire
+    std::vector<uint64_t> new_id(n, UINT64_MAX), kept;
+    for (uint64_t i = 0; i < n; ++i)
+        if (i == 0 || shard_of_bin[owner_of_ibf[i]] == shard_rank) { new_id[i] = kept.size(); kept.push_back(i); }
+    const txq_ibf_desc& root = desc->ibf[0];
+    std::vector<uint64_t> keep_mask(root.bin_words, 0);
+    for (uint64_t b = 0; b < root.bins; ++b)
+        if (shard_of_bin[b] == shard_rank) keep_mask[b >> 6] |= 1ULL << (b & 63);
+    std::vector<uint64_t> root_words((size_t)root.bin_size * root.bin_words);
+    for (uint64_t r = 0; r < root.bin_size; ++r)
+        for (uint64_t w = 0; w < root.bin_words; ++w) root_words[r * root.bin_words + w] = root.words[r * root.bin_words + w] & keep_mask[w];
+    std::vector<txq_ibf_desc> ibfs;
+    std::vector<std::vector<uint64_t>> next(kept.size()), user(kept.size());
+    std::vector<const uint64_t*> next_p, user_p;
+    for (size_t j = 0; j < kept.size(); ++j) {
+        const uint64_t i = kept[j];
+        txq_ibf_desc d = desc->ibf[i];
+        if (i == 0) d.words = root_words.data();
+        ibfs.push_back(d);
+        next[j].assign(desc->ibf[i].bins, 0);
+        user[j].assign(desc->ibf[i].bins, 0);
+        for (uint64_t b = 0; b < desc->ibf[i].bins; ++b) {
+            const uint64_t ub = desc->tb_to_user_bin[i][b];
+            if (i == 0 && shard_of_bin[b] != shard_rank) { user[j][b] = 0; continue; }  // (cleared column: user bin 0 is never reported through it)
+            user[j][b] = ub;
+            if (ub == TXQ_MERGED_BIN) next[j][b] = new_id[desc->next_ibf_id[i][b]];
+        }
+    }
+    for (size_t j = 0; j < kept.size(); ++j) { next_p.push_back(next[j].data()); user_p.push_back(user[j].data()); }
+    const txq_index_desc pruned{kept.size(), ibfs.data(), next_p.data(), user_p.data(), desc->user_bins};
+    if (int rc = upload_impl(&pruned, true, shard_rank, 0, 1, out)) return rc;
+    (*out)->join_or = true;
+    (*out)->n_shards = n_shards;
+    return TXQ_OK;
+}
+
 int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, int shard_rank, int n_shards, txq_index** out) {
     if (int rc = require_init()) return rc;
     if (!out || n_shards < 1 || shard_rank < 0 || shard_rank >= n_shards) return fail(TXQ_ERR_ARG, "bad arguments");
@@ -357,6 +481,8 @@ int txq_index_create_ibf(uint64_t bins, uint64_t bin_size, uint64_t hash_funs, i
     if (int rc = bind_device(ix->device)) { delete ix; return rc; }
     ix->user_bins = bins;
     ix->mask_words = d.bin_words;
+    ix->shard_rank = shard_rank;
+    ix->n_shards = n_shards;
     uint64_t lo, hi;
     shard_range(ix->mask_words, shard_rank, n_shards, &lo, &hi);
     ix->shard_word0 = lo;
@@ -381,6 +507,10 @@ int txq_index_get_info(const txq_index* ix, txq_index_info* info) {
     info->device_bytes = ix->device_bytes;
     info->is_hibf = ix->is_hibf ? 1 : 0;
     info->device = ix->device;
+    info->join_or = ix->join_or ? 1 : 0;
+    info->shard_rank = ix->shard_rank;
+    info->n_shards = ix->n_shards;
+    info->reserved = 0;
     return TXQ_OK;
 }
 

@@ -770,11 +770,23 @@ __device__ __forceinline__ void dense_codes(const txq_dense_op* __restrict__ d, 
 struct SparseGroup { uint32_t op; uint32_t fixed; };  // fixed != kNotFixed: the host knows the entries (FILL: its shape)
 static constexpr uint32_t kNotFixed = 0xFFFFFFFFu;
 static constexpr uint32_t kSparseChunk = 64;
+static constexpr uint32_t kUnitChunk = 256;      // most entries per chunk of sparse_units_kernel: one decoding thread each
+static constexpr uint32_t kUnitFresh = 1024;     // fresh destination entries it collects per chunk (more: appended one by one)
+// sparse_units_kernel cuts a group's list into chunks of about 512 UNITS (entry x residue), not of a fixed number of entries: a
+// chunk is the same work whether the step rolls one residue in or twenty (a 64-entry chunk of a wildcard step is forty times
+// the work of a literal's; with 256 entries the heaviest chunks were a level's critical path), and a step with few residues
+// amortises a chunk's fixed trips (list, bitmap words, the append) over more entries
+__host__ __device__ __forceinline__ uint32_t unit_chunk_entries(uint32_t n_r) {
+    uint32_t c = n_r ? 512u / n_r : kUnitChunk;
+    if (c > kUnitChunk) c = kUnitChunk;
+    if (c < 16u) c = 16u;
+    return c & ~7u;
+}
 static constexpr uint32_t kUnitStepWords = 32;  // masks up to this wide (2048 bins) step by units (sparse_kernel, narrow masks)
 static constexpr uint32_t kMaxSparseGroups = 1024;  // per launch (the chunk totals sit in LDS)
 
 __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __restrict__ groups, uint32_t n_groups, const txq_dense_op* __restrict__ dops,
-                                                           const DenseOpPtr* __restrict__ optr, uint32_t W, uint32_t pos, uint32_t* __restrict__ counts,
+                                                           const DenseOpPtr* __restrict__ optr, uint32_t W, uint32_t pos, uint32_t chunk, uint32_t* __restrict__ counts,
                                                            uint32_t* __restrict__ prefix) {
     __shared__ uint32_t scan[1024];
     const uint32_t t = threadIdx.x;
@@ -795,7 +807,8 @@ __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __
                 n = *reinterpret_cast<const uint32_t*>(q.src + (size_t)q.src_cap * W);
         }
         counts[t] = n;
-        chunks = (n + kSparseChunk - 1) / kSparseChunk;
+        const uint32_t per = chunk ? chunk : unit_chunk_entries((uint32_t)__popc(dops[g.op].r_mask));  // (0: by units, sparse_units_kernel)
+        chunks = (n + per - 1) / per;
     }
     scan[t] = chunks;
     __syncthreads();
@@ -922,7 +935,9 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             for (uint32_t e = first + grp; e < end; e += ngrp) {
                 const uint32_t idx = m.list[e];
                 for (uint32_t w = sub; w < W; w += wl) q.dst[(size_t)idx * W + w] = 0;
-                if (sub == 0) __hip_atomic_fetch_and(m.bitmap + (idx >> 6), ~(1ULL << (idx & 63u)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // every bit of the bitmap is a listed entry and the ZERO clears all of them: the whole word goes (no atomic needed —
+                // nothing else of the level touches this block, and the other entries of the word store the same zero)
+                if (sub == 0) m.bitmap[idx >> 6] = 0;
             }
             continue;
         }
@@ -1074,7 +1089,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     }
 }
 
-struct StepParams { uint32_t k, bits, pos, canonical; };
+struct StepParams { uint32_t k, bits, pos, canonical; uint32_t experiment; };  // experiment: TXQ_EXPERIMENTS builds only (timing experiments: wrong masks)
 
 // ---- pushed steps on narrow masks: by units -------------------------------------------------------------------------
 // The STEP groups of a level when a mask is a cache line or two (W <= kUnitStepWords: up to 2048 bins per shard), where every
@@ -1082,11 +1097,11 @@ struct StepParams { uint32_t k, bits, pos, canonical; };
 // rounds of one entry per lane group — list -> mask chunk -> rows -> listing, twice per chunk, with one k-mer in flight per
 // group for a literal residue.  Here the chunk's entries are decoded by one thread each, and the lane groups then share out
 // the chunk's UNITS — (entry, residue) pairs — UA at a time: a unit's loads are the entry's mask chunk and the h rows of its
-// k-mer, all in ONE trip, and UA units are in flight per group whatever the step's number of residues.  Whether a
-// destination entry was empty is asked with a returning atomic on dst's bitmap; the answer is looked at a trip later, behind
-// the next trip's loads.  A chunk is: list (coalesced) -> its units' trips -> one append of the fresh entries.
+// k-mer, all in ONE trip, and UA units are in flight per group whatever the step's number of residues.  Which destination
+// entries received bits is collected in LDS as bits of dst's bitmap words and asked of the bitmap with one returning atomic per
+// word at the end of the chunk.  A chunk is: list (coalesced) -> its units' trips -> bitmap words -> one append of the fresh entries.
 template <int H, bool WIDE, int UA, class ROWS>
-__global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void sparse_units_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
                                                            const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
                                                            uint32_t W, uint32_t G, StepParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
@@ -1095,10 +1110,13 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
     __shared__ uint8_t rcode[32], rrank[32];  // the step's residues: code, and rank in the last position of dst's geometry (0xFF: not in it)
     __shared__ GeomTables sg, dg;
-    __shared__ uint32_t fresh_list[kSparseChunk * 32];
+    __shared__ uint32_t fresh_list[kUnitFresh];
     __shared__ uint32_t fresh_n, fresh_at;
-    __shared__ uint32_t e_idx[kSparseChunk], e_dst0[kSparseChunk];  // the chunk's entries, decoded
-    __shared__ uint64_t e_high[kSparseChunk];
+    __shared__ uint32_t e_idx[kUnitChunk], e_dst0[kUnitChunk];  // the chunk's entries, decoded
+    __shared__ uint64_t e_high[kUnitChunk];
+    // the destination entries the chunk's units left bits in, as bits of dst's bitmap words: an entry's residues land in
+    // consecutive destination entries (the rolled-in residue is the last digit), i.e. in the bitmap word of dst0 or the next one
+    __shared__ unsigned long long live_bits[kUnitChunk][2];
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
         return;
@@ -1129,9 +1147,6 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
     uint32_t c_products = 0, c_hits = 0;            // this lane's non-empty products; this group's units that left a bit
     for (uint32_t t = lo; t < hi; ++t) {
         while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
-        const uint32_t first = (t - pre[g]) * kSparseChunk;
-        const uint32_t n = counts[g];
-        const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
         __syncthreads();  // the previous chunk has copied its fresh entries out and is done with the tables
         if (tid == 0) fresh_n = 0;
         if (loaded != g) {
@@ -1152,6 +1167,8 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
             n_r = (uint32_t)__builtin_popcount(r_mask);
             loaded = g;
         }
+        const uint32_t per = unit_chunk_entries(n_r), first = (t - pre[g]) * per, n = counts[g];
+        const uint32_t end = first + per < n ? first + per : n;
         const uint32_t n_e = end > first ? end - first : 0u;
         if (tid < n_e) {  // decode: one thread per entry
             const uint32_t idx = src_list[first + tid];
@@ -1172,17 +1189,17 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
             e_idx[tid] = live ? idx : 0xFFFFFFFFu;
             e_high[tid] = high << P.bits;
             e_dst0[tid] = dst0;
+            live_bits[tid][0] = live_bits[tid][1] = 0ULL;
         }
         __syncthreads();
         const uint32_t units = n_e * n_r;
         if (tid == 0) { c_entries += n_e; c_units += units; }
-        // destination entries whose bitmap word was asked for in the previous trip (the group's first lane keeps them)
-        uint64_t asked_old[UA];
-        uint32_t asked_entry[UA];
-        uint32_t asked = 0;  // bit u: asked_*[u] is waiting
         for (uint32_t u0 = grp * UA; u0 < units; u0 += ngrp * UA) {
             typename ROWS::Loads x[UA];
-            uint32_t dent[UA];  // the unit's destination entry, or none
+#ifdef TXQ_EXPERIMENTS
+            typename ROWS::Loads x2[UA];
+#endif
+            uint32_t dent[UA], del[UA];  // the unit's destination entry (or none) and its entry of the chunk
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 const uint32_t unit = u0 + u;
@@ -1190,6 +1207,7 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
                 if (unit < units) {
                     const uint32_t el = unit / n_r, ri = unit - el * n_r;
                     const uint32_t idx = e_idx[el], rk = rrank[ri];
+                    del[u] = el;
                     if (idx != 0xFFFFFFFFu && rk != 0xFFu) {
                         dent[u] = e_dst0[el] + rk;
                         if (lane_on) {
@@ -1199,6 +1217,9 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
                                 uint64_t v = e_high[el] | rcode[ri];
                                 if (P.canonical) v = canonical_dna(v, P.k);
                                 rows.template issue<true>(src_slot, v, x[u]);
+#ifdef TXQ_EXPERIMENTS
+                                if (P.experiment & 4u) rows.template issue<false>(src_slot, v ^ 0x2A5u, x2[u]);  // the row gathers of another k-mer beside them
+#endif
                             }
                         }
                     }
@@ -1209,34 +1230,46 @@ __global__ __launch_bounds__(256) void sparse_units_kernel(ROWS rows, const Spar
                 for (int u = 0; u < UA; ++u)
                     if (dent[u] != 0xFFFFFFFFu && lane_on) rows.template issue_late<true>(x[u]);
             }
-            // the previous trip's answers (they have arrived behind this trip's loads)
-#pragma unroll
-            for (int u = 0; u < UA; ++u)
-                if (((asked >> u) & 1u) && !((asked_old[u] >> (asked_entry[u] & 63u)) & 1ULL)) fresh_list[atomicAdd(&fresh_n, 1u)] = asked_entry[u];
-            asked = 0;
 #pragma unroll
             for (int u = 0; u < UA; ++u) {
                 bool nz = false;
                 if (dent[u] != 0xFFFFFFFFu && lane_on) {
                     const T y = noprobe ? x[u].x[0] : rows.combine(x[u]);
                     nz = L::any(y);
+#ifdef TXQ_EXPERIMENTS
+                    // (timing experiments that keep the masks: every destination atomic twice — OR is idempotent —; the doubled row
+                    // gathers looked at, so that they are not optimised away: a product is dropped for a value no row ever has)
+                    if ((P.experiment & 4u) && !noprobe) { const T z = rows.combine(x2[u]); if (!L::any(z ^ ~L::zero())) nz = false; }  // (a row of all ones: no such row)
+                    if ((P.experiment & 1u) && nz) atomic_or_chunk<WIDE>(q.dst + (size_t)dent[u] * W + (size_t)sub * L::kWords, y);
+#endif
                     if (nz) atomic_or_chunk<WIDE>(q.dst + (size_t)dent[u] * W + (size_t)sub * L::kWords, y);
                     c_products += nz;
                 }
                 const bool group_hit = (__ballot(nz) & group_lanes) != 0ULL;
-                if (group_hit && sub == 0) {  // a product of this unit is not empty: its destination entry is (now) live
+                if (group_hit && sub == 0) {  // a product of this unit is not empty: its destination entry is (now) live — noted in LDS
                     ++c_hits;
-                    asked_entry[u] = dent[u];
-                    asked_old[u] = __hip_atomic_fetch_or(dm.bitmap + (dent[u] >> 6), 1ULL << (dent[u] & 63u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    asked |= 1u << u;
+                    atomicOr(&live_bits[del[u]][(dent[u] >> 6) - (e_dst0[del[u]] >> 6)], 1ULL << (dent[u] & 63u));
                 }
             }
         }
-#pragma unroll
-        for (int u = 0; u < UA; ++u)
-            if (((asked >> u) & 1u) && !((asked_old[u] >> (asked_entry[u] & 63u)) & 1ULL)) fresh_list[atomicAdd(&fresh_n, 1u)] = asked_entry[u];
         __syncthreads();
-        const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
+        // ONE returning atomic per bitmap word the chunk touched (at most two per entry, whatever the number of residues — the
+        // per-residue atomics were a third of this kernel's time): the bits that were clear until now are the fresh entries
+        for (uint32_t p = tid; p < 2u * n_e; p += blockDim.x) {
+            const uint32_t el = p >> 1, w = p & 1u;
+            const unsigned long long bits = live_bits[el][w];
+            if (bits) {
+                const uint32_t word = (e_dst0[el] >> 6) + w;
+                const unsigned long long was = __hip_atomic_fetch_or(reinterpret_cast<unsigned long long*>(dm.bitmap) + word, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned long long f = bits & ~was; f; f &= f - 1) {
+                    const uint32_t entry = word * 64u + (uint32_t)__builtin_ctzll(f), at = atomicAdd(&fresh_n, 1u);
+                    if (at < kUnitFresh) fresh_list[at] = entry;
+                    else append_live(dm, entry);  // (more fresh entries than the list holds: one by one)
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t n_fresh = fresh_n < kUnitFresh ? fresh_n : kUnitFresh;
         if (n_fresh) {
             if (tid == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
@@ -2068,12 +2101,12 @@ template <bool WIDE, template <int, bool> class ROWS, class MAKE>
 static hipError_t launch_sparse_units(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
                                       size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G,
                                       const StepParams& P, const LevelUnits& U, unsigned long long* ctr, int ua, hipStream_t st) {
-    // ua: units in flight per lane group (TXQ_SPARSE_UNROLL: A/B knob; 3 = 149 VGPRs at h = 3, 2 = a wave more per SIMD)
+    // ua: units in flight per lane group (TXQ_SPARSE_UNROLL: A/B knob; 3 fits the 128 VGPRs of four waves per SIMD up to h = 3)
 #define TXQ_UNITS(H) \
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        if (ua <= 2) sparse_units_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
+        if (ua <= 2 || H >= 4) sparse_units_kernel<H, WIDE, 2, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
         else sparse_units_kernel<H, WIDE, 3, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
     } while (0)
     switch (hash_funs) {
@@ -2546,13 +2579,14 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
             for (int range = 0; range < 2; ++range) {
                 const size_t r_lo = range == 0 ? 0 : n_misc, r_hi = range == 0 ? n_misc : plan[l].sparse;
                 const bool steps = range == 1;
-                const size_t range_chunks = steps ? plan[l].step_chunks : plan[l].sparse_chunks;
+                size_t range_chunks = steps ? plan[l].step_chunks : plan[l].sparse_chunks;
+                if (steps && by_units) range_chunks = range_chunks * (kSparseChunk / 16);  // (counted in chunks of kSparseChunk entries; a chunk by units holds 16 at least)
                 for (size_t off = r_lo; off < r_hi; off += kMaxSparseGroups, ++sparse_launch) {
                     const uint32_t ng = (uint32_t)std::min<size_t>(kMaxSparseGroups, r_hi - off);
                     const SparseGroup* gr = d_sgroups + first_sparse + off;
                     uint32_t* counts = d_scounts + first_sparse + off;
                     uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
-                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, counts, prefix);
+                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, steps && by_units ? 0u : kSparseChunk, counts, prefix);
                     TXQ_HIP(hipGetLastError());
                     const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && !rode ? (uint32_t)cnt : 0u, g_units_log2};
                     rode = true;
@@ -2560,7 +2594,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(range_chunks, 2048));
                     hipError_t e;
                     if (steps && by_units) {
-                        const StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical};
+                        StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical, 0u};
+#ifdef TXQ_EXPERIMENTS
+                        if (const char* ex = std::getenv("TXQ_STEP_EXPERIMENT")) sp.experiment = (uint32_t)std::atoi(ex);  // 1: destination atomics twice, 2: bitmap atomics twice, 4: row gathers twice
+#endif
                         if (table) {
                             auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
                             e = wide ? launch_sparse_units<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st)

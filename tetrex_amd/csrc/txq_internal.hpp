@@ -203,6 +203,8 @@ struct Index {
     static constexpr size_t kArenaKeepBytes = (size_t)64 << 30;
     uint64_t user_tag = 0;  // txq_index_set_tag
     int open_sessions = 0;  // txq_index_free refuses while a session still points at this index
+    bool join_or = false;   // a sub-tree shard of a general HIBF (txq_index_upload_subtrees): full-width masks, ORed with the other shards'
+    int shard_rank = 0, n_shards = 1;
 
     // txq_probe (host buffers): two streams with their device and pinned bounce buffers
     struct HostPipe {

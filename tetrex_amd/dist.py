@@ -49,3 +49,16 @@ def or_reduce_alive(alive, group=None):
     for p in parts[1:]:
         out |= p
     return out
+
+
+def or_join_final_masks(local, group=None):
+    """Sub-tree shards of a general HIBF (txq_index_upload_subtrees, info.join_or == 1): every rank holds FULL-WIDTH masks
+    [n, mask_words] with the user bins of its own sub-trees; a split bin may straddle ranks, so the join is a bitwise OR.
+    RCCL has no bitwise-OR reduction (and a SUM would carry where two ranks set the same bit): gathered and ORed locally."""
+    world = dist.get_world_size(group)
+    parts = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(parts, local.contiguous(), group=group)
+    out = parts[0].clone()
+    for p in parts[1:]:
+        out |= p
+    return out
