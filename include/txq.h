@@ -46,7 +46,9 @@ extern "C" {
  *   TXQ_DENSE_TREE=0|1|2                              dense steps on a regular HIBF: generic descent | TreeRows | TreeRowsByLane
  *   TXQ_DENSE_UNROLL, TXQ_DENSE_SLICES, TXQ_DENSE_TILE_ROUNDS, TXQ_DENSE_NT   shape of a dense step's tiles, cache policy of its destination accesses
  *   TXQ_FUSE_UNITS=0, TXQ_ONE_STREAM                  one launch per kind and level; no second stream
- *   TXQ_SPARSE_STEPS=0, TXQ_SPARSE_UNROLL=2|3         pushed steps of tracked blocks on narrow masks: rounds of entries instead of units; units in flight
+ *   TXQ_SPARSE_STEPS=0, TXQ_SPARSE_UNROLL=2|3, TXQ_SPARSE_UNITS=<n>
+ *                                                     pushed steps of tracked blocks on narrow masks: rounds of entries instead of units; units in
+ *                                                     flight per lane group; units per chunk (default 512)
  *   TXQ_KMER_TABLE_MB=<n>, TXQ_KMER_TABLE_MIN=<n>     most an index's table of all k-mers' masks may take (default 512; 0: none);
  *                                                     the session of fewest programs that builds it (default 16)
  *   TXQ_HIBF_INTERLEAVE=0, TXQ_HIBF_INTERLEAVE_PROBE=0, TXQ_HIBF_LEVELS=1, TXQ_HIBF_STATIONARY=0, TXQ_HIBF_SMALL=0,

@@ -219,8 +219,18 @@ def test_motif_batches_are_verified_bin_major_with_the_same_files(tmp_path, dna)
         for j, w in enumerate(planted):
             if (b + j) % 7 == 0:
                 seqs[j] = seqs[j][:40 + b] + w + seqs[j][40 + b + len(w):]
-        p = tmp_path / ("bin%02d.fa" % b)
-        p.write_text("".join(">r%d_%d\n%s\n" % (b, i, s_) for i, s_ in enumerate(seqs)))
+        # records in 60-column lines like UniProt's FASTA, every third bin gzip-compressed, one without a final newline
+        body = "".join(">r%d_%d some description\n%s\n" % (b, i, "\n".join(s_[c:c + 60] for c in range(0, len(s_), 60))) for i, s_ in enumerate(seqs))
+        if b == 5:
+            body = body[:-1]
+        if b % 3 == 0:
+            import gzip
+            p = tmp_path / ("bin%02d.fa.gz" % b)
+            with gzip.open(p, "wt") as f:
+                f.write(body)
+        else:
+            p = tmp_path / ("bin%02d.fa" % b)
+            p.write_text(body)
         files.append(str(p))
     k = "6" if dna else "4"
     rc, so, se = run("index", *(["-n"] if dna else []), "-k", k, "-i", str(tmp_path / "ix"), *files)

@@ -5,6 +5,8 @@
 #pragma once
 #include <functional>
 #include <string>
+#include <string_view>
+#include <vector>
 
 namespace tetrex {
 
@@ -15,5 +17,18 @@ struct FastaRecord {
 // Calls `fn` for every record of `path`; returns the record count.
 // Throws std::runtime_error if the file cannot be opened.
 size_t for_each_record(const std::string& path, const std::function<void(const FastaRecord&)>& fn);
+
+// All records of a file at once: the sequences back to back in ONE buffer, a '\n' behind each (no sequence holds one), so
+// that a string can be searched for in the whole bin with one memmem and mapped back to its record.  Same record semantics
+// as for_each_record.  A plain file is read with one read() and split with memchr; a gzip file is inflated through zlib.
+struct RecordSet {
+    std::string text;                 // seq_0 '\n' seq_1 '\n' ...
+    std::vector<size_t> start;        // start[i] = offset of record i in `text`; start[n] = text.size()
+    std::vector<std::string> names;   // first word after '>' / '@'
+    size_t size() const { return names.size(); }
+    std::string_view seq(size_t i) const { return std::string_view(text).substr(start[i], start[i + 1] - start[i] - 1); }
+    size_t record_at(size_t offset) const;  // the record that holds text[offset]
+};
+void load_records(const std::string& path, RecordSet& out);  // throws std::runtime_error if the file cannot be opened
 
 }  // namespace tetrex

@@ -4,6 +4,7 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
+#include <cstring>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -111,7 +112,9 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
 #pragma omp parallel num_threads(opt.threads > 0 ? opt.threads : 1)
     {
         std::vector<std::unique_ptr<Matcher::Cache>> caches(nq);  // this thread's automata, built on first use, kept from bin to bin
-        std::string seq, rc;
+        RecordSet recs;                                            // the bin's records: sequences back to back, '\n' behind each
+        std::string rc;                                            // ... and their reverse complements, laid out the same way (DNA)
+        std::vector<size_t> hits;                                  // records that hold a motif's required literal
 #pragma omp for schedule(dynamic)
         for (size_t i = 0; i < todo.size(); ++i) {
             try {
@@ -119,40 +122,59 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                 const std::vector<uint32_t>& qs = wanted[todo[i]];
                 std::vector<Rows>& mine = rows[i];
                 mine.resize(qs.size());
-                for_each_record(path, [&](const FastaRecord& rec) {
-                    const std::string* text = &rec.seq;
-                    if (reduced) {
-                        seq = rec.seq;
-                        for (char& c : seq) c = enc.reduce((unsigned char)c);
-                        text = &seq;
+                load_records(path, recs);  // ONE read of the bin for all its motifs
+                if (reduced)
+                    for (char& c : recs.text) if (c != '\n') c = enc.reduce((unsigned char)c);
+                if (dna) {
+                    rc.resize(recs.text.size());
+                    for (size_t r = 0; r < recs.size(); ++r) {
+                        const size_t lo = recs.start[r], hi = recs.start[r + 1] - 1;  // [lo, hi): the sequence; text[hi] = '\n'
+                        for (size_t p = lo; p < hi; ++p) rc[lo + (hi - 1 - p)] = complement(recs.text[p]);
+                        rc[hi] = '\n';
                     }
-                    bool have_rc = false;
-                    for (size_t j = 0; j < qs.size(); ++j) {
-                        const uint32_t q = qs[j];
-                        const Matcher& m = *rx[q];
-                        if (!caches[q]) caches[q] = std::make_unique<Matcher::Cache>();
-                        if (m.may_match(*text))
-                            m.find_all(*text, *caches[q], [&](size_t s, size_t n) {
-                                std::string& o = mine[j].fwd;
-                                o += path; o += "\t>"; o += rec.name; o += '\t'; o.append(*text, s, n); o += '\t';
-                                o += std::to_string(s); o += ','; o += std::to_string(s + n); o += '\n';
+                }
+                // the records of `text` that can hold a match of m: all of them, or — where m has a required literal that is rare
+                // enough — the ones the literal occurs in, found with memmem over the whole bin (no sequence holds the '\n' between
+                // records, so an occurrence never straddles two)
+                auto candidates = [&](const Matcher& m, const std::string& text) {
+                    hits.clear();
+                    const std::string& lit = m.required_literal();
+                    if (lit.size() < 2) return false;  // every record
+                    const char* base = text.data();
+                    const char* const end = base + text.size();
+                    size_t last = (size_t)-1;
+                    for (const char* p = base; p < end;) {
+                        const char* f = static_cast<const char*>(memmem(p, (size_t)(end - p), lit.data(), lit.size()));
+                        if (!f) break;
+                        const size_t r = recs.record_at((size_t)(f - base));
+                        if (r != last) { hits.push_back(r); last = r; }
+                        p = base + recs.start[r + 1];  // on to the next record
+                        if (hits.size() * 2 > recs.size()) return false;  // (not rare: the per-record prefilter does as well)
+                    }
+                    return true;
+                };
+                for (size_t j = 0; j < qs.size(); ++j) {
+                    const uint32_t q = qs[j];
+                    const Matcher& m = *rx[q];
+                    if (!caches[q]) caches[q] = std::make_unique<Matcher::Cache>();
+                    auto scan = [&](const std::string& text, bool reverse_strand) {
+                        const bool listed = candidates(m, text);
+                        const size_t n_scan = listed ? hits.size() : recs.size();
+                        for (size_t at = 0; at < n_scan; ++at) {
+                            const size_t r = listed ? hits[at] : at;
+                            const std::string_view seq(text.data() + recs.start[r], recs.start[r + 1] - recs.start[r] - 1);
+                            m.find_all(seq, *caches[q], [&](size_t s, size_t n) {
+                                std::string& o = reverse_strand ? mine[j].rev : mine[j].fwd;
+                                o += path; o += "\t>"; o += recs.names[r]; o += '\t'; o.append(seq.data() + s, n);
+                                if (reverse_strand) o += "\tREVERSE STRAND HIT\n";
+                                else { o += '\t'; o += std::to_string(s); o += ','; o += std::to_string(s + n); o += '\n'; }
                                 ++found[i];
                             });
-                        if (dna) {
-                            if (!have_rc) {
-                                rc.assign(text->rbegin(), text->rend());
-                                for (char& c : rc) c = complement(c);
-                                have_rc = true;
-                            }
-                            if (m.may_match(rc))
-                                m.find_all(rc, *caches[q], [&](size_t s, size_t n) {
-                                    std::string& o = mine[j].rev;
-                                    o += path; o += "\t>"; o += rec.name; o += '\t'; o.append(rc, s, n); o += "\tREVERSE STRAND HIT\n";
-                                    ++found[i];
-                                });
                         }
-                    }
-                });
+                    };
+                    scan(recs.text, false);
+                    if (dna) scan(rc, true);
+                }
             } catch (const std::exception& e) {
 #pragma omp critical
                 error = e.what();

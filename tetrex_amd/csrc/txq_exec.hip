@@ -771,13 +771,13 @@ struct SparseGroup { uint32_t op; uint32_t fixed; };  // fixed != kNotFixed: the
 static constexpr uint32_t kNotFixed = 0xFFFFFFFFu;
 static constexpr uint32_t kSparseChunk = 64;
 static constexpr uint32_t kUnitChunk = 256;      // most entries per chunk of sparse_units_kernel: one decoding thread each
-static constexpr uint32_t kUnitFresh = 1024;     // fresh destination entries it collects per chunk (more: appended one by one)
+static constexpr uint32_t kUnitFresh = 2048;     // fresh destination entries it collects per chunk (more: appended one by one)
 // sparse_units_kernel cuts a group's list into chunks of about 512 UNITS (entry x residue), not of a fixed number of entries: a
 // chunk is the same work whether the step rolls one residue in or twenty (a 64-entry chunk of a wildcard step is forty times
 // the work of a literal's; with 256 entries the heaviest chunks were a level's critical path), and a step with few residues
 // amortises a chunk's fixed trips (list, bitmap words, the append) over more entries
-__host__ __device__ __forceinline__ uint32_t unit_chunk_entries(uint32_t n_r) {
-    uint32_t c = n_r ? 512u / n_r : kUnitChunk;
+__host__ __device__ __forceinline__ uint32_t unit_chunk_entries(uint32_t n_r, uint32_t target) {  // target: units per chunk (TXQ_SPARSE_UNITS, 512)
+    uint32_t c = n_r ? target / n_r : kUnitChunk;
     if (c > kUnitChunk) c = kUnitChunk;
     if (c < 16u) c = 16u;
     return c & ~7u;
@@ -807,7 +807,8 @@ __global__ __launch_bounds__(1024) void sparse_plan_kernel(const SparseGroup* __
                 n = *reinterpret_cast<const uint32_t*>(q.src + (size_t)q.src_cap * W);
         }
         counts[t] = n;
-        const uint32_t per = chunk ? chunk : unit_chunk_entries((uint32_t)__popc(dops[g.op].r_mask));  // (0: by units, sparse_units_kernel)
+        // (bit 31: by units — sparse_units_kernel — the low bits are the units per chunk)
+        const uint32_t per = chunk >> 31 ? unit_chunk_entries((uint32_t)__popc(dops[g.op].r_mask), chunk & 0x7FFFFFFFu) : chunk;
         chunks = (n + per - 1) / per;
     }
     scan[t] = chunks;
@@ -1089,7 +1090,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
     }
 }
 
-struct StepParams { uint32_t k, bits, pos, canonical; uint32_t experiment; };  // experiment: TXQ_EXPERIMENTS builds only (timing experiments: wrong masks)
+struct StepParams { uint32_t k, bits, pos, canonical; uint32_t units; uint32_t experiment; };  // units: per chunk (unit_chunk_entries);  // experiment: TXQ_EXPERIMENTS builds only (timing experiments: wrong masks)
 
 // ---- pushed steps on narrow masks: by units -------------------------------------------------------------------------
 // The STEP groups of a level when a mask is a cache line or two (W <= kUnitStepWords: up to 2048 bins per shard), where every
@@ -1167,7 +1168,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
             n_r = (uint32_t)__builtin_popcount(r_mask);
             loaded = g;
         }
-        const uint32_t per = unit_chunk_entries(n_r), first = (t - pre[g]) * per, n = counts[g];
+        const uint32_t per = unit_chunk_entries(n_r, P.units), first = (t - pre[g]) * per, n = counts[g];
         const uint32_t end = first + per < n ? first + per : n;
         const uint32_t n_e = end > first ? end - first : 0u;
         if (tid < n_e) {  // decode: one thread per entry
@@ -2586,7 +2587,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     const SparseGroup* gr = d_sgroups + first_sparse + off;
                     uint32_t* counts = d_scounts + first_sparse + off;
                     uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
-                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, steps && by_units ? 0u : kSparseChunk, counts, prefix);
+                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, steps && by_units ? (0x80000000u | (uint32_t)s.kn.sparse_units) : kSparseChunk, counts, prefix);
                     TXQ_HIP(hipGetLastError());
                     const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && !rode ? (uint32_t)cnt : 0u, g_units_log2};
                     rode = true;
@@ -2594,7 +2595,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                     const size_t grid = lu.n_units + std::max<size_t>(1, std::min<size_t>(range_chunks, 2048));
                     hipError_t e;
                     if (steps && by_units) {
-                        StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical, 0u};
+                        StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical, (uint32_t)s.kn.sparse_units, 0u};
 #ifdef TXQ_EXPERIMENTS
                         if (const char* ex = std::getenv("TXQ_STEP_EXPERIMENT")) sp.experiment = (uint32_t)std::atoi(ex);  // 1: destination atomics twice, 2: bitmap atomics twice, 4: row gathers twice
 #endif
