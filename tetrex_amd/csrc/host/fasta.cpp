@@ -5,6 +5,9 @@
 #include <cstring>
 #include <stdexcept>
 #include <zlib.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 namespace tetrex {
 
@@ -81,6 +84,65 @@ size_t for_each_record(const std::string& path, const std::function<void(const F
     return count;
 }
 
+namespace {
+// candidate positions of `needle` in [s, s + n): called with every position whose first and last byte match
+template <class Fn>
+void scan_plain(const char* s, size_t n, const std::string& needle, Fn&& at) {
+    const size_t m = needle.size();
+    if (n < m) return;
+    const char first = needle[0], last = needle[m - 1];
+    for (size_t i = 0; i + m <= n; ++i)
+        if (s[i] == first && s[i + m - 1] == last && !at(i)) return;
+}
+#if defined(__x86_64__)
+template <class Fn>
+__attribute__((target("avx2"))) void scan_avx2(const char* s, size_t n, const std::string& needle, Fn&& at) {
+    const size_t m = needle.size();
+    if (n < m) return;
+    const __m256i first = _mm256_set1_epi8(needle[0]), last = _mm256_set1_epi8(needle[m - 1]);
+    size_t i = 0;
+    for (; i + m - 1 + 32 <= n; i += 32) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + m - 1));
+        uint32_t mask = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(_mm256_cmpeq_epi8(a, first), _mm256_cmpeq_epi8(b, last)));
+        while (mask) {
+            const size_t at_i = i + (size_t)__builtin_ctz(mask);
+            mask &= mask - 1;
+            if (!at(at_i)) return;
+        }
+    }
+    for (; i + m <= n; ++i)
+        if (s[i] == needle[0] && s[i + m - 1] == needle[m - 1] && !at(i)) return;
+}
+#endif
+}  // namespace
+
+bool records_with(const RecordSet& set, const std::string& text, const std::string& needle, size_t limit, std::vector<size_t>& records) {
+    records.clear();
+    const size_t m = needle.size();
+    if (m < 2 || text.size() != set.text.size()) return false;
+    bool ok = true;
+    size_t last_record = (size_t)-1, skip_below = 0;  // (positions below skip_below lie in a record that is listed already)
+    auto at = [&](size_t i) {
+        if (i < skip_below) return true;
+        if (m > 2 && std::memcmp(text.data() + i + 1, needle.data() + 1, m - 2) != 0) return true;
+        const size_t r = set.record_at(i);
+        if (r != last_record) {
+            records.push_back(r);
+            last_record = r;
+            if (records.size() > limit) { ok = false; return false; }
+        }
+        skip_below = set.start[r + 1];
+        return true;
+    };
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) scan_avx2(text.data(), text.size(), needle, at);
+    else
+#endif
+        scan_plain(text.data(), text.size(), needle, at);
+    return ok;
+}
+
 size_t RecordSet::record_at(size_t offset) const {
     size_t lo = 0, hi = names.size();  // the last record whose start is <= offset
     while (hi - lo > 1) {
@@ -96,7 +158,8 @@ void load_records(const std::string& path, RecordSet& out) {
     out.names.clear();
     // the whole file in memory: plain files with one read, gzip files through zlib (gzread is transparent for plain data, but
     // its 64 KB buffer and the byte-wise line search above cost more than the matching they feed)
-    std::string raw;
+    std::string& raw = out.raw;
+    raw.clear();
     {
         std::FILE* f = std::fopen(path.c_str(), "rb");
         if (!f) throw std::runtime_error("File not found. Did you move/rename an indexed file? (" + path + ")");
@@ -117,6 +180,7 @@ void load_records(const std::string& path, RecordSet& out) {
             if (!g) throw std::runtime_error("File not found. Did you move/rename an indexed file? (" + path + ")");
             gzbuffer(g, 1 << 20);
             size_t used = 0;
+            raw.resize(raw.capacity());
             for (;;) {
                 if (raw.size() - used < (1u << 20)) raw.resize(raw.size() + (4u << 20));
                 const int n = gzread(g, raw.data() + used, (unsigned)std::min<size_t>(raw.size() - used, 1u << 30));

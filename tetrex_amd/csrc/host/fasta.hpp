@@ -25,10 +25,16 @@ struct RecordSet {
     std::string text;                 // seq_0 '\n' seq_1 '\n' ...
     std::vector<size_t> start;        // start[i] = offset of record i in `text`; start[n] = text.size()
     std::vector<std::string> names;   // first word after '>' / '@'
+    std::string raw;                  // (scratch: the file as read; kept so that loading bin after bin allocates nothing)
     size_t size() const { return names.size(); }
     std::string_view seq(size_t i) const { return std::string_view(text).substr(start[i], start[i + 1] - start[i] - 1); }
     size_t record_at(size_t offset) const;  // the record that holds text[offset]
 };
 void load_records(const std::string& path, RecordSet& out);  // throws std::runtime_error if the file cannot be opened
+
+// The records of `set`-shaped text (`text`: set.text itself, or a buffer laid out like it) in which `needle` (2 bytes at least)
+// occurs, ascending, into `records`; false — and nothing useful in `records` — as soon as more than `limit` records hold it.
+// (32 positions per step where the CPU has AVX2: first and last byte compared at once, the rest only where both match.)
+bool records_with(const RecordSet& set, const std::string& text, const std::string& needle, size_t limit, std::vector<size_t>& records);
 
 }  // namespace tetrex

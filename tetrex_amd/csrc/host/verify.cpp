@@ -134,24 +134,12 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                     }
                 }
                 // the records of `text` that can hold a match of m: all of them, or — where m has a required literal that is rare
-                // enough — the ones the literal occurs in, found with memmem over the whole bin (no sequence holds the '\n' between
+                // enough — the ones the literal occurs in, found in one pass over the whole bin (no sequence holds the '\n' between
                 // records, so an occurrence never straddles two)
                 auto candidates = [&](const Matcher& m, const std::string& text) {
-                    hits.clear();
                     const std::string& lit = m.required_literal();
-                    if (lit.size() < 2) return false;  // every record
-                    const char* base = text.data();
-                    const char* const end = base + text.size();
-                    size_t last = (size_t)-1;
-                    for (const char* p = base; p < end;) {
-                        const char* f = static_cast<const char*>(memmem(p, (size_t)(end - p), lit.data(), lit.size()));
-                        if (!f) break;
-                        const size_t r = recs.record_at((size_t)(f - base));
-                        if (r != last) { hits.push_back(r); last = r; }
-                        p = base + recs.start[r + 1];  // on to the next record
-                        if (hits.size() * 2 > recs.size()) return false;  // (not rare: the per-record prefilter does as well)
-                    }
-                    return true;
+                    // (not rare — in more than half of the records —: the per-record prefilter does as well)
+                    return lit.size() >= 2 && records_with(recs, text, lit, recs.size() / 2, hits);
                 };
                 for (size_t j = 0; j < qs.size(); ++j) {
                     const uint32_t q = qs[j];
