@@ -70,9 +70,12 @@ def measure(capi, torch, n=1 << 20, tmax=64, user_bins=65536):
         ts.append(time.perf_counter() - t)
     t_layout = min(ts)
     want0 = ox.probe(kmers[:1])[0]
-    if not np.array_equal(res[0], want0):
+    if not os.environ.get("PERF_HIBF_NO_CHECK") and not np.array_equal(res[0], want0):
         raise SystemExit("layout-order stage: RESULT differs from the oracle's mask of the first k-mer")
     info = ix.info
+    if os.environ.get("PERF_HIBF_PROBE_ONLY"):  # (profiling runs: the probes only)
+        ix.free()
+        return {"probe_user_order": {"seconds": t_user, "kmers_per_s": n / t_user}, "probe_layout_order": {"seconds": t_layout, "kmers_per_s": n / t_layout}}
     motifs = random_prosite_motifs(200, 3, wildcard=0.08, ranges=0.04, min_len=6, max_len=12)
     timings = {}
     masks = {}

@@ -63,6 +63,7 @@ void read_knobs() {
     k.hibf_small = !is("TXQ_HIBF_SMALL", '0');
     k.hibf_lane_hash = flag("TXQ_HIBF_LANE_HASH");
     k.hibf_layout_order = !is("TXQ_HIBF_LAYOUT_ORDER", '0');
+    k.hibf_layout_fused = !is("TXQ_HIBF_LAYOUT_FUSED", '0');
     k.hibf_steps_per_group = (int)std::max(0LL, num("TXQ_HIBF_STEPS_PER_GROUP", 0));
     k.hibf_tile = (int)std::max(0LL, num("TXQ_HIBF_TILE", 0));
     k.hibf_unroll = (int)num("TXQ_HIBF_UNROLL", 1);
@@ -70,7 +71,7 @@ void read_knobs() {
 #ifdef TXQ_EXPERIMENTS
     // timing experiments of tools/ab_hibf*.sh (`make EXPERIMENTS=1`): bit 4 no row gathers, bit 5 (almost) no stores — WRONG masks,
     // which is why the product build does not contain them
-    k.hibf_store |= (int)num("TXQ_HIBF_STORE", 0) & 48;
+    k.hibf_store |= (int)num("TXQ_HIBF_STORE", 0) & 112;  // (64: the layout-order level kernel without its gate loads)
 #endif
     k.hibf_waves = std::max(0LL, num("TXQ_HIBF_WAVES", 0));
     k.probe_blocks_per_cu = (int)std::max(1LL, num("TXQ_PROBE_BLOCKS_PER_CU", 256));
@@ -196,9 +197,9 @@ void Index::release() {
                     (void*)session_cache.set[0].d_masks, (void*)session_cache.set[1].d_masks})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
-    for (void* p : {(void*)d_vchunks, (void*)d_vpaths, (void*)d_vleaf, (void*)d_vuser, (void*)d_vgroups})
+    for (void* p : {(void*)d_vchunks, (void*)d_vpaths, (void*)d_vleaf, (void*)d_vuser, (void*)d_vgroups, (void*)d_vnodes})
         if (p) (void)hipFree(p);
-    d_vchunks = nullptr; d_vpaths = nullptr; d_vleaf = nullptr; d_vuser = nullptr; d_vgroups = nullptr;
+    d_vchunks = nullptr; d_vpaths = nullptr; d_vleaf = nullptr; d_vuser = nullptr; d_vgroups = nullptr; d_vnodes = nullptr;
     v_words = n_vchunks = 0;
     vlevels.clear();
     if (d_children) (void)hipFree(d_children);

@@ -159,7 +159,10 @@ __device__ __forceinline__ void wave_sync() {
 // evaluations as the tree's IBFs have (h_max, wave-uniform).  A k-mer visits every IBF at most
 // once (the IBFs form a tree), so a stack of n_ibf entries cannot overflow.
 // LDS per wave: w_out * 8 + stack_cap * 4 bytes (dynamic); launch: 64 * waves threads per block.
-template <int G>
+// LAYOUT: the row is the tree's layout-order row (txq_internal.hpp VChunk) — t.nodes are then the records whose ident_word is
+// the IBF's first word IN THAT ROW (Index::d_vnodes), t.descend = t.merged, and an IBF's ANDed row words go into its segment
+// as they are, merged bins' bits included (one lane owns a word: plain LDS stores; no technical-bin -> user-bin mapping).
+template <int G, bool LAYOUT = false>
 __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint64_t* __restrict__ kmers, size_t n,
                                                          uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0,
                                                          uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
@@ -256,8 +259,12 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                             if (count > stack_cap) count = stack_cap;  // unreachable for a tree; keeps the indexes in range
                         }
                     }
-                    uint64_t hits = acc[q] & ~mg[q];
                     const uint32_t w = w0 + (uint32_t)q;
+                    if constexpr (LAYOUT) {
+                        if (live && w < words_per_row) row[nd.ident_word + w] = acc[q];
+                        continue;
+                    }
+                    uint64_t hits = acc[q] & ~mg[q];
                     if (hits && nd.ident_word != kNoIdent) {  // the row word is a mask word
                         const uint64_t word = (uint64_t)nd.ident_word + w;
                         if (word >= word0 && word < (uint64_t)word0 + w_out) atomicOr((unsigned long long*)(row + (word - word0)), hits);
@@ -294,6 +301,18 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
         }
         wave_sync();  // the next k-mer reuses the row
     }
+}
+
+template <int G, bool LAYOUT = false>
+static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes, hipStream_t s, HibfView t, const uint64_t* kmers, size_t n,
+                               uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
+                               uint32_t h_max, uint64_t* alive) {
+    if (lds_bytes > (48u << 10)) {  // (more dynamic LDS than the default limit: ask for it)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hibf_fused_kernel<G, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hibf_fused_kernel<G, LAYOUT><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive);
+    return hipGetLastError();
 }
 
 // Small trees (every IBF at most 256 technical bins, at most 32 IBFs, at most 16 mask words — the
@@ -587,8 +606,9 @@ __global__ __launch_bounds__(256) void mask_alive_kernel(const uint64_t* __restr
 template <int CW, int H>
 __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __restrict__ chunks, const uint32_t* __restrict__ group_first,
                                                                 uint32_t n_groups, const uint64_t* __restrict__ kmers, size_t n,
-                                                                uint64_t* __restrict__ rows, uint32_t v_words, uint32_t n_tiles, uint32_t tile) {
+                                                                uint64_t* __restrict__ rows, uint32_t v_words, uint32_t n_tiles, uint32_t tile, uint32_t experiment) {
     constexpr int U = 4;  // k-mers in flight per lane: U gates, then up to U * h row gathers
+    (void)experiment;  // (TXQ_EXPERIMENTS builds: 16 no row gathers, 32 no stores, 64 no gate loads — timing only, wrong rows)
     const uint32_t gsel = blockIdx.x % 8u, t = (blockIdx.x / 8u) % n_tiles, phase = blockIdx.x / (8u * n_tiles);
     const uint32_t g = phase * 8u + gsel;
     if (g >= n_groups) return;
@@ -613,6 +633,9 @@ __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __
                 const size_t i = i0 + (size_t)u * k_step;
                 pass[u] = i < k1;
                 v[u] = pass[u] ? kmers[i] : 0;
+#ifdef TXQ_EXPERIMENTS
+                if (experiment & 64u) { if (rec.gate_word != kNoGate) pass[u] = pass[u] && ((v[u] >> 3) & 1ULL); continue; }
+#endif
                 if (pass[u] && rec.gate_word != kNoGate) pass[u] = (gload(rows + i * v_words + rec.gate_word) >> rec.gate_bit) & 1ULL;
             }
             ulonglong2 x[U][H];
@@ -622,6 +645,9 @@ __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __
                 for (int j = 0; j < H; ++j) {
                     x[u][j] = ulonglong2{~0ULL, ~0ULL};
                     if ((uint32_t)j >= hf || !pass[u]) continue;
+#ifdef TXQ_EXPERIMENTS
+                    if (experiment & 16u) continue;
+#endif
                     const uint64_t r = hash_row_seeded32(v[u] * kSeeds[j], shift, rec.bin_size);
                     if (CW == 1 || single) x[u][j].x = gload(words + r * stride + rec.col);
                     else x[u][j] = gload2(words + r * stride + rec.col);
@@ -638,6 +664,9 @@ __global__ __launch_bounds__(256) void hibf_layout_level_kernel(const VChunk* __
                     if (single) b = 0;
                 }
                 uint64_t* out = rows + i * v_words + (size_t)(c - 0) * CW;
+#ifdef TXQ_EXPERIMENTS
+                if ((experiment & 32u) && (a | b) != 0x123456789ULL) continue;
+#endif
                 if (CW == 1) __builtin_nontemporal_store(a, out);
                 else store_row16(reinterpret_cast<hu32x4*>(out), hu32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)}, 0);
             }
@@ -669,7 +698,7 @@ __global__ __launch_bounds__(256) void hibf_layout_to_user_kernel(const uint64_t
 // padded to whole 16-byte chunks; per chunk its record, per IBF its ancestors, which bits are user bins, and the user
 // bin behind every bit.  Single shard only (a column shard of the USER bins does not cut the layout-order row in one piece).
 static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::vector<int>& level, const std::vector<uint64_t>& next,
-                              const std::vector<uint64_t>& tbu, const std::vector<uint64_t>& off) {
+                              const std::vector<uint64_t>& tbu, const std::vector<uint64_t>& off, const std::vector<HibfNode>* nodes) {
     const uint64_t n = desc.n_ibf;
     if (ix.shard_words != ix.mask_words || ix.shard_word0 != 0 || ix.depth > kMaxVDepth + 1 || desc.user_bins >= kNoGate) return TXQ_OK;
     for (const IbfDev& f : ix.ibf)
@@ -758,6 +787,16 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
         const uint32_t ng = (uint32_t)L.group_first.size() - 1;
         L.group_first.assign({at, ng});
     }
+    if (nodes) {  // the fused kernel's node records with every IBF's place in the layout-order row (hibf_fused_kernel<G, LAYOUT>)
+        std::vector<HibfNode> vn(*nodes);
+        for (uint64_t i = 0; i < n; ++i)
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+                if (tbu[off[i] + b] == TXQ_MERGED_BIN) vn[off[i] + b].ident_word = (uint32_t)seg[next[off[i] + b]];
+        vn[off[n]].ident_word = (uint32_t)seg[0];
+        TXQ_HIP(hipMalloc((void**)&ix.d_vnodes, vn.size() * sizeof(HibfNode)));
+        TXQ_HIP(hipMemcpy(ix.d_vnodes, vn.data(), vn.size() * sizeof(HibfNode), hipMemcpyHostToDevice));
+        ix.device_bytes += vn.size() * sizeof(HibfNode);
+    }
     TXQ_HIP(hipMalloc((void**)&ix.d_vchunks, chunks.size() * sizeof(VChunk)));
     TXQ_HIP(hipMalloc((void**)&ix.d_vpaths, paths.size() * sizeof(VPath)));
     TXQ_HIP(hipMalloc((void**)&ix.d_vleaf, leaf.size() * 8));
@@ -784,9 +823,51 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     return TXQ_OK;
 }
 
+// The layout-order rows with ONE wave per k-mer (hibf_fused_kernel<G, LAYOUT>): the wave walks the IBFs the k-mer reaches,
+// keeps the row in LDS and writes it once, coalesced — a k-mer of the 65 536-bin trees reaches a few hundred of the row's
+// 1237 chunks, where the level kernels below visit every chunk of every level for every k-mer.  Where a row (plus the stack)
+// does not fit a wave's share of the LDS, or TXQ_HIBF_LAYOUT_FUSED=0, false: the level kernels.
+static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uint64_t* d_rows, hipStream_t s, int* rc) {
+    const Knobs kn = knobs();
+    if (!ix.d_vnodes || !kn.hibf_layout_fused) return false;
+    const uint32_t w_out = ix.v_words, stack_cap = (uint32_t)ix.ibf.size();
+    const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2, wave_bytes = wave_words * 8;
+    if (wave_bytes > (64u << 10)) return false;
+    uint32_t h_max = 1;
+    for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
+    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged, ix.d_merged_off, (const HibfNode*)ix.d_vnodes, (uint32_t)ix.hibf_total_tbs};
+    unsigned waves = 4;
+    while (waves > 1 && wave_bytes * waves > (64u << 10)) waves >>= 1;
+    const size_t want_waves = kn.hibf_waves > 0 ? (size_t)kn.hibf_waves : (size_t)256 * 64;
+    const size_t total_waves = n < want_waves ? n : want_waves;
+    const unsigned grid = (unsigned)((total_waves + waves - 1) / waves);
+    const uint32_t quads = (ix.max_stride + 3) / 4;  // a lane owns four row words
+    int g = 1;
+    while (g < 64 && (uint32_t)g < quads) g <<= 1;
+    const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
+    hipError_t e;
+#define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr)
+    switch (g) {
+        case 1: TXQ_FUSED(1); break;
+        case 2: TXQ_FUSED(2); break;
+        case 4: TXQ_FUSED(4); break;
+        case 8: TXQ_FUSED(8); break;
+        case 16: TXQ_FUSED(16); break;
+        case 32: TXQ_FUSED(32); break;
+        default: TXQ_FUSED(64); break;
+    }
+#undef TXQ_FUSED
+    *rc = e == hipSuccess ? TXQ_OK : fail_hip(e, "layout-order fused kernel launch");
+    return true;
+}
+
 int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all, uint64_t* d_rows_all, hipStream_t s) {
     if (!ix.d_vchunks) return fail(TXQ_ERR_STATE, "the index has no layout order");
     if (!n_all) return TXQ_OK;
+    {
+        int rc = TXQ_OK;
+        if (layout_order_fused(ix, d_kmers_all, n_all, d_rows_all, s, &rc)) return rc;
+    }
     const uint32_t tile = 2048;
     // A level reads the gates the level above it wrote (the words of the IBFs that have children: v_inner_words of a row):
     // a very large batch goes through the levels in pieces whose gates (about 100 MB) are still in the Infinity Cache when
@@ -803,7 +884,7 @@ int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all
             const uint32_t at = L.group_first[0], ng = L.group_first[1];
             const uint32_t phases = (ng + 7) / 8;
             if ((uint64_t)phases * n_tiles * 8 >= ((uint64_t)1 << 31)) return fail(TXQ_ERR_ARG, "too many k-mers for one layout-order probe");
-#define TXQ_LEVEL(CW, H) hibf_layout_level_kernel<CW, H><<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile)
+#define TXQ_LEVEL(CW, H) hibf_layout_level_kernel<CW, H><<<phases * n_tiles * 8, 256, 0, s>>>(ix.d_vchunks, ix.d_vgroups + at, ng, d_kmers, n, d_rows, ix.v_words, n_tiles, tile, (uint32_t)knobs().hibf_store & 112u)
             if (ix.v_chunk_words == 1) {
                 switch (ix.tree_hash_max) { case 1: TXQ_LEVEL(1, 1); break; case 2: TXQ_LEVEL(1, 2); break; case 3: TXQ_LEVEL(1, 3); break; case 4: TXQ_LEVEL(1, 4); break; default: TXQ_LEVEL(1, 5); break; }
             } else {
@@ -945,8 +1026,9 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     // node records by technical bin for the fused kernel (skipped for trees too large for it)
     bool compact = off[n] < kRootEntry && moff[n] < 0xFFFFFFFFull && off[n] <= ((size_t)256 << 20) / sizeof(HibfNode);
     for (const IbfDev& f : ix.ibf) compact = compact && !(f.bin_size >> 32) && f.stride < (1u << 20) && f.hash_shift < 64 && f.hash_funs < 8;
+    std::vector<HibfNode> nodes;
     if (compact) {
-        std::vector<HibfNode> nodes(off[n] + 1);
+        nodes.resize(off[n] + 1);
         std::memset(nodes.data(), 0, nodes.size() * sizeof(HibfNode));
         auto node_of = [&](uint64_t i) {
             const IbfDev& f = ix.ibf[i];
@@ -1038,7 +1120,7 @@ int hibf_upload(Index& ix, const txq_index_desc& desc) {
     }
     // any other tree: sessions work in layout order
     if (!ix.d_children)
-        if (int rc = build_layout_order(ix, desc, level, next, tbu, off)) return rc;
+        if (int rc = build_layout_order(ix, desc, level, next, tbu, off, compact ? &nodes : nullptr)) return rc;
     return TXQ_OK;
 }
 
@@ -1047,14 +1129,6 @@ static hipError_t launch_level(unsigned grid, hipStream_t s, HibfView t, const u
                                const uint32_t* in_count, uint32_t n0, WorkItem* out, uint32_t* out_count, uint32_t cap,
                                uint32_t* overflow, uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters) {
     hibf_level_kernel<G><<<grid, 256, 0, s>>>(t, kmers, in, in_count, n0, out, out_count, cap, overflow, masks, w_out, word0, w_iters);
-    return hipGetLastError();
-}
-
-template <int G>
-static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes, hipStream_t s, HibfView t, const uint64_t* kmers, size_t n,
-                               uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
-                               uint32_t h_max, uint64_t* alive) {
-    hibf_fused_kernel<G><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive);
     return hipGetLastError();
 }
 

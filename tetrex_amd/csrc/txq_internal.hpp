@@ -35,6 +35,7 @@ struct Knobs {
     bool hibf_stationary = true;        // TXQ_HIBF_STATIONARY=0: no child-stationary descent
     bool hibf_small = true;             // TXQ_HIBF_SMALL=0: no lane-per-k-mer kernel for small trees
     bool hibf_lane_hash = false;        // TXQ_HIBF_LANE_HASH: per-lane hashing on a uniform tree
+    bool hibf_layout_fused = true;      // TXQ_HIBF_LAYOUT_FUSED=0: the layout-order rows of plain k-mers level by level (hibf_layout_level_kernel), not one wave per k-mer
     bool hibf_layout_order = true;      // TXQ_HIBF_LAYOUT_ORDER=0: sessions on general trees work in user-bin order (descent kernels)
     int hibf_steps_per_group = 0, hibf_tile = 0, hibf_unroll = 1, hibf_store = 0;  // TXQ_HIBF_STEPS_PER_GROUP / _TILE / _UNROLL / _STORE_KIND (store instruction: 0-3)
     long long hibf_waves = 0;           // TXQ_HIBF_WAVES
@@ -146,6 +147,7 @@ struct Index {
     uint64_t* d_vleaf = nullptr;     // [v_words] bits of technical bins that are user bins (the ONES of a layout-order session)
     uint32_t* d_vuser = nullptr;     // [v_words * 64] user bin of a layout-order bit (kNoGate: none)
     uint32_t* d_vgroups = nullptr;   // per level its groups' first chunks, concatenated (+ end)
+    void* d_vnodes = nullptr;        // HibfNode records (as d_nodes) whose ident_word is the IBF's first word in the layout-order row
     uint32_t v_inner_words = 0;  // of a row: the words of IBFs with merged bins (what the next level reads as gates)
     uint32_t v_words = 0, n_vchunks = 0, v_depth = 0, v_chunk_words = 2;  // (chunks of 16 bytes, or of 8 for trees of narrow IBFs)
     std::vector<VLevel> vlevels;
