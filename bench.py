@@ -1315,6 +1315,16 @@ def main():
             out.setdefault("hibf", {"error": repr(e)})
             if not strong:
                 out.setdefault("hibf_1024", {"error": repr(e)})
+        if world > 1 and not strong:  # the general tree sharded by sub-trees over the ranks (tests/perf_hibf_ragged.py measure_sharded)
+            try:
+                from perf_hibf_ragged import measure_sharded
+                leg = measure_sharded(capi, torch, dist, args.coll_device, rank, world)
+                if rank == 0:
+                    out["hibf_irregular"] = leg
+            except SystemExit:
+                raise
+            except Exception as e:  # noqa: BLE001
+                out["hibf_irregular"] = {"error": repr(e)}
         if world == 1 and rank == 0 and not strong:
             # ... and a GENERAL tree as seqan::hibf's layout shapes the reference's index (include/index_hibf.h:114-129): 65 536 user
             # bins scattered over IBFs of at most 256 technical bins, split bins, user bins next to merged bins (tests/helpers.py

@@ -109,6 +109,9 @@ def test_bench_two_rank_rehearsal_prints_one_contract_line():
     assert "error" not in out["hibf"], out["hibf"]
     assert out["hibf"]["column_shards"] == 2 and out["hibf"]["mask_bytes_per_kmer"] == 4096
     _check_wide_legs(out, 2)
+    irr = out["hibf_irregular"]  # the general tree, sharded by sub-trees over the two ranks, masks ORed
+    assert "error" not in irr, irr
+    assert irr["collective"]["ranks"] == 2 and irr["oracle_masks_compared"] > 20 and irr["queries_layout_order"]["queries_per_s"] > 0
     one = e2e["one_process_n_devices"]
     assert "error" not in one and one["mask_words"] == 32 and one["queries_per_s"] > 0, one
 
