@@ -193,7 +193,7 @@ def hbm_leg(capi, torch, args, h):
     bytes_per_probe = h * W * 8 + W * 8 + 8
     achieved = bytes_per_probe * n / kernel_s / 1e9
     traffic, source = pmc_traffic("S-IBF-1024-rows62500000", n, W, h)
-    out = {"bound": "hbm", "kernel": "txq::probe_kernel<8,3,2,false>", "workload": "S-IBF-1024-rows62500000 (8 GB, the 8192-bin index's per-GPU shard)",
+    out = {"bound": "hbm", "kernel": "txq::probe_kernel<8,3,2,false,NoRoot>", "workload": "S-IBF-1024-rows62500000 (8 GB, the 8192-bin index's per-GPU shard)",
            "matrix_bytes": int(ix.info.device_bytes), "kmer_bits": bits, "kmers_per_step": n, "steps": steps,
            "probes_per_s": n * steps / elapsed, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
            "bytes_per_probe": bytes_per_probe, "avg_kernel_ms": kernel_s * 1e3, "traffic": traffic, "self_check_rows": present}
@@ -1232,7 +1232,7 @@ def main():
             "bound": "hbm",
             "resident": ("infinity-cache: the %.0f MB matrix fits the 256 MB MALL, so this is a cache gather rate — see roofline_hbm for the "
                          "out-of-cache figure" % (int(ix.info.device_bytes) / 1e6)) if cache_resident else "hbm (matrix far larger than the 256 MB Infinity Cache)",
-            "kernel": "txq::probe_kernel<8,3,2,false>" if (W == 16 and h == 3) else "txq::probe_kernel",
+            "kernel": "txq::probe_kernel<8,3,2,false,NoRoot>" if (W == 16 and h == 3) else "txq::probe_kernel",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",

@@ -11,7 +11,7 @@
 //   * the row indices travel from the hashing lane to the gathering lane group by ds_bpermute
 //     (__shfl), no LDS allocation, no redundant 64-bit multiplies,
 //   * two steps are in flight at a time (2*h independent 16-byte gathers per lane before the
-//     first AND, 8 waves/SIMD); output rows of one step are contiguous (coalesced 1-KiB stores),
+//     first AND, 94 VGPRs = 5 waves/SIMD); output rows of one step are contiguous (coalesced 1-KiB stores),
 //   * `alive` (mask != 0, the collector's path_.none() test) falls out of one __ballot per step.
 // Algorithmic HBM bytes per probe: h*W*8 (rows) + W*8 (mask) + 8 (k-mer); W = shard_words.
 #include "txq_internal.hpp"
@@ -222,7 +222,7 @@ static hipError_t launch_lpk(const IbfDev& f, const uint64_t* k, size_t n, uint6
     // (profiles/r1_probe_variants_ab.txt: 1/2/4/8 steps in flight differ by <= 2 % — occupancy already
     // supplies the memory-level parallelism, and 4 steps cost 124 VGPRs = half the waves per SIMD;
     // non-temporal ROW loads cost 20 % on a cache-resident matrix and gain nothing on an 8 GB one.
-    // Default: 2 steps in flight, 8 waves/SIMD, plain row loads.)
+    // Default: 2 steps in flight, 5 waves/SIMD (94 VGPRs), plain row loads.)
     const int unroll = knobs().probe_unroll;
     const bool nt = knobs().probe_nt;
     if (f.hash_funs == 3 && LPK == 8 && (unroll != 2 || nt)) {
