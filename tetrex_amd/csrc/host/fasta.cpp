@@ -4,6 +4,10 @@
 #include <cstdio>
 #include <cstring>
 #include <stdexcept>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #if defined(__x86_64__)
 #include <immintrin.h>
@@ -160,22 +164,38 @@ void load_records(const std::string& path, RecordSet& out) {
     // its 64 KB buffer and the byte-wise line search above cost more than the matching they feed)
     std::string& raw = out.raw;
     raw.clear();
+    const char* data = nullptr;  // the file's bytes: a mapping of a plain file (no copy at all), or `raw` for an inflated one
+    size_t data_size = 0;
+    void* mapping = nullptr;
+    size_t mapping_size = 0;
+    struct Unmap { void*& m; size_t& n; ~Unmap() { if (m) ::munmap(m, n); } } unmap{mapping, mapping_size};
     {
-        std::FILE* f = std::fopen(path.c_str(), "rb");
-        if (!f) throw std::runtime_error("File not found. Did you move/rename an indexed file? (" + path + ")");
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) throw std::runtime_error("File not found. Did you move/rename an indexed file? (" + path + ")");
         unsigned char magic[2] = {0, 0};
-        const size_t got = std::fread(magic, 1, 2, f);
+        const ssize_t got = ::pread(fd, magic, 2, 0);
         const bool gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        struct stat st;
         if (!gz) {
-            std::fseek(f, 0, SEEK_END);
-            const long size = std::ftell(f);
-            std::fseek(f, 0, SEEK_SET);
-            raw.resize(size > 0 ? (size_t)size : 0);
-            const size_t n = raw.empty() ? 0 : std::fread(raw.data(), 1, raw.size(), f);
-            raw.resize(n);
-            std::fclose(f);
+            if (::fstat(fd, &st) == 0 && st.st_size > 0) {
+                void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                if (m != MAP_FAILED) {
+                    mapping = m;
+                    mapping_size = (size_t)st.st_size;
+                    data = static_cast<const char*>(m);
+                    data_size = mapping_size;
+                } else {  // (a file that cannot be mapped — a pipe, an odd file system —: read it)
+                    raw.resize((size_t)st.st_size);
+                    size_t used = 0;
+                    for (ssize_t n; used < raw.size() && (n = ::pread(fd, raw.data() + used, raw.size() - used, (off_t)used)) > 0;) used += (size_t)n;
+                    raw.resize(used);
+                    data = raw.data();
+                    data_size = raw.size();
+                }
+            }
+            ::close(fd);
         } else {
-            std::fclose(f);
+            ::close(fd);
             gzFile g = gzopen(path.c_str(), "r");
             if (!g) throw std::runtime_error("File not found. Did you move/rename an indexed file? (" + path + ")");
             gzbuffer(g, 1 << 20);
@@ -189,12 +209,14 @@ void load_records(const std::string& path, RecordSet& out) {
             }
             gzclose(g);
             raw.resize(used);
+            data = raw.data();
+            data_size = raw.size();
         }
     }
-    out.text.reserve(raw.size());
+    out.text.reserve(data_size);
     bool open = false, in_quality = false;
-    const char* p = raw.data();
-    const char* const e = p + raw.size();
+    const char* p = data;
+    const char* const e = p + data_size;
     auto close_record = [&]() {
         if (open) out.text.push_back('\n');
         open = false;

@@ -879,7 +879,7 @@ __device__ __forceinline__ void load_geometry(GeomTables& g, const uint32_t* __r
 // WITH_STEP = false: the launch holds no STEP group (on flat indexes and tables of k-mer masks a level's STEP groups get a
 // launch of their own) — the STEP code, its tables and its registers are compiled out (ROWS is not used then).
 template <int H, bool WIDE, class ROWS, bool WITH_STEP = true>
-__global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                      const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
                                                      const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
                                                      uint32_t W, uint32_t G, DenseParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
@@ -1018,16 +1018,28 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
             high <<= P.bits;
             live = live && idx < q.src_cap;
             uint32_t hit = 0;  // bit i: residue codes[pos][i] left a bit in this lane's chunk
-            for (uint32_t c0 = 0; c0 < chunks_w; c0 += G) {
-                const uint32_t c = c0 + sub;
-                bool mine = live && c < chunks_w;
-                T sv = L::zero();
-                if (mine) {
-                    rows.prepare(c);
-                    sv = L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords);
-                    mine = L::any(sv);
+            // A lane owns one chunk of every pass of G chunks over the mask.  Wide masks are sparse (a layout-order row of the
+            // 65 536-bin trees: 20 passes, a handful of chunks with bits): first the lane finds WHICH of its chunks hold a bit —
+            // four passes' loads in flight at a time, nothing else done for them —, then it works on those alone (the chunk comes
+            // out of the cache again; the row source is only prepared — PathRows: the chunk's record and its ancestors' — for a
+            // chunk that needs it).  Lanes whose bits sit in different passes work side by side: the wave takes as many turns as
+            // its busiest lane has chunks, not one per pass.
+            for (uint32_t pb = 0; pb < chunks_w; pb += G * 32u) {
+                uint32_t nz = 0;
+                for (uint32_t p0 = 0; p0 < 32u && pb + p0 * G < chunks_w; p0 += 4u) {
+                    T s4[4];
+#pragma unroll
+                    for (uint32_t jj = 0; jj < 4u; ++jj) {
+                        const uint32_t c = pb + (p0 + jj) * G + sub;
+                        s4[jj] = live && c < chunks_w ? L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords) : L::zero();
+                    }
+#pragma unroll
+                    for (uint32_t jj = 0; jj < 4u; ++jj) nz |= (L::any(s4[jj]) ? 1u : 0u) << (p0 + jj);
                 }
-                if (!mine) continue;
+                for (; nz; nz &= nz - 1) {
+                const uint32_t c = pb + (uint32_t)__builtin_ctz(nz) * G + sub;
+                rows.prepare(c);
+                const T sv = L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords);
                 uint32_t i = 0;
                 if (noprobe) {
                     for (; i < n_r; ++i) {
@@ -1070,6 +1082,7 @@ __global__ __launch_bounds__(256) void sparse_kernel(ROWS rows, const SparseGrou
                         atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
                         hit |= 1u << i;
                     }
+                }
                 }
             }
             for (uint32_t o = 1; o < G; o <<= 1) hit |= (uint32_t)__shfl_xor((int)hit, (int)o);
