@@ -694,7 +694,6 @@ def verified_end_to_end(args):
             hits = sum(1 for i in range(len(motifs)) if os.path.exists(os.path.join(work, "M%03d.tsv" % i)) and os.path.getsize(os.path.join(work, "M%03d.tsv" % i)) > 0)
             runs["threads_%d" % threads] = {"queries_per_s": len(motifs) / whole["batch_seconds"], "seconds": whole["batch_seconds"],
                                             "mask_seconds": mask["mask_seconds"], "verify_seconds": whole["verify_seconds"],
-                                            "verify_scan_seconds": whole.get("verify_scan_seconds"),
                                             "refused_fraction": whole["refused"] / len(motifs), "motifs_with_verified_matches": hits}
         # CPU baseline: the oracle's mask stage on the index file the CLI wrote, plus the single-threaded verification measured above
         img = H.IndexFile.load(os.path.join(work, "sp.ibf"))

@@ -463,11 +463,10 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
 
 @pytest.fixture(params=["compacted", "lane-groups"])
 def step_kernel(request, monkeypatch):
-    """Pushed steps run by units on narrow masks (sparse_units_kernel) and by items on wide ones (sparse_items_kernel) or, with
-    TXQ_SPARSE_STEPS=0 / TXQ_SPARSE_ITEMS=0, in sparse_kernel's rounds of one entry per lane group — all must give the oracle's masks."""
+    """Pushed steps on a flat index run compacted (sparse_step_kernel: items queued in LDS, one per lane) or, with
+    TXQ_SPARSE_STEPS=0, in sparse_kernel with a lane group per entry like the trees' — both must give the oracle's masks."""
     if request.param == "lane-groups":
         monkeypatch.setenv("TXQ_SPARSE_STEPS", "0")
-        monkeypatch.setenv("TXQ_SPARSE_ITEMS", "0")  # (wide masks: sparse_items_kernel otherwise)
     return request.param
 
 

@@ -57,8 +57,7 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
     # (the index's table of all k-mers' masks would take the dense steps over — these trees are small enough for it — so it is
     # switched off for the ways that name a path, and gets a way of its own, last: once built it stays with the index)
     # ("layout": the rows of plain k-mers by one wave per k-mer — hibf_fused_kernel<G, LAYOUT> —, "layout-levels": level by level)
-    # ("layout-tracked": pushed steps by items — sparse_items_kernel<PathRows> —, "layout-tracked-rounds": in sparse_kernel's rounds)
-    for way in ("layout", "layout-levels", "layout-blocks", "layout-tracked", "layout-tracked-rounds", "user-order", "table", "table-tracked"):
+    for way in ("layout", "layout-levels", "layout-blocks", "layout-tracked", "user-order", "table", "table-tracked"):
         monkeypatch.setenv("TXQ_KMER_TABLE_MB", "512" if way.startswith("table") else "0")
         monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
         monkeypatch.delenv("TETREX_DENSE_MIN", raising=False)
@@ -71,11 +70,8 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
         if way not in ("layout", "layout-levels"):
             monkeypatch.setenv("TETREX_DENSE_MIN", "2")
             monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
-        monkeypatch.delenv("TXQ_SPARSE_ITEMS", raising=False)
-        if way in ("layout-tracked", "layout-tracked-rounds", "table-tracked"):
+        if way in ("layout-tracked", "table-tracked"):
             monkeypatch.setenv("TETREX_DENSE_TRACKED", "1")
-        if way == "layout-tracked-rounds":
-            monkeypatch.setenv("TXQ_SPARSE_ITEMS", "0")
         if way == "user-order":
             monkeypatch.setenv("TXQ_HIBF_LAYOUT_ORDER", "0")
         got, status, stats = ix.query_masks(qs, False, 4)
@@ -89,7 +85,7 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
         assert hits >= 10, way
         if way not in ("layout", "layout-levels"):
             assert stats["dense_ops"] > 0
-        if way in ("layout-tracked", "layout-tracked-rounds", "table-tracked"):
+        if way in ("layout-tracked", "table-tracked"):
             assert stats["tracked_queries"] > 0
     for way, got in results.items():
         assert np.array_equal(got, results["user-order"]), way

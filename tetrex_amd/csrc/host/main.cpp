@@ -221,8 +221,7 @@ int cmd_query(int argc, char** argv) {
                 bin_major = false;
             }
         }
-        const double scan_seconds = now() - t_verify;  // (-S: reading and searching the candidate bins; what follows writes the result files)
-        const double per_motif = bin_major ? scan_seconds / std::max<size_t>(1, motifs.size()) : 0.0;
+        const double per_motif = bin_major ? (now() - t_verify) / std::max<size_t>(1, motifs.size()) : 0.0;
         for (size_t i = 0; i < motifs.size(); ++i) {
             std::cerr << ids[i] << "\t";
             if (status[i]) {  // its mask is incomplete: verifying the bins it happens to hold would silently lose matches
@@ -244,8 +243,7 @@ int cmd_query(int argc, char** argv) {
         // -S: the whole batch as the reference times a query — from after the index is loaded to the last output byte
         // (include/query.h:256,287-289): candidate masks + verification of the candidate bins
         if (a.has("stats"))
-            std::cerr << "{\"batch_seconds\": " << (now() - t0) << ", \"verify_seconds\": " << (now() - t_verify) << ", \"verify_scan_seconds\": " << (bin_major ? scan_seconds : 0.0)
-                      << ", \"threads\": " << vopt.threads
+            std::cerr << "{\"batch_seconds\": " << (now() - t0) << ", \"verify_seconds\": " << (now() - t_verify) << ", \"threads\": " << vopt.threads
                       << ", \"refused\": " << failed << "}" << std::endl;
         return failed ? 1 : 0;
     }

@@ -52,7 +52,6 @@ void read_knobs() {
     k.fuse_units = !is("TXQ_FUSE_UNITS", '0');
     k.one_stream = flag("TXQ_ONE_STREAM");
     k.sparse_steps = !is("TXQ_SPARSE_STEPS", '0');
-    k.sparse_items = !is("TXQ_SPARSE_ITEMS", '0');
     k.sparse_unroll = (int)num("TXQ_SPARSE_UNROLL", 3);
     k.sparse_units = (int)std::min(1536LL, std::max(64LL, num("TXQ_SPARSE_UNITS", 512)));
     k.kmer_table_mb = std::max(0LL, num("TXQ_KMER_TABLE_MB", 512));

@@ -1297,259 +1297,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void s
     }
 }
 
-// ---- pushed steps on WIDE masks: by items ---------------------------------------------------------------------------
-// The STEP groups of a level where a mask is many cache lines (W > kUnitStepWords: a layout-order row of the 65 536-bin general
-// trees is 19.8 KB, a live entry holds bits in a handful of its 1237 chunks).  sparse_kernel gives an entry a lane group that
-// covers the mask in passes: the few lanes whose chunk holds a bit roll it forward residue by residue while the others idle.
-// Here a workgroup turns its entries into ITEMS first — an item = one 16-byte chunk of one live entry that holds a bit, with what
-// its pushes need (the chunk, the k-mer without the residue rolled in, the destination entry without that residue's rank) —
-// queued in LDS, and whenever 256 items wait every lane takes ONE and rolls it forward by all residues of the step: all 64 lanes
-// of a wave gather.  (On narrow masks this loses the coalescing of a lane group's row gathers — sparse_units_kernel is for
-// those; on wide masks the chunks with bits sit in different cache lines anyway.)
-//   fill:     one thread per entry decodes it; then the workgroup loads the entries' chunks coalesced, two rounds in flight, and
-//             the lanes whose chunk holds a bit append an item (wave ballot: one LDS atomic per wave)
-//   process:  item per lane (the row source is prepared for the item's chunk: PathRows — its IBF and its ancestors' gates); a
-//             non-empty product is ORed atomically into the destination entry's chunk, an entry that gets its first bit joins
-//             dst's list (collected in LDS, appended with one atomic on the block's count per flush)
-// Items of one group (op) accumulate over the group's chunks; the queue is drained when the group changes.
-static constexpr uint32_t kStepQueue = 768;   // items: fewer than 256 that wait + two fill rounds of 256
-static constexpr uint32_t kStepFresh = 2048;  // fresh destination entries collected per flush (more: appended one by one)
-static constexpr uint32_t kStepFillRounds = 2;
-template <class T> struct alignas(16) StepItem { T sv; uint64_t high; uint32_t dst0, c; };
-
-// one trip of an item: N residues' rows in flight, the non-empty products ORed into the destination entries; bit u of the
-// result: residue code[u] left a bit
-template <int N, bool WIDE, class ROWS>
-__device__ __forceinline__ uint32_t step_trip(ROWS& rows, uint64_t high, typename Lane<WIDE>::T sv, const uint8_t* code, const uint8_t* rank, uint64_t* dchunk,
-                                              uint32_t dst0, uint32_t W, const StepParams& P) {
-    using L = Lane<WIDE>;
-    using T = typename L::T;
-    typename ROWS::Loads x[N];
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        uint64_t v = high | code[u];
-        if (P.canonical) v = canonical_dna(v, P.k);
-        rows.template issue<false>(nullptr, v, x[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < N; ++u) rows.template issue_late<false>(x[u]);
-    uint32_t hit = 0;
-#pragma unroll
-    for (int u = 0; u < N; ++u) {
-        const T y = sv & rows.combine(x[u]);
-        const uint32_t rk = rank[u];
-        if (L::any(y) && rk != 0xFFu) {
-            atomic_or_chunk<WIDE>(dchunk + (size_t)(dst0 + rk) * W, y);
-            hit |= 1u << u;
-        }
-    }
-    return hit;
-}
-
-template <int H, bool WIDE, class ROWS>
-__global__ __launch_bounds__(256) void sparse_items_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
-                                                          const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
-                                                          const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                          uint32_t W, StepParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
-    using L = Lane<WIDE>;
-    using T = typename L::T;
-    constexpr int UA = ROWS::kPushUnroll;
-    __shared__ uint32_t pre[kMaxSparseGroups + 1];
-    __shared__ uint8_t rcode[32], rrank[32];  // the step's residues: code, and rank in the last position of dst's geometry (0xFF: not in it)
-    __shared__ GeomTables sg, dg;
-    __shared__ StepItem<T> queue[kStepQueue];
-    __shared__ uint32_t q_head, q_tail, fresh_n, fresh_at, n_hits;
-    __shared__ uint32_t fresh_list[kStepFresh];
-    __shared__ uint32_t e_idx[kSparseChunk], e_dst0[kSparseChunk];
-    __shared__ uint64_t e_high[kSparseChunk];
-    if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
-        run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
-        return;
-    }
-    const uint32_t tid = threadIdx.x, lane = tid & 63u;
-    for (uint32_t i = tid; i <= n_groups; i += blockDim.x) pre[i] = prefix[i];
-    if (tid == 0) { q_head = 0; q_tail = 0; fresh_n = 0; n_hits = 0; }
-    __syncthreads();
-    const uint32_t total = pre[n_groups];
-    const uint32_t j = blockIdx.x - U.n_units, J = gridDim.x - U.n_units;
-    const uint32_t lo = (uint32_t)((uint64_t)total * j / J), hi = (uint32_t)((uint64_t)total * (j + 1) / J);
-    if (lo >= hi) return;
-    uint32_t g = 0;  // the group of chunk lo: the last one that starts at or before it
-    for (uint32_t b = n_groups; b - g > 1;) {
-        const uint32_t m = (g + b) / 2;
-        if (pre[m] <= lo) g = m; else b = m;
-    }
-    const uint32_t chunks_w = (W + L::kWords - 1) / L::kWords;
-    const bool cw_pow2 = (chunks_w & (chunks_w - 1)) == 0;
-    const uint32_t cw_shift = 31u - (uint32_t)__builtin_clz(chunks_w);
-    unsigned long long c_entries = 0, c_units = 0;  // (thread 0: what this workgroup did, for TXQ_TRACE)
-    // One loop, one copy of every phase; what it does next follows from values every thread sees alike (shared counters read
-    // behind a barrier, the chunk cursor).  The group whose items are queued:
-    uint32_t loaded = 0xFFFFFFFFu, n_r = 0;
-    bool noprobe = false;
-    DenseOpPtr q{};
-    BlockMeta dm{};
-    const uint32_t* src_list = nullptr;
-    // the chunk being filled from
-    uint32_t t = lo, base = 0, pairs = 0;
-    bool decoded = false, switch_group = false;
-    for (;;) {
-        const uint32_t waiting = q_tail - q_head;
-        const bool input_done = t >= hi, force = input_done || switch_group;
-        if (waiting >= 256u || (force && waiting)) {
-            // ---- process: up to 256 waiting items, one per lane, rolled forward by every residue of the step
-            const uint32_t n = waiting < 256u ? waiting : 256u;
-            if (tid < n) {
-                const StepItem<T> it = queue[(q_head + tid) % kStepQueue];
-                const T sv = it.sv;
-                const uint32_t c = it.c;
-                rows.prepare(c);
-                uint64_t* const dchunk = q.dst + (size_t)c * L::kWords;
-                uint32_t hit = 0;  // bit i: residue rcode[i] left a bit in this chunk
-                if (noprobe) {  // states that are still filling their first k-mer: the mask moves on as it is
-                    for (uint32_t i = 0; i < n_r; ++i) {
-                        const uint32_t rk = rrank[i];
-                        if (rk == 0xFFu) continue;
-                        atomic_or_chunk<WIDE>(dchunk + (size_t)(it.dst0 + rk) * W, sv);
-                        hit |= 1u << i;
-                    }
-                } else {
-                    uint32_t i = 0;
-                    for (; i + UA <= n_r; i += UA)
-                        hit |= step_trip<UA, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i;
-                    // the last, partial trip: its residues in flight together (n_r is the same in every lane)
-                    if constexpr (UA > 2) { if (n_r - i == 2) { hit |= step_trip<2, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; i += 2; } }
-                    if constexpr (UA > 1) { if (n_r - i == 1) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
-                    if constexpr (UA > 3) { for (; i < n_r; ++i) hit |= step_trip<1, WIDE>(rows, it.high, sv, rcode + i, rrank + i, dchunk, it.dst0, W, P) << i; }
-                }
-                if (ctr && hit) atomicAdd(&n_hits, (uint32_t)__builtin_popcount(hit));
-                for (uint32_t h = hit; h; h &= h - 1) {  // destinations that were empty until now join dst's list
-                    const uint32_t entry = it.dst0 + rrank[__builtin_ctz(h)];
-                    // (most hits land in entries that are listed already — other chunks of the same entry, other sources —: a
-                    // plain look at the bitmap first, the returning atomic only where the bit seems clear; it decides)
-                    if (!((dm.bitmap[entry >> 6] >> (entry & 63u)) & 1ULL) && mark_live(dm, entry)) {
-                        const uint32_t at = atomicAdd(&fresh_n, 1u);
-                        if (at < kStepFresh) fresh_list[at] = entry;
-                        else append_live(dm, entry);
-                    }
-                }
-            }
-            __syncthreads();
-            if (tid == 0) { q_head += n; c_units += (unsigned long long)n * n_r; }
-            __syncthreads();
-            if (fresh_n < kStepFresh / 2) continue;
-        }
-        if (force || fresh_n >= kStepFresh / 2) {
-            // ---- flush: the fresh destination entries join dst's list with one atomic on the block's count
-            const uint32_t n_fresh = fresh_n < kStepFresh ? fresh_n : kStepFresh;
-            if (n_fresh) {
-                if (tid == 0) fresh_at = __hip_atomic_fetch_add(dm.count, n_fresh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                for (uint32_t i = tid; i < n_fresh; i += blockDim.x) dm.list[fresh_at + i] = fresh_list[i];
-                __syncthreads();
-                if (tid == 0) fresh_n = 0;
-                __syncthreads();
-            }
-            if (!force || q_tail != q_head) continue;  // (a flush in the middle, or items are still waiting)
-            if (input_done) break;
-            // ---- the queue is empty: the tables of the next chunk's group
-            const uint32_t op = groups[g].op;
-            q = optr[op];
-            dm = block_meta(q.dst, q.dst_cap, W);
-            const BlockMeta sm = block_meta(const_cast<uint64_t*>(q.src), q.src_cap, W);
-            src_list = sm.list;
-            noprobe = (dops[op].reserved & TXQ_DENSE_NOPROBE) != 0;
-            load_geometry(dg, dm.geom, P.pos);
-            load_geometry(sg, sm.geom, P.pos);
-            const uint32_t r_mask = dops[op].r_mask;
-            if (tid == 0) {
-                uint32_t m = 0;
-                for (uint32_t c = 0; c < 32; ++c)
-                    if ((r_mask >> c) & 1u) { rcode[m] = (uint8_t)c; rrank[m] = dg.rank[P.pos - 1][c]; ++m; }
-            }
-            n_r = (uint32_t)__builtin_popcount(r_mask);
-            __syncthreads();
-            loaded = g;
-            switch_group = false;
-            continue;
-        }
-        if (!decoded) {
-            // ---- decode the next chunk's entries, one thread each
-            while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
-            if (loaded != g) { switch_group = true; continue; }  // its items may not mix with the queued ones: drain first
-            const uint32_t first = (t - pre[g]) * kSparseChunk;
-            const uint32_t n = counts[g];
-            const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
-            const uint32_t n_e = end > first ? end - first : 0u;
-            if (tid < n_e) {
-                const uint32_t idx = src_list[first + tid];
-                bool live = idx < q.src_cap;
-                uint64_t high = 0;   // the k-mer without the residue rolled in
-                uint32_t dst0 = 0;   // the destination entry without that residue's rank
-                for (uint32_t jj = P.pos, rest = idx; jj-- > 0;) {
-                    const uint32_t cn = sg.cnt[jj];
-                    const uint32_t c = sg.code[jj][rest % cn];
-                    rest /= cn;
-                    high |= (uint64_t)c << (P.bits * (P.pos - 1 - jj));
-                    if (jj > 0) {
-                        const uint32_t rk = dg.rank[jj - 1][c];
-                        live = live && rk != 0xFFu;
-                        dst0 += rk * dg.stride[jj - 1];
-                    }
-                }
-                e_idx[tid] = live ? idx : 0xFFFFFFFFu;
-                e_high[tid] = high << P.bits;
-                e_dst0[tid] = dst0;
-            }
-            __syncthreads();
-            if (tid == 0) c_entries += n_e;
-            pairs = n_e * chunks_w;
-            base = 0;
-            decoded = pairs != 0;
-            if (!decoded) ++t;
-            continue;
-        }
-        // ---- fill: the chunks of the decoded entries, coalesced, two rounds in flight; a chunk that holds a bit becomes an item
-        {
-            T sv[kStepFillRounds];
-            uint32_t el[kStepFillRounds], cc[kStepFillRounds];
-#pragma unroll
-            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
-                const uint32_t f = base + r * 256u + tid;
-                el[r] = cw_pow2 ? f >> cw_shift : f / chunks_w;
-                cc[r] = cw_pow2 ? f & (chunks_w - 1) : f % chunks_w;
-                sv[r] = L::zero();
-                if (f < pairs) {
-                    const uint32_t idx = e_idx[el[r]];
-                    if (idx != 0xFFFFFFFFu) sv[r] = L::load(q.src + (size_t)idx * W + (size_t)cc[r] * L::kWords);
-                }
-            }
-#pragma unroll
-            for (uint32_t r = 0; r < kStepFillRounds; ++r) {
-                const bool push = L::any(sv[r]);
-                const unsigned long long votes = __ballot(push);
-                uint32_t at = 0;
-                if (lane == 0 && votes) at = atomicAdd(&q_tail, (uint32_t)__popcll(votes));
-                at = (uint32_t)__shfl((int)at, 0);
-                if (push) {
-                    const uint32_t slot = (at + (uint32_t)__popcll(votes & ((1ULL << lane) - 1ULL))) % kStepQueue;
-                    queue[slot] = StepItem<T>{sv[r], e_high[el[r]], e_dst0[el[r]], cc[r]};
-                }
-            }
-            base += 256u * kStepFillRounds;
-            if (base >= pairs) { decoded = false; ++t; }
-            __syncthreads();  // (the items are visible; the entries' table may be overwritten by the next decode)
-        }
-    }
-    if (ctr && tid == 0) {
-        atomicAdd(ctr + 0, c_entries);
-        atomicAdd(ctr + 1, (unsigned long long)q_tail);
-        atomicAdd(ctr + 2, c_units);
-        atomicAdd(ctr + 3, (unsigned long long)n_hits);
-    }
-}
-
-
 // ---- dense steps on an HIBF --------------------------------------------------------------------
 // M[k-mer] of an HIBF is a tree descent (txq_hibf.hip), not h row gathers, so a step cannot be fused.  It runs as
 // three launches over a chunk of step tiles: the predecessor k-mers of every destination suffix are written out
@@ -2363,29 +2110,6 @@ __global__ __launch_bounds__(256) void iota_kernel(uint64_t* __restrict__ v, uin
     for (uint64_t i = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) v[i] = i;
 }
 
-// the STEP groups of a level on wide masks (sparse_items_kernel)
-template <bool WIDE, template <int, bool> class ROWS, class MAKE>
-static hipError_t launch_sparse_items(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
-                                      size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W,
-                                      const StepParams& P, const LevelUnits& U, hipStream_t st) {
-#define TXQ_ITEMS(H) \
-    do { \
-        ROWS<H, WIDE> rows{}; \
-        rows_of(rows); \
-        sparse_items_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, P, U, nullptr); \
-    } while (0)
-    switch (hash_funs) {
-        case 1: TXQ_ITEMS(1); break;
-        case 2: TXQ_ITEMS(2); break;
-        case 3: TXQ_ITEMS(3); break;
-        case 4: TXQ_ITEMS(4); break;
-        case 5: TXQ_ITEMS(5); break;
-        default: return hipErrorInvalidValue;
-    }
-#undef TXQ_ITEMS
-    return hipGetLastError();
-}
-
 // the STEP groups of a level on narrow masks (sparse_units_kernel)
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
 static hipError_t launch_sparse_units(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
@@ -2544,13 +2268,10 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     double t1 = now_s();
     // on a flat index / through the table of k-mer masks a level's STEP groups get a launch of their own: the ZERO / REDUCE / FILL
     // groups then run in the sparse_kernel variant without step code (66 VGPRs instead of 110)
-    const bool split_steps = true;
+    const bool split_steps = !vspace && !tree && (table || !ix.is_hibf);
     // ... and where a mask is a cache line or two, that launch shares the steps out by units (sparse_units_kernel; TXQ_SPARSE_STEPS=0:
     // sparse_kernel's rounds of entries, A/B and tests)
-    const bool by_units = s.kn.sparse_steps && W <= kUnitStepWords && !vspace && !tree && (table || !ix.is_hibf);
-    // ... and where a mask is many cache lines (W > kUnitStepWords: layout-order rows, 8192-bin shards), by items (sparse_items_kernel:
-    // the chunks that hold bits, one per lane; TXQ_SPARSE_ITEMS=0: sparse_kernel's rounds)
-    const bool by_items = s.kn.sparse_items && W > kUnitStepWords;
+    const bool by_units = split_steps && s.kn.sparse_steps && W <= kUnitStepWords;
     const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, split_steps, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
@@ -2899,25 +2620,6 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                             auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
                             e = wide ? launch_sparse_units<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st)
                                      : launch_sparse_units<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, sp, lu, s.d_step_ctr, s.kn.sparse_unroll, st);
-                        }
-                    } else if (steps && by_items) {
-                        const StepParams sp{bv.dense.k, bv.dense.bits, bv.dense.pos, bv.dense.canonical, 0u, 0u};
-                        if (vspace) {
-                            auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                            e = wide ? launch_sparse_items<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st)
-                                     : launch_sparse_items<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st);
-                        } else if (tree) {  // (wide masks: never the interleaved children, whose masks are at most 32 words)
-                            auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                            e = wide ? launch_sparse_items<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st)
-                                     : launch_sparse_items<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st);
-                        } else if (table) {
-                            auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
-                            e = wide ? launch_sparse_items<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st)
-                                     : launch_sparse_items<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st);
-                        } else {
-                            auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                            e = wide ? launch_sparse_items<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st)
-                                     : launch_sparse_items<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, sp, lu, st);
                         }
                     } else if (split_steps && !steps) {  // ZERO / REDUCE / FILL only: the variant without the step code (its row source is not used)
                         FlatRows<1, true> none{};

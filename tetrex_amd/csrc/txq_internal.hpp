@@ -25,7 +25,6 @@ struct Knobs {
     bool one_stream = false;    // TXQ_ONE_STREAM: independent stages do not run beside each other
     int sparse_units = 512;     // TXQ_SPARSE_UNITS: (entry x residue) units per chunk of sparse_units_kernel, 64 .. 1536
     int sparse_unroll = 3;      // TXQ_SPARSE_UNROLL: units in flight per lane group in sparse_units_kernel (2 or 3)
-    bool sparse_items = true;   // TXQ_SPARSE_ITEMS=0: pushed steps on wide masks run in sparse_kernel (a lane group per entry), not by items (sparse_items_kernel)
     bool sparse_steps = true;   // TXQ_SPARSE_STEPS=0: pushed steps on narrow masks run in sparse_kernel (rounds of one entry per lane group), not by units (sparse_units_kernel)
     long long kmer_table_mb = 512;  // TXQ_KMER_TABLE_MB: most an index's table of ALL k-mers' masks may take (0: dense steps always gather rows)
     long long kmer_table_min = 16;  // TXQ_KMER_TABLE_MIN: the session of fewest programs that builds the table (a single query does not pay for it; once built it is used)
