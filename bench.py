@@ -686,6 +686,8 @@ def verified_end_to_end(args):
                 if r.returncode != 0:
                     return {"error": "tetrex query failed: " + r.stderr[-500:]}
                 stats = [json.loads(ln) for ln in r.stderr.splitlines() if ln.startswith("{")]
+                if os.environ.get("TETREX_TRACE"):  # (tools/verify_leg.py under TETREX_TRACE: where the verification's time goes)
+                    sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[tetrex] verify_batch")))
                 whole = [x for x in stats if "batch_seconds" in x][-1]
                 mask = [x for x in stats if "mask_seconds" in x][-1]
                 if best is None or whole["batch_seconds"] < best[0]["batch_seconds"]:

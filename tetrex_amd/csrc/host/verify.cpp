@@ -4,6 +4,9 @@
 #include "regex_front.hpp"
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <sstream>
@@ -109,6 +112,12 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
     std::vector<std::vector<Rows>> rows(todo.size());
     std::vector<size_t> found(todo.size(), 0);
     std::string error;
+    // TETREX_TRACE: where the time goes (summed over the threads) and how much the required literals save
+    const bool trace = std::getenv("TETREX_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_load = 0, t_literal = 0, t_match = 0;
+    size_t n_pairs = 0, n_listed_pairs = 0, n_records_scanned = 0, n_records_total = 0;
+    const double t_begin = now();
 #pragma omp parallel num_threads(opt.threads > 0 ? opt.threads : 1)
     {
         std::vector<std::unique_ptr<Matcher::Cache>> caches(nq);  // this thread's automata, built on first use, kept from bin to bin
@@ -122,6 +131,7 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                 const std::vector<uint32_t>& qs = wanted[todo[i]];
                 std::vector<Rows>& mine = rows[i];
                 mine.resize(qs.size());
+                const double t0 = trace ? now() : 0;
                 load_records(path, recs);  // ONE read of the bin for all its motifs
                 if (reduced)
                     for (char& c : recs.text) if (c != '\n') c = enc.reduce((unsigned char)c);
@@ -141,13 +151,21 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                     // (not rare — in more than half of the records —: the per-record prefilter does as well)
                     return lit.size() >= 2 && records_with(recs, text, lit, recs.size() / 2, hits);
                 };
+                double my_literal = 0, my_match = 0;
+                size_t my_listed = 0, my_scanned = 0;
+                const double t1 = trace ? now() : 0;
                 for (size_t j = 0; j < qs.size(); ++j) {
                     const uint32_t q = qs[j];
                     const Matcher& m = *rx[q];
                     if (!caches[q]) caches[q] = std::make_unique<Matcher::Cache>();
                     auto scan = [&](const std::string& text, bool reverse_strand) {
+                        const double ta = trace ? now() : 0;
                         const bool listed = candidates(m, text);
+                        const double tb = trace ? now() : 0;
+                        my_literal += tb - ta;
                         const size_t n_scan = listed ? hits.size() : recs.size();
+                        my_listed += listed;
+                        my_scanned += n_scan;
                         for (size_t at = 0; at < n_scan; ++at) {
                             const size_t r = listed ? hits[at] : at;
                             const std::string_view seq(text.data() + recs.start[r], recs.start[r + 1] - recs.start[r] - 1);
@@ -163,6 +181,14 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                     scan(recs.text, false);
                     if (dna) scan(rc, true);
                 }
+                if (trace) {
+                    my_match = now() - t1 - my_literal;
+#pragma omp critical
+                    {
+                        t_load += t1 - t0; t_literal += my_literal; t_match += my_match;
+                        n_pairs += qs.size(); n_listed_pairs += my_listed; n_records_scanned += my_scanned; n_records_total += recs.size() * qs.size();
+                    }
+                }
             } catch (const std::exception& e) {
 #pragma omp critical
                 error = e.what();
@@ -170,6 +196,10 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
         }
     }
     if (!error.empty()) throw std::runtime_error(error);
+    if (trace)
+        std::fprintf(stderr, "[tetrex] verify_batch: %zu bins, %zu (motif, bin) pairs in %.3f s; thread time: load %.3f s, literal search %.3f s, automata + rows %.3f s; "
+                             "%zu pairs narrowed by their literal, %zu of %zu records given to the automata\n",
+                     todo.size(), n_pairs, now() - t_begin, t_load, t_literal, t_match, n_listed_pairs, n_records_scanned, n_records_total);
     size_t total = 0;
     for (size_t i = 0; i < todo.size(); ++i) {
         const std::vector<uint32_t>& qs = wanted[todo[i]];
