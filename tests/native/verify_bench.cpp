@@ -8,19 +8,24 @@
 #include <chrono>
 #include <cstdio>
 #include <fstream>
+#include <cstdlib>
 #include <random>
+#include <string>
 #include <sstream>
 using namespace tetrex;
 int main(int argc, char** argv) {
-    const int bins = 1024, per_bin = 200000, nq = argc > 2 ? atoi(argv[2]) : 200;
+    const int bins = getenv("VERIFY_BENCH_BINS") ? atoi(getenv("VERIFY_BENCH_BINS")) : 1024;   // (a multiple of 64)
+    const int per_bin = getenv("VERIFY_BENCH_PER_BIN") ? atoi(getenv("VERIFY_BENCH_PER_BIN")) : 200000;
+    const int nq = argc > 2 ? atoi(argv[2]) : 200;
+    const std::string dir = std::string("/tmp/tetrex_verify_bench_") + std::to_string(bins) + "_" + std::to_string(per_bin);
     const int threads = argc > 1 ? atoi(argv[1]) : 1;
     const bool plain = argc > 3;  // the bench leg's shape only (long motifs, 11 candidate bins each): timing; otherwise also short motifs that DO match
     std::mt19937_64 rng(11);
-    (void)!system("mkdir -p /tmp/tetrex_verify_bench");
+    (void)!system(("mkdir -p " + dir).c_str());
     const char* aa = "ACDEFGHIKLMNPQRSTVWY";
     std::vector<std::string> paths;
     for (int b = 0; b < bins; ++b) {
-        char name[64]; snprintf(name, sizeof name, "/tmp/tetrex_verify_bench/bin%04d.fa", b);
+        char name[160]; snprintf(name, sizeof name, "%s/bin%04d.fa", dir.c_str(), b);
         paths.push_back(name);
         std::ifstream test(name);
         if (test.good()) continue;

@@ -147,6 +147,118 @@ bool records_with(const RecordSet& set, const std::string& text, const std::stri
     return ok;
 }
 
+namespace {
+inline bool in_set(const std::array<uint64_t, 4>& st, unsigned char c) { return (st[c >> 6] >> (c & 63)) & 1ULL; }
+inline int set_size(const std::array<uint64_t, 4>& st) {
+    int b = 0;
+    for (int w = 0; w < 4; ++w) b += __builtin_popcountll(st[w]);
+    return b;
+}
+#if defined(__x86_64__)
+// membership of 32 bytes in a byte set by two nibble look-ups: lo[c & 15] holds one bit per HIGH nibble value that occurs in
+// the set together with that low nibble, hi[c >> 4] the bit of that high nibble; usable when the set's bytes have at most 8
+// different high nibbles (letters: 4, 5, 6, 7)
+struct NibbleSet {
+    __m256i lo, hi;
+    bool ok;
+    int single = -1;  // the set is this one byte: a plain compare does
+};
+__attribute__((target("avx2"))) NibbleSet nibble_set(const std::array<uint64_t, 4>& st) {
+    unsigned char lo[16] = {0}, hi[16] = {0};
+    int bit_of_hi[16];
+    int used = 0;
+    for (int h = 0; h < 16; ++h) {
+        bit_of_hi[h] = -1;
+        bool any = false;
+        for (int l = 0; l < 16 && !any; ++l) any = in_set(st, (unsigned char)(h * 16 + l));
+        if (any) { if (used == 8) return NibbleSet{_mm256_setzero_si256(), _mm256_setzero_si256(), false, -1}; bit_of_hi[h] = used++; }
+    }
+    for (int h = 0; h < 16; ++h) {
+        if (bit_of_hi[h] < 0) continue;
+        hi[h] = (unsigned char)(1u << bit_of_hi[h]);
+        for (int l = 0; l < 16; ++l)
+            if (in_set(st, (unsigned char)(h * 16 + l))) lo[l] |= (unsigned char)(1u << bit_of_hi[h]);
+    }
+    const __m128i l128 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(lo)), h128 = _mm_loadu_si128(reinterpret_cast<const __m128i*>(hi));
+    NibbleSet out{_mm256_broadcastsi128_si256(l128), _mm256_broadcastsi128_si256(h128), true};
+    if (set_size(st) == 1)
+        for (int c = 0; c < 256; ++c) if (in_set(st, (unsigned char)c)) out.single = c;
+    return out;
+}
+__attribute__((target("avx2"))) inline __m256i member(const NibbleSet& s, __m256i bytes) {
+    if (s.single >= 0) return _mm256_cmpeq_epi8(bytes, _mm256_set1_epi8((char)s.single));
+    const __m256i low = _mm256_and_si256(bytes, _mm256_set1_epi8(0x0F));
+    const __m256i high = _mm256_and_si256(_mm256_srli_epi16(bytes, 4), _mm256_set1_epi8(0x0F));
+    const __m256i both = _mm256_and_si256(_mm256_shuffle_epi8(s.lo, low), _mm256_shuffle_epi8(s.hi, high));
+    return _mm256_xor_si256(_mm256_cmpeq_epi8(both, _mm256_setzero_si256()), _mm256_set1_epi8(-1));  // non-zero <=> member
+}
+// candidate positions i (run start) in [0, n - m]: bytes at i + a and i + b are in the sets a and b
+template <class Fn>
+__attribute__((target("avx2"))) void scan_run_avx2(const char* s, size_t n, size_t m, size_t a, size_t b, const NibbleSet& sa, const NibbleSet& sb, Fn&& at) {
+    if (n < m) return;
+    size_t i = 0;
+    for (; i + m - 1 + 32 <= n; i += 32) {
+        const __m256i x = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + a));
+        const __m256i y = _mm256_loadu_si256(reinterpret_cast<const __m256i*>(s + i + b));
+        uint32_t mask = (uint32_t)_mm256_movemask_epi8(_mm256_and_si256(member(sa, x), member(sb, y)));
+        while (mask) {
+            const size_t at_i = i + (size_t)__builtin_ctz(mask);
+            mask &= mask - 1;
+            if (!at(at_i)) return;
+        }
+    }
+    for (; i + m <= n; ++i)
+        if (!at(i)) return;  // (the tail: `at` checks every position of the run itself)
+}
+#endif
+}  // namespace
+
+bool records_with_run(const RecordSet& set, const std::string& text, const std::vector<std::array<uint64_t, 4>>& run, size_t limit, std::vector<size_t>& records) {
+    records.clear();
+    const size_t m = run.size();
+    if (m == 0 || text.size() != set.text.size()) return false;
+    // the two most selective positions of the run
+    size_t a = 0, b = 0;
+    {
+        int best_a = 1 << 30, best_b = 1 << 30;
+        for (size_t j = 0; j < m; ++j) {
+            const int z = set_size(run[j]);
+            if (z < best_a) { best_b = best_a; b = a; best_a = z; a = j; }
+            else if (z < best_b) { best_b = z; b = j; }
+        }
+        if (m == 1) b = a;
+        if (a > b) std::swap(a, b);
+    }
+    bool ok = true;
+    size_t last_record = (size_t)-1, skip_below = 0;  // (positions below skip_below lie in a record that is listed already)
+    const unsigned char* t = reinterpret_cast<const unsigned char*>(text.data());
+    auto at = [&](size_t i) {
+        if (i < skip_below) return true;
+        for (size_t j = 0; j < m; ++j)
+            if (!in_set(run[j], t[i + j])) return true;  // (the '\n' between records is in no residue class: a run never straddles two)
+        const size_t r = set.record_at(i);
+        if (r != last_record) {
+            records.push_back(r);
+            last_record = r;
+            if (records.size() > limit) { ok = false; return false; }
+        }
+        skip_below = set.start[r + 1];
+        return true;
+    };
+#if defined(__x86_64__)
+    if (__builtin_cpu_supports("avx2")) {
+        const NibbleSet sa = nibble_set(run[a]), sb = nibble_set(run[b]);
+        if (sa.ok && sb.ok) {
+            scan_run_avx2(text.data(), text.size(), m, a, b, sa, sb, at);
+            return ok;
+        }
+    }
+#endif
+    for (size_t i = 0; i + m <= text.size(); ++i)
+        if (in_set(run[a], t[i + a]) && in_set(run[b], t[i + b]) && !at(i)) break;
+    return ok;
+}
+
 size_t RecordSet::record_at(size_t offset) const {
     size_t lo = 0, hi = names.size();  // the last record whose start is <= offset
     while (hi - lo > 1) {

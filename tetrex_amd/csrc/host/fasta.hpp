@@ -3,6 +3,8 @@
 // name = first word after '>' or '@', comment = rest of the header line, sequence = following
 // lines concatenated until a line starts with '>', '@' or '+'.
 #pragma once
+#include <array>
+#include <cstdint>
 #include <functional>
 #include <string>
 #include <string_view>
@@ -36,5 +38,8 @@ void load_records(const std::string& path, RecordSet& out);  // throws std::runt
 // occurs, ascending, into `records`; false — and nothing useful in `records` — as soon as more than `limit` records hold it.
 // (32 positions per step where the CPU has AVX2: first and last byte compared at once, the rest only where both match.)
 bool records_with(const RecordSet& set, const std::string& text, const std::string& needle, size_t limit, std::vector<size_t>& records);
+// The same for a RUN of byte sets (Matcher::required_run): the records in which, at consecutive positions, one byte of each set
+// occurs.  The two most selective sets are tested at 32 positions per step (AVX2, nibble look-ups), the rest where both hold.
+bool records_with_run(const RecordSet& set, const std::string& text, const std::vector<std::array<uint64_t, 4>>& run, size_t limit, std::vector<size_t>& records);
 
 }  // namespace tetrex

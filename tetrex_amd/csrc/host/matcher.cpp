@@ -222,6 +222,44 @@ Matcher::Matcher(const std::string& pattern, Semantics semantics) : semantics_(s
         };
         walk(root);
     }
+    // ... and the most selective run of single-byte factors, whatever their sets (selectivity: the product of |set| / 256 over the
+    // run — the run whose product is smallest; '.' contributes nothing but keeps the run together)
+    {
+        std::vector<uint32_t> cur;
+        double best = 1.0;
+        auto weight = [&](uint32_t set) {
+            int bits = 0;
+            for (int w = 0; w < 4; ++w) bits += __builtin_popcountll(sets_[set][w]);
+            return bits >= 200 ? 1.0 : bits / 24.0;  // (a class of residues: out of some twenty letters; '.' and negated sets: no help)
+        };
+        auto close = [&]() {
+            double prod = 1.0;
+            for (uint32_t x : cur) prod *= std::min(1.0, weight(x));
+            if (!cur.empty() && prod < best) {
+                best = prod;
+                run_.clear();
+                for (uint32_t x : cur) run_.push_back(sets_[x]);
+            }
+            cur.clear();
+        };
+        std::function<void(int)> walk = [&](int id) {
+            const Node n = ps.nodes[id];
+            switch (n.type) {
+                case nCat: walk(n.a); walk(n.b); return;
+                case nSet: cur.push_back(n.set); if (cur.size() >= 64) close(); return;
+                case nPlus: close(); walk(n.a); close(); return;
+                case nRepeat: close(); if (n.lo >= 1) walk(n.a); close(); return;
+                case nEmpty: return;
+                default: close(); return;
+            }
+        };
+        walk(root);
+        close();
+        // leading / trailing factors that select nothing are dropped; a run that selects less than one position in 400 is not kept
+        while (!run_.empty() && [&] { int b = 0; for (int w = 0; w < 4; ++w) b += __builtin_popcountll(run_.back()[w]); return b >= 200; }()) run_.pop_back();
+        while (!run_.empty() && [&] { int b = 0; for (int w = 0; w < 4; ++w) b += __builtin_popcountll(run_.front()[w]); return b >= 200; }()) run_.erase(run_.begin());
+        if (best > 1.0 / 400) run_.clear();
+    }
 }
 
 bool Matcher::may_match(std::string_view text) const {

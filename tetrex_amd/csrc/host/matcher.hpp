@@ -86,6 +86,11 @@ class Matcher {
     // (required_literal(): the longest run of plain bytes on the pattern's spine; empty when there is none).
     bool may_match(std::string_view text) const;
     const std::string& required_literal() const { return literal_; }
+    // The same idea for motifs made of residue classes: the most selective RUN of consecutive single-byte factors on the
+    // pattern's spine (literals, [classes], '.'): every match contains, at consecutive positions, one byte of each of the run's
+    // sets.  `[LIVM]-x-[DE]-A-[ST]` has no literal worth searching for, but its run occurs at one position in 10^4.
+    // (A literal is a run of one-byte sets.)  Empty: nothing usable.
+    const std::vector<std::array<uint64_t, 4>>& required_run() const { return run_; }
 
   private:
     struct Inst { uint8_t op; uint32_t x, y; };  // Char: x = set index, y unused; Split: x preferred over y; Jmp: x
@@ -99,6 +104,7 @@ class Matcher {
     Semantics semantics_;
     bool has_begin_ = false;                     // the pattern has a `^`
     std::string literal_;                        // a string every match contains (may be empty)
+    std::vector<std::array<uint64_t, 4>> run_;   // the byte sets of the most selective run of single-byte factors (may be empty)
     std::vector<std::array<uint64_t, 4>> sets_;  // byte sets of the pattern
     std::array<uint8_t, 256> class_of_{};        // byte -> equivalence class
     std::vector<std::vector<uint8_t>> set_has_class_;  // [set][class]

@@ -147,8 +147,10 @@ size_t verify_batch(const std::vector<const uint64_t*>& masks, uint64_t bins, co
                 // enough — the ones the literal occurs in, found in one pass over the whole bin (no sequence holds the '\n' between
                 // records, so an occurrence never straddles two)
                 auto candidates = [&](const Matcher& m, const std::string& text) {
+                    // the run of residue classes first (a literal is such a run; a motif of classes has no literal worth the search);
+                    // not rare — in more than half of the records —: the per-record prefilter does as well
+                    if (!m.required_run().empty()) return records_with_run(recs, text, m.required_run(), recs.size() / 2, hits);
                     const std::string& lit = m.required_literal();
-                    // (not rare — in more than half of the records —: the per-record prefilter does as well)
                     return lit.size() >= 2 && records_with(recs, text, lit, recs.size() / 2, hits);
                 };
                 double my_literal = 0, my_match = 0;
