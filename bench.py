@@ -677,6 +677,10 @@ def verified_end_to_end(args):
         r = subprocess.run([tetrex, "index", "-k", str(k), "-i", "sp", *files], capture_output=True, text=True, cwd=work)
         if r.returncode != 0:
             return {"error": "tetrex index failed: " + r.stderr[-500:]}
+        if os.environ.get("BENCH_CLI_TRACE"):  # (tools/verify_leg.py: what a cold process spends its mask stage on)
+            r = subprocess.run([tetrex, "query", "-S", "-f", "-t", "16", "sp.ibf", "motifs.tsv"], capture_output=True, text=True, cwd=work,
+                               env=dict(os.environ, TXQ_TRACE="1", TETREX_TRACE="1"))
+            sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[t") or ln.startswith("{")))
         runs = {}
         for threads in (1, 16):
             best = None
