@@ -882,11 +882,10 @@ template <int H, bool WIDE, class ROWS, bool WITH_STEP = true>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void sparse_kernel(ROWS rows, const SparseGroup* __restrict__ groups, uint32_t n_groups, const uint32_t* __restrict__ counts,
                                                      const uint32_t* __restrict__ prefix, const txq_dense_op* __restrict__ dops,
                                                      const DenseOpPtr* __restrict__ optr, uint64_t* const* __restrict__ slot_base, uint32_t n_programs,
-                                                     uint32_t W, uint32_t G, DenseParams P, LevelUnits U, unsigned long long* __restrict__ ctr) {
+                                                     uint32_t W, uint32_t G, DenseParams P, LevelUnits U, uint32_t chunk) {
     using L = Lane<WIDE>;
     using T = typename L::T;
     constexpr int UA = ROWS::kPushUnroll;  // residues in flight per lane: UA * H row gathers
-    (void)ctr;
     __shared__ uint32_t pre[kMaxSparseGroups + 1];
     __shared__ uint8_t codes[TXQ_DENSE_MAX_POSITIONS + 1][32];  // of the op's shape (FILL) and, [pos], of its r_mask (STEP)
     __shared__ uint32_t cnt[TXQ_DENSE_MAX_POSITIONS + 1];
@@ -914,9 +913,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     uint32_t loaded = 0xFFFFFFFFu;
     for (uint32_t t = lo; t < hi; ++t) {
         while (pre[g + 1] <= t) ++g;  // (groups without a chunk)
-        const uint32_t first = (t - pre[g]) * kSparseChunk;
+        const uint32_t first = (t - pre[g]) * chunk;  // (chunk: entries per chunk, <= kSparseChunk — the plan kernel cut the lists by it)
         const uint32_t n = counts[g];
-        const uint32_t end = first + kSparseChunk < n ? first + kSparseChunk : n;
+        const uint32_t end = first + chunk < n ? first + chunk : n;
         const SparseGroup sgr = groups[g];
         const txq_dense_op d = dops[sgr.op];
         const DenseOpPtr q = optr[sgr.op];
@@ -2087,12 +2086,12 @@ static hipError_t launch_dense(int ua, uint32_t hash_funs, MAKE rows_of, const D
 template <bool WIDE, template <int, bool> class ROWS, class MAKE>
 static hipError_t launch_sparse(uint32_t hash_funs, MAKE rows_of, const SparseGroup* groups, uint32_t n_groups, const uint32_t* counts, const uint32_t* prefix,
                                 size_t grid, const txq_dense_op* dops, const DenseOpPtr* optr, uint64_t* const* base, uint32_t n_programs, uint32_t W, uint32_t G,
-                                const DenseParams& P, const LevelUnits& U, unsigned long long* ctr, hipStream_t st) {
+                                const DenseParams& P, const LevelUnits& U, uint32_t chunk, hipStream_t st) {
 #define TXQ_SPARSE(H) \
     do { \
         ROWS<H, WIDE> rows{}; \
         rows_of(rows); \
-        sparse_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, ctr); \
+        sparse_kernel<H, WIDE, ROWS<H, WIDE>><<<(unsigned)grid, 256, 0, st>>>(rows, groups, n_groups, counts, prefix, dops, optr, base, n_programs, W, G, P, U, chunk); \
     } while (0)
     switch (hash_funs) {
         case 1: TXQ_SPARSE(1); break;
@@ -2266,12 +2265,12 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
     std::vector<SparseGroup> sparse_groups;
     std::vector<DenseOpPtr> optr;
     double t1 = now_s();
-    // on a flat index / through the table of k-mer masks a level's STEP groups get a launch of their own: the ZERO / REDUCE / FILL
-    // groups then run in the sparse_kernel variant without step code (66 VGPRs instead of 110)
-    const bool split_steps = !vspace && !tree && (table || !ix.is_hibf);
+    // a level's STEP groups get a launch of their own (chunked by work, below); the ZERO / REDUCE / FILL groups run in the
+    // sparse_kernel variant without step code (66 VGPRs)
+    const bool split_steps = true;
     // ... and where a mask is a cache line or two, that launch shares the steps out by units (sparse_units_kernel; TXQ_SPARSE_STEPS=0:
     // sparse_kernel's rounds of entries, A/B and tests)
-    const bool by_units = split_steps && s.kn.sparse_steps && W <= kUnitStepWords;
+    const bool by_units = s.kn.sparse_steps && W <= kUnitStepWords && !vspace && !tree && (table || !ix.is_hibf);
     const size_t n_small = plan_units(s, bv, blob, W, g_dense * sl_dense, ix.is_hibf && !tree && !vspace && !table, split_steps, &units, &tile_groups, &n_tiles, &work, &hsteps, &hstep_na,
                                       &sparse_groups, &optr, &plan);
     if (n_small == (size_t)-1) return TXQ_ERR_PROGRAM;
@@ -2595,12 +2594,18 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 const bool steps = range == 1;
                 size_t range_chunks = steps ? plan[l].step_chunks : plan[l].sparse_chunks;
                 if (steps && by_units) range_chunks = range_chunks * (kSparseChunk / 16);  // (counted in chunks of kSparseChunk entries; a chunk by units holds 16 at least)
+                // The STEPs of sparse_kernel (trees; masks wider than kUnitStepWords): a chunk is ONE round of the workgroup's lane groups
+                // on wide masks — the live lists of a layout-order session are short (thousands of entries of 19.8 KB), and a
+                // chunk of 64 of them was sixteen rounds of dozens of dependent trips in one workgroup while most of the device
+                // idled (level 2 of the 200-motif batch: 2900 entries, 6.1 ms) — and kSparseChunk entries where a round holds that many
+                const uint32_t step_chunk = steps && !by_units && W > kUnitStepWords ? std::max<uint32_t>(1u, std::min<uint32_t>(kSparseChunk, 256u / g_dense)) : kSparseChunk;
+                if (steps && !by_units) range_chunks = range_chunks * (kSparseChunk / step_chunk);
                 for (size_t off = r_lo; off < r_hi; off += kMaxSparseGroups, ++sparse_launch) {
                     const uint32_t ng = (uint32_t)std::min<size_t>(kMaxSparseGroups, r_hi - off);
                     const SparseGroup* gr = d_sgroups + first_sparse + off;
                     uint32_t* counts = d_scounts + first_sparse + off;
                     uint32_t* prefix = d_sprefix + first_sparse + off + sparse_launch;
-                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, steps && by_units ? (0x80000000u | (uint32_t)s.kn.sparse_units) : kSparseChunk, counts, prefix);
+                    sparse_plan_kernel<<<1, 1024, 0, st>>>(gr, ng, d_dops, d_optr, W, bv.dense.pos, steps && by_units ? (0x80000000u | (uint32_t)s.kn.sparse_units) : step_chunk, counts, prefix);
                     TXQ_HIP(hipGetLastError());
                     const LevelUnits lu{d_units + first, d_ops, d_masks, ride_sparse && !rode ? (uint32_t)cnt : 0u, g_units_log2};
                     rode = true;
@@ -2623,29 +2628,29 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                         }
                     } else if (split_steps && !steps) {  // ZERO / REDUCE / FILL only: the variant without the step code (its row source is not used)
                         FlatRows<1, true> none{};
-                        if (wide) sparse_kernel<1, true, FlatRows<1, true>, false><<<(unsigned)grid, 256, 0, st>>>(none, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, nullptr);
-                        else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, nullptr); }
+                        if (wide) sparse_kernel<1, true, FlatRows<1, true>, false><<<(unsigned)grid, 256, 0, st>>>(none, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, kSparseChunk);
+                        else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, kSparseChunk); }
                         e = hipGetLastError();
                     } else if (vspace) {
                         auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
-                        e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
-                                 : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
+                        e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
+                                 : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     } else if (interleaved) {
                         auto rows_il = [&](auto& r) { r.f = ix.interleaved; r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
-                                 : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
+                        e = wide ? launch_sparse<true, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
+                                 : launch_sparse<false, InterleavedRows>(ix.tree_hash_max, rows_il, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     } else if (tree) {
                         auto rows_of = [&](auto& r) { r.root = ix.root_node; r.children = (const ChildRec*)ix.d_children; r.wpr_log2 = wpr_log2; };
-                        e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
-                                 : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
+                        e = wide ? launch_sparse<true, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
+                                 : launch_sparse<false, TreeRows>(ix.tree_hash_max, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     } else if (table) {
                         auto rows_tab = [&](auto& r) { r.table = ix.kmer_table; r.stride = W; };
-                        e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
-                                 : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
+                        e = wide ? launch_sparse<true, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
+                                 : launch_sparse<false, TableRows>(1, rows_tab, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     } else {
                         auto rows_of = [&](auto& r) { r.f = ix.ibf[0]; };
-                        e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st)
-                                 : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, s.d_step_ctr, st);
+                        e = wide ? launch_sparse<true, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
+                                 : launch_sparse<false, FlatRows>(ix.ibf[0].hash_funs, rows_of, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     }
                     if (e != hipSuccess) return fail_hip(e, "sparse kernel launch");
                     if (s.kn.trace_sync && s.kn.trace_stages) {  // (profiling aid: TXQ_TRACE_SYNC + TXQ_TRACE_STAGES) what each sparse launch amounted to
