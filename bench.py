@@ -872,18 +872,26 @@ def dna_batch_8192(capi, torch, dist, args, rank, world):
                 windows[sel] = DNA_LETTERS[codes[torch.from_numpy(home[sel] % 64).cuda()[:, None], idx].cpu().numpy()]
             if g == check_word and rank == 0:
                 check_codes = codes.cpu().numpy()
-    ix = dna_build_shard(capi, torch, bins_total, rows, h, k, seq_len, rank, world)
-    w0, nw = int(ix.info.shard_word0), ix.shard_words
+    err = ix = None
+    nw = 0
+    try:  # (rank-local: a failure here must still let this rank enter the collectives below)
+        ix = dna_build_shard(capi, torch, bins_total, rows, h, k, seq_len, rank, world)
+        nw = ix.shard_words
+    except Exception as e:  # noqa: BLE001 - reported in the line
+        err = repr(e)
     build_s = time.perf_counter() - t0
     motifs = dna_motifs(rng, windows, n_motifs)
-    err = None
     masks = status = stats = None
     runs = []
     try:
-        ix.query_masks(motifs[:200], True, k)  # warm: arena, staging sets
-        if world > 1:
-            dist.barrier()
-        for _ in range(3 if world == 1 else 1):
+        if err is None:
+            ix.query_masks(motifs[:200], True, k)  # warm: arena, staging sets
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    if world > 1:
+        dist.barrier()
+    try:
+        for _ in range((3 if world == 1 else 1) if err is None else 0):
             ta = time.perf_counter()
             m_, s_, st_ = ix.query_masks(motifs, True, k)
             runs.append(time.perf_counter() - ta)
@@ -891,16 +899,18 @@ def dna_batch_8192(capi, torch, dist, args, rank, world):
                 masks, status, stats = m_, s_, st_
     except Exception as e:  # noqa: BLE001 - reported in the line
         err = repr(e)
-        if world == 1:
+    if world == 1 and err:
+        if ix is not None:
             ix.free()
-            return {"error": err}, None
+        return {"error": err}, None
     local_s = min(runs) if runs else 0.0
     total, gather_s, full = local_s, 0.0, masks
     if world > 1:
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=args.coll_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 0:
-            ix.free()
+            if ix is not None:
+                ix.free()
             return {"error": err or "another rank failed"}, None
         tg = time.perf_counter()
         loc = torch.from_numpy(masks.view(np.int64)).to(args.coll_device)
@@ -984,6 +994,19 @@ def hibf_descent(capi, torch, dist, args, rank, world, user_bins=65536, children
         ix.free()
         return words
 
+    with_queries = queries and not args.no_queries
+    try:  # (everything up to the query batch is rank-local: a failure here must still let this rank enter the batch's collectives)
+        return _hibf_descent_local(capi, torch, dist, args, rank, world, user_bins, children, with_queries, values, filled, per_bin, per_child, h, rng)
+    except SystemExit:
+        raise
+    except Exception as e:  # noqa: BLE001
+        out = {"error": repr(e)}
+        if with_queries and world > 1:
+            out["query_batch"] = hibf_query_batch(torch, dist, args, None, None, user_bins, rank, world, failed=repr(e))
+        return out
+
+
+def _hibf_descent_local(capi, torch, dist, args, rank, world, user_bins, children, with_queries, values, filled, per_bin, per_child, h, rng):
     t0 = time.perf_counter()
     m_child = compute_bitcount(per_bin, 0.05)
     m_root = compute_bitcount(per_bin * per_child, 0.05)
@@ -1036,18 +1059,13 @@ def hibf_descent(capi, torch, dist, args, rank, world, user_bins=65536, children
            "kmers": n, "kmers_per_s_per_gpu": n / dt, "seconds_per_batch": dt, "mask_bytes_per_kmer": W * 8,
            "mask_write_GBps": n * W * 8 / dt / 1e9, "column_shards": world, "tree_bytes": int(ix.info.device_bytes),
            "index_build_s": round(build_s, 1), "checked_present_values": int(mine.sum())}
-    if queries and not args.no_queries:
-        try:
-            out["query_batch"] = hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world)
-        except SystemExit:
-            raise
-        except Exception as e:  # noqa: BLE001 - reported in the line; the ranks stay in step (see hibf_query_batch)
-            out["query_batch"] = {"error": repr(e)}
+    if with_queries:
+        out["query_batch"] = hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world)
     ix.free()
     return out
 
 
-def hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world):
+def hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world, failed=None):
     """BASELINE configs[4]: whole queries on the 65536-user-bin HIBF — Murphy-reduced alphabet, k = 5, 8 KiB masks — the tree
     replicated, its user-bin columns sharded over the ranks (every rank descends only into sub-trees of its own columns), the
     final masks all-gathered.  200 PROSITE-style motifs (the batch of tests/perf_config5_queries.py); a sample of the gathered
@@ -1056,12 +1074,16 @@ def hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world):
     from tetrex_amd.dist import gather_final_masks
     k, reduction = 5, 1
     motifs = random_prosite_motifs(200, 6)
-    err, masks, status, stats, runs = None, None, None, None, []
+    err, masks, status, stats, runs = failed, None, None, None, []  # (failed: this rank has no index — it only keeps the others company)
     try:
-        ix.query_masks(motifs[:5], False, k, reduction)
-        if world > 1:
-            dist.barrier()
-        for _ in range(3 if world == 1 else 1):
+        if err is None:
+            ix.query_masks(motifs[:5], False, k, reduction)
+    except Exception as e:  # noqa: BLE001
+        err = repr(e)
+    if world > 1:
+        dist.barrier()
+    try:
+        for _ in range((3 if world == 1 else 1) if err is None else 0):
             t0 = time.perf_counter()
             m_, s_, st_ = ix.query_masks(motifs, False, k, reduction)
             runs.append(time.perf_counter() - t0)
@@ -1069,8 +1091,8 @@ def hibf_query_batch(torch, dist, args, ix, descs, user_bins, rank, world):
                 masks, status, stats = m_, s_, st_
     except Exception as e:  # noqa: BLE001
         err = repr(e)
-        if world == 1:
-            return {"error": err}
+    if world == 1 and err:
+        return {"error": err}
     total, gather_s, full = (min(runs) if runs else 0.0), 0.0, masks
     if world > 1:
         ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=args.coll_device)
