@@ -770,7 +770,6 @@ __device__ __forceinline__ void dense_codes(const txq_dense_op* __restrict__ d, 
 struct SparseGroup { uint32_t op; uint32_t fixed; };  // fixed != kNotFixed: the host knows the entries (FILL: its shape)
 static constexpr uint32_t kNotFixed = 0xFFFFFFFFu;
 static constexpr uint32_t kSparseChunk = 64;
-static constexpr uint32_t kWideItems = 256;     // chunks with bits of one entry that a lane group lists (sparse_kernel, wide masks)
 static constexpr uint32_t kUnitChunk = 256;      // most entries per chunk of sparse_units_kernel: one decoding thread each
 static constexpr uint32_t kUnitFresh = 2048;     // fresh destination entries it collects per chunk (more: appended one by one)
 // sparse_units_kernel cuts a group's list into chunks of about 512 UNITS (entry x residue), not of a fixed number of entries: a
@@ -894,7 +893,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
     // destination entries a chunk's pushes have made live: collected here and appended to dst's list with ONE atomic on the
     // block's count per chunk (one per wave and round, thousands on one address per launch, was what the big steps waited for)
     __shared__ uint32_t fresh_list[WITH_STEP ? kSparseChunk * 32 : 1];
-    __shared__ uint32_t wide_items[WITH_STEP ? 8 : 1][WITH_STEP ? kWideItems : 1];  // per lane group (G >= 32: at most 8): its entry's chunks that hold a bit
     __shared__ uint32_t fresh_n, fresh_at;
     if (blockIdx.x < U.n_units) {  // the level's ordinary ops ride along (the whole workgroup: no barrier has been reached)
         run_unit(U.units[blockIdx.x], U.ops, slot_base, n_programs, U.M, W, U.g_log2);
@@ -1036,52 +1034,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     }
 #pragma unroll
                     for (uint32_t jj = 0; jj < 4u; ++jj) nz |= (L::any(s4[jj]) ? 1u : 0u) << (p0 + jj);
-                }
-                if (W > kUnitStepWords && G >= 32u) {
-                    // Wide masks: the entry's chunks that hold a bit are few and sit in a few lanes — the lane group lists them (ballots,
-                    // the list in LDS) and shares out (chunk, residue) UNITS over ALL its lanes: a wildcard step on an entry with five such
-                    // chunks is 100 units = two trips of the group instead of twenty residues in sequence in five lanes.
-                    const uint32_t lane = threadIdx.x & 63u;
-                    const unsigned long long group_lanes = (G >= 64u ? ~0ULL : ((1ULL << G) - 1ULL)) << (lane & ~(G - 1u));
-                    uint32_t total = 0;
-                    for (uint32_t p = 0; p < 32u && pb + p * G < chunks_w; ++p) {
-                        const bool mine = (nz >> p) & 1u;
-                        const unsigned long long m = __ballot(mine) & group_lanes;
-                        if (mine) {
-                            const uint32_t at = total + (uint32_t)__popcll(m & ((1ULL << lane) - 1ULL));
-                            if (at < kWideItems) wide_items[grp][at] = pb + p * G + sub;
-                        }
-                        total += (uint32_t)__popcll(m);
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (total <= kWideItems) {  // (an entry with more such chunks than the list holds: lane by lane, below)
-                        const uint32_t units = total * n_r;
-                        for (uint32_t u = sub; u < units; u += G) {
-                            const uint32_t item = u / n_r, i = u - item * n_r;
-                            const uint32_t c = wide_items[grp][item];
-                            const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
-                            if (rk == 0xFFu) continue;
-                            const T sv = L::load(q.src + (size_t)idx * W + (size_t)c * L::kWords);
-                            T y = sv;
-                            if (!noprobe) {
-                                rows.prepare(c);
-                                typename ROWS::Loads x0;
-                                uint64_t v = high | codes[P.pos][i];
-                                if (P.canonical) v = canonical_dna(v, P.k);
-                                rows.template issue<false>(nullptr, v, x0);
-                                rows.template issue_late<false>(x0);
-                                y = sv & rows.combine(x0);
-                            }
-                            if (L::any(y)) {
-                                atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
-                                hit |= 1u << i;
-                            }
-                        }
-                        nz = 0;
-                    }
-                    __builtin_amdgcn_wave_barrier();  // (the list is rewritten by the next block of passes / the next round)
                 }
                 for (; nz; nz &= nz - 1) {
                 const uint32_t c = pb + (uint32_t)__builtin_ctz(nz) * G + sub;
