@@ -1085,11 +1085,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                 }
             }
             for (uint32_t o = 1; o < G; o <<= 1) hit |= (uint32_t)__shfl_xor((int)hit, (int)o);
-            if (sub == 0)  // the entry's first lane notes the destinations that were empty until now
+            if (sub == 0 && hit) {
+                // the entry's first lane notes the destinations that were empty until now.  An entry's residues land in consecutive
+                // destination entries (the rolled-in residue is the last digit): the bitmap word of dst0 or the next one — TWO
+                // returning atomics side by side, not one per residue in sequence (twenty round trips for a wildcard step)
+                const uint32_t w0 = dst0 >> 6;
+                unsigned long long b0 = 0, b1 = 0;
                 for (uint32_t h = hit; h; h &= h - 1) {
-                    const uint32_t i = (uint32_t)__builtin_ctz(h), entry = dst0 + dg.rank[P.pos - 1][codes[P.pos][i]];
-                    if (mark_live(dm, entry)) fresh_list[atomicAdd(&fresh_n, 1u)] = entry;
+                    const uint32_t entry = dst0 + dg.rank[P.pos - 1][codes[P.pos][__builtin_ctz(h)]];
+                    if ((entry >> 6) == w0) b0 |= 1ULL << (entry & 63u);
+                    else b1 |= 1ULL << (entry & 63u);
                 }
+                unsigned long long* const bm = reinterpret_cast<unsigned long long*>(dm.bitmap) + w0;
+                const unsigned long long was0 = b0 ? __hip_atomic_fetch_or(bm, b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+                const unsigned long long was1 = b1 ? __hip_atomic_fetch_or(bm + 1, b1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
+                for (unsigned long long f = b0 & ~was0; f; f &= f - 1) fresh_list[atomicAdd(&fresh_n, 1u)] = w0 * 64u + (uint32_t)__builtin_ctzll(f);
+                for (unsigned long long f = b1 & ~was1; f; f &= f - 1) fresh_list[atomicAdd(&fresh_n, 1u)] = (w0 + 1u) * 64u + (uint32_t)__builtin_ctzll(f);
+            }
         }
         __syncthreads();
         const uint32_t n_fresh = fresh_n;  // at most 64 entries x 32 residues
