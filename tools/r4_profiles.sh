@@ -16,24 +16,8 @@ python tools/trace_timeline.py $O/prof_k6/k6_kernel_trace.csv > $O/k6_timeline.t
 python tools/trace_timeline.py $O/prof_raggedq/q_kernel_trace.csv > $O/hibf_ragged_queries_timeline.txt 2>&1
 rm -f $O/*/*_kernel_trace.csv $O/*/*.db
 # dense_kernel (k = 4 batch, table of all k-mers' masks): L2 hits / misses and requests (one --pmc pass; program directly after --)
-(cd /tmp && REPS=4 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum --kernel-trace --output-format csv -d $O/pmc_dense_l2 -o l2 -- python3 $GRAFT_REPO_ROOT/tools/e2e_profile.py > $O/e2e_under_pmc.txt 2> /dev/null)
-python - <<'PY' > $O/pmc_dense_l2.json
-import collections, csv, glob, json, os
-O = os.environ.get("GRAFT_REPO_ROOT", ".") + "/gpurun_out/r4_final"
-tot = collections.defaultdict(collections.Counter)
-n = collections.Counter()
-for f in glob.glob(O + "/pmc_dense_l2/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0][:60]
-        tot[k][r["Counter_Name"]] += float(r["Counter_Value"])
-        if r["Counter_Name"] == "TCC_REQ_sum": n[k] += 1
-out = {}
-for k, c in tot.items():
-    if "dense_kernel" in k or "probe_kernel" in k:
-        h, m = c.get("TCC_HIT_sum", 0), c.get("TCC_MISS_sum", 0)
-        out[k] = {"launches": n[k], **dict(c), "l2_hit_rate": h / (h + m) if h + m else None}
-print(json.dumps(out, indent=1))
-PY
+(cd /tmp && REPS=4 timeout -k 10 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_dense_l2 -o l2 -- python3 $GRAFT_REPO_ROOT/tools/e2e_profile.py > $O/e2e_under_pmc.txt 2> /dev/null)
+python tools/sum_pmc.py $O/pmc_dense_l2 $O/pmc_dense_l2.json > /dev/null
 rm -rf $O/pmc_dense_l2
-TXQ_TRACE=1 timeout -k 10 300 python tools/verify_leg.py 1 > $O/verify_leg.txt 2>&1
+TETREX_TRACE=1 timeout -k 10 300 python tools/verify_leg.py 2 > $O/verify_leg.txt 2>&1
 tail -c 400 $O/bench_default.json; echo; head -8 $O/k6_timeline.txt; head -8 $O/hibf_ragged_queries_timeline.txt; cat $O/pmc_dense_l2.json | head -30; tail -3 $O/verify_leg.txt | cut -c1-300
