@@ -27,6 +27,13 @@ int txh_preprocess(const char* regex, int dna, unsigned k, unsigned reduction, c
 int txh_kgraph(const char* postfix, unsigned k, int reduced, int32_t* labels, int32_t* next_a, int32_t* next_b,
                int32_t cap);
 
+/* The k-graph the EXPANSION works on (base alphabet, no -a): unions of single residues — `.`, `[LIVM]`, `(A|G)` — are one
+ * node each (label >= 260) instead of the reference's Split / Ghost tree over one node per residue; it accepts the same
+ * strings.  members: per node one line — the residues it stands for, in the query's order (empty for Ghost / Split / Match
+ * nodes).  Returns n or <0.  (tetrex_amd/csrc/host/kgraph.hpp KGraph::kClass; TETREX_FUSE_CLASSES=0 switches fusing off.) */
+int txh_kgraph_fused(const char* postfix, unsigned k, int32_t* labels, int32_t* next_a, int32_t* next_b, int32_t cap,
+                     char* members, size_t members_cap);
+
 /* Graphviz text of the k-graph (`tetrex query -d`); augment != 0 applies -a first */
 int txh_kgraph_dot(const char* postfix, unsigned k, int reduced, int augment, char* out, size_t cap);
 

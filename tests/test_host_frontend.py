@@ -79,6 +79,57 @@ def test_kgraph_is_node_for_node_the_oracle_graph(host, oracle, k):
         assert got["succ"] == [tuple(s) for s in want["succ"]], rx
 
 
+def _language(labels, succ, members=None, limit=60000):
+    """Every residue string a k-graph (a DAG: loops are unrolled) accepts, by walking it from node 0 to the Match node."""
+    out, todo = set(), [(0, "")]
+    while todo:
+        v, text = todo.pop()
+        lab = labels[v]
+        if lab == 256:  # Match
+            out.add(text)
+            if len(out) > limit:
+                return None  # too many to write out
+            continue
+        if lab >= 260:
+            nexts = [text + c for c in members[v]]
+        elif lab < 256 and lab != ord("$"):
+            nexts = [text + chr(lab)]
+        else:
+            nexts = [text]
+        for t in {s for s in succ[v] if s >= 0}:
+            for nx in nexts:
+                todo.append((t, nx))
+    return out
+
+
+@pytest.mark.parametrize("k", [2, 4, 6])
+def test_fused_kgraph_accepts_the_same_strings_with_one_node_per_class(host, oracle, k):
+    """The graph the expansion works on (unions of single residues fused into class nodes, include/txh.h txh_kgraph_fused)
+    against the reference's node-for-node graph: the same language, far fewer nodes."""
+    queries = ["A[LIVM]C", "AC(D|E)F", "(A|C|D)(E|F)", "A.C", "[AC]{2}D", "W[DE]{1,2}K", "A([LI]|MC)D", "A[LL]C", "(A|[CD])E",
+               "LMA(E|Q)GLYN", "M[KR]+S", "A[DE]*C", "(AC|D)E", "([AC]|[DE])F", "A[CD]?E"]
+    queries += [q for q in random_prosite_motifs(40, 9, wildcard=0.1, ranges=0.1) if q.count(".") <= 2 and "{" not in q.replace(".{", "")][:25]
+    checked = 0
+    for rx in queries:
+        postfix = oracle.translate(rx)
+        plain = host.kgraph(postfix, k)
+        fused = host.kgraph_fused(postfix, k)
+        want = _language(plain["labels"], plain["succ"])
+        if want is None:
+            continue
+        checked += 1
+        got = _language(fused["labels"], fused["succ"], fused["members"])
+        assert got == want, rx
+        assert len(fused["labels"]) <= len(plain["labels"]), rx
+        for lab, m in zip(fused["labels"], fused["members"]):
+            if lab >= 260:
+                assert len(m) >= 1 and len(set(m)) == len(m), (rx, m)  # ([LL] is a class of one)
+    assert checked >= 25
+    g = host.kgraph_fused(oracle.translate("A.[LIVM](E|Q)C"), 4)
+    assert [m for m in g["members"] if len(m) > 1] == ["FQLTKPAYRNHGECIVDWSM", "LIVM", "EQ"]
+    assert len(g["labels"]) == 7  # start ghost, A, three classes, C, Match
+
+
 def test_kgraph_config1_hand_trace(host, golden):
     g = golden("kgraph_config1.json")
     kg = host.kgraph(g["postfix"], g["k"])

@@ -105,6 +105,36 @@ def test_default_policy_on_sparse_and_dense_indexes_at_k5(host, oracle):
         assert int(sim.result(i)[0]) == 0xFFFFFFFFFFFFFFFF
 
 
+@pytest.mark.parametrize("per_query", [0, 3, 50, 1 << 30])
+def test_node_for_node_graphs_and_fused_classes_give_the_same_masks(host, oracle, monkeypatch, per_query):
+    """By default the expansion works on k-graphs whose unions of single residues are ONE node each (KGraph::kClass);
+    TETREX_FUSE_CLASSES=0 keeps the reference's node per residue.  Both against the oracle, at budgets that stop a class
+    between two of its residues (3 ops: after every residue).  In one stage (nothing pruned) the two probe exactly the same
+    k-mers, and the fused graph never needs more ops (states that arrive at a class merge once, not once per residue)."""
+    ox = _index(oracle, bins=150, m=20011, h=3, k=4, dna=False, per_bin=700, seed=21)
+    qs = ["A.C.E", "L[LIVM].[DE]K", "W.{1,3}[KR]D", "(A|C|D)(E|F).G", "M[KR]+S.L", "A[CD]?E.[FGH]{2}K"] + \
+        random_prosite_motifs(20, 13, wildcard=0.15, ranges=0.05)
+    if per_query == 1 << 30:
+        monkeypatch.setenv("TETREX_WAVE_OPS", "0")
+    stats, probed = {}, {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("TETREX_FUSE_CLASSES", fuse)
+        probed[fuse] = set()
+        real_parse = host.parse_blob
+
+        def spy(blob, into=probed[fuse]):
+            kmers, progs = real_parse(blob)
+            into.update(int(x) for x in kmers)
+            return kmers, progs
+        monkeypatch.setattr(host, "parse_blob", spy)
+        checked, stats[fuse], _ = _run(host, ox, qs, False, 4, per_query)
+        monkeypatch.setattr(host, "parse_blob", real_parse)
+        assert checked >= len(qs) - 4
+    if per_query == 1 << 30:
+        assert probed["1"] == probed["0"] and len(probed["1"]) > 10000
+        assert stats["1"]["ops"] <= stats["0"]["ops"]
+
+
 @pytest.mark.parametrize("wave_ops", ["0", "64", "2000"])
 def test_waves_of_queries_give_the_same_masks(host, oracle, monkeypatch, wave_ops):
     """Queries begin in waves (TETREX_WAVE_OPS; the k-graph of a query is built when it begins), the later waves while

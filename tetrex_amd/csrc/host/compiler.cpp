@@ -271,9 +271,9 @@ void QueryExpansion::compute_static_shapes() {
             const int32_t lab = g_.label[item];
             if (lab == KGraph::kMatch) continue;
             if (lab == KGraph::kGap) out = Geometry{};
-            else if (lab < 256) {
+            else if (g_.takes_residue(item)) {
                 for (unsigned j = 0; j + 1 < dense_pos_; ++j) out[j] = static_shape_[item][j + 1];
-                out[dense_pos_ - 1] = 1u << enc_.code((unsigned char)lab);
+                out[dense_pos_ - 1] = code_mask(item);
             } else out = static_shape_[item];
         }
         forward_all(item, out);
@@ -301,6 +301,13 @@ uint32_t QueryExpansion::capacity_of(const Geometry& g) const {
     uint64_t cap = 64;
     while (cap < n) cap <<= 1;
     return (uint32_t)std::min<uint64_t>(cap, (uint64_t)1 << TXQ_DENSE_BLOCK_SHIFT);  // (n <= A^(k-1) <= 2^22)
+}
+
+// the codes of the residues a residue node or fused class stands for
+uint32_t QueryExpansion::code_mask(int32_t node) const {
+    uint32_t m = 0;
+    g_.for_each_residue(node, [&](unsigned char c) { m |= 1u << enc_.code(c); });
+    return m;
 }
 
 // a state leaves item `from` (a residue node or the entry): to its join or only target
@@ -723,9 +730,9 @@ void QueryExpansion::dense_receivers(int32_t item, std::vector<int32_t>& out) co
     if (item > n_nodes_) {
         for (uint32_t i = fan_first_[item - n_nodes_ - 1]; i < fan_first_[item - n_nodes_]; ++i) {
             const int32_t t = fan_[i];
-            if (g_.label[t] < 256) add(forward_[t]);
+            if (g_.takes_residue(t)) add(forward_[t]);
         }
-    } else if (g_.label[item] < 256) add(forward_[item]);
+    } else if (g_.takes_residue(item)) add(forward_[item]);
 }
 
 void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams, bool verified_only, DenseVec* dense) {
@@ -759,8 +766,10 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             for (uint32_t b : parked_blocks_) free_by_cap_[block_cap_[b]].ids.push_back(b);
             parked_blocks_.clear();
         }
+        // a fused class that stopped between two of its residues when the budget ran out goes on where it stopped
+        const bool resuming = resume_item_ != KGraph::kNone;
         bool densify_here = false;
-        if (dense_ok_) {
+        if (dense_ok_ && !resuming) {
             // Dense part of this item's input.  First, shapes that have shrunk to a few entries are enumerated again (so is
             // everything when this call has nowhere to put dense ops).  Then the blocks the item will need are reserved: one
             // per list its steps accumulate into that has none yet, plus its own if its enumerated states are about to become
@@ -824,7 +833,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
         NodeStates ns;
         ns.items.swap(table_[item].items);
         ns.dense.swap(table_[item].dense);
-        waiting_ -= ns.items.size();
+        if (!resuming) waiting_ -= ns.items.size();
         if (densify_here) densify(item, ns, out, table_[item].append_only);
         for (const DenseRef& d : ns.dense)  // (densify has just added the list's own states to the shape)
             if (d.owned) shape_zero(d);
@@ -859,10 +868,10 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 std::vector<Group> groups;
                 for (uint32_t i = lo; i < hi; ++i) {
                     const int32_t t = fan_[i];
-                    if (g_.label[t] < 256) {
+                    if (g_.takes_residue(t)) {
                         if (dangling_[t]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
                         if (forward_[t] == KGraph::kNone) continue;
-                        const uint32_t bit = 1u << enc_.code((unsigned char)g_.label[t]);
+                        const uint32_t bit = code_mask(t);
                         bool found = false;
                         for (Group& g : groups)
                             if (g.receiver == forward_[t]) { g.r_mask |= bit; found = true; }
@@ -910,12 +919,15 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                     if (q.open_joins_[i] == join) { q.open_joins_[i] = q.open_joins_.back(); q.open_joins_.pop_back(); break; }
             }
         } release{*this, input_of_[item]};
-        if (input_of_[item] != KGraph::kNone) {
-            input = &table_[input_of_[item]].items;
+        const int32_t in_join = input_of_[item];
+        if (in_join != KGraph::kNone) {
+            input = &table_[in_join].items;
             input_of_[item] = KGraph::kNone;
-            waiting_ -= input->size();
-            states_ += input->size();
-            if (states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+            if (!resuming) {
+                waiting_ -= input->size();
+                states_ += input->size();
+                if (states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+            }
         }
         const int32_t lab = g_.label[item];
         for (const DenseRef& r : ns.dense) {
@@ -939,7 +951,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
                 hand_on(item, State{0, acc, 0, 0, 0, 0, 0}, out);
             } else {
                 if (dangling_[item]) throw std::runtime_error("k-graph node without successor (the reference fails here too)");
-                dense_step(r, 1u << enc_.code((unsigned char)lab), forward_[item], out);
+                dense_step(r, code_mask(item), forward_[item], out);
             }
             release_block(r.block);
         }
@@ -990,6 +1002,39 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             for (size_t i = 0; i < n_pending; ++i) arrive(receiver, pending[i], out);
             n_pending = 0;
         };
+        // A fused class (KGraph::kClass) stands for n residue nodes that read one list: residue by residue, as those nodes would
+        // in their turn — every state is handed on once per residue, so it takes n - 1 more references first (what the join in
+        // front of the n nodes used to give it).  Will the arrivals merge at the receiver?  Asked of the list as a join asks.
+        // Like the n nodes, the class can stop BETWEEN two residues when the call's budget is spent (a wildcard behind 20^3
+        // states is 160 000 ops per residue: stages would overshoot their budget twenty-fold, and on a sparse index the states
+        // the next stage's answers would have pruned are expanded): the list stays where it was and the next call goes on.
+        unsigned char one_residue = 0;
+        const auto [members, n_residues] = g_.residues(item, &one_residue);
+        uint32_t r0 = 0;
+        if (resuming) {
+            r0 = resume_residue_;
+            resume_item_ = KGraph::kNone;
+            waiting_ -= (uint64_t)input->size() * (n_residues - r0);
+        } else if (n_residues > 1) {
+            for (const State& s : *input)
+                if (refs_[s.slot] != kPinned) refs_[s.slot] += n_residues - 1;
+            states_ += (uint64_t)input->size() * (n_residues - 1);
+            if (states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
+            if (receiver != KGraph::kNone && !single_source_[receiver] && table_[receiver].items.empty() &&
+                input->size() >= merge_sample_threshold() && !merging_pays(*input))
+                table_[receiver].append_only = true;
+        }
+        for (uint32_t r = r0; r < n_residues; ++r) {
+        if (r > r0 && out.size() - start >= op_budget) {  // out of budget: the rest of the residues in the next call
+            resume_item_ = item;
+            resume_residue_ = r;
+            --cursor_;
+            waiting_ += (uint64_t)input->size() * (n_residues - r);
+            if (in_join != KGraph::kNone) { input_of_[item] = in_join; release.join = KGraph::kNone; }
+            else table_[item].items.swap(ns.items);
+            break;
+        }
+        const unsigned char lab = members[r];
         for (State s : *input) {
             if (s.gapped) {  // update_gapped: three residues complete the d-gram
                 if (s.shift == 0) { s.kmer += 400ULL * dgram_residue_code(lab); s.res1 = (uint8_t)lab; s.shift = 1; }
@@ -1044,6 +1089,7 @@ void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTa
             }
         }
         if (n_pending) flush();
+        }
     }
 }
 
@@ -1096,11 +1142,14 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         items.swap(keep);
         return true;
     };
+    // a class that stopped between two residues (resume_item_) holds one reference per state and residue still to come
+    const uint32_t class_holds = resume_item_ != KGraph::kNone ? g_.residue_count(resume_item_) - resume_residue_ : 0;
     for (size_t c = cursor_; c < order_.size(); ++c) {
         NodeStates& ns = table_[order_[c]];
-        if (!sweep(ns.items, 1)) continue;
+        const bool stopped_here = order_[c] == resume_item_;
+        if (!sweep(ns.items, stopped_here ? class_holds : 1)) continue;
         ns.by_key.clear();
-        if (single_source_[order_[c]] || ns.append_only) continue;
+        if (stopped_here || single_source_[order_[c]] || ns.append_only) continue;
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
@@ -1108,7 +1157,10 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
                                        : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits))), i);
         }
     }
-    for (int32_t j : open_joins_) sweep(table_[j].items, readers_[j - n_nodes_ - 1]);
+    for (int32_t j : open_joins_) {
+        const bool read_by_class = resume_item_ != KGraph::kNone && input_of_[resume_item_] == j;
+        sweep(table_[j].items, readers_[j - n_nodes_ - 1] + (read_by_class ? class_holds - 1 : 0));
+    }
 }
 
 // ---- level scheduling ---------------------------------------------------------------------

@@ -65,6 +65,24 @@ int txh_kgraph(const char* postfix, unsigned k, int reduced, int32_t* labels, in
     } catch (const std::exception& e) { return fail(e.what()); }
 }
 
+int txh_kgraph_fused(const char* postfix, unsigned k, int32_t* labels, int32_t* next_a, int32_t* next_b, int32_t cap,
+                     char* members, size_t members_cap) {
+    try {
+        KGraph g = build_kgraph(postfix, k, false, false, true);
+        if (g.size() > cap) return fail("graph larger than output buffers", -2);
+        std::memcpy(labels, g.label.data(), g.size() * 4);
+        std::memcpy(next_a, g.next_a.data(), g.size() * 4);
+        std::memcpy(next_b, g.next_b.data(), g.size() * 4);
+        std::string lines;
+        for (int32_t v = 0; v < g.size(); ++v) {
+            if (g.takes_residue(v)) g.for_each_residue(v, [&](unsigned char c) { lines.push_back((char)c); });
+            lines.push_back('\n');
+        }
+        const int r = put(lines, members, members_cap);
+        return r < 0 ? r : g.size();
+    } catch (const std::exception& e) { return fail(e.what()); }
+}
+
 int txh_kgraph_dot(const char* postfix, unsigned k, int reduced, int augment, char* out, size_t cap) {
     try {
         KGraph g = build_kgraph(postfix, k, reduced != 0);
@@ -86,7 +104,7 @@ int txh_compile_batch(const char* const* regex, size_t n, int dna, unsigned k, u
                 if (bins <= 1) batch.add_passthrough();
                 else {
                     const std::string postfix = preprocess_query(regex[i], enc);
-                    batch.add(build_kgraph(postfix, k, enc.alphabet() != Alphabet::Base));
+                    batch.add(build_kgraph(postfix, k, enc.alphabet() != Alphabet::Base, false, true));
                 }
             } catch (const std::exception& e) {
                 g_err = std::string("query ") + std::to_string(i) + ": " + e.what();

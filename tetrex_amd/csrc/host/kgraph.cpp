@@ -168,9 +168,16 @@ struct Fragment {
 
 class Builder {
   public:
-    Builder(unsigned k, bool reduced, bool path_stats) : k_(k), reduced_(reduced), stats_(path_stats) {}
+    Builder(unsigned k, bool reduced, bool path_stats, bool fuse) : k_(k), reduced_(reduced), stats_(path_stats), fuse_(fuse && !reduced && !path_stats) {}
 
     KGraph finish(const std::string& postfix) {
+        {  // a node per residue and two per operator at most (quantifiers that duplicate sub-graphs grow the vectors later)
+            const size_t guess = postfix.size() + 2;
+            g_.label.reserve(guess); g_.gap.reserve(guess); g_.next_a.reserve(guess); g_.next_b.reserve(guess);
+            g_.arc_src.reserve(guess * 2); g_.arc_dst.reserve(guess * 2);
+            if (fuse_) { g_.classes.reserve(16); g_.class_bytes.reserve(postfix.size()); }
+            stack_.reserve(16);
+        }
         const int32_t start = g_.add(KGraph::kGhost);
         bool skip_concat = false;
         for (size_t i = 0; i < postfix.size(); ++i) {
@@ -193,7 +200,21 @@ class Builder {
                     break;
                 }
                 case '}': case ',': break;
-                default: symbol(c); break;
+                default:
+                    if (fuse_ && c >= 'A' && c <= 'Z') {
+                        // `XY|Z|...`: a letter, then letters each followed by '|' — the union of a fresh operand with single
+                        // residues, i.e. a class (a wildcard is spelt as 39 such characters): one node, made in one go
+                        size_t j = i + 1;
+                        uint32_t n = 1;
+                        while (j + 1 < postfix.size() && postfix[j] >= 'A' && postfix[j] <= 'Z' && postfix[j + 1] == '|') { j += 2; ++n; }
+                        if (n > 1) {
+                            class_node(postfix, i, j);
+                            i = j - 1;
+                            break;
+                        }
+                    }
+                    symbol(c);
+                    break;
             }
         }
         if (stack_.empty()) throw std::runtime_error("empty query: nothing to search for");
@@ -212,6 +233,7 @@ class Builder {
     unsigned k_;
     bool reduced_;
     bool stats_;  // keep path statistics (for -a)
+    bool fuse_;   // unions of single residues become one class node
     std::vector<Fragment> stack_;
     std::vector<int32_t> symbols_;  // reduced builder: residues waiting to become nodes
 
@@ -247,6 +269,20 @@ class Builder {
         f = Fragment::residue(n, false, stats_);
     }
 
+    // the class of postfix[from], postfix[from + 1], postfix[from + 3], ... (to = one past its last '|')
+    void class_node(const std::string& postfix, size_t from, size_t to) {
+        char members[32];
+        uint32_t n = 0, letters = 0;
+        auto put = [&](char c) {
+            if (!((letters >> (c - 'A')) & 1u)) { letters |= 1u << (c - 'A'); members[n++] = c; }
+        };
+        put(postfix[from]);
+        for (size_t j = from + 1; j < to; j += 2) put(postfix[j]);
+        g_.classes.push_back(KGraph::ResidueClass{(uint32_t)g_.class_bytes.size(), n, letters});
+        g_.class_bytes.append(members, n);
+        stack_.push_back(Fragment::residue(g_.add(KGraph::kClass + (int32_t)g_.classes.size() - 1), false, stats_));
+    }
+
     void symbol(int32_t s) {
         if (reduced_) {
             symbols_.push_back(s);
@@ -271,8 +307,47 @@ class Builder {
         stack_.push_back(both);
     }
 
+    // A single-node fragment on the stack is a node nothing is linked to yet (operators replace what they take by spans),
+    // and everything the graph has gained since `left` was pushed belongs to `right`: when both are letters or classes,
+    // `right` is the graph's newest node and the two operands' class bytes are the tail of class_bytes.
+    bool fusable(const Fragment& f) const {
+        if (f.pending || f.entry != f.exit) return false;
+        const int32_t lab = g_.label[f.entry];
+        return lab >= KGraph::kClass || (lab >= 'A' && lab <= 'Z');
+    }
+    bool fuse(const Fragment& left, const Fragment& right) {
+        if (!fusable(left) || !fusable(right) || right.entry != g_.size() - 1 || left.entry == right.entry) return false;
+        char members[32];
+        uint32_t n = 0, letters = 0;
+        size_t cut = g_.class_bytes.size(), owned = 0;
+        for (const int32_t v : {left.entry, right.entry})
+            if (g_.label[v] >= KGraph::kClass) {
+                const KGraph::ResidueClass& c = g_.classes[(size_t)(g_.label[v] - KGraph::kClass)];
+                cut = std::min<size_t>(cut, c.first);
+                owned += c.count;
+            }
+        if (g_.class_bytes.size() - cut != owned) return false;  // (never seen: somebody else's bytes would be cut off)
+        auto take_in = [&](int32_t v) {
+            g_.for_each_residue(v, [&](unsigned char c) {
+                if (!((letters >> (c - 'A')) & 1u)) { letters |= 1u << (c - 'A'); members[n++] = (char)c; }
+            });
+        };
+        take_in(left.entry);
+        take_in(right.entry);
+        g_.class_bytes.resize(cut);
+        g_.classes.push_back(KGraph::ResidueClass{(uint32_t)cut, n, letters});
+        g_.class_bytes.append(members, n);
+        g_.label[left.entry] = KGraph::kClass + (int32_t)g_.classes.size() - 1;
+        g_.label.pop_back();  // `right`, the newest node, never had an arc
+        g_.gap.pop_back();
+        g_.next_a.pop_back();
+        g_.next_b.pop_back();
+        return true;
+    }
+
     void alternate() {
         Fragment right = take(), left = take();
+        if (fuse_ && fuse(left, right)) { stack_.push_back(left); return; }
         if (reduced_) {
             const size_t n = symbols_.size();
             if (left.single() && right.single() && n >= 2 && symbols_[n - 1] == symbols_[n - 2]) {
@@ -320,7 +395,14 @@ class Builder {
     // duplicate the sub-graph between f.entry and f.exit (nodes on some entry->exit path)
     Fragment duplicate(const Fragment& f) {
         if (f.single()) {
-            Fragment copy = Fragment::residue(g_.add(reduced_ ? waiting_symbol() : g_.label[f.entry]), false, stats_);
+            int32_t lab = reduced_ ? waiting_symbol() : g_.label[f.entry];
+            if (lab >= KGraph::kClass) {  // a class of its own for the copy: its bytes must be the tail of class_bytes while it can still fuse
+                const KGraph::ResidueClass c = g_.classes[(size_t)(lab - KGraph::kClass)];
+                g_.classes.push_back(KGraph::ResidueClass{(uint32_t)g_.class_bytes.size(), c.count, c.letters});
+                g_.class_bytes.append(g_.class_bytes, c.first, c.count);
+                lab = KGraph::kClass + (int32_t)g_.classes.size() - 1;
+            }
+            Fragment copy = Fragment::residue(g_.add(lab), false, stats_);
             copy.paths = f.paths;
             copy.lengths = f.lengths;
             return copy;
@@ -440,8 +522,8 @@ class Builder {
 
 }  // namespace
 
-KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats) {
-    return Builder(k, reduced_alphabet, path_stats).finish(postfix);
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats, bool fuse_classes) {
+    return Builder(k, reduced_alphabet, path_stats, fuse_classes).finish(postfix);
 }
 
 }  // namespace tetrex

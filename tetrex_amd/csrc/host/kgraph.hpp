@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace tetrex {
@@ -27,6 +28,12 @@ struct CatSite {
 struct KGraph {
     static constexpr int32_t kMatch = 256, kGhost = 257, kSplit = 258, kGap = 259;
     static constexpr int32_t kNone = -1;
+    // Labels from kClass up: a FUSED residue class (build_kgraph with fuse_classes) — one node standing for a union of
+    // single residues (`[LIVM]`, `.`, `(A|G)`), which the reference's builders spell as a tree of Split / Ghost nodes over
+    // one node per residue (58 nodes for a wildcard).  The strings the graph accepts are the same; only the expansion
+    // (QueryExpansion) reads such graphs — drawing and -a keep the reference's node-for-node graph.
+    static constexpr int32_t kClass = 260;
+    struct ResidueClass { uint32_t first, count, letters; };  // class_bytes[first, first + count); letters: bit (c - 'A')
 
     std::vector<int32_t> label;   // per node
     std::vector<int32_t> next_a;  // first successor slot (kNone = no arc yet)
@@ -34,6 +41,26 @@ struct KGraph {
     std::vector<int32_t> arc_src, arc_dst;
     std::vector<uint64_t> gap;       // gap length of a kGap node (0 elsewhere)
     std::vector<CatSite> catsites;   // filled by build_kgraph
+    std::vector<ResidueClass> classes;  // label - kClass indexes this (entries no label points at are leftovers of fusing)
+    std::string class_bytes;            // the members of the classes, in the order the query names them, each once
+
+    bool is_class(int32_t v) const { return label[v] >= kClass; }
+    // a node that consumes one residue of the text: a residue node or a fused class
+    bool takes_residue(int32_t v) const { return label[v] >= kClass || (label[v] < 256 && label[v] != '$'); }
+    // the residues a node stands for, in the query's order: fn(byte)
+    template <class Fn>
+    void for_each_residue(int32_t v, Fn&& fn) const {
+        if (label[v] < kClass) { fn((unsigned char)label[v]); return; }
+        const ResidueClass& c = classes[(size_t)(label[v] - kClass)];
+        for (uint32_t i = 0; i < c.count; ++i) fn((unsigned char)class_bytes[c.first + i]);
+    }
+    // the same as an array: (bytes, count); `one` receives a residue node's single byte
+    std::pair<const unsigned char*, uint32_t> residues(int32_t v, unsigned char* one) const {
+        if (label[v] < kClass) { *one = (unsigned char)label[v]; return {one, 1u}; }
+        const ResidueClass& c = classes[(size_t)(label[v] - kClass)];
+        return {reinterpret_cast<const unsigned char*>(class_bytes.data()) + c.first, c.count};
+    }
+    uint32_t residue_count(int32_t v) const { return label[v] < kClass ? 1u : classes[(size_t)(label[v] - kClass)].count; }
 
     int32_t size() const { return (int32_t)label.size(); }
     int32_t add(int32_t lab);
@@ -57,6 +84,8 @@ struct KGraph {
 // (stack underflow, empty symbol buffer) instead of reproducing it.
 // path_stats: keep the reference's path statistics (Subgraph::paths / lengths) and record the concatenations that -a would
 // bypass (catsites) — only KGraph::augment() needs them; a graph built without them cannot be augmented
-KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats = true);
+// fuse_classes: unions of single residues become ONE node each (KGraph::kClass; ignored for reduced alphabets, whose
+// builder buffers symbols, and with path_stats, whose catsites are defined on the reference's node-for-node graph)
+KGraph build_kgraph(const std::string& postfix, unsigned k, bool reduced_alphabet, bool path_stats = true, bool fuse_classes = false);
 
 }  // namespace tetrex

@@ -11,54 +11,63 @@ namespace {
 
 enum Kind : uint8_t { Literal, AnyChar, CharSet, Open, Close, Alternate, Concat, Repeat, Stop };
 
+// what a token contributes to the postfix string: text[at, at + len) of the scanner's pool (one string for all tokens:
+// a Lexeme with a std::string of its own cost an allocation per wildcard and per quantifier)
 struct Lexeme {
     Kind kind;
-    std::string text;  // what the token contributes to the postfix string
+    uint32_t at = 0, len = 0;
 };
 
 constexpr char kAmino[] = "ACDEFGHIKLMNPQRSTVWY";                          // include/utils.h:58-79
 constexpr char kAnyUnion[] = "FQ|L|T|K|P|A|Y|R|N|H|G|E|C|I|V|D|W|S|M|";    // include/utils.h:365
 
-std::string union_of(const std::vector<char>& members) {
-    std::string s(1, members.at(0));
-    for (size_t i = 1; i < members.size(); ++i) {
-        s.push_back(members[i]);
-        s.push_back('|');
-    }
-    return s;
-}
-
 class Scanner {
   public:
-    explicit Scanner(const std::string& src) : s_(src) {}
+    explicit Scanner(const std::string& src) : s_(src) {
+        pool_.reserve(src.size() * 2 + sizeof kAnyUnion + 16);
+        pool_.append(kAnyUnion);  // [0, 39): every wildcard points here
+        pool_.append("|-");       // [39], [40]
+    }
+    const std::string& pool() const { return pool_; }
+    static Lexeme concat() { return {Concat, (uint32_t)sizeof kAnyUnion, 1}; }
 
     std::vector<Lexeme> run() {
         std::vector<Lexeme> out;
+        out.reserve(s_.size() + 1);
         while (at_ < s_.size()) {
             const char c = s_[at_];
             switch (c) {
-                case '.': out.push_back({AnyChar, kAnyUnion}); ++at_; break;
-                case '*': case '+': case '?': out.push_back({Repeat, std::string(1, c)}); ++at_; break;
-                case '|': out.push_back({Alternate, "|"}); ++at_; break;
-                case '(': out.push_back({Open, ""}); ++at_; break;
-                case ')': out.push_back({Close, ""}); ++at_; break;
+                case '.': out.push_back({AnyChar, 0, (uint32_t)sizeof kAnyUnion - 1}); ++at_; break;
+                case '*': case '+': case '?': out.push_back(one(Repeat, c)); ++at_; break;
+                case '|': out.push_back({Alternate, (uint32_t)sizeof kAnyUnion - 1, 1}); ++at_; break;
+                case '(': out.push_back({Open, 0, 0}); ++at_; break;
+                case ')': out.push_back({Close, 0, 0}); ++at_; break;
                 case '[': out.push_back(char_set()); break;
                 case '{': out.push_back(counted()); break;
                 case '\\':
                     if (++at_ >= s_.size()) throw std::runtime_error("Invalid escape: end of input after '\\'");
-                    out.push_back({Literal, std::string(1, s_[at_++])});
+                    out.push_back(one(Literal, s_[at_++]));
                     break;
-                default: out.push_back({Literal, std::string(1, c)}); ++at_; break;
+                default: out.push_back(one(Literal, c)); ++at_; break;
             }
         }
-        out.push_back({Stop, ""});
+        out.push_back({Stop, 0, 0});
         return out;
     }
 
   private:
     const std::string& s_;
+    std::string pool_;
     size_t at_ = 0;
 
+    Lexeme one(Kind kind, char c) {
+        pool_.push_back(c);
+        return {kind, (uint32_t)pool_.size() - 1, 1};
+    }
+    Lexeme text(Kind kind, const std::string& t) {
+        pool_.append(t);
+        return {kind, (uint32_t)(pool_.size() - t.size()), (uint32_t)t.size()};
+    }
     bool digit() const { return at_ < s_.size() && std::isdigit((unsigned char)s_[at_]); }
     int number() {
         int v = 0;
@@ -94,7 +103,14 @@ class Scanner {
             if (rest.empty()) throw std::runtime_error("Negated character class excludes every residue");
             members.swap(rest);
         }
-        return {CharSet, union_of(members)};
+        // the union of the members: "AB|C|..."
+        const uint32_t at = (uint32_t)pool_.size();
+        pool_.push_back(members[0]);
+        for (size_t i = 1; i < members.size(); ++i) {
+            pool_.push_back(members[i]);
+            pool_.push_back('|');
+        }
+        return {CharSet, at, (uint32_t)pool_.size() - at};
     }
 
     Lexeme counted() {
@@ -104,7 +120,7 @@ class Scanner {
         if (at_ >= s_.size()) throw std::runtime_error("Invalid quantifier: unexpected end of input");
         if (s_[at_] == '}') {
             ++at_;
-            return {Repeat, "{" + std::to_string(lo) + "}"};
+            return text(Repeat, "{" + std::to_string(lo) + "}");
         }
         if (s_[at_] != ',') throw std::runtime_error("Invalid quantifier: expected ',' or '}' after min value");
         if (++at_ >= s_.size()) throw std::runtime_error("Invalid quantifier: unexpected end after ','");
@@ -114,7 +130,7 @@ class Scanner {
         if (at_ >= s_.size() || s_[at_] != '}') throw std::runtime_error("Invalid quantifier: expected '}' after max value");
         ++at_;
         if (lo > hi) throw std::runtime_error("Invalid quantifier: min > max");
-        return {Repeat, "{" + std::to_string(lo) + "," + std::to_string(hi) + "}"};
+        return text(Repeat, "{" + std::to_string(lo) + "," + std::to_string(hi) + "}");
     }
 };
 
@@ -124,12 +140,17 @@ inline int binding(Kind k) { return k == Alternate ? 1 : k == Concat ? 2 : k == 
 }  // namespace
 
 std::string regex_to_postfix(const std::string& regex) {
-    const std::vector<Lexeme> toks = Scanner(regex).run();
+    Scanner scanner(regex);
+    const std::vector<Lexeme> toks = scanner.run();
+    const std::string& pool = scanner.pool();
     std::string out;
+    out.reserve(pool.size());
+    auto write = [&](const Lexeme& t) { out.append(pool, t.at, t.len); };
     std::vector<Lexeme> pending;  // operator stack
+    pending.reserve(16);
     auto apply = [&](const Lexeme& op) {
         while (!pending.empty() && pending.back().kind != Open && binding(pending.back().kind) >= binding(op.kind)) {
-            out += pending.back().text;
+            write(pending.back());
             pending.pop_back();
         }
         pending.push_back(op);
@@ -138,13 +159,13 @@ std::string regex_to_postfix(const std::string& regex) {
         const Lexeme& t = toks[i];
         if (i > 0) {  // implicit concatenation between an operand/')'/repeat and an operand/'('
             const Kind prev = toks[i - 1].kind;
-            if ((operand(prev) || prev == Close || prev == Repeat) && (operand(t.kind) || t.kind == Open)) apply({Concat, "-"});
+            if ((operand(prev) || prev == Close || prev == Repeat) && (operand(t.kind) || t.kind == Open)) apply(Scanner::concat());
         }
-        if (operand(t.kind)) out += t.text;
+        if (operand(t.kind)) write(t);
         else if (t.kind == Open) pending.push_back(t);
         else if (t.kind == Close) {
             while (!pending.empty() && pending.back().kind != Open) {
-                out += pending.back().text;
+                write(pending.back());
                 pending.pop_back();
             }
             if (!pending.empty()) pending.pop_back();
@@ -152,7 +173,7 @@ std::string regex_to_postfix(const std::string& regex) {
         else apply(t);
     }
     while (!pending.empty()) {
-        out += pending.back().text;  // an unmatched '(' contributes nothing, as in the reference
+        write(pending.back());  // an unmatched '(' contributes nothing, as in the reference
         pending.pop_back();
     }
     return out;

@@ -170,6 +170,8 @@ class StagedRun {
           fin_pruned_(n_, 0), ahead_(n_, 0), run_on_stages_(n_, 0), started_(n_, 0), unbuilt_(n_, 0), flushed_(n_, 0), released_(n_, 0), held_(n_, 0),
           busy_(threads_, 0.0), blob_store_(lease_.buffers().blob) {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
+        // unions of single residues as one k-graph node each (KGraph::kClass); TETREX_FUSE_CLASSES=0: the reference's node-for-node graph
+        if (const char* e = std::getenv("TETREX_FUSE_CLASSES")) fuse_classes_ = std::atoi(e) != 0;
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
         overlap_ = !env_is("TETREX_NO_OVERLAP", '1');
@@ -264,7 +266,7 @@ class StagedRun {
     }
     void build_one(size_t i) {  // throws what the front-end throws
         const std::string postfix = preprocess_query(regexes_[i], enc_);
-        q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base, opt_.gaps.augment), opt_.limits, opt_.gaps, dense_);
+        q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base, opt_.gaps.augment, fuse_classes_), opt_.limits, opt_.gaps, dense_);
     }
 
     // ops of earlier stages only ever reach RESULT through a Match op, so an abandoned query is
@@ -503,15 +505,17 @@ class StagedRun {
         if (at_level & 1) lv[at_level] = 0;
         if (v3) std::memcpy(blob, &h3, sizeof h3);
         else std::memcpy(blob, &h, sizeof h);
+        lap("programs");
         // the blob holds the stage now: the per-query buffers are free for the next one
-        pool_.run(touched_.size(), [&](size_t j, int) {
+        auto clear_one = [&](size_t j, int) {
             const uint32_t i = touched_[j];
             if (!q_[i]) flushed_[i] = 1;  // finished, and its last ops are in this blob
             dense_ops_[i].clear();
             if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
             else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); DenseVec().swap(dense_ops_[i]); }  // finished: storage back to the cache
             levels_[i].clear();
-        });
+        };
+        pool_.run(touched_.size(), clear_one);
         lap("blob");
         return Blob{blob, h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7), stage_kmers + stage_dgrams};
     }
@@ -650,7 +654,7 @@ class StagedRun {
     StagedStats st_;
     size_t run_on_budget_ = 0, feedback_budget_ = 0;  // the latter: what a query that asks gets per stage (advance_stage sets it)
     size_t wave_ops_ = 0, wave_growth_percent_ = 100;
-    bool trace_ = false, verified_levels_ = true, overlap_ = true;
+    bool trace_ = false, verified_levels_ = true, overlap_ = true, fuse_classes_ = true;
     double lap_at_ = 0;
 };
 

@@ -67,6 +67,20 @@ def kgraph(postfix, k, reduced=False):
     return dict(labels=list(lab[:n]), succ=list(zip(na[:n], nb[:n])))
 
 
+def kgraph_fused(postfix, k):
+    """The k-graph the expansion works on: unions of single residues fused into class nodes (include/txh.h)."""
+    L = lib()
+    i32p = C.POINTER(C.c_int32)
+    L.txh_kgraph_fused.argtypes = [C.c_char_p, C.c_uint, i32p, i32p, i32p, C.c_int32, C.c_char_p, C.c_size_t]
+    cap = 1 << 18
+    lab, na, nb = (C.c_int32 * cap)(), (C.c_int32 * cap)(), (C.c_int32 * cap)()
+    buf = C.create_string_buffer(1 << 20)
+    n = L.txh_kgraph_fused(postfix.encode(), k, lab, na, nb, cap, buf, len(buf))
+    if n < 0:
+        raise _err()
+    return dict(labels=list(lab[:n]), succ=list(zip(na[:n], nb[:n])), members=buf.value.decode().split("\n")[:n])
+
+
 def kgraph_dot(postfix, k, reduced=False, augment=False):
     L = lib()
     L.txh_kgraph_dot.argtypes = [C.c_char_p, C.c_uint, C.c_int, C.c_int, C.c_char_p, C.c_size_t]
