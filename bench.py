@@ -681,6 +681,10 @@ def verified_end_to_end(args):
             r = subprocess.run([tetrex, "query", "-S", "-f", "-t", "16", "sp.ibf", "motifs.tsv"], capture_output=True, text=True, cwd=work,
                                env=dict(os.environ, TXQ_TRACE="1", TETREX_TRACE="1"))
             sys.stderr.write("".join(ln + "\n" for ln in r.stderr.splitlines() if ln.startswith("[t") or ln.startswith("{")))
+        if os.environ.get("BENCH_CLI_ROCPROF"):  # (tools/verify_leg.py: the device's timeline of a COLD process; the binary itself after `--`)
+            subprocess.run(["rocprofv3", "--kernel-trace", *(["--hip-trace"] if os.environ.get("BENCH_CLI_ROCPROF_HIP") else []), "--stats", "--output-format", "csv", "-d", os.environ["BENCH_CLI_ROCPROF"], "-o", "cold",
+                            "--", tetrex, "query", "-S", "-f", "-t", "16", "sp.ibf", "motifs.tsv"], capture_output=True, text=True, cwd=work,
+                           env=dict(os.environ, TMPDIR="/tmp"))
         runs = {}
         for threads in (1, 16):
             best = None

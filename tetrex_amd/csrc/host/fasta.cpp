@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <fcntl.h>
@@ -268,6 +269,15 @@ size_t RecordSet::record_at(size_t offset) const {
     return lo;
 }
 
+// plain files from this size on are mapped instead of read (TETREX_MAP_FROM_MB: A/B knob; 0 = map every file)
+static size_t map_from() {
+    static const size_t v = [] {
+        const char* e = std::getenv("TETREX_MAP_FROM_MB");
+        return (size_t)(e ? std::max(0LL, std::atoll(e)) : 64) << 20;
+    }();
+    return v;
+}
+
 void load_records(const std::string& path, RecordSet& out) {
     out.text.clear();
     out.start.clear();
@@ -290,7 +300,10 @@ void load_records(const std::string& path, RecordSet& out) {
         struct stat st;
         if (!gz) {
             if (::fstat(fd, &st) == 0 && st.st_size > 0) {
-                void* m = ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+                // Small files are READ into this thread's buffer (kept from bin to bin): mapping and unmapping a few hundred
+                // kilobytes per bin costs page faults and, with many verification threads in one address space, a TLB
+                // shoot-down per file — more threads made a batch slower.  Large files are mapped (no second copy).
+                void* m = (size_t)st.st_size < map_from() ? MAP_FAILED : ::mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
                 if (m != MAP_FAILED) {
                     mapping = m;
                     mapping_size = (size_t)st.st_size;

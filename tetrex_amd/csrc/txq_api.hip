@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -284,6 +285,18 @@ int txq_init(int n_devices, const int* device_ids) {
         preload_hibf_kernels();
         // A non-blocking stream is a hardware queue of its own: 9 ms to create.  A session needs two; the first session of a
         // process takes them from here instead of paying 18 ms inside its first query (later sessions on an index inherit its streams).
+        // The first copy between pageable host memory and the device makes the runtime set up its staging buffers: 8-12 ms in a
+        // fresh process, which the first session's final masks paid (`tetrex query`: half of a cold batch's mask stage).
+        {
+            void* d = nullptr;
+            if (hipMalloc(&d, 1 << 16) == hipSuccess) {
+                std::vector<char> h(1 << 16, 0);
+                (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
+                (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
+                (void)hipFree(d);
+            }
+            (void)hipGetLastError();
+        }
         std::lock_guard<std::mutex> lk(g_spare_mutex);
         while (g_spare_streams[devices[i]].size() < 2) {
             hipStream_t st = nullptr;
@@ -753,6 +766,10 @@ int txq_session_end(txq_session* s, uint64_t* final_masks) {
     if (!s) return TXQ_OK;
     int rc = bind_index(s->ix);  // the calling thread may never have selected the device
     if (rc != TXQ_OK) { delete static_cast<Session*>(s); return rc; }
+    const bool trace = s->kn.trace;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    double t_finish = t0, t_copy = t0;
     if (final_masks && s->failed) {
         // a stage of this session failed: its slots hold half-executed state, there are no final masks to hand out
         rc = fail(TXQ_ERR_STATE, "a stage of this session failed: it has no final masks");
@@ -761,13 +778,19 @@ int txq_session_end(txq_session* s, uint64_t* final_masks) {
         const size_t bytes = s->n_programs * (size_t)ix.shard_words * 8;  // (a layout-order session hands out user-bin masks too)
         rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);
         if (rc == TXQ_OK) rc = session_finish(*s, ix.scratch_final, nullptr);
+        t_finish = now();
         if (rc == TXQ_OK) {
             hipError_t e = hipMemcpy(final_masks, ix.scratch_final, bytes, hipMemcpyDeviceToHost);
             if (e != hipSuccess) rc = fail_hip(e, "copying final masks");
         }
+        t_copy = now();
     }
     (void)hipDeviceSynchronize();
+    const double t_sync = now();
     delete static_cast<Session*>(s);
+    if (trace)
+        fprintf(stderr, "[txq] session end: last launches %.2f ms, masks to the host %.2f ms, device idle after %.2f ms, session released in %.2f ms\n",
+                (t_finish - t0) * 1e3, (t_copy - t_finish) * 1e3, (t_sync - t_copy) * 1e3, (now() - t_sync) * 1e3);
     return rc;
 }
 

@@ -1657,8 +1657,8 @@ Session::~Session() {
                 (unsigned long long)n_step_pairs, (unsigned long long)n_step_suffixes, (unsigned long long)n_zero_slots, (unsigned long long)n_reduce_entries, W);
     if (kn.trace && n_beside) fprintf(stderr, "[txq]   %zu stage(s) ran beside the previous one (second stream)\n", n_beside);
     if (kn.trace && n_blocks_made + n_block_memsets + n_blocks_relisted)
-        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all), %zu cleared for tracked programs, %zu taken over as a tracked program left them; %zu sparse launches (%zu groups)\n",
-                n_blocks_made, block_bytes_made / 1e6, n_block_memsets, n_blocks_relisted, n_sparse_launches, n_sparse_groups);
+        fprintf(stderr, "[txq]   dense blocks: %zu made (%.1f MB in all; %zu chunks of block memory, %.2f ms in hipMalloc), %zu cleared for tracked programs, %zu taken over as a tracked program left them; %zu sparse launches (%zu groups)\n",
+                n_blocks_made, block_bytes_made / 1e6, block_chunks.size(), block_alloc_seconds * 1e3, n_block_memsets, n_blocks_relisted, n_sparse_launches, n_sparse_groups);
     if (aux) --aux->open_sessions;
     if (ix) --ix->open_sessions;
     for (Index::StagingSet& t : set)  // nothing of the session may still be running when its buffers change hands
@@ -1812,7 +1812,9 @@ static int block_arena_alloc(Session& s, size_t words, uint64_t** out) {
         size_t cap = std::max((size_t)8 << 20, s.block_arena_words);  // 64 MiB first, then as much again as there is
         if (words > cap) cap = words;
         uint64_t* c = nullptr;
+        const double t0 = now_s();
         TXQ_HIP(hipMalloc((void**)&c, cap * 8));
+        s.block_alloc_seconds += now_s() - t0;
         s.block_chunks.push_back(Index::ArenaChunk{c, cap});
         s.block_arena_words += cap;
         s.bcur = s.block_chunks.size() - 1;

@@ -266,6 +266,7 @@ struct Session {
     std::vector<DenseBlock> given_back[2];
     uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet): the capacity of untracked blocks
     size_t block_bytes_made = 0;
+    double block_alloc_seconds = 0;  // spent in hipMalloc for block chunks (TXQ_TRACE)
     size_t n_blocks_live = 0, n_blocks_made = 0, n_block_memsets = 0, n_blocks_relisted = 0, n_sparse_launches = 0, n_sparse_groups = 0;
     std::vector<uint32_t> last_stage;  // per program: the last stage (1-based) that had ops for it
     hipStream_t side = nullptr;        // a stage that continues nothing of the stage in flight runs beside it, on the other stream
