@@ -46,6 +46,7 @@ extern "C" {
  *   TXQ_DENSE_TREE=0|1|2                              dense steps on a regular HIBF: generic descent | TreeRows | TreeRowsByLane
  *   TXQ_DENSE_UNROLL, TXQ_DENSE_SLICES, TXQ_DENSE_TILE_ROUNDS, TXQ_DENSE_NT   shape of a dense step's tiles, cache policy of its destination accesses
  *   TXQ_FUSE_UNITS=0, TXQ_ONE_STREAM                  one launch per kind and level; no second stream
+ *   TXQ_FINAL_PINNED=0                                a session's final masks gathered on the device and copied, not written straight into pinned host memory
  *   TXQ_SPARSE_STEPS=0, TXQ_SPARSE_UNROLL=2|3, TXQ_SPARSE_UNITS=<n>
  *                                                     pushed steps of tracked blocks on narrow masks: rounds of entries instead of units; units in
  *                                                     flight per lane group; units per chunk (default 512)

@@ -22,6 +22,7 @@ KNOBS = [
     {"TXQ_HIBF_STORE": "48"},  # (the removed experiment switch: must change nothing)
     # pushed steps of tracked blocks (TETREX_DENSE_TRACKED=1 is the host's switch for them): by units, in rounds, and the units' knobs
     {"TETREX_DENSE_TRACKED": "1"}, {"TETREX_DENSE_TRACKED": "1", "TXQ_SPARSE_STEPS": "0"}, {"TETREX_DENSE_TRACKED": "1", "TXQ_SPARSE_UNROLL": "2"},
+    {"TXQ_FINAL_PINNED": "0"},
     {"TETREX_DENSE_TRACKED": "1", "TXQ_SPARSE_UNITS": "64"}, {"TETREX_DENSE_TRACKED": "1", "TXQ_SPARSE_UNITS": "1536", "TXQ_KMER_TABLE_MIN": "1"},
     {"TXQ_HIBF_WAVES": "512"}, {"TXQ_PROBE_BLOCKS_PER_CU": "2"}, {"TXQ_PROBE_UNROLL": "1"}, {"TXQ_PROBE_UNROLL": "4"}, {"TXQ_PROBE_NT": "1"},
 ]

@@ -65,6 +65,7 @@ void read_knobs() {
     k.hibf_lane_hash = flag("TXQ_HIBF_LANE_HASH");
     k.hibf_layout_order = !is("TXQ_HIBF_LAYOUT_ORDER", '0');
     k.hibf_layout_fused = !is("TXQ_HIBF_LAYOUT_FUSED", '0');
+    k.final_pinned = !is("TXQ_FINAL_PINNED", '0');
     k.hibf_steps_per_group = (int)std::max(0LL, num("TXQ_HIBF_STEPS_PER_GROUP", 0));
     k.hibf_tile = (int)std::max(0LL, num("TXQ_HIBF_TILE", 0));
     k.hibf_unroll = (int)num("TXQ_HIBF_UNROLL", 1);
@@ -224,6 +225,7 @@ void Index::release() {
     d_ibf = nullptr; d_next = d_tb_user = nullptr; d_map_off = nullptr;
     scratch_kmers = scratch_masks = nullptr; frontier[0] = frontier[1] = nullptr; d_counts = nullptr;
     scratch_blob = nullptr; scratch_slots = scratch_final = nullptr;
+    if (host_final) { (void)hipHostFree(host_final); host_final = nullptr; cap_host_final = 0; }
     scratch_dense_kmers = scratch_dense_masks = nullptr; cap_dense_kmers = cap_dense_masks = 0;
 }
 
@@ -285,18 +287,6 @@ int txq_init(int n_devices, const int* device_ids) {
         preload_hibf_kernels();
         // A non-blocking stream is a hardware queue of its own: 9 ms to create.  A session needs two; the first session of a
         // process takes them from here instead of paying 18 ms inside its first query (later sessions on an index inherit its streams).
-        // The first copy between pageable host memory and the device makes the runtime set up its staging buffers: 8-12 ms in a
-        // fresh process, which the first session's final masks paid (`tetrex query`: half of a cold batch's mask stage).
-        {
-            void* d = nullptr;
-            if (hipMalloc(&d, 1 << 16) == hipSuccess) {
-                std::vector<char> h(1 << 16, 0);
-                (void)hipMemcpy(d, h.data(), h.size(), hipMemcpyHostToDevice);
-                (void)hipMemcpy(h.data(), d, h.size(), hipMemcpyDeviceToHost);
-                (void)hipFree(d);
-            }
-            (void)hipGetLastError();
-        }
         std::lock_guard<std::mutex> lk(g_spare_mutex);
         while (g_spare_streams[devices[i]].size() < 2) {
             hipStream_t st = nullptr;
@@ -776,12 +766,35 @@ int txq_session_end(txq_session* s, uint64_t* final_masks) {
     } else if (final_masks && s->n_programs && s->W) {
         Index& ix = *s->ix;
         const size_t bytes = s->n_programs * (size_t)ix.shard_words * 8;  // (a layout-order session hands out user-bin masks too)
-        rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);
-        if (rc == TXQ_OK) rc = session_finish(*s, ix.scratch_final, nullptr);
-        t_finish = now();
-        if (rc == TXQ_OK) {
-            hipError_t e = hipMemcpy(final_masks, ix.scratch_final, bytes, hipMemcpyDeviceToHost);
-            if (e != hipSuccess) rc = fail_hip(e, "copying final masks");
+        if (s->kn.final_pinned && !s->vspace && bytes <= ((size_t)64 << 20)) {  // (layout-order rows are first put back in user-bin order, with atomics: on the device)
+            // The gather kernel writes the masks straight into pinned host memory (kept with the index): no copy engine is
+            // involved.  In a fresh process (`tetrex query`) the device-to-host copy of a session's 25 KB of final masks took
+            // 8 ms with the device idle — pageable or pinned destination, hipMemcpy or hipMemcpyAsync alike —, as much as the
+            // whole batch on the device; the kernel's stores over the link take 0.02 ms (profiles/r4_cold_cli_final_masks.txt).
+            if (ix.cap_host_final < bytes) {
+                if (ix.host_final) (void)hipHostFree(ix.host_final);
+                ix.host_final = nullptr;
+                ix.cap_host_final = 0;
+                const size_t cap = std::max<size_t>(bytes + bytes / 2, (size_t)1 << 20);
+                hipError_t e = hipHostMalloc((void**)&ix.host_final, cap, hipHostMallocDefault);
+                if (e != hipSuccess) rc = fail_hip(e, "pinned buffer for the final masks");
+                else ix.cap_host_final = cap;
+            }
+            if (rc == TXQ_OK) rc = session_finish(*s, ix.host_final, nullptr);
+            t_finish = now();
+            if (rc == TXQ_OK) {
+                hipError_t e = hipStreamSynchronize(nullptr);
+                if (e != hipSuccess) rc = fail_hip(e, "waiting for the final masks");
+                else std::memcpy(final_masks, ix.host_final, bytes);
+            }
+        } else {
+            rc = ensure((void**)&ix.scratch_final, &ix.cap_final, bytes);
+            if (rc == TXQ_OK) rc = session_finish(*s, ix.scratch_final, nullptr);
+            t_finish = now();
+            if (rc == TXQ_OK) {
+                hipError_t e = hipMemcpy(final_masks, ix.scratch_final, bytes, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) rc = fail_hip(e, "copying final masks");
+            }
         }
         t_copy = now();
     }

@@ -35,6 +35,7 @@ struct Knobs {
     bool hibf_stationary = true;        // TXQ_HIBF_STATIONARY=0: no child-stationary descent
     bool hibf_small = true;             // TXQ_HIBF_SMALL=0: no lane-per-k-mer kernel for small trees
     bool hibf_lane_hash = false;        // TXQ_HIBF_LANE_HASH: per-lane hashing on a uniform tree
+    bool final_pinned = true;           // TXQ_FINAL_PINNED=0: a session's final masks through a device buffer and hipMemcpy
     bool hibf_layout_fused = true;      // TXQ_HIBF_LAYOUT_FUSED=0: the layout-order rows of plain k-mers level by level (hibf_layout_level_kernel), not one wave per k-mer
     bool hibf_layout_order = true;      // TXQ_HIBF_LAYOUT_ORDER=0: sessions on general trees work in user-bin order (descent kernels)
     int hibf_steps_per_group = 0, hibf_tile = 0, hibf_unroll = 1, hibf_store = 0;  // TXQ_HIBF_STEPS_PER_GROUP / _TILE / _UNROLL / _STORE_KIND (store instruction: 0-3)
@@ -165,6 +166,7 @@ struct Index {
     unsigned char* scratch_blob = nullptr; size_t cap_blob = 0;
     uint64_t* scratch_slots = nullptr; size_t cap_slots = 0;
     uint64_t* scratch_final = nullptr; size_t cap_final = 0;
+    uint64_t* host_final = nullptr; size_t cap_host_final = 0;  // pinned: a session's final masks are gathered straight into host memory
     uint64_t* scratch_dense_kmers = nullptr; size_t cap_dense_kmers = 0;  // dense steps on an HIBF: the pairs' k-mers ...
     uint64_t* scratch_dense_masks = nullptr; size_t cap_dense_masks = 0;  // ... and their descended masks
     // A flat index's masks of ALL k-mers, M[v] at kmer_table + v * shard_words for every packed value v < 2^(bits * k) (txq_exec.hip
