@@ -90,6 +90,11 @@ int64_t txh_dgram_values(const char* seq, size_t len, uint64_t min_gap, uint64_t
  * Exported by libtetrex_query.so (which links libtxq.so), not by libtetrex_host.so. */
 int txe_query_masks(void* txq_index_handle, int dna, unsigned k, unsigned reduction, const char* const* regex, size_t n,
                     size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6);
+/* The same for motifs given the way `tetrex query` receives a batch — one text, one motif per line (the reference's motif file,
+ * src/query.cpp:318-327, without the name column): text[0, text_bytes) holds n lines separated by '\n' (a final '\n' is optional).
+ * For bindings whose strings are not C strings: no array of n pointers to build (6 ms per 10 000 motifs from Python). */
+int txe_query_masks_text(void* txq_index_handle, int dna, unsigned k, unsigned reduction, const char* text, size_t text_bytes, size_t n,
+                         size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6);
 /* the same with -a/-g: aux_index_handle is the GPU-resident d-gram index (or NULL) */
 int txe_query_masks_gapped(void* txq_index_handle, void* aux_index_handle, const txh_gap_options* gaps, int dna, unsigned k,
                            unsigned reduction, const char* const* regex, size_t n, size_t ops_per_query_per_stage,

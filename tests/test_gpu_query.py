@@ -125,3 +125,30 @@ def test_hibf_queries(capi, host, oracle):
         hits += int(want.any())
     assert hits >= 5
     ix.free()
+
+
+def test_motifs_as_one_text_equal_motifs_as_an_array(capi, oracle):
+    """txe_query_masks_text (include/txh.h: one motif per line, as `tetrex query` reads a batch) against txe_query_masks on the
+    same motifs — Index.query_masks takes the text route whenever no motif holds a line break —, with empty lines and a
+    motif that fails to parse in the batch; a text of the wrong number of lines is refused."""
+    import ctypes as C
+    ox = _oracle_index(oracle, bins=200, m=4099, h=3, k=4, dna=False, per_bin=900, seed=5)
+    sh = ox.shape()
+    ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
+    qs = ["LMAEGLYN", "", "A.C[DE]F", "A{2,}", "W.{1,2}K", ""]
+    got, status, _ = ix.query_masks(qs, False, 4)                       # the text
+    got_arr, status_arr, _ = ix.query_masks(qs + ["A\nC"], False, 4)    # (a line break in a motif: the array of C strings)
+    assert status == status_arr[:len(qs)] and np.array_equal(got, got_arr[:len(qs)])
+    assert status[3] != 0 and status[0] == 0 and isinstance(status, list)
+    for q, g, st in zip(qs, got, status):
+        if st == 0 and q:
+            assert np.array_equal(g, ox.query(q)), q
+    Lq = capi._query_lib()
+    masks = np.zeros((3, ix.shard_words), dtype=np.uint64)
+    st3 = (C.c_int * 3)()
+    for text in (b"ACDE\nLMAE", b"ACDE\nLMAE\nWKWK\nAAAA"):  # two lines, four lines: not the three stated
+        rc = Lq.txe_query_masks_text(ix._h, 0, 4, 0, text, len(text), 3, 0, masks.ctypes.data_as(C.POINTER(C.c_uint64)), st3, None)
+        assert rc == -1 and b"number of motifs" in Lq.txe_last_error()
+    rc = Lq.txe_query_masks_text(ix._h, 0, 4, 0, b"ACDE\nLMAE\nWKWK\n", 15, 3, 0, masks.ctypes.data_as(C.POINTER(C.c_uint64)), st3, None)
+    assert rc == 0 and np.array_equal(masks[1], ox.query("LMAE"))      # (a final line break is optional)
+    ix.free()

@@ -104,6 +104,8 @@ def _query_lib():
         L.txe_last_error.restype = C.c_char_p
         L.txe_query_masks.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.POINTER(C.c_char_p), C.c_size_t, C.c_size_t,
                                       u64p, C.POINTER(C.c_int), u64p]
+        L.txe_query_masks_text.argtypes = [C.c_void_p, C.c_int, C.c_uint, C.c_uint, C.c_char_p, C.c_size_t, C.c_size_t, C.c_size_t,
+                                           u64p, C.POINTER(C.c_int), u64p]
         _QLIB = L
     return _QLIB
 
@@ -343,18 +345,24 @@ class Index:
         returns (masks [n, shard_words], status list, stats dict)."""
         Lq = _query_lib()
         n = len(regexes)
-        arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
         masks = np.zeros((n, self.shard_words), dtype=np.uint64)
-        status = (C.c_int * n)()
+        status = np.zeros(n, dtype=np.int32)
         stats = (C.c_uint64 * 8)()
-        rc = Lq.txe_query_masks(self._h, int(dna), k, reduction, arr, n, ops_per_query_per_stage,
-                                masks.ctypes.data_as(u64p), status, stats)
+        text = "\n".join(regexes)
+        if n and text.count("\n") == n - 1:  # one text, one motif per line: no array of n C strings to build
+            raw = text.encode()
+            rc = Lq.txe_query_masks_text(self._h, int(dna), k, reduction, raw, len(raw), n, ops_per_query_per_stage,
+                                         masks.ctypes.data_as(u64p), status.ctypes.data_as(C.POINTER(C.c_int)), stats)
+        else:
+            arr = (C.c_char_p * n)(*[r.encode() for r in regexes])
+            rc = Lq.txe_query_masks(self._h, int(dna), k, reduction, arr, n, ops_per_query_per_stage,
+                                    masks.ctypes.data_as(u64p), status.ctypes.data_as(C.POINTER(C.c_int)), stats)
         if rc < 0:
             raise TxqError(rc, Lq.txe_last_error().decode(errors="replace"))
         keys = ("stages", "ops", "kmers", "states", "pruned", "feedback_queries", "expand_us", "execute_us")
         Lq.txe_last_dense_ops.restype = C.c_uint64
         Lq.txe_last_tracked_queries.restype = C.c_uint64
-        return masks, list(status), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
+        return masks, status.tolist(), dict(zip(keys, (int(x) for x in stats)), dense_ops=int(Lq.txe_last_dense_ops()), tracked_queries=int(Lq.txe_last_tracked_queries()))
 
     def supports_dense(self):
         """txq_index_supports_dense: 0 no dense steps, 1 through the descent, 2 fused (tracked programs, too)."""

@@ -23,6 +23,27 @@ int txe_query_masks(void* handle, int dna, unsigned k, unsigned reduction, const
     return txe_query_masks_gapped(handle, nullptr, nullptr, dna, k, reduction, regex, n, ops_per_query_per_stage, masks, status, stats6);
 }
 
+int txe_query_masks_text(void* handle, int dna, unsigned k, unsigned reduction, const char* text, size_t text_bytes, size_t n,
+                         size_t ops_per_query_per_stage, uint64_t* masks, int* status, uint64_t* stats6) {
+    // the lines of the text as C strings: one copy of the text with the separators turned into terminators
+    std::string copy(text ? text : "", text ? text_bytes : 0);
+    std::vector<const char*> lines;
+    lines.reserve(n);
+    size_t at = 0;
+    while (lines.size() < n && at <= copy.size()) {
+        lines.push_back(copy.data() + at);
+        const size_t nl = copy.find('\n', at);
+        if (nl == std::string::npos) { at = copy.size() + 1; break; }
+        copy[nl] = '\0';
+        at = nl + 1;
+    }
+    if (lines.size() != n || (at < copy.size())) {
+        g_qerr = "the text does not hold the stated number of motifs (one per line)";
+        return -1;
+    }
+    return txe_query_masks_gapped(handle, nullptr, nullptr, dna, k, reduction, lines.data(), n, ops_per_query_per_stage, masks, status, stats6);
+}
+
 int txe_query_masks_gapped(void* handle, void* aux_handle, const txh_gap_options* gaps, int dna, unsigned k, unsigned reduction,
                            const char* const* regex, size_t n, size_t ops_per_query_per_stage, uint64_t* masks, int* status,
                            uint64_t* stats6) {

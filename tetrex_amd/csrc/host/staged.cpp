@@ -507,15 +507,18 @@ class StagedRun {
         else std::memcpy(blob, &h, sizeof h);
         lap("programs");
         // the blob holds the stage now: the per-query buffers are free for the next one
-        auto clear_one = [&](size_t j, int) {
+        // A query that goes on has its buffers emptied here, before it emits again.  A FINISHED query's buffers go back to the
+        // allocator — thousands of frees per stage of a large batch, by threads that did not allocate them — once the stage has
+        // been handed to the device (release_finished, from execute()): nothing waits for them.
+        pool_.run(touched_.size(), [&](size_t j, int) {
             const uint32_t i = touched_[j];
-            if (!q_[i]) flushed_[i] = 1;  // finished, and its last ops are in this blob
             dense_ops_[i].clear();
             if (q_[i]) { ops_[i].clear(); tables_[i].clear(); dgram_tables_[i].clear(); }
-            else { OpVec().swap(ops_[i]); tables_[i] = KmerTable(false); dgram_tables_[i] = KmerTable(false); DenseVec().swap(dense_ops_[i]); }  // finished: storage back to the cache
+            else flushed_[i] = 1;  // finished, and its last ops are in this blob
             levels_[i].clear();
-        };
-        pool_.run(touched_.size(), clear_one);
+        });
+        for (const uint32_t i : touched_)
+            if (!q_[i]) finished_.push_back(i);
         lap("blob");
         return Blob{blob, h.levels_offset + (((size_t)h.n_levels * 4 + 7) & ~(size_t)7), stage_kmers + stage_dgrams};
     }
@@ -547,6 +550,18 @@ class StagedRun {
 
     // The device runs the stage; meanwhile the queries that do not wait for its answer go on, and the next wave of
     // queries begins (`ahead`; their ops are carried into the next stage).
+    void release_finished() {
+        pool_.run(finished_.size(), [&](size_t j, int) {
+            const uint32_t i = finished_[j];
+            OpVec().swap(ops_[i]);
+            tables_[i] = KmerTable(false);
+            dgram_tables_[i] = KmerTable(false);
+            DenseVec().swap(dense_ops_[i]);
+        });
+        finished_.clear();
+        lap("release");
+    }
+
     void execute(const Blob& blob, Frontier& fr) {
         const double start = now_seconds();
         if (overlap_ && (!fr.run_on.empty() || fr.waiting)) {
@@ -562,11 +577,19 @@ class StagedRun {
             for (uint32_t i : begun_now) ahead_[i] = 1;
             const double ahead_s = now_seconds() - start;
             lap("ahead");
+            release_finished();
             running.get();
             st_.expand_seconds += ahead_s;
             st_.execute_seconds += now_seconds() - start - ahead_s;  // what the device added beyond the overlapped expansion
         } else {
-            exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive);
+            if (overlap_ && !finished_.empty()) {  // (nothing to expand beside the stage: the buffers of the finished queries still are)
+                std::future<void> running = std::async(std::launch::async, [&]() { exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive); });
+                release_finished();
+                running.get();
+            } else {
+                exec_.stage(blob.data, blob.bytes, fr.program, fr.slot, fr.alive);
+                release_finished();
+            }
             st_.execute_seconds += now_seconds() - start;
         }
         lap("execute");
@@ -622,6 +645,7 @@ class StagedRun {
     std::vector<std::string> why_;
     std::vector<std::unique_ptr<QueryExpansion>> q_;  // null: failed, finished or a pass-through
     std::vector<uint8_t> passthrough_;
+    std::vector<uint32_t> finished_;  // queries whose last ops have gone into a blob: their buffers are released beside the stage (release_finished)
     std::vector<OpVec> ops_;       // per query: the ops of the stage being built
     std::vector<uint32_t> slots_;  // per query: slots in use (what the device sizes the slot region by)
     // one k-mer table per query and stage: small enough to stay cache-resident, and a k-mer shared

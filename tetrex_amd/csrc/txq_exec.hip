@@ -1679,7 +1679,13 @@ Session::~Session() {
                             "per unit with a bit one bitmap word)\n", c[0], c[1], c[2], (unsigned long long)piece, c[3], bytes, (unsigned long long)rows_per_unit, W * 8);
         }
     }
+    const double t_retire = now_s();
     for (void* p : retired) (void)hipFree(p);
+    struct Lap {  // TXQ_TRACE: what releasing the session costs (the members' own destructors come after this)
+        bool on; double t0; size_t retired;
+        ~Lap() { if (on) fprintf(stderr, "[txq]   release: %zu outgrown staging buffers freed, then %.2f ms for buffers and blocks going back to the index\n", retired, (now_s() - t0) * 1e3); }
+    } lap{kn.trace, now_s(), retired.size()};
+    if (kn.trace && !retired.empty()) fprintf(stderr, "[txq]   release: hipFree of outgrown staging buffers %.2f ms\n", (lap.t0 - t_retire) * 1e3);
     if (owns_cache && ix) {  // hand the buffers back for the next session (the chunks up to a total of kArenaKeepBytes)
         Index::SessionCache& c = ix->session_cache;
         size_t kept = 0;
@@ -1699,10 +1705,10 @@ Session::~Session() {
             c.blocks.swap(pool);
             for (size_t p = 0; p < blocks.size(); ++p)
                 for (const DenseBlock& b : blocks[p])
-                    if (b.p) c.blocks.emplace(b.cap, DenseBlock{b.p, b.cap, (uint8_t)(tracked[p] ? kListed : kGarbage)});
-            for (const auto& kv : free_blocks) c.blocks.emplace(kv.first, kv.second);
+                    if (b.p) c.blocks.put(DenseBlock{b.p, b.cap, (uint8_t)(tracked[p] ? kListed : kGarbage)});
+            c.blocks.absorb(free_blocks);
             for (const std::vector<DenseBlock>& v : given_back)
-                for (const DenseBlock& b : v) c.blocks.emplace(b.cap, b);
+                for (const DenseBlock& b : v) c.blocks.put(b);
         } else
             for (const Index::ArenaChunk& k : block_chunks) (void)hipFree(k.p);
         c.set[0] = set[0];
@@ -1826,14 +1832,8 @@ static int block_arena_alloc(Session& s, size_t words, uint64_t** out) {
 }
 
 static int take_block(Session& s, uint32_t cap, Session::DenseBlock* out) {
-    for (auto* from : {&s.free_blocks, &s.pool}) {  // given back in this session; left by earlier sessions on this index
-        auto it = from->find(cap);
-        if (it != from->end()) {
-            *out = it->second;
-            from->erase(it);
-            return TXQ_OK;
-        }
-    }
+    for (auto* from : {&s.free_blocks, &s.pool})  // given back in this session; left by earlier sessions on this index
+        if (from->take(cap, out)) return TXQ_OK;
     Session::DenseBlock b{nullptr, cap, Session::kGarbage};
     if (int rc = block_arena_alloc(s, block_alloc_words(cap, s.W), &b.p)) return rc;
     ++s.n_blocks_made;
@@ -1852,7 +1852,7 @@ static int grow_slot_regions(Session& s, const BlobView& bv, const unsigned char
     }
     // Blocks given back two stages ago serve other programs now: whatever used them has finished (a stage waits for the
     // stage before the previous one, whose staging set it takes over), so a recycled block ties its new owner to nobody.
-    for (const Session::DenseBlock& b : s.given_back[1]) s.free_blocks.emplace(b.cap, b);
+    for (const Session::DenseBlock& b : s.given_back[1]) s.free_blocks.put(b);
     s.given_back[1].swap(s.given_back[0]);
     s.given_back[0].clear();
     // a program that reports no dense blocks any more is finished with them

@@ -192,6 +192,37 @@ struct Index {
     // untracked program), kListed (left by a tracked program: all zero except the entries in its list, which is intact — the
     // ZERO that re-creates it for a tracked program clears exactly those, so such a block needs no clearing at all).
     struct DenseBlock { uint64_t* p; uint32_t cap; uint8_t state; };
+    // blocks by capacity: a handful of capacities (powers of two for tracked blocks, A^(k-1) for untracked ones) with thousands
+    // of blocks each — a vector per capacity (a multimap's node per block made releasing a 10 000-query session 2.5 ms)
+    struct BlockBins {
+        std::vector<std::pair<uint32_t, std::vector<DenseBlock>>> bins;
+        std::vector<DenseBlock>& of(uint32_t cap) {
+            for (auto& b : bins) if (b.first == cap) return b.second;
+            bins.emplace_back(cap, std::vector<DenseBlock>());
+            return bins.back().second;
+        }
+        void put(const DenseBlock& b) { of(b.cap).push_back(b); }
+        bool take(uint32_t cap, DenseBlock* out) {
+            for (auto& b : bins)
+                if (b.first == cap) {
+                    if (b.second.empty()) return false;
+                    *out = b.second.back();
+                    b.second.pop_back();
+                    return true;
+                }
+            return false;
+        }
+        void absorb(BlockBins& other) {  // everything of `other` moves in
+            for (auto& b : other.bins) {
+                std::vector<DenseBlock>& mine = of(b.first);
+                if (mine.empty()) mine.swap(b.second);
+                else { mine.insert(mine.end(), b.second.begin(), b.second.end()); b.second.clear(); }
+            }
+        }
+        void swap(BlockBins& o) { bins.swap(o.bins); }
+        size_t size() const { size_t n = 0; for (const auto& b : bins) n += b.second.size(); return n; }
+        void clear() { bins.clear(); }
+    };
     struct SessionCache {
         std::vector<ArenaChunk> chunks;  // slot-arena chunks, at most kArenaKeepBytes in all
         // dense blocks live in chunks of their own, and ALL blocks of a session go back into a pool by capacity when it ends:
@@ -199,7 +230,7 @@ struct Index {
         // (5.3 GB of memset per 200-motif batch at k = 6 before)
         std::vector<ArenaChunk> block_chunks;
         size_t block_cur = 0, block_used = 0;
-        std::multimap<uint32_t, DenseBlock> blocks;
+        BlockBins blocks;
         uint32_t blocks_W = 0;  // the mask width the pooled blocks were laid out for
         StagingSet set[2];
         hipStream_t upload = nullptr, side = nullptr;
@@ -260,10 +291,10 @@ struct Session {
     enum : uint8_t { kGarbage = 0, kListed = 1 };
     std::vector<Index::ArenaChunk> block_chunks;  // the blocks' own arena (bump allocation in block_chunks[bcur]); kept with the index
     size_t bcur = 0, bused = 0, block_arena_words = 0;
-    std::multimap<uint32_t, DenseBlock> pool;     // blocks earlier sessions on this index left behind, by capacity
+    Index::BlockBins pool;     // blocks earlier sessions on this index left behind, by capacity
     std::vector<std::vector<DenseBlock>> blocks;  // per program, by block id (p == nullptr: a tracked block no ZERO has created yet)
     std::vector<uint8_t> tracked;                 // per program: TXQ_PROGRAM_TRACKED_BIT (fixed with its first block)
-    std::multimap<uint32_t, DenseBlock> free_blocks;  // blocks of finished programs by capacity, reusable ...
+    Index::BlockBins free_blocks;  // blocks of finished programs by capacity, reusable ...
     // ... two stages after they were given back: the stage before the current one may still be running, on another stream
     std::vector<DenseBlock> given_back[2];
     uint32_t block_slots = 0;       // N = A^(k-1) of this session's blobs (0: no dense blob seen yet): the capacity of untracked blocks
