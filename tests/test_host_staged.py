@@ -1,6 +1,8 @@
 """CPU tests of staged execution (host/compiler.cpp run_staged): the frontier is expanded piecewise
 and dead states are pruned on feedback.  The device session is replaced by a numpy simulator over
 oracle-probed masks; the final masks must equal the oracle's collect() for every stage budget."""
+import os
+
 import numpy as np
 import pytest
 
@@ -132,7 +134,8 @@ def test_node_for_node_graphs_and_fused_classes_give_the_same_masks(host, oracle
         assert checked >= len(qs) - 4
     if per_query == 1 << 30:
         assert probed["1"] == probed["0"] and len(probed["1"]) > 10000
-        assert stats["1"]["ops"] <= stats["0"]["ops"]
+        if "TETREX_MERGE_SAMPLE" not in os.environ:  # (test_host_variants.py: lists that do not merge at all — no such promise)
+            assert stats["1"]["ops"] <= stats["0"]["ops"]
 
 
 @pytest.mark.parametrize("wave_ops", ["0", "64", "2000"])

@@ -339,9 +339,17 @@ void QueryExpansion::emit(OpVec& out, uint32_t kmer, uint32_t dst, uint32_t a, u
     out.push_back(txq_op{kmer, dst, a, b});
 }
 
+// length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just above them, so paths of
+// different length < k-1 never share a key; a state collecting the residues after a gap is identified by its partial d-gram
+// and how many residues it has seen (bits 60-62 keep it apart from every ordinary state)
+uint64_t QueryExpansion::key_of(const State& s) const {
+    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
+    const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
+    return s.gapped ? (s.kmer | ((uint64_t)(4 + s.shift) << 60)) : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)));
+}
+
 // hand a state (owning one reference to its slot) to node `to`
 void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
-    const unsigned k = enc_.k(), bits = enc_.bits_per_symbol();
     NodeStates& ns = table_[to];
     if (ns.items.capacity() == 0) adopt_storage(ns);
     if (waiting_ >= limits_.max_live_states) throw std::runtime_error("query holds too many states at the same time");
@@ -352,23 +360,31 @@ void QueryExpansion::arrive(int32_t to, State s, OpVec& out) {
         if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         return;
     }
-    // length-prefixed key: the symbols seen so far (at most the k-1 newest) with a marker bit just
-    // above them, so paths of different length < k-1 never share a key
-    const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;
-    // a state collecting the residues after a gap is identified by its partial d-gram and how many
-    // residues it has seen (bits 60-62 keep it apart from every ordinary state)
-    const uint64_t key = s.gapped ? (s.kmer | ((uint64_t)(4 + s.shift) << 60))
-                                  : ((s.kmer & enc_.suffix_mask()) | (1ULL << (phase * bits)));
-    ns.by_key.want_direct(direct_key_bits_);
-    auto [where, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
-    if (inserted) {
+    const uint64_t key = key_of(s);
+    // A list of a few states is searched, not hashed: the merge table (an allocation per node) is made when the list reaches
+    // kSearched states — along a run of literals every list holds one state, and the tables were a third of its expansion.
+    uint32_t at = kNoState;
+    if (ns.by_key.size() == 0 && ns.items.size() < kSearched) {
+        for (uint32_t i = 0; i < ns.items.size(); ++i)
+            if (key_of(ns.items[i]) == key) { at = i; break; }
+        if (at == kNoState && ns.items.size() + 1 == kSearched) {  // the list outgrows the search with this state: everybody into the table
+            ns.by_key.want_direct(direct_key_bits_);
+            for (uint32_t i = 0; i < ns.items.size(); ++i) ns.by_key.emplace(key_of(ns.items[i]), i);
+            ns.by_key.emplace(key, (uint32_t)ns.items.size());
+        }
+    } else {
+        ns.by_key.want_direct(direct_key_bits_);
+        auto [where, inserted] = ns.by_key.emplace(key, (uint32_t)ns.items.size());
+        if (!inserted) at = *where;
+    }
+    if (at == kNoState) {
         s.asked = 0;
         ns.items.push_back(s);
         ++waiting_;
         if (++states_ > limits_.max_states) throw std::runtime_error("query expands to too many states");
         return;
     }
-    State& have = ns.items[*where];
+    State& have = ns.items[at];
     if (have.shift < s.shift) have.shift = s.shift;  // k-1 and k behave alike from here on
     if (have.slot == s.slot) { drop(s.slot); return; }
     // absorb: have.path |= s.path
@@ -1149,7 +1165,7 @@ void QueryExpansion::prune(const std::vector<uint8_t>& dead) {
         const bool stopped_here = order_[c] == resume_item_;
         if (!sweep(ns.items, stopped_here ? class_holds : 1)) continue;
         ns.by_key.clear();
-        if (stopped_here || single_source_[order_[c]] || ns.append_only) continue;
+        if (stopped_here || single_source_[order_[c]] || ns.append_only || ns.items.size() < kSearched) continue;  // (short lists are searched: arrive)
         for (uint32_t i = 0; i < ns.items.size(); ++i) {
             const State& s = ns.items[i];
             const unsigned phase = s.shift < k - 1 ? s.shift : k - 1;

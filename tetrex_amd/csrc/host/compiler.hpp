@@ -215,6 +215,8 @@ class QueryExpansion {
     struct NodeStates { StateVec items; FlatMap by_key; bool append_only = false; std::vector<DenseRef> dense; };
     static constexpr uint32_t kMergeSample = 4096;  // lists shorter than this are not worth the question
     bool merging_pays(const StateVec& list);
+    uint64_t key_of(const State& s) const;
+    static constexpr uint32_t kSearched = 4, kNoState = 0xFFFFFFFFu;  // lists shorter than kSearched have no merge table (arrive)
     uint32_t code_mask(int32_t node) const;
     int32_t resume_item_ = KGraph::kNone;  // a fused class whose residues from resume_residue_ on are still to be rolled in (advance)
     uint32_t resume_residue_ = 0;
