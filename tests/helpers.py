@@ -90,7 +90,7 @@ def random_hibf(O, seed, user_bins=300, tmax=128, h=2, n_values=40, value_bits=2
     return ox, descs, values
 
 
-def layout_hibf(O, seed, user_bins, tmax=64, h=2, n_values=20, value_bits=20, direct=6, fpr=0.05, k=4):
+def layout_hibf(O, seed, user_bins, tmax=64, h=2, n_values=20, value_bits=20, direct=6, fpr=0.05, k=4, plant=None):
     """An HIBF shaped like the layouts seqan::hibf computes (reference include/index_hibf.h:114-129 hands the layout to it):
     every IBF has at most `tmax` technical bins; user bins are taken in a SHUFFLED order (the layout sorts them by size, so
     the user bins of a leaf are no run of ids); an IBF that cannot hold its user bins directly keeps a few of them as
@@ -98,6 +98,8 @@ def layout_hibf(O, seed, user_bins, tmax=64, h=2, n_values=20, value_bits=20, di
     sized children — as many levels as that takes.  Returns (oracle index, upload descriptors, values per user bin)."""
     rng = np.random.default_rng(seed)
     values = [rng.integers(0, 1 << value_bits, size=n_values, dtype=np.uint64) for _ in range(user_bins)]
+    if plant is not None:
+        plant(values)  # (a split bin's parts are runs of its value list: the first and the last value lie in different parts)
     ibfs = []
 
     def build(ubs):

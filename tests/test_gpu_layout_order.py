@@ -119,6 +119,51 @@ def test_a_65536_bin_three_level_tree(capi, oracle, monkeypatch):
     ix.free()
 
 
+def _value(s):
+    v = 0
+    for c in s:
+        v = (v << 5) | "ACDEFGHIKLMNPQRSTVWY".index(c)
+    return v
+
+
+@pytest.mark.parametrize("way", ["default", "enumerated", "level-kernels", "tracked", "untracked", "two-shards"])
+def test_a_motif_whose_kmers_lie_in_different_parts_of_a_split_user_bin(capi, oracle, monkeypatch, way):
+    """A user bin that the layout splits over several technical bins holds a k-mer when ANY part does, and the collector
+    combines masks per USER bin (reference include/index_hibf.h:132-147).  In layout order a split bin is therefore one bit,
+    its first part's: here the k-mers of `LMKACD` are planted in the FIRST, the LAST and a MIDDLE value of every seventh user
+    bin — different parts wherever such a bin is split —, so a row ANDed part by part loses those bins (found by
+    tools/gpu_regex_fuzz.py, seed 52: `((...){2,3})+` on this tree)."""
+    def plant(values):
+        for ub in range(0, len(values), 7):
+            values[ub][0], values[ub][-1], values[ub][len(values[ub]) // 2] = _value("LMKA"), _value("KACD"), _value("MKAC")
+    ox, descs, values = layout_hibf(oracle, 5, user_bins=900, tmax=32, n_values=30, plant=plant)
+    split = set()
+    for d in descs:
+        ubs = [int(u) for u in d["tb_to_user"] if int(u) != MERGED]
+        split |= {u for u in ubs if ubs.count(u) > 1}
+    assert len([u for u in range(0, 900, 7) if u in split]) >= 10
+    env = {"enumerated": {"TETREX_DENSE": "0"}, "level-kernels": {"TXQ_HIBF_LAYOUT_FUSED": "0"}, "tracked": {"TETREX_DENSE_TRACKED": "1"},
+           "untracked": {"TETREX_DENSE_TRACKED": "-1"}}.get(way, {})
+    for k_, v_ in env.items():
+        monkeypatch.setenv(k_, v_)
+    qs = ["LMKAC", "LMKACD", "MKACD", "L.KAC", "LMKA[CD]D", "LM..CD", "L.{1,2}KACD", "((...){2,3})+", "(LMKA|A)C.?D"]
+    if way == "two-shards":
+        shards = [capi.Index.upload_hibf(900, descs, shard_rank=r, n_shards=2, subtrees=True) for r in range(2)]
+        got, status, _ = capi.query_masks_sharded(shards, qs, False, 4)
+        for ix in shards:
+            ix.free()
+    else:
+        ix = capi.Index.upload_hibf(900, descs)
+        got, status, _ = ix.query_masks(qs, False, 4)
+        ix.free()
+    planted = 0
+    for q, g, st in zip(qs, got, status):
+        want = ox.expected_mask(q)[0]
+        assert st == 0 and np.array_equal(g, want), (way, q, np.nonzero(np.unpackbits((g ^ want).view(np.uint8), bitorder="little"))[0][:8])
+        planted += int(sum((int(want[u >> 6]) >> (u & 63)) & 1 for u in range(0, 900, 7) if u in split))
+    assert planted >= 30  # the answers do hold split bins that only the OR of their parts puts there
+
+
 def test_a_five_level_tree_is_not_taken_in_layout_order(capi, oracle, monkeypatch):
     """The fused layout-order steps follow at most three ancestors (txq_internal.hpp kMaxVDepth): a deeper tree must not get a
     layout order at upload — its sessions run in user-bin order through the descent, and still equal the oracle."""

@@ -199,9 +199,10 @@ void Index::release() {
                     (void*)session_cache.set[0].d_masks, (void*)session_cache.set[1].d_masks})
         if (p) (void)hipFree(p);
     session_cache = SessionCache{};
-    for (void* p : {(void*)d_vchunks, (void*)d_vpaths, (void*)d_vleaf, (void*)d_vuser, (void*)d_vgroups, (void*)d_vnodes})
+    for (void* p : {(void*)d_vchunks, (void*)d_vpaths, (void*)d_vleaf, (void*)d_vuser, (void*)d_vgroups, (void*)d_vnodes, (void*)d_vnonrep, (void*)d_vrep, (void*)d_vsplit_range, (void*)d_vsplits, (void*)d_vside})
         if (p) (void)hipFree(p);
     d_vchunks = nullptr; d_vpaths = nullptr; d_vleaf = nullptr; d_vuser = nullptr; d_vgroups = nullptr; d_vnodes = nullptr;
+    d_vnonrep = nullptr; d_vrep = nullptr; d_vsplit_range = nullptr; d_vsplits = nullptr; d_vside = nullptr;
     v_words = n_vchunks = 0;
     vlevels.clear();
     if (d_children) (void)hipFree(d_children);

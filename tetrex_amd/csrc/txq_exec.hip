@@ -239,6 +239,12 @@ template <> struct Lane<true> {
     static __device__ __forceinline__ T load_nt(const uint64_t* p) { return __builtin_nontemporal_load(reinterpret_cast<const T*>(p)); }
     static __device__ __forceinline__ T zero() { return T{0u, 0u, 0u, 0u}; }
     static __device__ __forceinline__ bool any(T v) { return (v.x | v.y | v.z | v.w) != 0u; }
+    static __device__ __forceinline__ bool test(T v, uint32_t bit) { return (((bit & 64u) ? ((bit & 32u) ? v.w : v.z) : ((bit & 32u) ? v.y : v.x)) >> (bit & 31u)) & 1u; }
+    static __device__ __forceinline__ T with_bit(T v, uint32_t bit) {
+        const uint32_t m = 1u << (bit & 31u);
+        if (bit & 64u) { if (bit & 32u) v.w |= m; else v.z |= m; } else { if (bit & 32u) v.y |= m; else v.x |= m; }
+        return v;
+    }
     static __device__ __forceinline__ T keep(T v, bool word0, bool word1) {  // zero the words that are not kept
         const uint32_t m0 = word0 ? ~0u : 0u, m1 = word1 ? ~0u : 0u;
         return T{v.x & m0, v.y & m0, v.z & m1, v.w & m1};
@@ -257,6 +263,8 @@ template <> struct Lane<false> {
     static __device__ __forceinline__ T load_nt(const uint64_t* p) { return __builtin_nontemporal_load(p); }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool any(T v) { return v != 0; }
+    static __device__ __forceinline__ bool test(T v, uint32_t bit) { return (v >> (bit & 63u)) & 1ULL; }
+    static __device__ __forceinline__ T with_bit(T v, uint32_t bit) { return v | (1ULL << (bit & 63u)); }
     static __device__ __forceinline__ T keep(T v, bool word0, bool) { return word0 ? v : 0; }
     static __device__ __forceinline__ T shfl_xor(T v, uint32_t o) {
         return ((uint64_t)(uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), (int)o) << 32) | (uint32_t)__shfl_xor((int)(uint32_t)v, (int)o);
@@ -280,6 +288,7 @@ struct FlatRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; };
     static constexpr bool kRootByLane = false;
+    static constexpr bool kPullsSplit = false;
     static constexpr int kPushUnroll = 3;
     IbfDev f;
     uint32_t c;
@@ -315,6 +324,7 @@ struct TableRows {
     using T = typename L::T;
     struct Loads { T x[2]; };
     static constexpr bool kRootByLane = false;
+    static constexpr bool kPullsSplit = false;
     static constexpr int kPushUnroll = 3;
     const uint64_t* table;
     uint32_t stride;  // words per row (the session's mask width)
@@ -344,6 +354,7 @@ struct TreeRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; uint64_t r[H]; uint64_t value; const uint64_t* src; bool hit; };
     static constexpr bool kRootByLane = false;
+    static constexpr bool kPullsSplit = false;
     static constexpr int kPushUnroll = 3;
     HibfNode root;
     const ChildRec* children;
@@ -431,6 +442,7 @@ struct InterleavedRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; uint64_t r[H]; };
     static constexpr bool kRootByLane = false;
+    static constexpr bool kPullsSplit = false;
     static constexpr int kPushUnroll = 3;
     IbfDev f;  // the interleaved children
     HibfNode root;
@@ -475,6 +487,7 @@ struct InterleavedRows {
 template <int H, bool WIDE>
 struct TreeRowsByLane : TreeRows<H, WIDE> {
     static constexpr bool kRootByLane = true;
+    static constexpr bool kPullsSplit = false;
 };
 
 // A general HIBF in layout order (txq_internal.hpp VChunk): the lane's 16 bytes are two row words of ONE IBF of the tree, and
@@ -488,9 +501,15 @@ struct PathRows {
     using T = typename L::T;
     struct Loads { T x[H + 1]; uint64_t g[kMaxVDepth][H]; uint64_t sv[H]; const uint64_t* src; bool hit; };
     static constexpr bool kRootByLane = false;
+    static constexpr bool kPullsSplit = true;  // split user bins: pull_split below
     static constexpr int kPushUnroll = 1;  // (a lane keeps its ancestors' gates in registers: one residue's loads at a time)
     const VChunk* chunks;
     const VPath* paths;
+    const VSplitRange* split_range;  // per chunk: its representatives of split user bins (null: the tree has none)
+    const VSplit* splits;
+    uint32_t sp_first, sp_count, sp_bit0, sp_stride;
+    const uint64_t* sp_side;
+    T sp_reps;  // the chunk's representatives
     // the lane's chunk: its IBF and the ancestors' gates
     const uint64_t* cw;
     uint32_t c, c_rows, c_packed, col, depth;
@@ -498,6 +517,17 @@ struct PathRows {
     uint32_t a_rows[kMaxVDepth], a_packed[kMaxVDepth], a_word[kMaxVDepth], a_bit[kMaxVDepth];
     __device__ __forceinline__ void prepare(uint32_t chunk) {
         c = chunk;
+        sp_first = sp_count = 0;
+        if (split_range) {
+            const VSplitRange r = split_range[chunk];
+            sp_first = r.first;
+            sp_count = r.count;
+            sp_bit0 = r.bit0;
+            sp_stride = r.side_stride;
+            sp_side = (const uint64_t*)r.side;
+            if constexpr (WIDE) sp_reps = T{r.reps[0], r.reps[1], r.reps[2], r.reps[3]};
+            else sp_reps = (uint64_t)r.reps[0] | ((uint64_t)r.reps[1] << 32);
+        }
         const VChunk rec = chunks[chunk];
         cw = (const uint64_t*)rec.words;
         c_rows = rec.bin_size;
@@ -561,6 +591,38 @@ struct PathRows {
         T y = l.x[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) y &= l.x[h];
+        return y;
+    }
+    // Split user bins (txq_internal.hpp VSplit).  y = mask & M[k-mer] of this chunk as the IBF's rows give it, `mask` in the
+    // session's form — a split bin is its representative's bit.  A representative that is set in `mask` also stays when ANOTHER
+    // part of its bin holds the k-mer: the k-mer's h rows of the IBF's side matrix, ANDed, are those parts' hits — one word per
+    // row for the whole chunk, asked only when a representative is open; a hit names its representative through the chunk's
+    // entries (the other parts' own bits are zero in `mask`, so they vanish from y by themselves).
+    __device__ __forceinline__ T pull_split(const Loads& l, T mask, T y) const {
+        if (!sp_count || !l.hit) return y;
+        const T open = mask & sp_reps & ~y;  // representatives that are asked for and that their own part does not answer
+        if (!L::any(open)) return y;
+        const uint32_t shift = (c_packed >> 20) & 63u, hf = (c_packed >> 26) & 7u;
+        const bool two = sp_bit0 + sp_count > 64u;  // (more parts than the first word has room for: they go on in the next)
+        uint64_t lo = ~0ULL, hi = two ? ~0ULL : 0ULL;
+#pragma unroll
+        for (int i = 0; i < H; ++i)
+            if ((uint32_t)i < hf) {
+                const uint64_t* p = sp_side + (size_t)hash_row_seeded32(l.sv[i], shift, c_rows) * sp_stride;
+                lo &= p[0];
+                if (two) hi &= p[1];
+            }
+        const uint32_t in_lo = two ? 64u - sp_bit0 : sp_count;
+        lo = (lo >> sp_bit0) & (in_lo >= 64u ? ~0ULL : ((1ULL << in_lo) - 1ULL));
+        if (two) hi &= (1ULL << (sp_count - in_lo)) - 1ULL;  // (fewer than 64 there: a chunk has at most 127 parts)
+        for (; lo; lo &= lo - 1) {
+            const uint32_t rep = splits[sp_first + (uint32_t)__builtin_ctzll(lo)].rep_bit;
+            if (L::test(open, rep)) y = L::with_bit(y, rep);
+        }
+        for (; hi; hi &= hi - 1) {
+            const uint32_t rep = splits[sp_first + in_lo + (uint32_t)__builtin_ctzll(hi)].rep_bit;
+            if (L::test(open, rep)) y = L::with_bit(y, rep);
+        }
         return y;
     }
 };
@@ -748,7 +810,11 @@ __global__ __launch_bounds__(256) void dense_kernel(ROWS rows, const DenseTile* 
                         if (have[u]) rows.issue_late(x[u]);
 #pragma unroll
                     for (int u = 0; u < UA; ++u)
-                        if (have[u]) acc |= rows.combine(x[u]);
+                        if (have[u]) {
+                            T y = rows.combine(x[u]);
+                            if constexpr (ROWS::kPullsSplit) y = rows.pull_split(x[u], x[u].x[H], y);
+                            acc |= y;
+                        }
                 }
             }
             for (uint32_t o = G; o < lanes; o <<= 1) acc |= L::shfl_xor(acc, o);
@@ -1061,7 +1127,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     for (int u = 0; u < UA; ++u) rows.template issue_late<false>(x[u]);
 #pragma unroll
                     for (int u = 0; u < UA; ++u) {
-                        const T y = sv & rows.combine(x[u]);
+                        T y = sv & rows.combine(x[u]);
+                        if constexpr (ROWS::kPullsSplit) y = rows.pull_split(x[u], sv, y);
                         const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i + u]];
                         if (L::any(y) && rk != 0xFFu) {
                             atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
@@ -1075,7 +1142,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void s
                     if (P.canonical) v = canonical_dna(v, P.k);
                     rows.template issue<false>(nullptr, v, x0);
                     rows.template issue_late<false>(x0);
-                    const T y = sv & rows.combine(x0);
+                    T y = sv & rows.combine(x0);
+                    if constexpr (ROWS::kPullsSplit) y = rows.pull_split(x0, sv, y);
                     const uint32_t rk = dg.rank[P.pos - 1][codes[P.pos][i]];
                     if (L::any(y) && rk != 0xFFu) {
                         atomic_or_chunk<WIDE>(q.dst + (size_t)(dst0 + rk) * W + (size_t)c * L::kWords, y);
@@ -2567,7 +2635,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                 const LevelUnits lu{d_units + first, d_ops, d_masks, ride ? (uint32_t)cnt : 0u, g_units_log2};
                 hipError_t e;
                 if (vspace) {  // (rows are whole 16-byte chunks: WIDE; two predecessors in flight — a lane keeps its ancestors' gates in registers)
-                    auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
+                    auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; r.split_range = ix.d_vsplit_range; r.splits = ix.d_vsplits; };
                     e = wide ? launch_dense<true, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st)
                              : launch_dense<false, PathRows>(2, ix.tree_hash_max, rows_path, d_tiles + first_tile, plan[l].tiles, d_dops, d_optr, s.d_base, np, W, g_dense, sl_dense, bv.dense, lu, st);
                 } else if (tree) {
@@ -2646,7 +2714,7 @@ int session_stage(Session& s, const void* blob_v, size_t bytes, const uint32_t* 
                         else { FlatRows<1, false> none1{}; sparse_kernel<1, false, FlatRows<1, false>, false><<<(unsigned)grid, 256, 0, st>>>(none1, gr, ng, counts, prefix, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, kSparseChunk); }
                         e = hipGetLastError();
                     } else if (vspace) {
-                        auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; };
+                        auto rows_path = [&](auto& r) { r.chunks = ix.d_vchunks; r.paths = ix.d_vpaths; r.split_range = ix.d_vsplit_range; r.splits = ix.d_vsplits; };
                         e = wide ? launch_sparse<true, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st)
                                  : launch_sparse<false, PathRows>(ix.tree_hash_max, rows_path, gr, ng, counts, prefix, grid, d_dops, d_optr, s.d_base, np, W, g_dense, bv.dense, lu, step_chunk, st);
                     } else if (interleaved) {

@@ -29,6 +29,10 @@ struct HibfView {
     // record, nodes[e] (no next_ibf_id -> descriptor chain); nodes[total technical bins] is the root
     const struct HibfNode* nodes;
     uint32_t root_entry;
+    // LAYOUT rows of trees with split user bins (txq_internal.hpp VSplit): per row word the bits that are not their bin's
+    // representative, and for such a bit the representative's position in the row (null: no split bins)
+    const uint64_t* nonrep = nullptr;
+    const uint32_t* rep_pos = nullptr;
 };
 
 
@@ -284,6 +288,28 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                             if (mw >= word0 && mw < (uint64_t)word0 + w_out) atomicOr((unsigned long long*)(row + (mw - word0)), 1ULL << (ub & 63));
                         }
                     }
+                }
+            }
+            if constexpr (LAYOUT) {
+                // Split user bins (txq_internal.hpp VSplit): a bin is its representative — the bits of its other parts move there.
+                // The round's IBFs have all their words in the row now (plain stores above, every IBF by its own lanes): each lane
+                // looks at its words once more; the rare word that holds such a bit gives it up with atomics.
+                if (t.nonrep) {  // (uniform)
+                    wave_sync();
+                    for (uint32_t wi = 0; wi < w_iters; ++wi)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const uint32_t w = (wi * G + sub) * 4u + (uint32_t)q;
+                            if (!live || w >= words_per_row) continue;
+                            const uint32_t j = nd.ident_word + w;
+                            uint64_t moved = row[j] & gload(t.nonrep + j);
+                            if (!moved) continue;
+                            atomicAnd((unsigned long long*)(row + j), ~moved);
+                            for (; moved; moved &= moved - 1) {
+                                const uint32_t to = t.rep_pos[(size_t)j * 64 + (uint32_t)__builtin_ctzll(moved)];
+                                atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
+                            }
+                        }
                 }
             }
         }
@@ -697,6 +723,25 @@ __global__ __launch_bounds__(256) void hibf_layout_to_user_kernel(const uint64_t
 // Layout order for a tree that is not regular (txq_internal.hpp VChunk): the rows of all IBFs, levels ascending, each IBF
 // padded to whole 16-byte chunks; per chunk its record, per IBF its ancestors, which bits are user bins, and the user
 // bin behind every bit.  Single shard only (a column shard of the USER bins does not cut the layout-order row in one piece).
+// The side matrix of an IBF with split user bins (txq_internal.hpp VSplit): one thread per row copies the bits of the IBF's
+// non-representative parts (`entries`) to their places in the side row (`pos`: word * 64 + bit).
+__global__ __launch_bounds__(256) void build_side_matrix_kernel(const uint64_t* __restrict__ words, uint32_t stride, uint64_t rows, const VSplit* __restrict__ entries,
+                                                                const uint32_t* __restrict__ pos, uint32_t n_entries, uint64_t* __restrict__ side, uint32_t side_stride) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const uint64_t* row = words + r * stride;
+    uint64_t* out = side + r * side_stride;
+    uint64_t acc = 0;
+    uint32_t word = 0;
+    for (uint32_t e = 0; e < n_entries; ++e) {  // (the entries are in side order)
+        const uint32_t p = pos[e];
+        if ((p >> 6) != word) { out[word] = acc; acc = 0; word = p >> 6; }
+        const VSplit sp = entries[e];
+        acc |= ((row[sp.part_word] >> sp.part_bit) & 1ULL) << (p & 63);
+    }
+    out[word] = acc;
+}
+
 static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::vector<int>& level, const std::vector<uint64_t>& next,
                               const std::vector<uint64_t>& tbu, const std::vector<uint64_t>& off, const std::vector<HibfNode>* nodes) {
     const uint64_t n = desc.n_ibf;
@@ -722,6 +767,7 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     if (pad_word) ++words;
     if (words >= (1u << 26)) return TXQ_OK;
     std::vector<VChunk> chunks;
+    std::vector<uint32_t> chunk0(n, 0);  // an IBF's first chunk
     std::vector<VPath> paths(n);
     std::vector<uint64_t> leaf(words, 0);
     std::vector<uint32_t> vuser(words * 64, kNoGate);
@@ -738,6 +784,7 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
             if (L.group_first.empty() || group_bytes + bytes > ((uint64_t)2 << 20)) { L.group_first.push_back((uint32_t)chunks.size()); group_bytes = 0; }
             group_bytes += bytes;
             const uint64_t padded = (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords;
+            chunk0[i] = (uint32_t)chunks.size();
             for (uint64_t c = 0; c < padded; c += cwords) {
                 VChunk r{};
                 r.words = (uint64_t)(uintptr_t)f.words;
@@ -807,6 +854,109 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     TXQ_HIP(hipMemcpy(ix.d_vleaf, leaf.data(), leaf.size() * 8, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_vuser, vuser.data(), vuser.size() * 4, hipMemcpyHostToDevice));
     TXQ_HIP(hipMemcpy(ix.d_vgroups, groups.data(), groups.size() * 4, hipMemcpyHostToDevice));
+    {   // split user bins (txq_internal.hpp VSplit): per IBF the technical bins by user bin; the lowest part represents the bin
+        std::vector<uint64_t> nonrep(words, 0);
+        std::vector<uint32_t> rep_pos;
+        std::vector<std::vector<VSplit>> per_chunk(chunks.size());
+        bool any = false;
+        std::vector<std::pair<uint64_t, uint64_t>> bins_of;  // (user bin, technical bin) of one IBF
+        for (uint64_t i = 0; i < n; ++i) {
+            bins_of.clear();
+            for (uint64_t b = 0; b < desc.ibf[i].bins; ++b)
+                if (tbu[off[i] + b] != TXQ_MERGED_BIN) bins_of.emplace_back(tbu[off[i] + b], b);
+            std::sort(bins_of.begin(), bins_of.end());
+            for (size_t at = 0; at < bins_of.size();) {
+                size_t end = at + 1;
+                while (end < bins_of.size() && bins_of[end].first == bins_of[at].first) ++end;
+                if (end - at > 1) {
+                    if (!any) { any = true; rep_pos.assign(words * 64, kNoGate); }
+                    const uint64_t rep = bins_of[at].second;  // (sorted: the lowest technical bin)
+                    const uint32_t chunk = chunk0[i] + (uint32_t)((rep >> 6) / cwords);
+                    const uint16_t rep_bit = (uint16_t)(rep - (uint64_t)((rep >> 6) / cwords) * cwords * 64);
+                    for (size_t j = at + 1; j < end; ++j) {
+                        const uint64_t part = bins_of[j].second;
+                        nonrep[seg[i] + (part >> 6)] |= 1ULL << (part & 63);
+                        rep_pos[(seg[i] + (part >> 6)) * 64 + (part & 63)] = (uint32_t)((seg[i] + (rep >> 6)) * 64 + (rep & 63));
+                        per_chunk[chunk].push_back(VSplit{(uint32_t)(part >> 6), rep_bit, (uint16_t)(part & 63)});
+                    }
+                }
+                at = end;
+            }
+        }
+        if (any) {
+            std::vector<VSplitRange> ranges(chunks.size());
+            std::vector<VSplit> flat;
+            std::vector<uint32_t> side_pos;             // per entry: its bit in its IBF's side row (word * 64 + bit)
+            std::vector<uint64_t> side_off(n + 1, 0);   // per IBF: first word of its side matrix in d_vside
+            std::vector<uint32_t> side_stride(n, 0);
+            for (uint64_t i = 0; i < n; ++i) {
+                uint32_t word = 0, used = 0, last_word = 0;
+                bool has = false;
+                const uint64_t padded = (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords;
+                for (uint32_t c = chunk0[i]; c < chunk0[i] + padded / cwords; ++c) {
+                    std::stable_sort(per_chunk[c].begin(), per_chunk[c].end(), [](const VSplit& x, const VSplit& y) { return x.rep_bit < y.rep_bit; });
+                    const uint32_t cnt = (uint32_t)per_chunk[c].size();
+                    ranges[c] = VSplitRange{(uint32_t)flat.size(), cnt, {0, 0, 0, 0}, 0, 0, 0};
+                    if (!cnt) continue;
+                    has = true;
+                    // a chunk's parts (at most 127) are consecutive side bits from bit0 of one word on, into the next word if need be
+                    if (used && used + cnt > 64) { ++word; used = 0; }
+                    ranges[c].bit0 = used;
+                    ranges[c].side = word;  // (the word for now; the pointer once the matrices have their place)
+                    for (uint32_t e = 0; e < cnt; ++e) {
+                        ranges[c].reps[per_chunk[c][e].rep_bit >> 5] |= 1u << (per_chunk[c][e].rep_bit & 31);
+                        side_pos.push_back(word * 64 + used + e);
+                    }
+                    used += cnt;
+                    last_word = word + (used - 1) / 64;
+                    while (used >= 64) { used -= 64; ++word; }
+                    flat.insert(flat.end(), per_chunk[c].begin(), per_chunk[c].end());
+                }
+                side_stride[i] = has ? last_word + 1 : 0;
+                side_off[i + 1] = side_off[i] + (uint64_t)side_stride[i] * ix.ibf[i].bin_size;
+            }
+            TXQ_HIP(hipMalloc((void**)&ix.d_vside, std::max<uint64_t>(side_off[n], 1) * 8));
+            TXQ_HIP(hipMemset(ix.d_vside, 0, std::max<uint64_t>(side_off[n], 1) * 8));
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint64_t padded = (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords;
+                for (uint32_t c = chunk0[i]; c < chunk0[i] + padded / cwords; ++c) {
+                    ranges[c].side_stride = side_stride[i];
+                    ranges[c].side = (uint64_t)(uintptr_t)(ix.d_vside + side_off[i] + ranges[c].side);
+                }
+            }
+            TXQ_HIP(hipMalloc((void**)&ix.d_vnonrep, nonrep.size() * 8));
+            TXQ_HIP(hipMalloc((void**)&ix.d_vrep, rep_pos.size() * 4));
+            TXQ_HIP(hipMalloc((void**)&ix.d_vsplit_range, ranges.size() * sizeof(VSplitRange)));
+            TXQ_HIP(hipMalloc((void**)&ix.d_vsplits, flat.size() * sizeof(VSplit)));
+            TXQ_HIP(hipMemcpy(ix.d_vnonrep, nonrep.data(), nonrep.size() * 8, hipMemcpyHostToDevice));
+            TXQ_HIP(hipMemcpy(ix.d_vrep, rep_pos.data(), rep_pos.size() * 4, hipMemcpyHostToDevice));
+            TXQ_HIP(hipMemcpy(ix.d_vsplit_range, ranges.data(), ranges.size() * sizeof(VSplitRange), hipMemcpyHostToDevice));
+            TXQ_HIP(hipMemcpy(ix.d_vsplits, flat.data(), flat.size() * sizeof(VSplit), hipMemcpyHostToDevice));
+            {   // the side matrices: every IBF's entries are consecutive in `flat` (its chunks are)
+                uint32_t* d_pos = nullptr;
+                TXQ_HIP(hipMalloc((void**)&d_pos, std::max<size_t>(side_pos.size(), 1) * 4));
+                TXQ_HIP(hipMemcpy(d_pos, side_pos.data(), side_pos.size() * 4, hipMemcpyHostToDevice));
+                for (uint64_t i = 0; i < n; ++i) {
+                    if (!side_stride[i]) continue;
+                    const uint64_t padded = (desc.ibf[i].bin_words + cwords - 1) / cwords * cwords;
+                    const uint32_t e0 = ranges[chunk0[i]].first;
+                    const VSplitRange& last = ranges[chunk0[i] + padded / cwords - 1];
+                    const uint32_t e1 = last.first + last.count;
+                    const IbfDev& f = ix.ibf[i];
+                    build_side_matrix_kernel<<<(unsigned)((f.bin_size + 255) / 256), 256>>>(f.words, f.stride, f.bin_size, ix.d_vsplits + e0, d_pos + e0, e1 - e0,
+                                                                                       ix.d_vside + side_off[i], side_stride[i]);
+                }
+                hipError_t e = hipDeviceSynchronize();
+                (void)hipFree(d_pos);
+                if (e != hipSuccess) return fail_hip(e, "building the side matrices of split bins");
+            }
+            ix.device_bytes += side_off[n] * 8;
+            ix.device_bytes += nonrep.size() * 8 + rep_pos.size() * 4 + ranges.size() * sizeof(VSplitRange) + flat.size() * sizeof(VSplit);
+            // the ONES of a layout-order session: a split bin is its representative
+            for (size_t w = 0; w < leaf.size(); ++w) leaf[w] &= ~nonrep[w];
+            TXQ_HIP(hipMemcpy(ix.d_vleaf, leaf.data(), leaf.size() * 8, hipMemcpyHostToDevice));
+        }
+    }
     ix.v_words = (uint32_t)words;
     ix.v_inner_words = 0;
     for (uint64_t i = 0; i < n; ++i) {
@@ -835,7 +985,9 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     if (wave_bytes > (64u << 10)) return false;
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
-    const HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged, ix.d_merged_off, (const HibfNode*)ix.d_vnodes, (uint32_t)ix.hibf_total_tbs};
+    HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged, ix.d_merged_off, (const HibfNode*)ix.d_vnodes, (uint32_t)ix.hibf_total_tbs};
+    t.nonrep = ix.d_vnonrep;
+    t.rep_pos = ix.d_vrep;
     unsigned waves = 4;
     while (waves > 1 && wave_bytes * waves > (64u << 10)) waves >>= 1;
     const size_t want_waves = kn.hibf_waves > 0 ? (size_t)kn.hibf_waves : (size_t)256 * 64;
@@ -861,12 +1013,40 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     return true;
 }
 
+// Rows of plain k-mers as the kernels above write them hold every technical bin's own bit; a split user bin becomes its
+// representative here (txq_internal.hpp VSplit): one thread per row word, the rare word with a set non-representative bit moves it.
+__global__ __launch_bounds__(256) void unify_split_rows_kernel(uint64_t* __restrict__ rows, size_t n_words, uint32_t w_out,
+                                                               const uint64_t* __restrict__ nonrep, const uint32_t* __restrict__ rep_pos) {
+    for (size_t at = (size_t)blockIdx.x * blockDim.x + threadIdx.x; at < n_words; at += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t j = (uint32_t)(at % w_out);
+        const uint64_t nr = nonrep[j];
+        if (!nr) continue;
+        uint64_t moved = rows[at] & nr;
+        if (!moved) continue;
+        uint64_t* const row = rows + (at - j);
+        atomicAnd((unsigned long long*)(row + j), ~moved);  // (another thread may be setting a representative in this very word)
+        for (; moved; moved &= moved - 1) {
+            const uint32_t to = rep_pos[(size_t)j * 64 + (uint32_t)__builtin_ctzll(moved)];
+            atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
+        }
+    }
+}
+
+static int unify_split_rows(const Index& ix, uint64_t* d_rows, size_t n, hipStream_t s) {
+    if (!ix.d_vnonrep || !n) return TXQ_OK;
+    const size_t n_words = n * (size_t)ix.v_words;
+    const size_t blocks = std::min<size_t>((n_words + 255) / 256, (size_t)256 * 32);
+    unify_split_rows_kernel<<<(unsigned)blocks, 256, 0, s>>>(d_rows, n_words, ix.v_words, ix.d_vnonrep, ix.d_vrep);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? TXQ_OK : fail_hip(e, "split-bin kernel launch");
+}
+
 int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all, uint64_t* d_rows_all, hipStream_t s) {
     if (!ix.d_vchunks) return fail(TXQ_ERR_STATE, "the index has no layout order");
     if (!n_all) return TXQ_OK;
     {
         int rc = TXQ_OK;
-        if (layout_order_fused(ix, d_kmers_all, n_all, d_rows_all, s, &rc)) return rc;
+        if (layout_order_fused(ix, d_kmers_all, n_all, d_rows_all, s, &rc)) return rc;  // (split bins: unified as the rows are written)
     }
     const uint32_t tile = 2048;
     // A level reads the gates the level above it wrote (the words of the IBFs that have children: v_inner_words of a row):
@@ -895,7 +1075,7 @@ int hibf_probe_layout_order(Index& ix, const uint64_t* d_kmers_all, size_t n_all
             if (e != hipSuccess) return fail_hip(e, "layout-order level kernel launch");
         }
     }
-    return TXQ_OK;
+    return unify_split_rows(ix, d_rows_all, n_all, s);
 }
 
 int hibf_layout_to_user(const Index& ix, const uint64_t* d_rows, size_t n, uint64_t* d_out, hipStream_t s) {

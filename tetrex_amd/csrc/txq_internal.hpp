@@ -100,6 +100,24 @@ struct VPath {           // the ancestors of an IBF, root first: whose merged bi
     uint32_t depth, pad;
     struct { uint64_t words; uint32_t bin_size, packed, word, bit; } anc[kMaxVDepth];
 };
+// Split user bins in layout order.  A user bin that the layout spreads over several technical bins of one IBF holds a k-mer when
+// ANY of its parts does, and masks are combined per USER bin (reference include/index_hibf.h:132-147 ORs the parts before the
+// collector ANDs anything) — so in a layout-order row a split bin is ONE bit, its first part's (the representative), which
+// stands for the OR of the parts; the other parts' bits are always zero.  Rows of plain k-mers are put into that form as they
+// are written (hibf_fused_kernel<G, LAYOUT>) or right after (unify_split_rows_kernel behind the level kernels).  A fused step
+// (PathRows) works on one 16-byte chunk of an IBF's row and does not see the other parts: for them every IBF with split bins has
+// a SIDE matrix — the columns of its non-representative parts once more, packed so that the parts belonging to one chunk's
+// representatives are consecutive bits of one 64-bit word per row.  ANDing the k-mer's h side rows gives those parts' hits
+// exactly (they are the IBF's own columns), and a hit sets its representative: VSplit entry e of the chunk (sorted by
+// representative) is side bit `bit0 + e`.
+struct VSplit { uint32_t part_word; uint16_t rep_bit, part_bit; };  // word column and bit of the part in the IBF's row; its representative's bit in the chunk
+struct VSplitRange {
+    uint32_t first, count;   // the chunk's entries in Index::d_vsplits (fewer than the chunk has bits)
+    uint32_t reps[4];        // the chunk's bits that are representatives (bit b of the 128: reps[b >> 5] >> (b & 31))
+    uint64_t side;           // device pointer: row 0 of the chunk's (first) word in the IBF's side matrix — entry e is bit bit0 + e from there
+    uint32_t side_stride;    // words per side row
+    uint32_t bit0;           // the chunk's first bit in that word
+};
 struct VLevel { uint32_t first_chunk, n_chunks; std::vector<uint32_t> group_first; };  // groups: chunk ranges whose IBFs share an L2's worth of rows
 
 // One HIBF work item: k-mer `kmer` (index into the batch) must be looked up in IBF `ibf`.
@@ -148,6 +166,11 @@ struct Index {
     uint64_t* d_vleaf = nullptr;     // [v_words] bits of technical bins that are user bins (the ONES of a layout-order session)
     uint32_t* d_vuser = nullptr;     // [v_words * 64] user bin of a layout-order bit (kNoGate: none)
     uint32_t* d_vgroups = nullptr;   // per level its groups' first chunks, concatenated (+ end)
+    uint64_t* d_vnonrep = nullptr;   // [v_words] bits of the parts of split user bins that are not their representative (null: no split bins)
+    uint32_t* d_vrep = nullptr;      // [v_words * 64] for such a bit: the representative's bit position in the row
+    VSplitRange* d_vsplit_range = nullptr;  // [n_vchunks]
+    VSplit* d_vsplits = nullptr;
+    uint64_t* d_vside = nullptr;     // the side matrices of all IBFs with split bins
     void* d_vnodes = nullptr;        // HibfNode records (as d_nodes) whose ident_word is the IBF's first word in the layout-order row
     uint32_t v_inner_words = 0;  // of a row: the words of IBFs with merged bins (what the next level reads as gates)
     uint32_t v_words = 0, n_vchunks = 0, v_depth = 0, v_chunk_words = 2;  // (chunks of 16 bytes, or of 8 for trees of narrow IBFs)
