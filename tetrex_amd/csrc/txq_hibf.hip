@@ -209,11 +209,22 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
             }
             // most rounds only meet leaves: then nothing is loaded or done for merged bins
             const bool any_merged = __ballot(live && nd.has_merged()) != 0;
+            uint64_t moved[4] = {0, 0, 0, 0};  // LAYOUT, split user bins: bits of this lane's words that belong at their bin's representative
             for (uint32_t wi = 0; wi < w_iters; ++wi) {
                 const uint32_t w0 = (wi * G + sub) * 4u;
                 uint64_t acc[4] = {0, 0, 0, 0}, mg[4] = {0, 0, 0, 0}, dn[4] = {0, 0, 0, 0};
+                if constexpr (LAYOUT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) moved[q] = 0;
+                }
                 if (live && w0 < words_per_row) {  // every load of the round issues before the first is used
                     const uint64_t* words = (const uint64_t*)nd.words;
+                    if constexpr (LAYOUT) {
+                        if (t.nonrep)  // (uniform) split user bins: which of these words' bits are not their bin's representative
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                if (w0 + (uint32_t)q < words_per_row) moved[q] = gload(t.nonrep + nd.ident_word + w0 + (uint32_t)q);
+                    }
                     if (stride == 1) {
                         uint64_t x = ~0ULL;
 #pragma unroll
@@ -265,7 +276,8 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                     }
                     const uint32_t w = w0 + (uint32_t)q;
                     if constexpr (LAYOUT) {
-                        if (live && w < words_per_row) row[nd.ident_word + w] = acc[q];
+                        moved[q] &= acc[q];  // (the bits that move to their representative once the round's words are in the row)
+                        if (live && w < words_per_row) row[nd.ident_word + w] = acc[q] & ~moved[q];
                         continue;
                     }
                     uint64_t hits = acc[q] & ~mg[q];
@@ -291,25 +303,21 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                 }
             }
             if constexpr (LAYOUT) {
-                // Split user bins (txq_internal.hpp VSplit): a bin is its representative — the bits of its other parts move there.
-                // The round's IBFs have all their words in the row now (plain stores above, every IBF by its own lanes): each lane
-                // looks at its words once more; the rare word that holds such a bit gives it up with atomics.
+                // Split user bins (txq_internal.hpp VSplit): a bin is its representative — the bits of its other parts were held
+                // back from the row above (their mask came with the rows' loads) and go to the representative now that all of the
+                // round's words are in the row (plain stores, every IBF by its own lanes): LDS atomics for the rare word that has any.
+                // (w_iters == 1 wherever this kernel runs in layout order: an IBF of more than 256 * G technical bins would need
+                // a second pass here.)
                 if (t.nonrep) {  // (uniform)
                     wave_sync();
-                    for (uint32_t wi = 0; wi < w_iters; ++wi)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const uint32_t w = (wi * G + sub) * 4u + (uint32_t)q;
-                            if (!live || w >= words_per_row) continue;
-                            const uint32_t j = nd.ident_word + w;
-                            uint64_t moved = row[j] & gload(t.nonrep + j);
-                            if (!moved) continue;
-                            atomicAnd((unsigned long long*)(row + j), ~moved);
-                            for (; moved; moved &= moved - 1) {
-                                const uint32_t to = t.rep_pos[(size_t)j * 64 + (uint32_t)__builtin_ctzll(moved)];
-                                atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
-                            }
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t j = nd.ident_word + sub * 4u + (uint32_t)q;
+                        for (uint64_t m = moved[q]; m; m &= m - 1) {
+                            const uint32_t to = t.rep_pos[(size_t)j * 64 + (uint32_t)__builtin_ctzll(m)];
+                            atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
                         }
+                    }
                 }
             }
         }
@@ -997,6 +1005,7 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     int g = 1;
     while (g < 64 && (uint32_t)g < quads) g <<= 1;
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
+    if (w_iters > 1 && ix.d_vnonrep) return false;  // (split bins are unified for one pass of words per lane: the level kernels then)
     hipError_t e;
 #define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr)
     switch (g) {
