@@ -518,7 +518,8 @@ struct PathRows {
     __device__ __forceinline__ void prepare(uint32_t chunk) {
         c = chunk;
         sp_first = sp_count = 0;
-        if (split_range) {
+        const VChunk rec = chunks[chunk];
+        if (split_range && ((rec.packed >> 30) & 1u)) {
             const VSplitRange r = split_range[chunk];
             sp_first = r.first;
             sp_count = r.count;
@@ -528,7 +529,6 @@ struct PathRows {
             if constexpr (WIDE) sp_reps = T{r.reps[0], r.reps[1], r.reps[2], r.reps[3]};
             else sp_reps = (uint64_t)r.reps[0] | ((uint64_t)r.reps[1] << 32);
         }
-        const VChunk rec = chunks[chunk];
         cw = (const uint64_t*)rec.words;
         c_rows = rec.bin_size;
         c_packed = rec.packed;

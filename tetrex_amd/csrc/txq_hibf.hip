@@ -932,6 +932,10 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
                     ranges[c].side = (uint64_t)(uintptr_t)(ix.d_vside + side_off[i] + ranges[c].side);
                 }
             }
+            // a chunk that holds representatives says so in its record (VChunk::packed bit 30): the others never look at their range
+            for (size_t c = 0; c < chunks.size(); ++c)
+                if (ranges[c].count) chunks[c].packed |= 1u << 30;
+            TXQ_HIP(hipMemcpy(ix.d_vchunks, chunks.data(), chunks.size() * sizeof(VChunk), hipMemcpyHostToDevice));
             TXQ_HIP(hipMalloc((void**)&ix.d_vnonrep, nonrep.size() * 8));
             TXQ_HIP(hipMalloc((void**)&ix.d_vrep, rep_pos.size() * 4));
             TXQ_HIP(hipMalloc((void**)&ix.d_vsplit_range, ranges.size() * sizeof(VSplitRange)));

@@ -87,7 +87,7 @@ static_assert(sizeof(ChildRec) == 16, "one 16-byte load per lane");
 struct VChunk {          // one chunk of the layout-order row: two row words (16 bytes) of one IBF, or one (Index::v_chunk_words)
     uint64_t words;      // the IBF's rows
     uint32_t bin_size;   // rows (< 2^32)
-    uint32_t packed;     // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | single-word rows (29)
+    uint32_t packed;     // stride (bits 0-19) | hash_shift (20-25) | hash_funs (26-28) | single-word rows (29) | holds representatives of split user bins (30)
     uint32_t col;        // word column of the chunk within the IBF's row
     uint32_t gate_word;  // layout-order word that holds the parent's merged bin leading here (kNoGate: the root)
     uint32_t gate_bit;
