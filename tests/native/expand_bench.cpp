@@ -14,7 +14,7 @@ struct Fake final : StageExecutor {
 };
 int main(int argc, char** argv) {
     std::vector<std::string> motifs; std::ifstream in(argv[1]); std::string l; while (std::getline(in, l)) if (!l.empty()) motifs.push_back(l);
-    KmerEncoder enc(Molecule::Peptide, getenv("EB_K") ? (unsigned)atoi(getenv("EB_K")) : 4u, Alphabet::Base);
+    KmerEncoder enc(getenv("EB_DNA") ? Molecule::DNA : Molecule::Peptide, getenv("EB_K") ? (unsigned)atoi(getenv("EB_K")) : 4u, Alphabet::Base);  // EB_DNA: nucleotide motifs
     StagedOptions opt; opt.threads = argc > 2 ? atoi(argv[2]) : 1;
     if (getenv("EB_DENSE")) { opt.dense.enabled = true; opt.dense.slot_bytes = 128; }
     if (getenv("EB_TRACKED")) opt.dense.tracked_ok = true;  // the executor is assumed to keep live lists (tracked blocks)

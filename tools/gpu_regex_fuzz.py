@@ -54,6 +54,7 @@ bad = 0
 cases = [("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)]
 cases += [(name, t[0], False, 4, AA, 6) for name, t in trees.items()]
 more = int(os.environ.get("FUZZ_MORE_LEAVES", "0"))  # larger regexes (the oracle enumerates every state: keep the count down)
+n_shards = int(os.environ.get("FUZZ_SHARDS", "1"))        # > 1: the HIBF cases as that many sub-tree shards (column shards for the regular tree)
 only = os.environ.get("FUZZ_ONLY")                    # a comma-separated choice of the cases above
 for name, ox, is_dna, k, alphabet, leaves in cases:
     if only and name not in only.split(","):
@@ -72,14 +73,18 @@ for name, ox, is_dna, k, alphabet, leaves in cases:
         else:
             os.environ.pop("TETREX_DENSE_EVIDENCE", None)
         for chunk in (len(qs), 40, 7):  # one batch, and batches small enough to leave the table of all k-mers' masks alone
-            if name in trees:
+            shards = None
+            if name in trees and n_shards > 1:  # FUZZ_SHARDS: the tree as sub-tree shards on this GPU, masks ORed (txq_index_upload_subtrees)
+                shards = [capi.Index.upload_hibf(trees[name][2], trees[name][1], shard_rank=r, n_shards=n_shards, subtrees=True) for r in range(n_shards)]
+                ix = None
+            elif name in trees:
                 ix = capi.Index.upload_hibf(trees[name][2], trees[name][1])
             else:
                 ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())  # a fresh index: it is asked
             checked = 0
             for at in range(0, len(qs), chunk):
                 part = qs[at:at + chunk]
-                got, status, stats = ix.query_masks(part, is_dna, k)
+                got, status, stats = capi.query_masks_sharded(shards, part, is_dna, k) if shards else ix.query_masks(part, is_dna, k)
                 for q, g, w, s_ in zip(part, got, wants[at:at + chunk], status):
                     if w is None:
                         if s_ == 0:
@@ -88,7 +93,8 @@ for name, ox, is_dna, k, alphabet, leaves in cases:
                     if s_ != 0 or not np.array_equal(g, w):
                         print("MISMATCH %s evidence %s batch %d: %r status %d" % (name, ev, chunk, q, s_)); bad += 1
                     checked += 1
-            ix.free()
+            for x in (shards or [ix]):
+                x.free()
             print("%s, evidence %s, batches of %d: %d of %d regexes compared with the oracle" % (name, ev or "asked", chunk, checked, len(qs)), flush=True)
 print("regex fuzz on the GPU: %d mismatches" % bad)
 sys.exit(1 if bad else 0)
