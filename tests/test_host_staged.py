@@ -138,6 +138,35 @@ def test_node_for_node_graphs_and_fused_classes_give_the_same_masks(host, oracle
             assert stats["1"]["ops"] <= stats["0"]["ops"]
 
 
+@pytest.mark.parametrize("dna", [False, True])
+def test_plain_strings_expand_without_a_graph_to_the_same_ops(host, oracle, monkeypatch, dna):
+    """A query that is a plain string of residues is expanded without a k-graph (QueryExpansion's literal constructor;
+    TETREX_LITERAL_FAST=0: the general way): the same masks — the oracle's —, ops, k-mers and states, also for strings shorter
+    than k (no probe: every bin) and of exactly k residues; an empty query fails in both."""
+    if dna:
+        ox = _index(oracle, bins=70, m=4099, h=2, k=6, dna=True, per_bin=300, seed=31)
+        qs = ["ACGTACGTAC", "ACGTAC", "ACGT", "A", "GGGGGGGGGGGG", "ACGTNACGTAC", "TTTTTTT", ""]
+        k = 6
+    else:
+        ox = _index(oracle, bins=130, m=4099, h=3, k=4, dna=False, per_bin=900, seed=32)
+        qs = ["LMAEGLYN", "LMAE", "LM", "A", "ACDEFGHIKLMNPQRSTVWY", "LMAEXGLYN", "WWWWWW", "", "LMA.GLYN"]
+        k = 4
+    runs = {}
+    for fast in ("1", "0"):
+        monkeypatch.setenv("TETREX_LITERAL_FAST", fast)
+        sim = SessionSimulator(ox, len(qs))
+        status, stats = host.run_staged(qs, dna, k, 0, ox.bins, sim.stage)
+        runs[fast] = (status, stats, [sim.result(i).copy() for i in range(len(qs))])
+    (st1, s1, m1), (st0, s0, m0) = runs["1"], runs["0"]
+    assert st1 == st0 and st1[qs.index("")] != 0
+    for key in ("ops", "kmers", "states", "stages"):
+        assert s1[key] == s0[key], (key, s1, s0)
+    for i, q in enumerate(qs):
+        assert np.array_equal(m1[i], m0[i]), q
+        if st1[i] == 0:
+            assert np.array_equal(m1[i], ox.query(q)), q
+
+
 @pytest.mark.parametrize("wave_ops", ["0", "64", "2000"])
 def test_waves_of_queries_give_the_same_masks(host, oracle, monkeypatch, wave_ops):
     """Queries begin in waves (TETREX_WAVE_OPS; the k-graph of a query is built when it begins), the later waves while

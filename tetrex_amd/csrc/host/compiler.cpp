@@ -751,8 +751,36 @@ void QueryExpansion::dense_receivers(int32_t item, std::vector<int32_t>& out) co
     } else if (g_.takes_residue(item)) add(forward_[item]);
 }
 
+QueryExpansion::QueryExpansion(const KmerEncoder& enc, std::string literal, CompileLimits limits)
+    : literal_mode_(true), literal_(std::move(literal)), enc_(enc), limits_(limits) {
+    if (enc_.k() < 2) throw std::runtime_error("k must be at least 2");
+    if (literal_.empty()) throw std::runtime_error("empty query: nothing to search for");
+    refs_.assign(TXQ_SLOT_FIRST_FREE, kPinned);
+}
+
 void QueryExpansion::advance(size_t op_budget, Intern intern, OpVec& out, KmerTable* dgrams, bool verified_only, DenseVec* dense) {
     const unsigned k = enc_.k();
+    if (literal_mode_) {
+        // one state from the start to the Match node: the first k - 1 residues fill its k-mer, every residue after them is a probe
+        // ANDed into its mask (a slot of its own from the first probe on), the Match node ORs the mask into RESULT
+        if (literal_done_) return;
+        uint64_t kmer = 0;
+        uint32_t slot = TXQ_SLOT_ONES;
+        unsigned shift = 0;
+        for (const char c : literal_) {
+            const uint64_t probe = enc_.roll((unsigned char)c, kmer);
+            if (shift < k - 1) { ++shift; continue; }
+            const uint32_t id = intern.intern(probe);
+            ++probes_;
+            if (slot == TXQ_SLOT_ONES) { slot = fresh(); emit(out, id, slot, TXQ_SLOT_ONES, TXQ_SLOT_ZERO); }
+            else emit(out, id, slot, slot, TXQ_SLOT_ZERO);
+        }
+        emit(out, TXQ_NO_KMER, TXQ_SLOT_RESULT, slot, TXQ_SLOT_RESULT);
+        drop(slot);
+        states_ += literal_.size() + 1;
+        literal_done_ = true;
+        return;
+    }
     const size_t start = out.size();
     dense_out_ = dense;
     if (dense && dense->size() < dense_seen_) {  // the stage driver has shipped the table: earlier ZERO ops are out of reach

@@ -160,9 +160,13 @@ class QueryExpansion {
   public:
     using Intern = KmerTable&;
     QueryExpansion(const KmerEncoder& enc, KGraph graph, CompileLimits limits, GapOptions gaps = {}, DenseOptions dense = {});
+    // A query that is a plain string of residues (no operator): its k-graph is a chain and its expansion one state walking
+    // along it — the ops are written out directly (no graph, no tables): what the constructor above and advance() emit for the
+    // chain, op for op.  The common nucleotide query.
+    QueryExpansion(const KmerEncoder& enc, std::string literal, CompileLimits limits);
     ~QueryExpansion();
 
-    bool done() const { return cursor_ >= order_.size(); }
+    bool done() const { return literal_mode_ ? literal_done_ : cursor_ >= order_.size(); }
     // Expand whole nodes until the query is finished or `op_budget` ops were emitted by this call.
     // Ops are appended to `out`.  Throws std::runtime_error when a limit is exceeded.
     // verified_only: stop before the first item that would consume a state the device has not yet
@@ -197,7 +201,7 @@ class QueryExpansion {
     uint64_t total_ops() const { return total_ops_; }
     // rough cost of running this query to its end (waiting states x remaining items): orders the
     // tasks of a stage, largest first
-    uint64_t weight() const { return (uint64_t)(order_.size() - cursor_) * (waiting_ + 1); }
+    uint64_t weight() const { return literal_mode_ ? (literal_done_ ? 0 : literal_.size()) : (uint64_t)(order_.size() - cursor_) * (waiting_ + 1); }
 
   private:
     struct State { uint64_t kmer; uint32_t slot; uint8_t shift; uint8_t asked; uint8_t gapped = 0; uint8_t res1 = 0, res2 = 0; };
@@ -218,6 +222,8 @@ class QueryExpansion {
     uint64_t key_of(const State& s) const;
     static constexpr uint32_t kSearched = 4, kNoState = 0xFFFFFFFFu;  // lists shorter than kSearched have no merge table (arrive)
     uint32_t code_mask(int32_t node) const;
+    bool literal_mode_ = false, literal_done_ = false;  // a plain string of residues: expanded without a graph (advance)
+    std::string literal_;
     int32_t resume_item_ = KGraph::kNone;  // a fused class whose residues from resume_residue_ on are still to be rolled in (advance)
     uint32_t resume_residue_ = 0;
     static size_t merge_sample_threshold();

@@ -172,6 +172,7 @@ class StagedRun {
         trace_ = std::getenv("TETREX_TRACE") != nullptr;  // per-stage phase times on stderr
         // unions of single residues as one k-graph node each (KGraph::kClass); TETREX_FUSE_CLASSES=0: the reference's node-for-node graph
         if (const char* e = std::getenv("TETREX_FUSE_CLASSES")) fuse_classes_ = std::atoi(e) != 0;
+        if (const char* e = std::getenv("TETREX_LITERAL_FAST")) literal_fast_ = std::atoi(e) != 0;
         verified_levels_ = opt.verified_levels;
         if (std::getenv("TETREX_VERIFIED_LEVELS")) verified_levels_ = env_is("TETREX_VERIFIED_LEVELS", '1');  // A/B knob
         overlap_ = !env_is("TETREX_NO_OVERLAP", '1');
@@ -265,7 +266,14 @@ class StagedRun {
         std::stable_sort(pending_.begin(), pending_.end(), [&](uint32_t x, uint32_t y) { return regexes_[x].size() > regexes_[y].size(); });
     }
     void build_one(size_t i) {  // throws what the front-end throws
-        const std::string postfix = preprocess_query(regexes_[i], enc_);
+        std::string plain;
+        const std::string postfix = preprocess_query(regexes_[i], enc_, &plain);
+        // a plain string of residues needs no graph (QueryExpansion's literal constructor); TETREX_LITERAL_FAST=0: the general way
+        if (literal_fast_ && enc_.alphabet() == Alphabet::Base && !plain.empty() &&
+            std::all_of(plain.begin(), plain.end(), [](char c) { return c >= 'A' && c <= 'Z'; })) {
+            q_[i] = std::make_unique<QueryExpansion>(enc_, std::move(plain), opt_.limits);
+            return;
+        }
         q_[i] = std::make_unique<QueryExpansion>(enc_, build_kgraph(postfix, enc_.k(), enc_.alphabet() != Alphabet::Base, opt_.gaps.augment, fuse_classes_), opt_.limits, opt_.gaps, dense_);
     }
 
@@ -678,7 +686,7 @@ class StagedRun {
     StagedStats st_;
     size_t run_on_budget_ = 0, feedback_budget_ = 0;  // the latter: what a query that asks gets per stage (advance_stage sets it)
     size_t wave_ops_ = 0, wave_growth_percent_ = 100;
-    bool trace_ = false, verified_levels_ = true, overlap_ = true, fuse_classes_ = true;
+    bool trace_ = false, verified_levels_ = true, overlap_ = true, fuse_classes_ = true, literal_fast_ = true;
     double lap_at_ = 0;
 };
 
