@@ -242,10 +242,12 @@ std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards,
 
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                   std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
-                                  const StagedOptions* options, txq_index* aux) {
+                                  const StagedOptions* options, txq_index* aux, uint64_t* into) {
     txq_index_info info{};
     txq_check(txq_index_get_info(ix, &info), "txq_index_get_info");
-    std::vector<uint64_t> masks(regexes.size() * info.shard_words);
+    // into: the caller's own n x shard_words words (a binding's array): the masks go there and nothing is returned — 10 000 masks
+    // of 8192 bins are 10 MB that would otherwise be zeroed, filled and copied once more
+    std::vector<uint64_t> masks(into ? 0 : regexes.size() * info.shard_words);
     if (status) status->assign(regexes.size(), 0);
     if (messages) messages->assign(regexes.size(), std::string());
     if (regexes.empty()) return masks;
@@ -273,7 +275,7 @@ std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const s
     if (st.dense_evidence != DenseOptions::kUnknown) (void)txq_index_set_tag(ix, (tag & ~(uint64_t)3) | (uint64_t)st.dense_evidence);
     if (stats) *stats = st;
     const auto t1 = std::chrono::steady_clock::now();
-    exec.finish(masks.data());  // waits for the device: a stage without feedback questions returns as soon as it is launched
+    exec.finish(into ? into : masks.data());  // waits for the device: a stage without feedback questions returns as soon as it is launched
     if (trace)
         std::fprintf(stderr, "[tetrex] run_staged %.2f ms, finish (device drain + result copy) %.2f ms\n",
                      std::chrono::duration<double, std::milli>(t1 - t0).count(),

@@ -53,7 +53,7 @@ class ShardedStageExecutor final : public StageExecutor {
 // Whole queries on an uploaded index: staged expansion + device execution.
 std::vector<uint64_t> run_queries(txq_index* ix, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                   std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,
-                                  const StagedOptions* options, txq_index* aux = nullptr);
+                                  const StagedOptions* options, txq_index* aux = nullptr, uint64_t* into = nullptr);
 // ... on all column shards of an index: full-width masks (n x mask_words)
 std::vector<uint64_t> run_queries_sharded(const std::vector<txq_index*>& shards, const KmerEncoder& enc, const std::vector<std::string>& regexes,
                                           std::vector<int>* status, std::vector<std::string>* messages, StagedStats* stats,

@@ -58,8 +58,7 @@ int txe_query_masks_gapped(void* handle, void* aux_handle, const txh_gap_options
         std::vector<int> st;
         std::vector<std::string> why;
         StagedStats s;
-        const std::vector<uint64_t> out = run_queries(ix, enc, rx, &st, &why, &s, &opt, aux);
-        std::copy(out.begin(), out.end(), masks);
+        (void)run_queries(ix, enc, rx, &st, &why, &s, &opt, aux, masks);  // (straight into the caller's array)
         g_dense_ops = s.dense_ops;
         g_tracked = s.tracked_queries;
         int failures = 0;
