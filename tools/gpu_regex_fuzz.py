@@ -44,9 +44,10 @@ for b in range(1024):
 # HIBFs: a random irregular 3-level tree, a tree as a layout algorithm shapes it, a regular 16 x 64 tree (tests/helpers.py)
 from helpers import layout_hibf, random_hibf, regular_hibf
 trees = {}
-ox_t, descs, _ = random_hibf(O, 21, user_bins=300, levels=3, n_values=60)
+tree_seed = int(os.environ.get("FUZZ_TREE_SEED", "0"))  # other shapes of the two general trees (0: the ones of the committed runs)
+ox_t, descs, _ = random_hibf(O, 21 + tree_seed, user_bins=300, levels=3 if tree_seed % 2 == 0 else 4, n_values=60)
 trees["hibf-irregular-300"] = (ox_t, descs, 300)
-ox_t, descs, _ = layout_hibf(O, 5, user_bins=900, tmax=32, n_values=30)
+ox_t, descs, _ = layout_hibf(O, 5 + tree_seed, user_bins=900, tmax=32 if tree_seed % 3 == 0 else (16 if tree_seed % 3 == 1 else 64), n_values=30)
 trees["hibf-layout-900"] = (ox_t, descs, 900)
 ox_t, descs, _ = regular_hibf(O, 1024, 16, 200, lambda b: np.random.default_rng(b).integers(0, 1 << 20, size=200, dtype=np.uint64), h=2)
 trees["hibf-regular-16x64"] = (ox_t, descs, 1024)
