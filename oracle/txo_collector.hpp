@@ -211,7 +211,11 @@ struct Collector {
         if (f == b.at.end()) { b.at.emplace(key, b.items.size()); b.items.push_back(std::move(it)); }
         else {
             Item& dst = b.items[f->second];
-            if (dst.shift != it.shift || dst.gapped != it.gapped || dst.res1 != it.res1 || dst.res2 != it.res2) ++stats.quirk_merges;
+            // (a state behind a Gap node carries its partial d-gram code in kmer: two such states with DIFFERENT codes that agree in
+            // the code's low bits meet in one table slot — the first one's d-gram is kept for both, which of the two it is follows
+            // from the order of the walk: counted with the other ill-defined merges)
+            if (dst.shift != it.shift || dst.gapped != it.gapped || dst.res1 != it.res1 || dst.res2 != it.res2 || (it.gapped && dst.kmer != it.kmer))
+                ++stats.quirk_merges;
             for (size_t w = 0; w < dst.path.size(); ++w) dst.path[w] |= it.path[w];
         }
     }
