@@ -52,12 +52,19 @@ trees["hibf-layout-900"] = (ox_t, descs, 900)
 ox_t, descs, _ = regular_hibf(O, 1024, 16, 200, lambda b: np.random.default_rng(b).integers(0, 1 << 20, size=200, dtype=np.uint64), h=2)
 trees["hibf-regular-16x64"] = (ox_t, descs, 1024)
 bad = 0
-cases = [("peptide", pep, False, 4, AA, 6), ("dna", dna, True, 3, "ACGT", 8), ("peptide-1024-bins", wide, False, 4, AA, 6)]
-cases += [(name, t[0], False, 4, AA, 6) for name, t in trees.items()]
+# reduced alphabets (the reduced k-graph builder: symbols buffered, equal reduced letters of a union collapse): Murphy k = 5, Li k = 4
+murphy = O.Index.ibf(130, 2053, 3, dna=False, k=5, reduction=1)
+li = O.Index.ibf(130, 2053, 3, dna=False, k=4, reduction=2)
+for b in range(130):
+    murphy.emplace(rng.integers(0, 1 << 20, size=900, dtype=np.uint64), b)
+    li.emplace(rng.integers(0, 1 << 16, size=900, dtype=np.uint64), b)
+cases = [("peptide", pep, False, 4, AA, 6, 0), ("dna", dna, True, 3, "ACGT", 8, 0), ("peptide-1024-bins", wide, False, 4, AA, 6, 0),
+         ("peptide-murphy", murphy, False, 5, AA, 6, 1), ("peptide-li", li, False, 4, AA, 6, 2)]
+cases += [(name, t[0], False, 4, AA, 6, 0) for name, t in trees.items()]
 more = int(os.environ.get("FUZZ_MORE_LEAVES", "0"))  # larger regexes (the oracle enumerates every state: keep the count down)
 n_shards = int(os.environ.get("FUZZ_SHARDS", "1"))        # > 1: the HIBF cases as that many sub-tree shards (column shards for the regular tree)
 only = os.environ.get("FUZZ_ONLY")                    # a comma-separated choice of the cases above
-for name, ox, is_dna, k, alphabet, leaves in cases:
+for name, ox, is_dna, k, alphabet, leaves, reduction in cases:
     if only and name not in only.split(","):
         continue
     qs = draw(regex_strategy(alphabet, max_leaves=leaves + more), n, seed)
@@ -85,7 +92,7 @@ for name, ox, is_dna, k, alphabet, leaves in cases:
             checked = 0
             for at in range(0, len(qs), chunk):
                 part = qs[at:at + chunk]
-                got, status, stats = capi.query_masks_sharded(shards, part, is_dna, k) if shards else ix.query_masks(part, is_dna, k)
+                got, status, stats = capi.query_masks_sharded(shards, part, is_dna, k) if shards else ix.query_masks(part, is_dna, k, reduction)
                 for q, g, w, s_ in zip(part, got, wants[at:at + chunk], status):
                     if w is None:
                         if s_ == 0:
