@@ -87,12 +87,15 @@ for name, ox, is_dna, k, alphabet, leaves, reduction in cases:
                 ix = None
             elif name in trees:
                 ix = capi.Index.upload_hibf(trees[name][2], trees[name][1])
+            elif n_shards > 1:  # a flat IBF as column shards, one expansion for all of them (txe_query_masks_sharded)
+                shards = [capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words(), shard_rank=r, n_shards=n_shards) for r in range(n_shards)]
+                ix = None
             else:
                 ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())  # a fresh index: it is asked
             checked = 0
             for at in range(0, len(qs), chunk):
                 part = qs[at:at + chunk]
-                got, status, stats = capi.query_masks_sharded(shards, part, is_dna, k) if shards else ix.query_masks(part, is_dna, k, reduction)
+                got, status, stats = capi.query_masks_sharded(shards, part, is_dna, k, reduction) if shards else ix.query_masks(part, is_dna, k, reduction)
                 for q, g, w, s_ in zip(part, got, wants[at:at + chunk], status):
                     if w is None:
                         if s_ == 0:
