@@ -555,20 +555,26 @@ def k6_end_to_end(capi, torch, args, check=True):
     import oracle as O
     bins, per_bin, h, k = 1024, 200000, 3, 6
     m = compute_bitcount(per_bin, 0.05)
-    ix = capi.Index.create_ibf(bins, m, h)
-    rng = np.random.default_rng(11)
     base_code = np.array([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19], dtype=np.uint64)  # "ACDEFGHIKLMNPQRSTVWY" in the Base alphabet
-    for b0 in range(0, bins, 64):  # 64 bins at a time: 12.8 M values
-        nb = min(64, bins - b0)
-        codes = base_code[rng.integers(0, 20, size=(nb, per_bin))]
-        vals = np.zeros((nb, per_bin - k + 1), dtype=np.uint64)
-        for j in range(k):
-            vals = (vals << np.uint64(5)) | codes[:, j:per_bin - k + 1 + j]
-        bins_of = np.repeat(np.arange(b0, b0 + nb, dtype=np.uint32), vals.shape[1])
-        dv = torch.from_numpy(vals.reshape(-1).view(np.int64)).cuda()
-        db = torch.from_numpy(bins_of.view(np.int32)).cuda()
-        ix.emplace_device(dv.data_ptr(), db.data_ptr(), vals.size, torch.cuda.current_stream().cuda_stream)
-        torch.cuda.synchronize()
+
+    def build(residues, seed):
+        """bins x m rows, h hashes: per bin the k-mers of `residues` uniform random residues, inserted on the device"""
+        index = capi.Index.create_ibf(bins, m, h)
+        rng = np.random.default_rng(seed)
+        for b0 in range(0, bins, 64):  # 64 bins at a time: 12.8 M values
+            nb = min(64, bins - b0)
+            codes = base_code[rng.integers(0, 20, size=(nb, residues))]
+            vals = np.zeros((nb, residues - k + 1), dtype=np.uint64)
+            for j in range(k):
+                vals = (vals << np.uint64(5)) | codes[:, j:residues - k + 1 + j]
+            bins_of = np.repeat(np.arange(b0, b0 + nb, dtype=np.uint32), vals.shape[1])
+            dv = torch.from_numpy(vals.reshape(-1).view(np.int64)).cuda()
+            db = torch.from_numpy(bins_of.view(np.int32)).cuda()
+            index.emplace_device(dv.data_ptr(), db.data_ptr(), vals.size, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+        return index
+
+    ix = build(per_bin, 11)
     motifs = random_prosite_motifs(200, 3, wildcard=0.05, ranges=0.02, min_len=8, max_len=14)
     ix.query_masks(random_prosite_motifs(200, 4, wildcard=0.05, ranges=0.02, min_len=8, max_len=14), False, k)  # warm: arena, staging sets
     best = None
@@ -618,6 +624,19 @@ def k6_end_to_end(capi, torch, args, check=True):
     rest = oracle_check_rest({"words": ox.words()}, {"kind": "ibf", "bins": bins, "rows": m, "h": h, "dna": False, "k": k}, motifs, best[2], others,
                              3 * getattr(args, "cpu_query_seconds", 10.0), "k = 6 batch")
     ix.free()
+    # ... and the WHOLE batch once more on a thinner index of the same shape (same bins, rows and hashes, a fifth of the residues per
+    # bin): there a k-mer is in ~1 bin instead of ~54, the oracle's states die out after a residue or two and it answers the motifs
+    # that begin with wildcards too — the ones tracked blocks exist for
+    thin_residues = per_bin // 5
+    thin = build(thin_residues, 12)
+    t_masks, t_status, t_stats = thin.query_masks(motifs, False, k)
+    thin_words = thin.download_words_rows(m)
+    thin.free()
+    thin_rest = oracle_check_rest({"words": thin_words}, {"kind": "ibf", "bins": bins, "rows": m, "h": h, "dna": False, "k": k}, motifs, t_masks,
+                                  [i for i in range(len(motifs)) if not t_status[i]], 3 * getattr(args, "cpu_query_seconds", 10.0), "k = 6 batch on the thin index")
+    thin_rest.update({"index": "%d bins x %d rows, h = %d: the 6-mers of %d random residues per bin" % (bins, m, h, thin_residues),
+                      "motifs_with_candidate_bins": int((t_masks != 0).any(axis=1).sum()),
+                      "tracked_queries": t_stats.get("tracked_queries"), "dense_ops": t_stats.get("dense_ops"), "ops": t_stats.get("ops")})
     refused = int(sum(1 for x in best[3] if x))
     roof = None
     try:  # the kernel of this leg against the HBM roofline: from the committed rocprofv3 passes of this very workload (tools/pmc_sparse.py)
@@ -636,7 +655,8 @@ def k6_end_to_end(capi, torch, args, check=True):
             "enumerated_states": {"what": "the same batch with TETREX_DENSE=0 (no blocks: states enumerated and pruned through host feedback)",
                                   "seconds": ref_dt, "ops": ref_stats["ops"], "masks_identical": True},
             "cpu_oracle": {"masks_compared": compared, "seconds": cpu_dt, "sample": "motifs of the batch without a wildcard among their first residues",
-                           "the_other_motifs": rest, "masks_compared_in_all": compared + rest.get("masks_compared", 0)}}
+                           "the_other_motifs": rest, "masks_compared_in_all": compared + rest.get("masks_compared", 0),
+                           "whole_batch_on_a_thin_index_of_the_same_shape": thin_rest}}
 
 
 def verified_end_to_end(args):

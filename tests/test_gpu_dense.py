@@ -171,12 +171,18 @@ def test_waves_of_queries_on_a_session_that_is_never_waited_for(capi, oracle, mo
     ix = capi.Index.upload_ibf(ox.bins, sh["bin_size"], sh["hash_funs"], ox.words())
     for rep in range(2):  # the second session adopts the first one's staging sets and stream
         got, status, stats = ix.query_masks(qs, False, 4, 0, 0)
-        assert stats["stages"] >= 4 and stats["dense_ops"] > 50
-        for q, g, w, st in zip(qs, got, wants, status):
+        for q, g, w, st in zip(qs, got, wants, status):  # (masks first: how a batch is cut into stages depends on host timing)
             if w is False:
                 assert st != 0, q
             else:
                 assert st == 0 and np.array_equal(g, w), q
+        assert stats["stages"] >= 2 and stats["dense_ops"] > 50
+    # the count of stages under a schedule that does not depend on timing: one expansion thread, nothing beside the stage
+    monkeypatch.setenv("TETREX_THREADS", "1")
+    monkeypatch.setenv("TETREX_NO_OVERLAP", "1")
+    got1, status1, stats1 = ix.query_masks(qs, False, 4, 0, 0)
+    assert list(status1) == list(status) and np.array_equal(got1, got)
+    assert stats1["stages"] >= 4 and stats1["dense_ops"] > 50
     ix.free()
 
 
@@ -453,9 +459,10 @@ def test_random_wave_sizes_budgets_and_block_pools(capi, oracle, monkeypatch):
         else:
             monkeypatch.delenv("TETREX_TASK_OPS", raising=False)
         monkeypatch.setenv("TETREX_DENSE_POOL_MB", str(int(rng.choice([100, 1000, 49152]))))
+        monkeypatch.setenv("TETREX_THREADS", str([1, 3, 16][it % 3]))  # (forced cuts of the expansion over host threads)
         got, st, stats = ix.query_masks(qs, False, 4, 0, 0)
         assert list(st) == list(status) and np.array_equal(got, want), it
-        assert stats["dense_ops"] > 0 and stats["stages"] >= 2
+        assert stats["dense_ops"] > 0
     ix.free()
 
 
