@@ -985,6 +985,22 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
     return TXQ_OK;
 }
 
+// Waves per workgroup of hibf_fused_kernel: its waves share nothing (a wave's row and stack are its own piece of the LDS, only
+// wave-level synchronisation), so the block size is free — taken so that the CU's 160 KB of LDS hold the most waves (a 22 KB
+// layout-order row of the 65 536-bin trees: 7 single-wave blocks against 3 blocks of two; an 11 KB user-order row: 14 against 12).
+static unsigned fused_waves_per_block(size_t wave_bytes) {
+    constexpr size_t kLdsPerCu = 160u << 10, kGranule = 1280;  // (allocation granule: the larger of the documented ones — a safe count)
+    unsigned best = 1;
+    size_t best_resident = 0;
+    for (unsigned w = 4; w >= 1; w >>= 1) {
+        if (wave_bytes * w > (64u << 10)) continue;
+        const size_t block = (wave_bytes * w + kGranule - 1) / kGranule * kGranule;
+        const size_t resident = kLdsPerCu / block * w;
+        if (resident > best_resident) { best_resident = resident; best = w; }  // (ties: the larger block, met first)
+    }
+    return best;
+}
+
 // The layout-order rows with ONE wave per k-mer (hibf_fused_kernel<G, LAYOUT>): the wave walks the IBFs the k-mer reaches,
 // keeps the row in LDS and writes it once, coalesced — a k-mer of the 65 536-bin trees reaches a few hundred of the row's
 // 1237 chunks, where the level kernels below visit every chunk of every level for every k-mer.  Where a row (plus the stack)
@@ -1000,8 +1016,7 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     HibfView t{ix.d_ibf, ix.d_next, ix.d_tb_user, ix.d_map_off, ix.d_merged, ix.d_merged, ix.d_merged_off, (const HibfNode*)ix.d_vnodes, (uint32_t)ix.hibf_total_tbs};
     t.nonrep = ix.d_vnonrep;
     t.rep_pos = ix.d_vrep;
-    unsigned waves = 4;
-    while (waves > 1 && wave_bytes * waves > (64u << 10)) waves >>= 1;
+    const unsigned waves = fused_waves_per_block(wave_bytes);
     const size_t want_waves = kn.hibf_waves > 0 ? (size_t)kn.hibf_waves : (size_t)256 * 64;
     const size_t total_waves = n < want_waves ? n : want_waves;
     const unsigned grid = (unsigned)((total_waves + waves - 1) / waves);
@@ -1412,9 +1427,8 @@ static bool hibf_probe_fused(Index& ix, const Knobs& kn, const uint64_t* d_kmers
         if (e != hipSuccess) *rc = fail_hip(e, "hibf small-tree kernel launch");
         return true;
     }
-    unsigned waves = 4;
-    while (waves > 1 && wave_bytes * waves > lds_budget) waves >>= 1;
-    // 64 waves per CU are launched: with an 8 KiB row the LDS keeps 16 of them resident and the rest queue up,
+    const unsigned waves = fused_waves_per_block(wave_bytes);
+    // 64 waves per CU are launched: with an 8 KiB row the LDS keeps 14 of them resident and the rest queue up,
     // with the short rows of a column shard more are resident and the finer grain is worth 14 % (TXQ_HIBF_WAVES overrides)
     size_t want_waves = (size_t)256 * 64;
     if (kn.hibf_waves > 0) want_waves = (size_t)kn.hibf_waves;
