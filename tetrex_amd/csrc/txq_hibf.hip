@@ -995,7 +995,7 @@ static unsigned fused_waves_per_block(size_t wave_bytes) {
     for (unsigned w = 4; w >= 1; w >>= 1) {
         if (wave_bytes * w > (64u << 10)) continue;
         const size_t block = (wave_bytes * w + kGranule - 1) / kGranule * kGranule;
-        const size_t resident = kLdsPerCu / block * w;
+        const size_t resident = std::min<size_t>(kLdsPerCu / block * w, 32);  // (a CU runs at most 8 waves per SIMD: short rows keep blocks of four)
         if (resident > best_resident) { best_resident = resident; best = w; }  // (ties: the larger block, met first)
     }
     return best;
