@@ -7,7 +7,7 @@ than one wave sweep, every hash-function count, column shards, all-zero / all-on
 import numpy as np
 import pytest
 
-from helpers import random_words, oracle_ibf_from_words, random_hibf, splitmix64
+from helpers import random_words, oracle_ibf_from_words, random_hibf, layout_hibf, splitmix64
 
 pytestmark = pytest.mark.gpu
 
@@ -408,3 +408,42 @@ def test_small_uniform_trees_are_probed_on_their_interleaved_children(capi, orac
         for n in (1, 63, 257):
             assert np.array_equal(ix.probe(kmers[:n]), want[:n, lo:lo + nw])
         ix.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", ["layout-16", "layout-64", "layout-32"])
+def test_hibf_stack_entries_beyond_the_lds_go_through_the_output_row(capi, oracle, shape, monkeypatch):
+    """hibf_fused_kernel keeps the first TXQ_HIBF_STACK_LDS entries (default 128) of a k-mer's stack of pending IBFs in LDS and
+    the rest in the k-mer's own output row until the finished row is written over them.  Trees whose bins draw their values
+    from a universe of 64: a k-mer reaches nearly every IBF, dozens to hundreds are pending at once.  Masks of plain probes
+    (user order) and of a session's rows of plain k-mers (layout order, through a literal query per k-mer) equal the oracle's
+    with 2, 32, 96 and the default number of entries in LDS (where the output row is too short for the rest — 2 * w_out entries;
+    user order on the narrower masks here — the whole stack stays in LDS)."""
+    if shape == "layout-16":
+        ox, descs, values = layout_hibf(oracle, 3, user_bins=1500, tmax=16, n_values=30, value_bits=6, direct=3)
+        ub = 1500
+    elif shape == "layout-64":
+        ox, descs, values = layout_hibf(oracle, 4, user_bins=6000, tmax=64, n_values=20, value_bits=6)
+        ub = 6000
+    else:
+        ox, descs, values = layout_hibf(oracle, 8, user_bins=4000, tmax=32, n_values=20, value_bits=6, h=3)
+        ub = 4000
+    assert len(descs) > 100  # (IBFs: more than the stacks' LDS parts hold)
+    kmers = np.concatenate([np.arange(64, dtype=np.uint64), splitmix64(3, 500) >> np.uint64(44)])
+    want = ox.probe(kmers)
+    assert (np.unpackbits(want[:64].view(np.uint8), axis=1).sum(axis=1) > ub // 4).any()  # saturated: some k-mers are nearly everywhere
+    ix = capi.Index.upload_hibf(ub, descs)
+    monkeypatch.setenv("TXQ_HIBF_SMALL", "0")
+    for in_lds in ("2", "32", "96", None):
+        if in_lds:
+            monkeypatch.setenv("TXQ_HIBF_STACK_LDS", in_lds)
+        else:
+            monkeypatch.delenv("TXQ_HIBF_STACK_LDS", raising=False)
+        assert np.array_equal(ix.probe(kmers), want), (shape, in_lds)
+        # peptide k = 4 literals: their masks are the rows of their one k-mer (layout order where the index has one)
+        qs = ["ACDE", "AAAA", "AAAC", "AACA"]
+        got, status, _ = ix.query_masks(qs, False, 4, 0, 0)
+        for q, g, st in zip(qs, got, status):
+            w, _ = ox.expected_mask(q)
+            assert st == 0 and np.array_equal(g, w), (shape, in_lds, q)
+    ix.free()

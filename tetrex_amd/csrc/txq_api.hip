@@ -76,6 +76,7 @@ void read_knobs() {
     k.hibf_store |= (int)num("TXQ_HIBF_STORE", 0) & 112;  // (64: the layout-order level kernel without its gate loads)
 #endif
     k.hibf_waves = std::max(0LL, num("TXQ_HIBF_WAVES", 0));
+    k.hibf_stack_lds = std::max(2LL, num("TXQ_HIBF_STACK_LDS", 128));
     k.probe_blocks_per_cu = (int)std::max(1LL, num("TXQ_PROBE_BLOCKS_PER_CU", 256));
     k.probe_unroll = (int)num("TXQ_PROBE_UNROLL", 2);
     k.probe_nt = flag("TXQ_PROBE_NT");

@@ -162,7 +162,11 @@ __device__ __forceinline__ void wave_sync() {
 // instruction-bound: hence few lanes per IBF (a 256-bin IBF is one lane) and only as many hash
 // evaluations as the tree's IBFs have (h_max, wave-uniform).  A k-mer visits every IBF at most
 // once (the IBFs form a tree), so a stack of n_ibf entries cannot overflow.
-// LDS per wave: w_out * 8 + stack_cap * 4 bytes (dynamic); launch: 64 * waves threads per block.
+// LDS per wave: w_out * 8 + stack_lds * 4 bytes (dynamic); launch: 64 * waves threads per block.
+// Only the first stack_lds entries of the stack live in LDS (a k-mer of a real tree has a few dozen IBFs pending, the bound is
+// EVERY IBF of the tree): entries beyond them go into the k-mer's own output row in HBM, which is this wave's alone until it
+// writes the finished row over it (the host checks that the row has the room: stack_cap - stack_lds <= 2 * w_out entries) —
+// the LDS the never-used tail of the stack took is worth one to four more resident waves per CU.
 // LAYOUT: the row is the tree's layout-order row (txq_internal.hpp VChunk) — t.nodes are then the records whose ident_word is
 // the IBF's first word IN THAT ROW (Index::d_vnodes), t.descend = t.merged, and an IBF's ANDed row words go into its segment
 // as they are, merged bins' bits included (one lane owns a word: plain LDS stores; no technical-bin -> user-bin mapping).
@@ -170,7 +174,7 @@ template <int G, bool LAYOUT = false>
 __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint64_t* __restrict__ kmers, size_t n,
                                                          uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0,
                                                          uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
-                                                         uint32_t h_max, uint64_t* __restrict__ alive) {
+                                                         uint32_t h_max, uint64_t* __restrict__ alive, uint32_t stack_lds) {
     extern __shared__ uint64_t lds[];
     const uint32_t lane = threadIdx.x & 63;
     uint64_t* row = lds + (size_t)(threadIdx.x >> 6) * wave_words;
@@ -183,6 +187,7 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
     for (size_t i = first; i < n; i += waves) {
         for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
         if (lane == 0) stack[0] = t.root_entry;
+        uint32_t* spill = reinterpret_cast<uint32_t*>(masks + i * (size_t)w_out);  // stack entries stack_lds.. (see above)
         // the k-mer is the same in every lane: make that visible, so that the seed products are
         // computed once per k-mer on the scalar unit instead of per IBF on the vector unit
         const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v_next >> 32)) << 32) |
@@ -198,7 +203,8 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
             count -= take;
             const bool live = group < take;
             // a stack entry is a technical-bin index; everything about the IBF behind it is one record
-            const HibfNode nd = t.nodes[live ? stack[count + group] : t.root_entry];
+            const uint32_t at = count + group;
+            const HibfNode nd = t.nodes[live ? (at < stack_lds ? stack[at] : spill[at - stack_lds]) : t.root_entry];
             const uint32_t stride = nd.stride(), words_per_row = nd.words_per_row();
             uint64_t r[5];
 #pragma unroll
@@ -268,7 +274,8 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                             const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int)first_tb, src);
                             if ((word >> lane) & 1) {
                                 const uint32_t pos = count + (uint32_t)__builtin_popcountll(word & ((1ULL << lane) - 1));
-                                if (pos < stack_cap) stack[pos] = base + lane;
+                                if (pos < stack_lds) stack[pos] = base + lane;
+                                else if (pos < stack_cap) spill[pos - stack_lds] = base + lane;
                             }
                             count += (uint32_t)__builtin_popcountll(word);
                             if (count > stack_cap) count = stack_cap;  // unreachable for a tree; keeps the indexes in range
@@ -340,12 +347,12 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
 template <int G, bool LAYOUT = false>
 static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes, hipStream_t s, HibfView t, const uint64_t* kmers, size_t n,
                                uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
-                               uint32_t h_max, uint64_t* alive) {
+                               uint32_t h_max, uint64_t* alive, uint32_t stack_lds) {
     if (lds_bytes > (48u << 10)) {  // (more dynamic LDS than the default limit: ask for it)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hibf_fused_kernel<G, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hibf_fused_kernel<G, LAYOUT><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive);
+    hibf_fused_kernel<G, LAYOUT><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive, stack_lds);
     return hipGetLastError();
 }
 
@@ -988,6 +995,14 @@ static int build_layout_order(Index& ix, const txq_index_desc& desc, const std::
 // Waves per workgroup of hibf_fused_kernel: its waves share nothing (a wave's row and stack are its own piece of the LDS, only
 // wave-level synchronisation), so the block size is free — taken so that the CU's 160 KB of LDS hold the most waves (a 22 KB
 // layout-order row of the 65 536-bin trees: 7 single-wave blocks against 3 blocks of two; an 11 KB user-order row: 14 against 12).
+// Entries of a wave's IBF stack kept in LDS (TXQ_HIBF_STACK_LDS, default 128; even: the stack follows the row's 8-byte words);
+// the whole stack when the output row could not take the rest.
+static uint32_t fused_stack_lds(const Knobs& kn, uint32_t stack_cap, uint32_t w_out) {
+    uint32_t in_lds = (uint32_t)std::max(2LL, kn.hibf_stack_lds) & ~1u;
+    if (in_lds >= stack_cap || (uint64_t)stack_cap - in_lds > 2ull * w_out) in_lds = (stack_cap + 1) & ~1u;
+    return in_lds;
+}
+
 static unsigned fused_waves_per_block(size_t wave_bytes) {
     constexpr size_t kLdsPerCu = 160u << 10, kGranule = 1280;  // (allocation granule: the larger of the documented ones — a safe count)
     unsigned best = 1;
@@ -1009,7 +1024,8 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     const Knobs kn = knobs();
     if (!ix.d_vnodes || !kn.hibf_layout_fused) return false;
     const uint32_t w_out = ix.v_words, stack_cap = (uint32_t)ix.ibf.size();
-    const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2, wave_bytes = wave_words * 8;
+    const uint32_t stack_lds = fused_stack_lds(kn, stack_cap, w_out);
+    const size_t wave_words = (size_t)w_out + stack_lds / 2, wave_bytes = wave_words * 8;
     if (wave_bytes > (64u << 10)) return false;
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
@@ -1026,7 +1042,7 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
     if (w_iters > 1 && ix.d_vnonrep) return false;  // (split bins are unified for one pass of words per lane: the level kernels then)
     hipError_t e;
-#define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr)
+#define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr, stack_lds)
     switch (g) {
         case 1: TXQ_FUSED(1); break;
         case 2: TXQ_FUSED(2); break;
@@ -1345,7 +1361,8 @@ static hipError_t launch_level(unsigned grid, hipStream_t s, HibfView t, const u
 static bool hibf_probe_fused(Index& ix, const Knobs& kn, const uint64_t* d_kmers, size_t n, uint64_t* d_masks, uint64_t* d_alive, hipStream_t s, int* rc) {
     const uint32_t w_out = (uint32_t)ix.shard_words;
     const uint32_t stack_cap = (uint32_t)ix.ibf.size();
-    const size_t wave_words = (size_t)w_out + ((size_t)stack_cap + 1) / 2;
+    const uint32_t stack_lds = fused_stack_lds(kn, stack_cap, w_out);
+    const size_t wave_words = (size_t)w_out + stack_lds / 2;
     const size_t wave_bytes = wave_words * 8;
     const size_t lds_budget = 64u << 10;
     if (!w_out || wave_bytes > lds_budget || !ix.d_nodes || kn.hibf_levels) return false;
@@ -1444,7 +1461,7 @@ static bool hibf_probe_fused(Index& ix, const Knobs& kn, const uint64_t* d_kmers
     }
     hipError_t e;
 #define TXQ_FUSED(G) e = launch_fused<G>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_masks, w_out, (uint32_t)ix.shard_word0, w_iters, \
-                                         stack_cap, (uint32_t)wave_words, h_max, d_alive)
+                                         stack_cap, (uint32_t)wave_words, h_max, d_alive, stack_lds)
     switch (g) {
         case 1: TXQ_FUSED(1); break;
         case 2: TXQ_FUSED(2); break;
