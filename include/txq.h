@@ -53,7 +53,7 @@ extern "C" {
  *   TXQ_KMER_TABLE_MB=<n>, TXQ_KMER_TABLE_MIN=<n>     most an index's table of all k-mers' masks may take (default 512; 0: none);
  *                                                     the session of fewest programs that builds it (default 16)
  *   TXQ_HIBF_INTERLEAVE=0, TXQ_HIBF_INTERLEAVE_PROBE=0, TXQ_HIBF_LEVELS=1, TXQ_HIBF_STATIONARY=0, TXQ_HIBF_SMALL=0,
- *   TXQ_HIBF_LAYOUT_ORDER=0, TXQ_HIBF_LAYOUT_FUSED=0, TXQ_HIBF_LANE_HASH, TXQ_HIBF_STEPS_PER_GROUP, TXQ_HIBF_TILE, TXQ_HIBF_UNROLL, TXQ_HIBF_STORE_KIND, TXQ_HIBF_WAVES, TXQ_HIBF_STACK_LDS
+ *   TXQ_HIBF_LAYOUT_ORDER=0, TXQ_HIBF_LAYOUT_FUSED=0, TXQ_HIBF_LANE_HASH, TXQ_HIBF_STEPS_PER_GROUP, TXQ_HIBF_TILE, TXQ_HIBF_UNROLL, TXQ_HIBF_STORE_KIND, TXQ_HIBF_WAVES, TXQ_HIBF_STACK_LDS, TXQ_HIBF_LAYOUT_DIRECT=0
  *                                                     which HIBF descent kernel runs, and its tiling
  *   TXQ_PROBE_BLOCKS_PER_CU, TXQ_PROBE_UNROLL, TXQ_PROBE_NT   grid and variant of the flat probe kernel
  * (tests/test_gpu_knobs.py runs a workload under each of them against the oracle.) */

@@ -57,7 +57,9 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
     # (the index's table of all k-mers' masks would take the dense steps over — these trees are small enough for it — so it is
     # switched off for the ways that name a path, and gets a way of its own, last: once built it stays with the index)
     # ("layout": the rows of plain k-mers by one wave per k-mer — hibf_fused_kernel<G, LAYOUT> —, "layout-levels": level by level)
-    for way in ("layout", "layout-levels", "layout-blocks", "layout-tracked", "user-order", "table", "table-tracked"):
+    # ("layout-lds": the same kernel with the k-mer's row kept in LDS and written out at the end, TXQ_HIBF_LAYOUT_DIRECT=0 — by default its
+    # lanes store their words straight into the row in HBM)
+    for way in ("layout", "layout-lds", "layout-levels", "layout-blocks", "layout-tracked", "user-order", "table", "table-tracked"):
         monkeypatch.setenv("TXQ_KMER_TABLE_MB", "512" if way.startswith("table") else "0")
         monkeypatch.setenv("TXQ_KMER_TABLE_MIN", "1")
         monkeypatch.delenv("TETREX_DENSE_MIN", raising=False)
@@ -65,9 +67,12 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
         monkeypatch.delenv("TETREX_DENSE_TRACKED", raising=False)
         monkeypatch.delenv("TXQ_HIBF_LAYOUT_ORDER", raising=False)
         monkeypatch.delenv("TXQ_HIBF_LAYOUT_FUSED", raising=False)
+        monkeypatch.delenv("TXQ_HIBF_LAYOUT_DIRECT", raising=False)
+        if way == "layout-lds":
+            monkeypatch.setenv("TXQ_HIBF_LAYOUT_DIRECT", "0")
         if way == "layout-levels":
             monkeypatch.setenv("TXQ_HIBF_LAYOUT_FUSED", "0")
-        if way not in ("layout", "layout-levels"):
+        if way not in ("layout", "layout-lds", "layout-levels"):
             monkeypatch.setenv("TETREX_DENSE_MIN", "2")
             monkeypatch.setenv("TETREX_DENSE_SPARSE_BELOW", "2")
         if way in ("layout-tracked", "table-tracked"):
@@ -83,7 +88,7 @@ def test_queries_on_general_trees_in_layout_order(capi, oracle, monkeypatch, tre
                 assert np.array_equal(g, want), (q, way)
                 hits += int(want.any())
         assert hits >= 10, way
-        if way not in ("layout", "layout-levels"):
+        if way not in ("layout", "layout-lds", "layout-levels"):
             assert stats["dense_ops"] > 0
         if way in ("layout-tracked", "table-tracked"):
             assert stats["tracked_queries"] > 0

@@ -435,10 +435,12 @@ def test_hibf_stack_entries_beyond_the_lds_go_through_the_output_row(capi, oracl
     ix = capi.Index.upload_hibf(ub, descs)
     monkeypatch.setenv("TXQ_HIBF_SMALL", "0")
     for in_lds in ("2", "32", "96", None):
-        if in_lds:
+        if in_lds:  # (layout order with the row in LDS: writing the row directly, the default, leaves the LDS to the whole stack)
             monkeypatch.setenv("TXQ_HIBF_STACK_LDS", in_lds)
+            monkeypatch.setenv("TXQ_HIBF_LAYOUT_DIRECT", "0")
         else:
             monkeypatch.delenv("TXQ_HIBF_STACK_LDS", raising=False)
+            monkeypatch.delenv("TXQ_HIBF_LAYOUT_DIRECT", raising=False)
         assert np.array_equal(ix.probe(kmers), want), (shape, in_lds)
         # peptide k = 4 literals: their masks are the rows of their one k-mer (layout order where the index has one)
         qs = ["ACDE", "AAAA", "AAAC", "AACA"]

@@ -77,6 +77,7 @@ void read_knobs() {
 #endif
     k.hibf_waves = std::max(0LL, num("TXQ_HIBF_WAVES", 0));
     k.hibf_stack_lds = std::max(2LL, num("TXQ_HIBF_STACK_LDS", 128));
+    k.hibf_layout_direct = num("TXQ_HIBF_LAYOUT_DIRECT", 1) != 0;
     k.probe_blocks_per_cu = (int)std::max(1LL, num("TXQ_PROBE_BLOCKS_PER_CU", 256));
     k.probe_unroll = (int)num("TXQ_PROBE_UNROLL", 2);
     k.probe_nt = flag("TXQ_PROBE_NT");

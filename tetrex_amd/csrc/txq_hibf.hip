@@ -174,20 +174,29 @@ template <int G, bool LAYOUT = false>
 __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint64_t* __restrict__ kmers, size_t n,
                                                          uint64_t* __restrict__ masks, uint32_t w_out, uint32_t word0,
                                                          uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
-                                                         uint32_t h_max, uint64_t* __restrict__ alive, uint32_t stack_lds) {
+                                                         uint32_t h_max, uint64_t* __restrict__ alive, uint32_t stack_lds, uint32_t row_lds_words) {
     extern __shared__ uint64_t lds[];
     const uint32_t lane = threadIdx.x & 63;
+    // LAYOUT with row_lds_words == 0: no row in LDS at all — every word of a layout-order row has ONE writer (the lane that ANDs
+    // it), so the wave clears the k-mer's row in HBM and the lanes store their non-zero words straight into it (the bits of
+    // split user bins move with global atomics); the LDS then only holds the stacks and the waves are bounded by registers
+    const bool direct = LAYOUT && row_lds_words == 0;
     uint64_t* row = lds + (size_t)(threadIdx.x >> 6) * wave_words;
-    uint32_t* stack = reinterpret_cast<uint32_t*>(row + w_out);
+    uint32_t* stack = reinterpret_cast<uint32_t*>(row + row_lds_words);
     const uint32_t sub = lane % G, group = lane / G;
     constexpr uint32_t kPerRound = 64 / G;
     const size_t waves = ((size_t)gridDim.x * blockDim.x) >> 6;
     const size_t first = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     uint64_t v_next = first < n ? kmers[first] : 0;
     for (size_t i = first; i < n; i += waves) {
-        for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
+        uint64_t* const out = masks + i * (size_t)w_out;
+        if (direct) {
+            for (uint32_t j = lane; j < w_out; j += 64) out[j] = 0;
+        } else {
+            for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
+        }
         if (lane == 0) stack[0] = t.root_entry;
-        uint32_t* spill = reinterpret_cast<uint32_t*>(masks + i * (size_t)w_out);  // stack entries stack_lds.. (see above)
+        uint32_t* spill = reinterpret_cast<uint32_t*>(out);  // stack entries stack_lds.. (see above; none when the row is written directly)
         // the k-mer is the same in every lane: make that visible, so that the seed products are
         // computed once per k-mer on the scalar unit instead of per IBF on the vector unit
         const uint64_t v = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v_next >> 32)) << 32) |
@@ -284,7 +293,11 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                     const uint32_t w = w0 + (uint32_t)q;
                     if constexpr (LAYOUT) {
                         moved[q] &= acc[q];  // (the bits that move to their representative once the round's words are in the row)
-                        if (live && w < words_per_row) row[nd.ident_word + w] = acc[q] & ~moved[q];
+                        if (live && w < words_per_row) {
+                            const uint64_t mine = acc[q] & ~moved[q];
+                            if (!direct) row[nd.ident_word + w] = mine;
+                            else if (mine) out[nd.ident_word + w] = mine;
+                        }
                         continue;
                     }
                     uint64_t hits = acc[q] & ~mg[q];
@@ -322,7 +335,8 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
                         const uint32_t j = nd.ident_word + sub * 4u + (uint32_t)q;
                         for (uint64_t m = moved[q]; m; m &= m - 1) {
                             const uint32_t to = t.rep_pos[(size_t)j * 64 + (uint32_t)__builtin_ctzll(m)];
-                            atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
+                            if (direct) atomicOr((unsigned long long*)(out + (to >> 6)), 1ULL << (to & 63));
+                            else atomicOr((unsigned long long*)(row + (to >> 6)), 1ULL << (to & 63));
                         }
                     }
                 }
@@ -330,11 +344,12 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
         }
         wave_sync();
         uint64_t any = 0;
-        uint64_t* out = masks + i * (size_t)w_out;
-        for (uint32_t j = lane; j < w_out; j += 64) {
-            const uint64_t x = row[j];
-            any |= x;
-            __builtin_nontemporal_store(x, out + j);
+        if (!direct) {
+            for (uint32_t j = lane; j < w_out; j += 64) {
+                const uint64_t x = row[j];
+                any |= x;
+                __builtin_nontemporal_store(x, out + j);
+            }
         }
         if (alive) {
             const uint64_t some = __ballot(any != 0);
@@ -347,12 +362,12 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
 template <int G, bool LAYOUT = false>
 static hipError_t launch_fused(unsigned grid, unsigned threads, size_t lds_bytes, hipStream_t s, HibfView t, const uint64_t* kmers, size_t n,
                                uint64_t* masks, uint32_t w_out, uint32_t word0, uint32_t w_iters, uint32_t stack_cap, uint32_t wave_words,
-                               uint32_t h_max, uint64_t* alive, uint32_t stack_lds) {
+                               uint32_t h_max, uint64_t* alive, uint32_t stack_lds, uint32_t row_lds_words) {
     if (lds_bytes > (48u << 10)) {  // (more dynamic LDS than the default limit: ask for it)
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&hibf_fused_kernel<G, LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hibf_fused_kernel<G, LAYOUT><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive, stack_lds);
+    hibf_fused_kernel<G, LAYOUT><<<grid, threads, lds_bytes, s>>>(t, kmers, n, masks, w_out, word0, w_iters, stack_cap, wave_words, h_max, alive, stack_lds, row_lds_words);
     return hipGetLastError();
 }
 
@@ -1024,8 +1039,11 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     const Knobs kn = knobs();
     if (!ix.d_vnodes || !kn.hibf_layout_fused) return false;
     const uint32_t w_out = ix.v_words, stack_cap = (uint32_t)ix.ibf.size();
-    const uint32_t stack_lds = fused_stack_lds(kn, stack_cap, w_out);
-    const size_t wave_words = (size_t)w_out + stack_lds / 2, wave_bytes = wave_words * 8;
+    // (TXQ_HIBF_LAYOUT_DIRECT=0: the row in LDS, written out when the k-mer is done — the A/B and what the tests compare with)
+    const bool direct = kn.hibf_layout_direct;
+    const uint32_t stack_lds = direct ? ((stack_cap + 1) & ~1u) : fused_stack_lds(kn, stack_cap, w_out);
+    const uint32_t row_lds_words = direct ? 0 : w_out;
+    const size_t wave_words = (size_t)row_lds_words + stack_lds / 2, wave_bytes = wave_words * 8;
     if (wave_bytes > (64u << 10)) return false;
     uint32_t h_max = 1;
     for (const IbfDev& f : ix.ibf) if (f.hash_funs > h_max) h_max = f.hash_funs;
@@ -1042,7 +1060,7 @@ static bool layout_order_fused(Index& ix, const uint64_t* d_kmers, size_t n, uin
     const uint32_t w_iters = (quads + (uint32_t)g - 1) / (uint32_t)g;
     if (w_iters > 1 && ix.d_vnonrep) return false;  // (split bins are unified for one pass of words per lane: the level kernels then)
     hipError_t e;
-#define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr, stack_lds)
+#define TXQ_FUSED(G) e = launch_fused<G, true>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_rows, w_out, 0u, w_iters, stack_cap, (uint32_t)wave_words, h_max, nullptr, stack_lds, row_lds_words)
     switch (g) {
         case 1: TXQ_FUSED(1); break;
         case 2: TXQ_FUSED(2); break;
@@ -1461,7 +1479,7 @@ static bool hibf_probe_fused(Index& ix, const Knobs& kn, const uint64_t* d_kmers
     }
     hipError_t e;
 #define TXQ_FUSED(G) e = launch_fused<G>(grid, waves * 64, wave_bytes * waves, s, t, d_kmers, n, d_masks, w_out, (uint32_t)ix.shard_word0, w_iters, \
-                                         stack_cap, (uint32_t)wave_words, h_max, d_alive, stack_lds)
+                                         stack_cap, (uint32_t)wave_words, h_max, d_alive, stack_lds, w_out)
     switch (g) {
         case 1: TXQ_FUSED(1); break;
         case 2: TXQ_FUSED(2); break;

@@ -40,6 +40,7 @@ struct Knobs {
     bool hibf_layout_order = true;      // TXQ_HIBF_LAYOUT_ORDER=0: sessions on general trees work in user-bin order (descent kernels)
     int hibf_steps_per_group = 0, hibf_tile = 0, hibf_unroll = 1, hibf_store = 0;  // TXQ_HIBF_STEPS_PER_GROUP / _TILE / _UNROLL / _STORE_KIND (store instruction: 0-3)
     long long hibf_waves = 0;           // TXQ_HIBF_WAVES
+    bool hibf_layout_direct = true;     // TXQ_HIBF_LAYOUT_DIRECT=0: hibf_fused_kernel<G, LAYOUT> keeps the row in LDS instead of writing it directly
     long long hibf_stack_lds = 128;     // TXQ_HIBF_STACK_LDS: entries of hibf_fused_kernel's IBF stack kept in LDS (the rest: in the k-mer's output row)
     // probe (txq_probe.hip)
     int probe_blocks_per_cu = 256, probe_unroll = 2;  // TXQ_PROBE_BLOCKS_PER_CU, TXQ_PROBE_UNROLL
