@@ -190,8 +190,13 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
     uint64_t v_next = first < n ? kmers[first] : 0;
     for (size_t i = first; i < n; i += waves) {
         uint64_t* const out = masks + i * (size_t)w_out;
+        const bool wide = (w_out & 1u) == 0 && (reinterpret_cast<uintptr_t>(masks) & 15u) == 0;  // (16-byte aligned rows: a lane stores two words at once)
         if (direct) {
-            for (uint32_t j = lane; j < w_out; j += 64) out[j] = 0;
+            if (wide) {
+                for (uint32_t j = lane * 2; j < w_out; j += 128) *reinterpret_cast<u64x2*>(out + j) = u64x2{0, 0};
+            } else {
+                for (uint32_t j = lane; j < w_out; j += 64) out[j] = 0;
+            }
         } else {
             for (uint32_t j = lane; j < w_out; j += 64) row[j] = 0;
         }
@@ -345,10 +350,18 @@ __global__ __launch_bounds__(256) void hibf_fused_kernel(HibfView t, const uint6
         wave_sync();
         uint64_t any = 0;
         if (!direct) {
-            for (uint32_t j = lane; j < w_out; j += 64) {
-                const uint64_t x = row[j];
-                any |= x;
-                __builtin_nontemporal_store(x, out + j);
+            if (wide) {
+                for (uint32_t j = lane * 2; j < w_out; j += 128) {
+                    const u64x2 x{row[j], row[j + 1]};
+                    any |= x.x | x.y;
+                    __builtin_nontemporal_store(x, reinterpret_cast<u64x2*>(out + j));
+                }
+            } else {
+                for (uint32_t j = lane; j < w_out; j += 64) {
+                    const uint64_t x = row[j];
+                    any |= x;
+                    __builtin_nontemporal_store(x, out + j);
+                }
             }
         }
         if (alive) {
